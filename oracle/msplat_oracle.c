@@ -1,0 +1,646 @@
+/*
+ * msplat_oracle.c -- CPU ORACLE (test infrastructure; see msplat_oracle.h for the rules).
+ * PARITY UNPINNED for the shader arithmetic (no runnable reference, no reference tests).
+ *
+ * Literal restatement, function by function, of the reference's hot path:
+ *   shader/presort_compute.glsl:31-57            -> orc_cull_key / orc_presort
+ *   src/splatrenderer.cpp:223-264 (sort contract) -> orc_sort
+ *   shader/splat_vert.glsl:51-127,153-222        -> sh_radiance / project_one
+ *   shader/splat_geom.glsl:22-87                 -> project_one (inverse, reject, extents)
+ *   shader/splat_frag.glsl:18-42 + src/app.cpp:153-160 -> orc_composite
+ *   src/gaussiancloud.cpp:86-94,119-122,254-361  -> orc_build_cloud
+ *   src/splatrenderer.cpp:161,175,327-335        -> orc_render_frame (host matrices)
+ *   src/core/util.cpp:420-480                    -> orc_create_projection
+ * glm (vcpkg "latest", unpinned, not under /root/reference) closed forms restated:
+ *   inverse(mat4) cofactor expansion, mat4*mat4, perspective (RH, -1..1), quat->mat3.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (oracle/Makefile).
+ */
+#include "msplat_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define M(m, c, r) ((m)[(c) * 4 + (r)])
+
+/* ------------------------------------------------------------------------------------- */
+/* matrices                                                                              */
+/* ------------------------------------------------------------------------------------- */
+
+void orc_mat4_mul(const float a[16], const float b[16], float out[16])
+{
+    /* glm: Result[c] = A[0]*B[c][0] + A[1]*B[c][1] + A[2]*B[c][2] + A[3]*B[c][3] */
+    float tmp[16];
+    for (int c = 0; c < 4; ++c) {
+        for (int r = 0; r < 4; ++r) {
+            float s = M(a, 0, r) * M(b, c, 0);
+            s = s + M(a, 1, r) * M(b, c, 1);
+            s = s + M(a, 2, r) * M(b, c, 2);
+            s = s + M(a, 3, r) * M(b, c, 3);
+            tmp[c * 4 + r] = s;
+        }
+    }
+    memcpy(out, tmp, sizeof(tmp));
+}
+
+void orc_mat4_inverse(const float m[16], float out[16])
+{
+    /* glm::inverse(mat4): 2x2 sub-determinant ("Coef") form */
+    float c00 = M(m,2,2) * M(m,3,3) - M(m,3,2) * M(m,2,3);
+    float c02 = M(m,1,2) * M(m,3,3) - M(m,3,2) * M(m,1,3);
+    float c03 = M(m,1,2) * M(m,2,3) - M(m,2,2) * M(m,1,3);
+    float c04 = M(m,2,1) * M(m,3,3) - M(m,3,1) * M(m,2,3);
+    float c06 = M(m,1,1) * M(m,3,3) - M(m,3,1) * M(m,1,3);
+    float c07 = M(m,1,1) * M(m,2,3) - M(m,2,1) * M(m,1,3);
+    float c08 = M(m,2,1) * M(m,3,2) - M(m,3,1) * M(m,2,2);
+    float c10 = M(m,1,1) * M(m,3,2) - M(m,3,1) * M(m,1,2);
+    float c11 = M(m,1,1) * M(m,2,2) - M(m,2,1) * M(m,1,2);
+    float c12 = M(m,2,0) * M(m,3,3) - M(m,3,0) * M(m,2,3);
+    float c14 = M(m,1,0) * M(m,3,3) - M(m,3,0) * M(m,1,3);
+    float c15 = M(m,1,0) * M(m,2,3) - M(m,2,0) * M(m,1,3);
+    float c16 = M(m,2,0) * M(m,3,2) - M(m,3,0) * M(m,2,2);
+    float c18 = M(m,1,0) * M(m,3,2) - M(m,3,0) * M(m,1,2);
+    float c19 = M(m,1,0) * M(m,2,2) - M(m,2,0) * M(m,1,2);
+    float c20 = M(m,2,0) * M(m,3,1) - M(m,3,0) * M(m,2,1);
+    float c22 = M(m,1,0) * M(m,3,1) - M(m,3,0) * M(m,1,1);
+    float c23 = M(m,1,0) * M(m,2,1) - M(m,2,0) * M(m,1,1);
+
+    float f0[4] = {c00, c00, c02, c03};
+    float f1[4] = {c04, c04, c06, c07};
+    float f2[4] = {c08, c08, c10, c11};
+    float f3[4] = {c12, c12, c14, c15};
+    float f4[4] = {c16, c16, c18, c19};
+    float f5[4] = {c20, c20, c22, c23};
+    float v0[4] = {M(m,1,0), M(m,0,0), M(m,0,0), M(m,0,0)};
+    float v1[4] = {M(m,1,1), M(m,0,1), M(m,0,1), M(m,0,1)};
+    float v2[4] = {M(m,1,2), M(m,0,2), M(m,0,2), M(m,0,2)};
+    float v3[4] = {M(m,1,3), M(m,0,3), M(m,0,3), M(m,0,3)};
+    static const float sa[4] = {+1.0f, -1.0f, +1.0f, -1.0f};
+    static const float sb[4] = {-1.0f, +1.0f, -1.0f, +1.0f};
+    float inv[16];
+    for (int i = 0; i < 4; ++i) {
+        float i0 = (v1[i] * f0[i] - v2[i] * f1[i]) + v3[i] * f2[i];
+        float i1 = (v0[i] * f0[i] - v2[i] * f3[i]) + v3[i] * f4[i];
+        float i2 = (v0[i] * f1[i] - v1[i] * f3[i]) + v3[i] * f5[i];
+        float i3 = (v0[i] * f2[i] - v1[i] * f4[i]) + v2[i] * f5[i];
+        inv[0 * 4 + i] = i0 * sa[i];
+        inv[1 * 4 + i] = i1 * sb[i];
+        inv[2 * 4 + i] = i2 * sa[i];
+        inv[3 * 4 + i] = i3 * sb[i];
+    }
+    float d0 = M(m,0,0) * inv[0 * 4 + 0];
+    float d1 = M(m,0,1) * inv[1 * 4 + 0];
+    float d2 = M(m,0,2) * inv[2 * 4 + 0];
+    float d3 = M(m,0,3) * inv[3 * 4 + 0];
+    float det = (d0 + d1) + (d2 + d3);
+    float ood = 1.0f / det;
+    for (int i = 0; i < 16; ++i) out[i] = inv[i] * ood;
+}
+
+void orc_perspective(float fovy, float aspect, float zn, float zf, float out[16])
+{
+    /* glm::perspective, right-handed, clip z in [-1,1]  (app.cpp:1042) */
+    float t = tanf(fovy / 2.0f);
+    memset(out, 0, 16 * sizeof(float));
+    M(out, 0, 0) = 1.0f / (aspect * t);
+    M(out, 1, 1) = 1.0f / t;
+    M(out, 2, 2) = -(zf + zn) / (zf - zn);
+    M(out, 2, 3) = -1.0f;
+    M(out, 3, 2) = -(2.0f * zf * zn) / (zf - zn);
+}
+
+void orc_create_projection(float tanL, float tanR, float tanU, float tanD,
+                           float zn, float zf, float m[16])
+{
+    /* util.cpp:420-480, GRAPHICS_OPENGL branch (offsetZ = nearZ, height = up - down) */
+    const float w = tanR - tanL;
+    const float h = tanU - tanD;
+    const float offsetZ = zn;
+    memset(m, 0, 16 * sizeof(float));
+    m[0] = 2 / w;
+    m[8] = (tanR + tanL) / w;
+    m[5] = 2 / h;
+    m[9] = (tanU + tanD) / h;
+    m[11] = -1;
+    if (zf <= zn) {
+        m[10] = -1;
+        m[14] = -(zn + offsetZ);
+    } else {
+        m[10] = -(zf + offsetZ) / (zf - zn);
+        m[14] = -(zf * (zn + offsetZ)) / (zf - zn);
+    }
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* load time                                                                             */
+/* ------------------------------------------------------------------------------------- */
+
+static void mat3_mul(const float a[9], const float b[9], float out[9])
+{
+    /* column-major 3x3, glm operator*: out[c][r] = a[0][r]*b[c][0] + a[1][r]*b[c][1] + a[2][r]*b[c][2] */
+    float t[9];
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) {
+            float s = a[0 * 3 + r] * b[c * 3 + 0];
+            s = s + a[1 * 3 + r] * b[c * 3 + 1];
+            s = s + a[2 * 3 + r] * b[c * 3 + 2];
+            t[c * 3 + r] = s;
+        }
+    memcpy(out, t, sizeof(t));
+}
+
+static void mat3_transpose(const float a[9], float out[9])
+{
+    float t[9];
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) t[c * 3 + r] = a[r * 3 + c];
+    memcpy(out, t, sizeof(t));
+}
+
+static void cov_from_rot_scale(const float rot[4], const float scale[3], float V[9])
+{
+    /* gaussiancloud.cpp:86-94: q = (w=rot0, x=rot1, y=rot2, z=rot3) normalised; R S S^T R^T */
+    float w = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    float t0 = w * w, t1 = x * x, t2 = y * y, t3 = z * z;
+    float len = sqrtf((t0 + t1) + (t2 + t3));
+    if (len <= 0.0f) { w = 1.0f; x = y = z = 0.0f; }
+    else { float ool = 1.0f / len; w *= ool; x *= ool; y *= ool; z *= ool; }
+    float qxx = x * x, qyy = y * y, qzz = z * z;
+    float qxz = x * z, qxy = x * y, qyz = y * z;
+    float qwx = w * x, qwy = w * y, qwz = w * z;
+    float R[9];
+    R[0] = 1.0f - 2.0f * (qyy + qzz);
+    R[1] = 2.0f * (qxy + qwz);
+    R[2] = 2.0f * (qxz - qwy);
+    R[3] = 2.0f * (qxy - qwz);
+    R[4] = 1.0f - 2.0f * (qxx + qzz);
+    R[5] = 2.0f * (qyz + qwx);
+    R[6] = 2.0f * (qxz + qwy);
+    R[7] = 2.0f * (qyz - qwx);
+    R[8] = 1.0f - 2.0f * (qxx + qyy);
+    float S[9] = {scale[0], 0, 0, 0, scale[1], 0, 0, 0, scale[2]};
+    float St[9], Rt[9], A[9], B[9];
+    mat3_transpose(S, St);
+    mat3_transpose(R, Rt);
+    mat3_mul(R, S, A);
+    mat3_mul(A, St, B);
+    mat3_mul(B, Rt, V);
+}
+
+void orc_build_cloud(size_t n, const float* xyz, const float* f_dc, const float* f_rest,
+                     const float* opacity, const float* log_scale, const float* rot,
+                     int full_sh, float* aos_out)
+{
+    const size_t stride = full_sh ? ORC_FULL_FLOATS : ORC_BASE_FLOATS;
+    for (size_t i = 0; i < n; ++i) {
+        float* o = aos_out + i * stride;
+        o[0] = xyz[i * 3 + 0];
+        o[1] = xyz[i * 3 + 1];
+        o[2] = xyz[i * 3 + 2];
+        o[3] = 1.0f / (1.0f + expf(-opacity[i]));            /* gaussiancloud.cpp:119-122 */
+        if (full_sh) {
+            /* gaussiancloud.cpp:262-314: channel c, coeff k: k=0 -> f_dc[c]; k>0 -> f_rest[c*15 + k-1] */
+            static const int off0[3] = {ORC_OFF_R_SH0, ORC_OFF_G_SH0, ORC_OFF_B_SH0};
+            static const int off1[3] = {ORC_OFF_R_SH1, ORC_OFF_G_SH1, ORC_OFF_B_SH1};
+            for (int c = 0; c < 3; ++c) {
+                o[off0[c] + 0] = f_dc[i * 3 + c];
+                for (int k = 1; k < 4; ++k) o[off0[c] + k] = f_rest[i * 45 + c * 15 + (k - 1)];
+                for (int k = 4; k < 16; ++k) o[off1[c] + (k - 4)] = f_rest[i * 45 + c * 15 + (k - 1)];
+            }
+        } else {
+            /* gaussiancloud.cpp:316-332 */
+            o[ORC_OFF_R_SH0] = f_dc[i * 3 + 0]; o[ORC_OFF_R_SH0 + 1] = o[ORC_OFF_R_SH0 + 2] = o[ORC_OFF_R_SH0 + 3] = 0.0f;
+            o[ORC_OFF_G_SH0] = f_dc[i * 3 + 1]; o[ORC_OFF_G_SH0 + 1] = o[ORC_OFF_G_SH0 + 2] = o[ORC_OFF_G_SH0 + 3] = 0.0f;
+            o[ORC_OFF_B_SH0] = f_dc[i * 3 + 2]; o[ORC_OFF_B_SH0 + 1] = o[ORC_OFF_B_SH0 + 2] = o[ORC_OFF_B_SH0 + 3] = 0.0f;
+        }
+        float sc[3] = {expf(log_scale[i * 3 + 0]), expf(log_scale[i * 3 + 1]), expf(log_scale[i * 3 + 2])};
+        float V[9];
+        cov_from_rot_scale(rot + i * 4, sc, V);
+        for (int k = 0; k < 9; ++k) o[ORC_OFF_COV0 + k] = V[k];   /* col0, col1, col2 */
+    }
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* cull + key                                                                            */
+/* ------------------------------------------------------------------------------------- */
+
+static inline void mat4_mul_point(const float m[16], float x, float y, float z, float p[4])
+{
+    /* m * vec4(x,y,z,1): ((m0*x + m1*y) + m2*z) + m3*1, one rounding per op */
+    for (int r = 0; r < 4; ++r) {
+        float s = M(m, 0, r) * x;
+        s = s + M(m, 1, r) * y;
+        s = s + M(m, 2, r) * z;
+        s = s + M(m, 3, r);
+        p[r] = s;
+    }
+}
+
+int orc_cull_key(const float xyz[3], const float mvp[16], float zfar, uint32_t* key_out)
+{
+    float p[4];
+    mat4_mul_point(mvp, xyz[0], xyz[1], xyz[2], p);
+    float depth = p[3];
+    float xx = p[0] / depth;
+    float yy = p[1] / depth;
+    const float CLIP = 1.5f;
+    if (depth > 0.0f && xx < CLIP && xx > -CLIP && yy < CLIP && yy > -CLIP) {
+        /* keyMax - uint((depth / far) * keyMax); float(0xFFFFFFFFu) == 2^32 */
+        float f = (depth / zfar) * 4294967296.0f;
+        uint32_t q;
+        if (f >= 4294967296.0f) q = 0xFFFFFFFFu;   /* GLSL: undefined; we saturate (far-clipped anyway) */
+        else q = (uint32_t)f;                      /* truncation; f > 0 here */
+        *key_out = 0xFFFFFFFFu - q;
+        return 1;
+    }
+    return 0;
+}
+
+uint32_t orc_presort(size_t n, const float* aos, size_t stride, const float mvp[16],
+                     float zfar, uint32_t* keys_out, uint32_t* idx_out)
+{
+    uint32_t v = 0;
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t key;
+        if (orc_cull_key(aos + i * stride, mvp, zfar, &key)) {
+            keys_out[v] = key;
+            idx_out[v] = (uint32_t)i;
+            ++v;
+        }
+    }
+    return v;
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* sort: ascending key, stable                                                           */
+/* ------------------------------------------------------------------------------------- */
+
+void orc_sort(uint32_t v, uint32_t* keys, uint32_t* idx)
+{
+    /* LSD radix, 4 x 8 bit, exactly the reference's contract (stable, ascending) */
+    if (v == 0) return;
+    uint32_t* k2 = (uint32_t*)malloc((size_t)v * sizeof(uint32_t));
+    uint32_t* i2 = (uint32_t*)malloc((size_t)v * sizeof(uint32_t));
+    uint32_t *ks = keys, *is = idx, *kd = k2, *id = i2;
+    for (int pass = 0; pass < 4; ++pass) {
+        size_t hist[257];
+        memset(hist, 0, sizeof(hist));
+        const int sh = pass * 8;
+        for (uint32_t i = 0; i < v; ++i) hist[((ks[i] >> sh) & 255u) + 1]++;
+        for (int b = 0; b < 256; ++b) hist[b + 1] += hist[b];
+        for (uint32_t i = 0; i < v; ++i) {
+            size_t d = hist[(ks[i] >> sh) & 255u]++;
+            kd[d] = ks[i];
+            id[d] = is[i];
+        }
+        uint32_t* t;
+        t = ks; ks = kd; kd = t;
+        t = is; is = id; id = t;
+    }
+    /* 4 passes: result is back in keys/idx */
+    free(k2);
+    free(i2);
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* vertex + geometry stage                                                               */
+/* ------------------------------------------------------------------------------------- */
+
+static void sh_radiance(const float* rec, int full_sh, const float v[3], float rgb[3])
+{
+    /* splat_vert.glsl:51-127 */
+    float b[16];
+    float vx = v[0], vy = v[1], vz = v[2];
+    float vx2 = vx * vx, vy2 = vy * vy, vz2 = vz * vz;
+    b[0] = 0.28209479177387814f;
+    float k1 = 0.4886025119029199f;
+    b[1] = -k1 * vy;
+    b[2] = k1 * vz;
+    b[3] = -k1 * vx;
+    const float* sh0[3] = {rec + ORC_OFF_R_SH0, rec + ORC_OFF_G_SH0, rec + ORC_OFF_B_SH0};
+    if (full_sh) {
+        float k2 = 1.0925484305920792f, k3 = 0.31539156525252005f, k4 = 0.5462742152960396f;
+        b[4] = k2 * vy * vx;
+        b[5] = -k2 * vy * vz;
+        b[6] = k3 * (3.0f * vz2 - 1.0f);
+        b[7] = -k2 * vx * vz;
+        b[8] = k4 * (vx2 - vy2);
+        float k5 = 0.5900435899266435f, k6 = 2.8906114426405543f, k7 = 0.4570457994644658f;
+        float k8 = 0.37317633259011546f, k9 = 1.4453057213202771f;
+        b[9] = -k5 * vy * (3.0f * vx2 - vy2);
+        b[10] = k6 * vy * vx * vz;
+        b[11] = -k7 * vy * (5.0f * vz2 - 1.0f);
+        b[12] = k8 * vz * (5.0f * vz2 - 3.0f);
+        b[13] = -k7 * vx * (5.0f * vz2 - 1.0f);
+        b[14] = k9 * vz * (vx2 - vy2);
+        b[15] = -k5 * vx * (vx2 - 3.0f * vy2);
+        const float* sh1[3] = {rec + ORC_OFF_R_SH1, rec + ORC_OFF_G_SH1, rec + ORC_OFF_B_SH1};
+        for (int c = 0; c < 3; ++c) {
+            float s = b[0] * sh0[c][0];
+            for (int k = 1; k < 4; ++k) s = s + b[k] * sh0[c][k];
+            for (int k = 4; k < 16; ++k) s = s + b[k] * sh1[c][k - 4];
+            rgb[c] = 0.5f + s;
+        }
+    } else {
+        for (int c = 0; c < 3; ++c) {
+            float s = b[0] * sh0[c][0];
+            for (int k = 1; k < 4; ++k) s = s + b[k] * sh0[c][k];
+            rgb[c] = 0.5f + s;
+        }
+    }
+}
+
+static float srgb_to_linear(float s)
+{
+    /* splat_vert.glsl:129-141 */
+    if (s <= 0.04045f) return s / 12.92f;
+    return powf((s + 0.055f) / 1.055f, 2.4f);
+}
+
+static void project_one(const float* rec, int full_sh, int srgb, const float viewMat[16],
+                        const float projMat[16], const float viewport[4], const float nearFar[2],
+                        const float eye[3], orc_splat2d* o)
+{
+    float alpha = rec[3];
+    float t[4];
+    mat4_mul_point(viewMat, rec[0], rec[1], rec[2], t);
+
+    float X0 = viewport[0] * (0.00001f * nearFar[0]);   /* splat_vert.glsl:160 */
+    float Y0 = viewport[1];
+    float WIDTH = viewport[2];
+    float HEIGHT = viewport[3];
+    float Z_NEAR = nearFar[0];
+    float Z_FAR = nearFar[1];
+
+    float SX = M(projMat, 0, 0);
+    float SY = M(projMat, 1, 1);
+    float WZ = M(projMat, 3, 2);
+    float tzSq = t[2] * t[2];
+    float jsx = -(SX * WIDTH) / (2.0f * t[2]);
+    float jsy = -(SY * HEIGHT) / (2.0f * t[2]);
+    float jtx = (SX * t[0] * WIDTH) / (2.0f * tzSq);
+    float jty = (SY * t[1] * HEIGHT) / (2.0f * tzSq);
+    float jtz = ((Z_FAR - Z_NEAR) * WZ) / (2.0f * tzSq);
+    /* GLSL mat3(vec3,vec3,vec3) takes COLUMNS */
+    float J[9] = {jsx, 0.0f, 0.0f, 0.0f, jsy, 0.0f, jtx, jty, jtz};
+    float W[9] = {M(viewMat,0,0), M(viewMat,0,1), M(viewMat,0,2),
+                  M(viewMat,1,0), M(viewMat,1,1), M(viewMat,1,2),
+                  M(viewMat,2,0), M(viewMat,2,1), M(viewMat,2,2)};
+    float V[9];
+    for (int k = 0; k < 9; ++k) V[k] = rec[ORC_OFF_COV0 + k];
+    float JW[9], JWt[9], A[9], Vp[9];
+    mat3_mul(J, W, JW);
+    mat3_transpose(JW, JWt);
+    mat3_mul(JW, V, A);
+    mat3_mul(A, JWt, Vp);
+
+    /* mat2(V_prime): columns (Vp[0][0],Vp[0][1]), (Vp[1][0],Vp[1][1]) */
+    float m00 = Vp[0 * 3 + 0], m01 = Vp[0 * 3 + 1], m10 = Vp[1 * 3 + 0], m11 = Vp[1 * 3 + 1];
+    m00 += 0.3f;
+    m11 += 0.3f;
+    o->cov[0] = m00; o->cov[1] = m01; o->cov[2] = m10; o->cov[3] = m11;
+
+    float p4[4];
+    {
+        /* projMat * t (t is a full vec4 with w = 1 from the affine viewMat) */
+        for (int r = 0; r < 4; ++r) {
+            float s = M(projMat, 0, r) * t[0];
+            s = s + M(projMat, 1, r) * t[1];
+            s = s + M(projMat, 2, r) * t[2];
+            s = s + M(projMat, 3, r) * t[3];
+            p4[r] = s;
+        }
+    }
+    float gx = p4[0] / p4[3];
+    float gy = p4[1] / p4[3];
+    o->px = 0.5f * (WIDTH + (gx * WIDTH) + (2.0f * X0));
+    o->py = 0.5f * (HEIGHT + (gy * HEIGHT) + (2.0f * Y0));
+
+    float d[3] = {rec[0] - eye[0], rec[1] - eye[1], rec[2] - eye[2]};
+    float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    float v[3] = {d[0] / len, d[1] / len, d[2] / len};
+    sh_radiance(rec, full_sh, v, o->rgb);
+    o->alpha = alpha;
+    if (srgb) {
+        for (int c = 0; c < 3; ++c) o->rgb[c] = srgb_to_linear(o->rgb[c]);
+    }
+
+    /* ---- geometry stage: splat_geom.glsl:34-87 ---- */
+    float det = m00 * m11 - m01 * m10;
+    o->inv[0] = m11 / det;
+    o->inv[1] = -m01 / det;
+    o->inv[2] = -m10 / det;
+    o->inv[3] = m00 / det;
+
+    o->ndc[0] = p4[0] / p4[3];
+    o->ndc[1] = p4[1] / p4[3];
+    o->ndc[2] = p4[2] / p4[3];
+    o->depth = p4[3];
+    int reject = 0;
+    if (o->ndc[2] < 0.25f || o->ndc[0] > 2.0f || o->ndc[0] < -2.0f ||
+        o->ndc[1] > 2.0f || o->ndc[1] < -2.0f) reject = 1;
+    /* fixed-function clip of the whole quad against the far plane (all 4 vertices share z,w);
+       NaN centres never rasterise */
+    if (!(o->ndc[2] <= 1.0f)) reject = 1;
+    if (!(p4[3] > 0.0f)) reject = 1;
+
+    /* oriented 3.5-sigma quad -> AABB half extents (superset of the rasterised pixels) */
+    float k = 3.5f;
+    float a = m00, b = m01, c = m11;
+    float apco2 = (a + c) / 2.0f;
+    float amco2 = (a - c) / 2.0f;
+    float term = sqrtf(amco2 * amco2 + b * b);
+    float maj = apco2 + term;
+    float mn = apco2 - term;
+    float theta;
+    if (b == 0.0f) theta = (a >= c) ? 0.0f : 1.57079632679489661923f;
+    else theta = atan2f(maj - a, b);
+    float r1 = k * sqrtf(maj);
+    float r2 = k * sqrtf(mn);
+    float majx = r1 * cosf(theta), majy = r1 * sinf(theta);
+    float minx = r2 * cosf(theta + 1.57079632679489661923f), miny = r2 * sinf(theta + 1.57079632679489661923f);
+    o->hx = fabsf(majx) + fabsf(minx);
+    o->hy = fabsf(majy) + fabsf(miny);
+    if (!(o->hx == o->hx) || !(o->hy == o->hy)) reject = 1;   /* NaN quad: nothing rasterised */
+    o->reject = reject;
+}
+
+void orc_project(uint32_t v, const uint32_t* idx, const float* aos, size_t stride,
+                 int full_sh, int srgb, const float viewMat[16], const float projMat[16],
+                 const float viewport[4], const float nearFar[2], const float eye[3],
+                 orc_splat2d* out)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < (int64_t)v; ++r) {
+        uint32_t i = idx ? idx[r] : (uint32_t)r;
+        project_one(aos + (size_t)i * stride, full_sh, srgb, viewMat, projMat, viewport, nearFar,
+                    eye, &out[r]);
+        out[r].index = i;
+    }
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* fragment stage + blend                                                                */
+/* ------------------------------------------------------------------------------------- */
+
+static uint64_t g_fragments = 0;
+uint64_t orc_last_fragment_count(void) { return g_fragments; }
+
+static inline void pixel_range(float centre, float half, int limit, int lo_clip, int hi_clip,
+                               int* lo, int* hi)
+{
+    /* pixels i whose centre i+0.5 lies in [centre-half, centre+half], padded by one pixel */
+    float a = floorf(centre - half - 0.5f) - 1.0f;
+    float b = ceilf(centre + half - 0.5f) + 1.0f;
+    if (a < (float)lo_clip) a = (float)lo_clip;
+    if (b > (float)(hi_clip - 1)) b = (float)(hi_clip - 1);
+    (void)limit;
+    if (!(a <= b)) { *lo = 0; *hi = -1; return; }
+    *lo = (int)a;
+    *hi = (int)b;
+}
+
+void orc_composite(uint32_t v, const orc_splat2d* s, int W, int H, float* rgba,
+                   int row0, int row1, int nthreads)
+{
+    if (row0 < 0) row0 = 0;
+    if (row1 > H) row1 = H;
+    if (nthreads < 1) nthreads = 1;
+    uint64_t frags = 0;
+    const int rows = row1 - row0;
+    if (rows <= 0) return;
+    if (nthreads > rows) nthreads = rows;
+#pragma omp parallel for schedule(static, 1) num_threads(nthreads) reduction(+ : frags)
+    for (int band = 0; band < nthreads; ++band) {
+        const int y0 = row0 + (int)(((int64_t)rows * band) / nthreads);
+        const int y1 = row0 + (int)(((int64_t)rows * (band + 1)) / nthreads);
+        /* clear: (0,0,0,1)  app.cpp:158-160 */
+        for (int y = y0; y < y1; ++y)
+            for (int x = 0; x < W; ++x) {
+                float* d = rgba + ((size_t)y * W + x) * 4;
+                d[0] = 0.0f; d[1] = 0.0f; d[2] = 0.0f; d[3] = 1.0f;
+            }
+        for (uint32_t k = 0; k < v; ++k) {        /* draw order = array order = far -> near */
+            const orc_splat2d* g = &s[k];
+            if (g->reject) continue;
+            int xa, xb, ya, yb;
+            pixel_range(g->px, g->hx, W, 0, W, &xa, &xb);
+            pixel_range(g->py, g->hy, H, y0, y1, &ya, &yb);
+            for (int y = ya; y <= yb; ++y) {
+                for (int x = xa; x <= xb; ++x) {
+                    /* splat_frag.glsl:20-41 */
+                    float dx = ((float)x + 0.5f) - g->px;
+                    float dy = ((float)y + 0.5f) - g->py;
+                    /* cov2Dinv * d : columns (inv0,inv1),(inv2,inv3) */
+                    float mx = g->inv[0] * dx + g->inv[2] * dy;
+                    float my = g->inv[1] * dx + g->inv[3] * dy;
+                    float q = dx * mx + dy * my;
+                    float e = expf(-0.5f * q);
+                    float sa = g->alpha * e;
+                    ++frags;
+                    if (sa <= (1.0f / 256.0f)) continue;        /* discard */
+                    float* d = rgba + ((size_t)y * W + x) * 4;
+                    float oma = 1.0f - sa;
+                    /* GL_ONE, GL_ONE_MINUS_SRC_ALPHA  (app.cpp:153-156) */
+                    d[0] = (sa * g->rgb[0]) + oma * d[0];
+                    d[1] = (sa * g->rgb[1]) + oma * d[1];
+                    d[2] = (sa * g->rgb[2]) + oma * d[2];
+                    d[3] = sa + oma * d[3];
+                }
+            }
+        }
+    }
+    g_fragments = frags;
+}
+
+void orc_composite_f64(uint32_t v, const orc_splat2d* s, int W, int H, double* rgba, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > H) nthreads = H;
+#pragma omp parallel for schedule(static, 1) num_threads(nthreads)
+    for (int band = 0; band < nthreads; ++band) {
+        const int y0 = (int)(((int64_t)H * band) / nthreads);
+        const int y1 = (int)(((int64_t)H * (band + 1)) / nthreads);
+        for (int y = y0; y < y1; ++y)
+            for (int x = 0; x < W; ++x) {
+                double* d = rgba + ((size_t)y * W + x) * 4;
+                d[0] = 0.0; d[1] = 0.0; d[2] = 0.0; d[3] = 1.0;
+            }
+        for (uint32_t k = 0; k < v; ++k) {
+            const orc_splat2d* g = &s[k];
+            if (g->reject) continue;
+            int xa, xb, ya, yb;
+            pixel_range(g->px, g->hx, W, 0, W, &xa, &xb);
+            pixel_range(g->py, g->hy, H, y0, y1, &ya, &yb);
+            for (int y = ya; y <= yb; ++y)
+                for (int x = xa; x <= xb; ++x) {
+                    double dx = ((double)x + 0.5) - (double)g->px;
+                    double dy = ((double)y + 0.5) - (double)g->py;
+                    double mx = (double)g->inv[0] * dx + (double)g->inv[2] * dy;
+                    double my = (double)g->inv[1] * dx + (double)g->inv[3] * dy;
+                    double q = dx * mx + dy * my;
+                    double sa = (double)g->alpha * exp(-0.5 * q);
+                    if (sa <= 1.0 / 256.0) continue;
+                    double* d = rgba + ((size_t)y * W + x) * 4;
+                    double oma = 1.0 - sa;
+                    d[0] = sa * (double)g->rgb[0] + oma * d[0];
+                    d[1] = sa * (double)g->rgb[1] + oma * d[1];
+                    d[2] = sa * (double)g->rgb[2] + oma * d[2];
+                    d[3] = sa + oma * d[3];
+                }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------- */
+/* whole frame                                                                           */
+/* ------------------------------------------------------------------------------------- */
+
+uint32_t orc_render_frame(size_t n, const float* aos, size_t stride, int full_sh, int srgb,
+                          const float sortCameraMat[16], const float sortProjMat[16],
+                          const float renderCameraMat[16], const float renderProjMat[16],
+                          const float viewport[4], const float nearFar[2],
+                          float* rgba, uint32_t* sorted_idx_out, uint32_t* sorted_keys_out,
+                          orc_splat2d* splats_out, int nthreads)
+{
+    /* Sort(): splatrenderer.cpp:161,175 */
+    float modelView[16], mvp[16];
+    orc_mat4_inverse(sortCameraMat, modelView);
+    orc_mat4_mul(sortProjMat, modelView, mvp);
+    uint32_t* keys = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    uint32_t* idx = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    uint32_t v = orc_presort(n, aos, stride, mvp, nearFar[1], keys, idx);
+    orc_sort(v, keys, idx);
+    if (sorted_idx_out) memcpy(sorted_idx_out, idx, (size_t)v * sizeof(uint32_t));
+    if (sorted_keys_out) memcpy(sorted_keys_out, keys, (size_t)v * sizeof(uint32_t));
+
+    /* Render(): splatrenderer.cpp:327-335 */
+    if (rgba || splats_out) {
+        float viewMat[16];
+        orc_mat4_inverse(renderCameraMat, viewMat);
+        float eye[3] = {M(renderCameraMat, 3, 0), M(renderCameraMat, 3, 1), M(renderCameraMat, 3, 2)};
+        orc_splat2d* sp = splats_out ? splats_out
+                                     : (orc_splat2d*)malloc((v ? v : 1) * sizeof(orc_splat2d));
+#ifdef _OPENMP
+        int saved = omp_get_max_threads();
+        omp_set_num_threads(nthreads > 0 ? nthreads : 1);
+#endif
+        orc_project(v, idx, aos, stride, full_sh, srgb, viewMat, renderProjMat, viewport, nearFar,
+                    eye, sp);
+#ifdef _OPENMP
+        omp_set_num_threads(saved);
+#endif
+        if (rgba) {
+            int W = (int)viewport[2], H = (int)viewport[3];
+            orc_composite(v, sp, W, H, rgba, 0, H, nthreads);
+        }
+        if (!splats_out) free(sp);
+    }
+    free(keys);
+    free(idx);
+    return v;
+}

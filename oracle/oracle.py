@@ -1,0 +1,239 @@
+"""ctypes face of the C oracle (oracle/msplat_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by the product package.  PARITY UNPINNED (see msplat_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class Splat2D(C.Structure):
+    _fields_ = [
+        ("px", C.c_float), ("py", C.c_float),
+        ("cov", C.c_float * 4), ("inv", C.c_float * 4),
+        ("rgb", C.c_float * 3), ("alpha", C.c_float),
+        ("ndc", C.c_float * 3), ("depth", C.c_float),
+        ("hx", C.c_float), ("hy", C.c_float),
+        ("reject", C.c_int32), ("index", C.c_uint32),
+    ]
+
+
+SPLAT2D_DTYPE = np.dtype([
+    ("px", "<f4"), ("py", "<f4"), ("cov", "<f4", (4,)), ("inv", "<f4", (4,)),
+    ("rgb", "<f4", (3,)), ("alpha", "<f4"), ("ndc", "<f4", (3,)), ("depth", "<f4"),
+    ("hx", "<f4"), ("hy", "<f4"), ("reject", "<i4"), ("index", "<u4"),
+])
+assert SPLAT2D_DTYPE.itemsize == C.sizeof(Splat2D)
+
+
+def build():
+    """Compile liboracle.so (and oracle/_ref when the reference checkout exists)."""
+    subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(_HERE, "liboracle.so")
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    fp = C.POINTER(C.c_float)
+    u32p = C.POINTER(C.c_uint32)
+    L.orc_mat4_mul.argtypes = [fp, fp, fp]
+    L.orc_mat4_inverse.argtypes = [fp, fp]
+    L.orc_perspective.argtypes = [C.c_float] * 4 + [fp]
+    L.orc_create_projection.argtypes = [C.c_float] * 6 + [fp]
+    L.orc_build_cloud.argtypes = [C.c_size_t, fp, fp, fp, fp, fp, fp, C.c_int, fp]
+    L.orc_presort.argtypes = [C.c_size_t, fp, C.c_size_t, fp, C.c_float, u32p, u32p]
+    L.orc_presort.restype = C.c_uint32
+    L.orc_cull_key.argtypes = [fp, fp, C.c_float, u32p]
+    L.orc_cull_key.restype = C.c_int
+    L.orc_sort.argtypes = [C.c_uint32, u32p, u32p]
+    L.orc_project.argtypes = [C.c_uint32, u32p, fp, C.c_size_t, C.c_int, C.c_int, fp, fp, fp, fp, fp,
+                              C.c_void_p]
+    L.orc_composite.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int]
+    L.orc_composite_f64.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
+    L.orc_render_frame.argtypes = [C.c_size_t, fp, C.c_size_t, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp,
+                                   fp, u32p, u32p, C.c_void_p, C.c_int]
+    L.orc_render_frame.restype = C.c_uint32
+    L.orc_last_fragment_count.restype = C.c_uint64
+    _LIB = L
+    return L
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def mat4_mul(a, b):
+    a, pa = _f(a); b, pb = _f(b)
+    out = np.empty(16, np.float32)
+    lib().orc_mat4_mul(pa, pb, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def mat4_inverse(m):
+    m, pm = _f(m)
+    out = np.empty(16, np.float32)
+    lib().orc_mat4_inverse(pm, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def perspective(fovy, aspect, zn, zf):
+    out = np.empty(16, np.float32)
+    lib().orc_perspective(fovy, aspect, zn, zf, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def create_projection(tanL, tanR, tanU, tanD, zn, zf):
+    out = np.empty(16, np.float32)
+    lib().orc_create_projection(tanL, tanR, tanU, tanD, zn, zf, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def build_cloud(xyz, f_dc, f_rest, opacity, log_scale, rot, full_sh):
+    n = xyz.shape[0]
+    stride = 61 if full_sh else 25
+    xyz, p0 = _f(xyz); f_dc, p1 = _f(f_dc)
+    if f_rest is None:
+        f_rest = np.zeros((n, 45), np.float32)
+    f_rest, p2 = _f(f_rest); opacity, p3 = _f(opacity); log_scale, p4 = _f(log_scale); rot, p5 = _f(rot)
+    out = np.empty((n, stride), np.float32)
+    lib().orc_build_cloud(n, p0, p1, p2, p3, p4, p5, int(bool(full_sh)),
+                          out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def presort(aos, mvp, zfar):
+    aos, pa = _f(aos)
+    mvp, pm = _f(mvp)
+    n, stride = aos.shape
+    keys = np.empty(max(n, 1), np.uint32)
+    idx = np.empty(max(n, 1), np.uint32)
+    v = lib().orc_presort(n, pa, stride, pm, zfar, _u(keys), _u(idx))
+    return keys[:v].copy(), idx[:v].copy()
+
+
+def sort(keys, idx):
+    keys = np.ascontiguousarray(keys, np.uint32).copy()
+    idx = np.ascontiguousarray(idx, np.uint32).copy()
+    lib().orc_sort(keys.shape[0], _u(keys), _u(idx))
+    return keys, idx
+
+
+def project(idx, aos, full_sh, srgb, viewMat, projMat, viewport, nearFar, eye):
+    aos, pa = _f(aos)
+    idx = np.ascontiguousarray(idx, np.uint32)
+    v = idx.shape[0]
+    out = np.zeros(max(v, 1), SPLAT2D_DTYPE)
+    vm, pv = _f(viewMat); pm_, pp = _f(projMat); vp, pvp = _f(viewport); nf, pnf = _f(nearFar); e, pe = _f(eye)
+    lib().orc_project(v, _u(idx), pa, aos.shape[1], int(bool(full_sh)), int(bool(srgb)), pv, pp, pvp, pnf, pe,
+                      out.ctypes.data)
+    return out[:v]
+
+
+def composite(splats, W, H, nthreads=1, row0=0, row1=None):
+    splats = np.ascontiguousarray(splats)
+    assert splats.dtype == SPLAT2D_DTYPE
+    rgba = np.zeros((H, W, 4), np.float32)
+    lib().orc_composite(splats.shape[0], splats.ctypes.data, W, H,
+                        rgba.ctypes.data_as(C.POINTER(C.c_float)), row0, H if row1 is None else row1, nthreads)
+    return rgba
+
+
+def composite_f64(splats, W, H, nthreads=1):
+    splats = np.ascontiguousarray(splats)
+    rgba = np.zeros((H, W, 4), np.float64)
+    lib().orc_composite_f64(splats.shape[0], splats.ctypes.data, W, H,
+                            rgba.ctypes.data_as(C.POINTER(C.c_double)), nthreads)
+    return rgba
+
+
+def render_frame(aos, full_sh, sort_cam, sort_proj, viewport, nearFar, render_cam=None, render_proj=None,
+                 srgb=False, nthreads=1, want_image=True, want_splats=False):
+    """Whole Sort()+Render().  Returns dict(V, image, sorted_idx, sorted_keys, splats)."""
+    aos, pa = _f(aos)
+    n, stride = aos.shape
+    if render_cam is None:
+        render_cam = sort_cam
+    if render_proj is None:
+        render_proj = sort_proj
+    sc, p_sc = _f(sort_cam); sp, p_sp = _f(sort_proj); rc, p_rc = _f(render_cam); rp, p_rp = _f(render_proj)
+    vp, p_vp = _f(viewport); nf, p_nf = _f(nearFar)
+    W, H = int(viewport[2]), int(viewport[3])
+    img = np.zeros((H, W, 4), np.float32) if want_image else None
+    sidx = np.empty(max(n, 1), np.uint32)
+    skeys = np.empty(max(n, 1), np.uint32)
+    splats = np.zeros(max(n, 1), SPLAT2D_DTYPE) if want_splats else None
+    v = lib().orc_render_frame(n, pa, stride, int(bool(full_sh)), int(bool(srgb)), p_sc, p_sp, p_rc, p_rp,
+                               p_vp, p_nf,
+                               img.ctypes.data_as(C.POINTER(C.c_float)) if want_image else None,
+                               _u(sidx), _u(skeys),
+                               splats.ctypes.data if want_splats else None, nthreads)
+    return dict(V=v, image=img, sorted_idx=sidx[:v].copy(), sorted_keys=skeys[:v].copy(),
+                splats=splats[:v] if want_splats else None,
+                fragments=int(lib().orc_last_fragment_count()) if want_image else 0)
+
+
+# ---- reference PLY parser (oracle/_ref, built from /root/reference sources) ------------------
+_REF = None
+
+
+def ref_ply_lib():
+    """Returns the ctypes handle of oracle/_ref/libref_ply.so or None if it was never built."""
+    global _REF
+    if _REF is not None:
+        return _REF
+    path = os.path.join(_HERE, "_ref", "libref_ply.so")
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    L.ref_ply_open.argtypes = [C.c_char_p]
+    L.ref_ply_open.restype = C.c_void_p
+    L.ref_ply_close.argtypes = [C.c_void_p]
+    L.ref_ply_vertex_count.argtypes = [C.c_void_p]
+    L.ref_ply_vertex_count.restype = C.c_ulonglong
+    L.ref_ply_vertex_size.argtypes = [C.c_void_p]
+    L.ref_ply_vertex_size.restype = C.c_ulonglong
+    L.ref_ply_get_property.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int),
+                                       C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    L.ref_ply_get_property.restype = C.c_int
+    L.ref_ply_copy_vertices.argtypes = [C.c_void_p, C.c_void_p]
+    _REF = L
+    return L
+
+
+def ref_ply_read(path, names):
+    """Parse `path` with the REAL reference parser.  Returns (count, vertex_size, props, raw bytes)."""
+    L = ref_ply_lib()
+    assert L is not None
+    h = L.ref_ply_open(path.encode())
+    if not h:
+        return None
+    try:
+        cnt = L.ref_ply_vertex_count(h)
+        vs = L.ref_ply_vertex_size(h)
+        props = {}
+        for nm in names:
+            t = C.c_int(); s = C.c_ulonglong(); o = C.c_ulonglong()
+            if L.ref_ply_get_property(h, nm.encode(), C.byref(t), C.byref(s), C.byref(o)):
+                props[nm] = (t.value, s.value, o.value)
+        raw = np.empty(cnt * vs, np.uint8)
+        if cnt:
+            L.ref_ply_copy_vertices(h, raw.ctypes.data)
+        return cnt, vs, props, raw
+    finally:
+        L.ref_ply_close(h)

@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""bench.py -- frames/s (+ Gsplats/s) of the splat Sort+Render hot path on N MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one frame = SplatRenderer::Sort + SplatRenderer::Render of the resident cloud from a
+camera on a 64-step orbit (stereo workloads: one Sort + two Renders).  With N > 1 the frame's tile
+rows are sharded across the ranks (interleaved, row % N == rank) and gathered to rank 0 over RCCL:
+total work is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
+
+PyTorch is plumbing only (device selection, the framebuffer tensor, torch.distributed); all compute
+is libmsplat.so's HIP kernels launched on torch's current stream.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "cfg2": dict(n=1_000_000, seed=0x5EED1234, pos_sigma=1.5, W=1920, H=1080, cam_z=7.0, fb="fp32", views=1,
+                 desc="1M synthetic Gaussians, SH3, 1920x1080 fp32, 64-step orbit (BASELINE configs[1])"),
+    # configs[2] fallback (no Inria scene on the box)
+    "cfg3": dict(n=6_000_000, seed=0x5EED6000, pos_sigma=3.0, W=1920, H=1080, cam_z=12.0, fb="fp32", views=1,
+                 desc="6M synthetic Gaussians, SH3, 1920x1080 fp32 (BASELINE configs[2] fallback)"),
+    "cfg4": dict(n=6_000_000, seed=0x5EED6000, pos_sigma=3.0, W=4096, H=4096, cam_z=12.0, fb="fp32", views=1,
+                 desc="6M synthetic Gaussians, SH3, 4096x4096 fp32 (BASELINE configs[3])"),
+    "cfg5": dict(n=1_000_000, seed=0x5EED1234, pos_sigma=1.5, W=2016, H=2240, cam_z=7.0, fb="fp16", views=2,
+                 desc="1M synthetic Gaussians, stereo 2x2016x2240 fp16, one sort (BASELINE configs[4])"),
+    "tiny": dict(n=20_000, seed=7, pos_sigma=1.5, W=640, H=360, cam_z=7.0, fb="fp32", views=1,
+                 desc="20k synthetic Gaussians, 640x360 (debug)"),
+}
+HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="CPU baseline frames (0 = auto, about 10-30 s)")
+    ap.add_argument("--profile-frames", type=int, default=20, help="extra frames timed per stage with hipEvents")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    from splatapult_amd import SplatRenderer, camera, synthetic
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    if rank == 0:
+        graft.build()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()
+
+    wl = WORKLOADS[args.workload]
+    n, W, H, views = wl["n"], wl["W"], wl["H"], wl["views"]
+    t0 = time.time()
+    cloud = synthetic.make_cloud(n, seed=wl["seed"], full_sh=True, pos_sigma=wl["pos_sigma"])
+    t_gen = time.time() - t0
+
+    # a dedicated (non-null) torch stream: libmsplat launches on it, so torch copies, RCCL's stream
+    # hand-off and torch.cuda.synchronize all order correctly with the HIP kernels
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    r = SplatRenderer(device=local_rank, fb_format=wl["fb"], stream=stream.cuda_stream, enable_timing=True)
+    if not r.Init(cloud, False, False):
+        raise SystemExit("Init failed: " + r.last_error())
+    if world > 1:
+        r.set_band(world, rank)
+
+    tiles_y = (H + 15) // 16
+    Hpad = tiles_y * 16
+    fdt = torch.float16 if wl["fb"] == "fp16" else torch.float32
+    bpp = 8 if wl["fb"] == "fp16" else 16
+    fbs = [torch.zeros((Hpad, W, 4), dtype=fdt, device=dev) for _ in range(views)]
+    vp, nf = [0, 0, W, H], [camera.Z_NEAR, camera.Z_FAR]
+    if views == 1:
+        projs = [camera.perspective(camera.FOVY, W / H)]
+    else:   # BASELINE config 5: asymmetric XR frusta (util.cpp:420-480)
+        projs = [camera.create_projection(-1.0, 0.8, 0.95, -0.95), camera.create_projection(-0.8, 1.0, 0.95, -0.95)]
+
+    def cams_for(step):
+        c = camera.orbit(wl["cam_z"], 2.0 * math.pi * (step % 64) / 64.0)
+        if views == 1:
+            return [c]
+        return [camera.translate_local(c, dx=-0.032), camera.translate_local(c, dx=+0.032)]
+
+    # gather plumbing: rank g owns tile rows g, g+G, ... ; bands are padded to the same row count
+    if world > 1:
+        max_rows = (tiles_y + world - 1) // world
+        send = [torch.zeros((max_rows, 16, W, 4), dtype=fdt, device=dev) for _ in range(views)]
+        recv = [[torch.zeros((max_rows, 16, W, 4), dtype=fdt, device=dev) for _ in range(world)]
+                for _ in range(views)] if rank == 0 else None
+        final = [torch.zeros((tiles_y, 16, W, 4), dtype=fdt, device=dev) for _ in range(views)] if rank == 0 else None
+
+    def frame(step):
+        cams = cams_for(step)
+        r.Sort(cams[0], projs[0], vp, nf)                      # sort once with view 0 (app.cpp:603-606)
+        for v in range(views):
+            r.Render(cams[v], projs[v], vp, nf, out_ptr=fbs[v].data_ptr(), pitch_bytes=W * bpp)
+            if world > 1:
+                mine = fbs[v].view(tiles_y, 16, W, 4)[rank::world]
+                send[v][:mine.shape[0]].copy_(mine)
+                dist.gather(send[v], recv[v] if rank == 0 else None, dst=0)
+                if rank == 0:
+                    for g in range(world):
+                        rows = final[v][g::world]
+                        rows.copy_(recv[v][g][:rows.shape[0]])
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for s in range(args.warmup):
+        frame(s)
+    sync_all()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        frame(args.warmup + s)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-stage hipEvent timing + V/D, on extra frames outside the timed region (each read synchronises)
+    prof = dict(sort_total=0.0, render_total=0.0, project=0.0, binning=0.0, composite=0.0)
+    Vs, Ds, drawn = [], [], []
+    pf = max(1, args.profile_frames)
+    for s in range(pf):
+        frame(args.warmup + args.steps + s)
+        tm = r.timings()
+        st = r.stats()
+        for k in prof:
+            prof[k] += tm[k] / pf
+        Vs.append(st["sort_count"]); Ds.append(st["pairs"]); drawn.append(st["drawn"])
+    st = r.stats()
+    V, D = float(np.mean(Vs)), float(np.mean(Ds))
+    if world > 1:
+        t = torch.tensor([V, D, prof["composite"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        D_total = float(t[1].item())
+    else:
+        D_total = D
+
+    fps = args.steps / elapsed
+    ms = 1e3 * elapsed / args.steps
+    # algorithmic bytes (SURVEY.md 8d / BASELINE.md):  B = 16 N + (8+68+S+48) V + views (52 D + W H bpp)
+    S = 244
+    B_frame = 16.0 * n + (8 + 68 + S + 48) * V + (52.0 * D_total + W * H * bpp) * views
+    # dominant kernel: composite.  per launch: 52 B per (splat,tile) pair + the framebuffer write
+    B_comp = 52.0 * D + (W * H * bpp) / world
+    comp_s = prof["composite"] * 1e-3              # the event pair brackets one launch (the last view's)
+    achieved = B_comp / comp_s if comp_s > 0 else 0.0
+
+    out = {
+        "metric": "frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "gsplats_per_sec": n * fps / 1e9,
+        "config": {"workload": wl["desc"], "key": args.workload, "splats": n, "width": W, "height": H,
+                   "views": views, "framebuffer": wl["fb"], "sharding": "tile rows, row %% %d == rank" % world,
+                   "visible_V": V, "pairs_D": D_total, "drawn": float(np.mean(drawn))},
+        "stages_ms": prof,
+        "frame_algorithmic_GB": B_frame / 1e9,
+        "frame_hbm_frac": (B_frame / (elapsed / args.steps)) / HBM_PEAK / world,
+        "roofline": {"kernel": "composite_kernel", "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                     "avg_launch_ms": prof["composite"],
+                     "note": "composite is VALU/LDS bound (exp + blend per pixel-splat); HBM fraction is honest-but-low"},
+    }
+
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cloud, wl, cams_for, projs, vp, nf, args.cpu_frames)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cloud, wl, cams_for, projs, vp, nf, frames):
+    """The oracle (C restatement of the reference shaders; the reference has no CPU path of its own)
+    timed on the host cores on a bounded sample: `frames` whole frames of the same workload."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    aos = cloud.as_array()
+    views = wl["views"]
+
+    def one(step):
+        cams = cams_for(step)
+        t = time.perf_counter()
+        for v in range(views):
+            orc.render_frame(aos, True, cams[0], projs[0], vp, nf, render_cam=cams[v], render_proj=projs[v],
+                             nthreads=cores)
+        return time.perf_counter() - t
+
+    t_first = one(0)
+    if frames <= 0:
+        frames = int(max(1, min(8, 15.0 // max(t_first, 1e-3))))
+    times = [t_first] + [one(s) for s in range(1, frames)]
+    sec = float(np.median(times))
+    return {"value": 1.0 / sec, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d frame(s) of the same workload (orbit steps 0..%d), median, all %d host threads, "
+                      "oracle/msplat_oracle.c via OpenMP row bands" % (len(times), len(times) - 1, cores),
+            "sec_per_frame": sec, "gsplats_per_sec": wl["n"] / sec / 1e9}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,191 @@
+/*
+ * msplat.h -- C ABI of libmsplat.so, the MI355X-native (gfx950 / CDNA4, HIP) replacement for
+ * the reference's SplatRenderer::Sort()/Render() hot path.
+ *
+ * The reference has no plugin/FFI layer: the seam is the C++ class SplatRenderer
+ * (/root/reference/src/splatrenderer.h:23-67) fed by GaussianCloud (src/gaussiancloud.h:17-91).
+ * Every entry point below names the reference interface it replaces.  The C++ shim
+ * splatapult_amd/host/msplat_host.hpp re-creates the reference's class surface on top of this
+ * ABI; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions (identical to the reference): matrices are float[16], column-major like glm;
+ * cameraMat = camera-to-world; viewport = (x, y, W, H); nearFar = (near, far).
+ * All functions return 0 (MSPLAT_OK) on success, a negative MSPLAT_ERR_* otherwise, and never
+ * throw.  A context is not thread-safe: calls on one context are serialised by the caller
+ * (same as the reference's single GL thread).  No torch / framework types cross this boundary.
+ */
+#ifndef MSPLAT_H
+#define MSPLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSPLAT_VERSION 1
+
+enum {
+    MSPLAT_OK = 0,
+    MSPLAT_ERR_INVALID_ARG = -1,
+    MSPLAT_ERR_NO_DEVICE = -2,     /* no HIP device / HIP runtime failure at create         */
+    MSPLAT_ERR_HIP = -3,           /* a HIP call failed; see msplat_last_error               */
+    MSPLAT_ERR_NO_CLOUD = -4,      /* sort/render before upload                              */
+    MSPLAT_ERR_NO_SORT = -5,       /* render before sort                                     */
+    MSPLAT_ERR_UNSUPPORTED = -6,   /* e.g. viewport larger than 4096x4096                    */
+    MSPLAT_ERR_PAIR_OVERFLOW = -7, /* (splat,tile) pair buffer too small and could not grow  */
+    MSPLAT_ERR_IO = -8             /* PLY open/parse failure                                 */
+};
+
+enum { MSPLAT_FB_RGBA32F = 0, MSPLAT_FB_RGBA16F = 1 };
+
+typedef struct msplat_ctx msplat_ctx;
+typedef struct msplat_cloud msplat_cloud;
+
+/* Construction parameters.  Replaces the implicit GL state the reference's renderer lives in:
+ * device = the GL context's GPU (sdl_main.cpp:98-100); fb_format = App's --fp16/--fp32 FBO
+ * choice (app.cpp:1000-1035); srgb = SplatRenderer::Init's isFramebufferSRGBEnabled
+ * (splatrenderer.cpp:60-72). */
+typedef struct msplat_config {
+    uint32_t struct_size;      /* sizeof(msplat_config), for ABI evolution                   */
+    int32_t device;            /* HIP device ordinal                                         */
+    int32_t fb_format;         /* MSPLAT_FB_*                                                */
+    int32_t srgb;              /* FRAMEBUFFER_SRGB path of splat_vert.glsl:129-151,209-218   */
+    float t_epsilon;           /* front-to-back early-out: stop a pixel when its             */
+                               /* transmittance < t_epsilon. 0 = never (exact).              */
+                               /* negative = library default (2^-14)                         */
+    uint64_t pair_capacity;    /* max (splat,tile) pairs per render; 0 = auto (grows)        */
+    void* stream;              /* hipStream_t to launch on; NULL = library-owned stream      */
+    int32_t enable_timing;     /* record hipEvents per stage (msplat_get_timings)            */
+    int32_t reserved;
+} msplat_config;
+
+/* Byte offsets of the attributes inside one AoS record, i.e. the BinaryAttribute offsets that
+ * SplatRenderer::BuildVertexArrayObject binds (splatrenderer.cpp:345-391;
+ * gaussiancloud.cpp:633-657).  r_sh1..b_sh3 are ignored unless full_sh. */
+typedef struct msplat_attr_offsets {
+    uint32_t pos_with_alpha;
+    uint32_t r_sh0, g_sh0, b_sh0;
+    uint32_t cov3_col0, cov3_col1, cov3_col2;
+    uint32_t r_sh1, r_sh2, r_sh3;
+    uint32_t g_sh1, g_sh2, g_sh3;
+    uint32_t b_sh1, b_sh2, b_sh3;
+} msplat_attr_offsets;
+
+typedef struct msplat_stats {
+    uint64_t num_splats;       /* N                                                          */
+    uint32_t sort_count;       /* V: splats that survived the presort cull (sortCount)       */
+    uint32_t drawn;            /* splats that passed the geometry-stage guard band           */
+    uint64_t pairs;            /* D: (splat, tile) pairs of the last render                  */
+    uint32_t tiles_x, tiles_y;
+    uint32_t width, height;
+    uint64_t pair_capacity;
+    uint64_t device_bytes;     /* device memory held by the context                          */
+} msplat_stats;
+
+typedef struct msplat_timings {
+    /* milliseconds, last frame, valid when enable_timing; names follow the reference's Tracy
+     * zones (splatrenderer.cpp:156,172,208,297,318) */
+    float sort_total;          /* "SplatRenderer::Sort"  (pre-sort + sort)                   */
+    float render_total;        /* "SplatRenderer::Render"                                    */
+    float project;             /* vertex+geometry stage equivalent                           */
+    float binning;             /* tile lists (count, scan, two stable partition passes)      */
+    float composite;           /* fragment+blend equivalent (the dominant kernel)            */
+    float reserved[3];
+} msplat_timings;
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* replaces SplatRenderer::SplatRenderer / ~SplatRenderer (splatrenderer.cpp:41-48) */
+int msplat_create(msplat_ctx** out, const msplat_config* cfg);
+void msplat_destroy(msplat_ctx* ctx);
+const char* msplat_last_error(const msplat_ctx* ctx);   /* ctx may be NULL: global last error */
+const char* msplat_version_string(void);
+
+/* replaces SplatRenderer::Init + BuildVertexArrayObject (splatrenderer.cpp:50-151,345-391):
+ * copies the interleaved cloud to the device (the caller may free it afterwards, as the
+ * reference does not retain the shared_ptr). `aos` is host memory, n records of stride_bytes. */
+int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t stride_bytes,
+                        const msplat_attr_offsets* off, int full_sh);
+
+/* Multi-GPU tile-row sharding (no reference counterpart).  Restricts this
+ * context to tile rows t with t % row_mod == row_rem (16-pixel rows, row 0 = GL bottom).
+ * row_mod = 1 (default) = whole image.  The framebuffer handed to msplat_render is always the
+ * full W x H image; only rows owned by the band are written. */
+int msplat_set_band(msplat_ctx* ctx, int32_t row_mod, int32_t row_rem);
+
+/* replaces SplatRenderer::Sort (splatrenderer.cpp:153-312): cull + depth key
+ * (presort_compute.glsl:31-57), stable ascending 32-bit radix sort, sorted index list kept as
+ * context state for subsequent renders.  Asynchronous: no host readback (the reference's
+ * 4-byte glMapBufferRange stall, splatrenderer.cpp:195-204, is not reproduced). */
+int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[16],
+                const float viewport[4], const float nearFar[2]);
+
+/* replaces SplatRenderer::Render (splatrenderer.cpp:315-343) *plus* the GL pipeline behind
+ * its glDrawElements: vertex (splat_vert.glsl), geometry (splat_geom.glsl), fragment
+ * (splat_frag.glsl) and the blend/clear state of app.cpp:144-164.  Writes W x H RGBA
+ * (float or half per cfg.fb_format), row 0 = GL bottom row, alpha = 1, into `rgba`.
+ * out_is_device != 0: `rgba` is a device pointer, the call is asynchronous on the stream.
+ * out_is_device == 0: `rgba` is host memory, the call returns after the copy completed.
+ * pitch_bytes = bytes between rows (0 = tightly packed). */
+int msplat_render(msplat_ctx* ctx, const float cameraMat[16], const float projMat[16],
+                  const float viewport[4], const float nearFar[2],
+                  void* rgba, uint64_t pitch_bytes, int out_is_device);
+
+/* blocks until everything queued on the context's stream has finished */
+int msplat_synchronize(msplat_ctx* ctx);
+
+/* sortCount of the last Sort (splatrenderer.cpp:198-199); synchronises */
+int msplat_sort_count(msplat_ctx* ctx, uint32_t* v);
+/* the element buffer the reference fills at splatrenderer.cpp:296-311 (draw order:
+ * ascending key = far to near; equal keys in ascending splat index); synchronises */
+int msplat_get_sorted_indices(msplat_ctx* ctx, uint32_t* dst, uint32_t cap);
+int msplat_get_sorted_keys(msplat_ctx* ctx, uint32_t* dst, uint32_t cap);
+
+int msplat_get_stats(msplat_ctx* ctx, msplat_stats* out);      /* synchronises */
+int msplat_get_timings(msplat_ctx* ctx, msplat_timings* out);  /* synchronises */
+
+/* ---- parity-test taps (intermediate results of the last render; synchronise) ------------ */
+/* per drawn-order splat r < V: 12 floats {px, py, A, B, C, log2(alpha), r, g, b, alpha, 0, 0}
+ * where w(dx,dy) = exp2(A dx^2 + B dx dy + C dy^2 + log2 alpha); rect = packed tile rectangle
+ * tx0 | ty0<<8 | tx1<<16 | ty1<<24 (0x0000FFFFu-style empty when tx0 > tx1) */
+int msplat_debug_get_projected(msplat_ctx* ctx, float* rec12, uint32_t* rect, uint32_t cap);
+/* tile_start has tiles_x*tiles_y+1 entries; pairs[k] & 0xFFFFFF = draw-order rank */
+int msplat_debug_get_tile_lists(msplat_ctx* ctx, uint32_t* tile_start, uint32_t tile_cap,
+                                uint32_t* pairs, uint64_t pair_cap);
+
+/* ---- scene data: GaussianCloud / Ply surface (gaussiancloud.h:17-91, ply.h:19-46) -------- */
+/* replaces GaussianCloud::GaussianCloud(Options{importFullSH}) */
+msplat_cloud* msplat_cloud_create(int import_full_sh);
+void msplat_cloud_destroy(msplat_cloud* c);
+/* replaces GaussianCloud::ImportPly (gaussiancloud.cpp:138-365) */
+int msplat_cloud_import_ply(msplat_cloud* c, const char* path);
+/* same per-vertex math as ImportPly's lambda (gaussiancloud.cpp:254-361) applied to raw
+ * attribute arrays instead of a file (synthetic scenes); f_rest may be NULL */
+int msplat_cloud_from_attributes(msplat_cloud* c, uint64_t n, const float* xyz, const float* f_dc,
+                                 const float* f_rest, const float* opacity, const float* log_scale,
+                                 const float* rot);
+/* GaussianCloud::ExportPly / InitDebugCloud / PruneSplats (gaussiancloud.cpp:367-626) */
+int msplat_cloud_export_ply(msplat_cloud* c, const char* path);
+int msplat_cloud_init_debug(msplat_cloud* c);
+int msplat_cloud_prune(msplat_cloud* c, const float origin[3], uint32_t keep);
+uint64_t msplat_cloud_num_gaussians(const msplat_cloud* c);   /* GetNumGaussians */
+uint64_t msplat_cloud_stride(const msplat_cloud* c);          /* GetStride       */
+uint64_t msplat_cloud_total_size(const msplat_cloud* c);      /* GetTotalSize    */
+const void* msplat_cloud_raw_data(const msplat_cloud* c);     /* GetRawDataPtr   */
+int msplat_cloud_has_full_sh(const msplat_cloud* c);          /* HasFullSH       */
+int msplat_cloud_attr_offsets(const msplat_cloud* c, msplat_attr_offsets* out); /* Get*Attrib */
+/* msplat_upload_cloud(ctx, raw, n, stride, offsets, has_full_sh) in one call */
+int msplat_upload_gaussian_cloud(msplat_ctx* ctx, const msplat_cloud* c);
+
+/* ---- host matrix helpers used by the shims (glm closed forms; app.cpp:1042, util.cpp:420) - */
+void msplat_mat4_inverse(const float m[16], float out[16]);
+void msplat_mat4_mul(const float a[16], const float b[16], float out[16]);
+void msplat_perspective(float fovy, float aspect, float zn, float zf, float out[16]);
+void msplat_create_projection(float tanL, float tanR, float tanU, float tanD, float zn, float zf,
+                              float out[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSPLAT_H */

@@ -1,0 +1,108 @@
+"""ctypes binding of libmsplat.so (include/msplat.h).  No CPU fallback: if the library is
+missing or no HIP device is present the product path raises, loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmsplat.so")
+
+OK = 0
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NO_CLOUD, ERR_NO_SORT, ERR_UNSUPPORTED, ERR_PAIR_OVERFLOW, ERR_IO = \
+    -1, -2, -3, -4, -5, -6, -7, -8
+FB_RGBA32F, FB_RGBA16F = 0, 1
+
+
+class MsplatError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("msplat error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("fb_format", C.c_int32),
+                ("srgb", C.c_int32), ("t_epsilon", C.c_float), ("pair_capacity", C.c_uint64),
+                ("stream", C.c_void_p), ("enable_timing", C.c_int32), ("reserved", C.c_int32)]
+
+
+class AttrOffsets(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in
+                ("pos_with_alpha", "r_sh0", "g_sh0", "b_sh0", "cov3_col0", "cov3_col1", "cov3_col2",
+                 "r_sh1", "r_sh2", "r_sh3", "g_sh1", "g_sh2", "g_sh3", "b_sh1", "b_sh2", "b_sh3")]
+
+
+class Stats(C.Structure):
+    _fields_ = [("num_splats", C.c_uint64), ("sort_count", C.c_uint32), ("drawn", C.c_uint32),
+                ("pairs", C.c_uint64), ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("pair_capacity", C.c_uint64),
+                ("device_bytes", C.c_uint64)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("sort_total", C.c_float), ("render_total", C.c_float), ("project", C.c_float),
+                ("binning", C.c_float), ("composite", C.c_float), ("reserved", C.c_float * 3)]
+
+
+# every symbol include/msplat.h declares: (name, restype, argtypes)
+_F16 = C.POINTER(C.c_float)
+_U32P = C.POINTER(C.c_uint32)
+SYMBOLS = [
+    ("msplat_create", C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Config)]),
+    ("msplat_destroy", None, [C.c_void_p]),
+    ("msplat_last_error", C.c_char_p, [C.c_void_p]),
+    ("msplat_version_string", C.c_char_p, []),
+    ("msplat_upload_cloud", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(AttrOffsets), C.c_int]),
+    ("msplat_set_band", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    ("msplat_sort", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16]),
+    ("msplat_render", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16, C.c_void_p, C.c_uint64, C.c_int]),
+    ("msplat_synchronize", C.c_int, [C.c_void_p]),
+    ("msplat_sort_count", C.c_int, [C.c_void_p, _U32P]),
+    ("msplat_get_sorted_indices", C.c_int, [C.c_void_p, _U32P, C.c_uint32]),
+    ("msplat_get_sorted_keys", C.c_int, [C.c_void_p, _U32P, C.c_uint32]),
+    ("msplat_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    ("msplat_get_timings", C.c_int, [C.c_void_p, C.POINTER(Timings)]),
+    ("msplat_debug_get_projected", C.c_int, [C.c_void_p, _F16, _U32P, C.c_uint32]),
+    ("msplat_debug_get_tile_lists", C.c_int, [C.c_void_p, _U32P, C.c_uint32, _U32P, C.c_uint64]),
+    ("msplat_cloud_create", C.c_void_p, [C.c_int]),
+    ("msplat_cloud_destroy", None, [C.c_void_p]),
+    ("msplat_cloud_import_ply", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("msplat_cloud_export_ply", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("msplat_cloud_init_debug", C.c_int, [C.c_void_p]),
+    ("msplat_cloud_prune", C.c_int, [C.c_void_p, _F16, C.c_uint32]),
+    ("msplat_cloud_from_attributes", C.c_int, [C.c_void_p, C.c_uint64, _F16, _F16, _F16, _F16, _F16, _F16]),
+    ("msplat_cloud_num_gaussians", C.c_uint64, [C.c_void_p]),
+    ("msplat_cloud_stride", C.c_uint64, [C.c_void_p]),
+    ("msplat_cloud_total_size", C.c_uint64, [C.c_void_p]),
+    ("msplat_cloud_raw_data", C.c_void_p, [C.c_void_p]),
+    ("msplat_cloud_has_full_sh", C.c_int, [C.c_void_p]),
+    ("msplat_cloud_attr_offsets", C.c_int, [C.c_void_p, C.POINTER(AttrOffsets)]),
+    ("msplat_upload_gaussian_cloud", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("msplat_mat4_inverse", None, [_F16, _F16]),
+    ("msplat_mat4_mul", None, [_F16, _F16, _F16]),
+    ("msplat_perspective", None, [C.c_float, C.c_float, C.c_float, C.c_float, _F16]),
+    ("msplat_create_projection", None, [C.c_float] * 6 + [_F16]),
+]
+
+_LIB = None
+
+
+def lib():
+    """Load libmsplat.so.  Raises if it has not been built (python __graft_entry__.py build)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(ctx, rc):
+    if rc != OK:
+        msg = lib().msplat_last_error(ctx)
+        raise MsplatError(rc, msg.decode() if msg else "")

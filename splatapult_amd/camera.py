@@ -1,0 +1,66 @@
+"""Camera / projection helpers for headless drivers (bench, tests).  Matrices are float32[16],
+column-major like glm.  Constants from /root/reference/src/app.cpp:73-75."""
+import ctypes as C
+import json
+import math
+
+import numpy as np
+
+from . import _capi
+
+Z_NEAR = 0.1
+Z_FAR = 1000.0
+FOVY = math.radians(45.0)
+
+
+def _out16():
+    a = np.zeros(16, np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def perspective(fovy, aspect, zn=Z_NEAR, zf=Z_FAR):
+    """glm::perspective as called at app.cpp:1042"""
+    a, p = _out16()
+    _capi.lib().msplat_perspective(fovy, aspect, zn, zf, p)
+    return a
+
+
+def create_projection(tanL, tanR, tanU, tanD, zn=Z_NEAR, zf=Z_FAR):
+    """asymmetric XR frustum, util.cpp:420-480"""
+    a, p = _out16()
+    _capi.lib().msplat_create_projection(tanL, tanR, tanU, tanD, zn, zf, p)
+    return a
+
+
+def pose(position=(0.0, 0.0, 0.0), yaw=0.0, pitch=0.0):
+    """camera-to-world matrix: rotation yaw (about +Y) then pitch (about camera X), looks down -Z"""
+    cy, sy, cp, sp = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch)
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], np.float64)
+    rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]], np.float64)
+    m = np.eye(4)
+    m[:3, :3] = ry @ rx
+    m[:3, 3] = position
+    return m.T.astype(np.float32).reshape(16).copy()      # column-major
+
+
+def orbit(radius, angle, height=0.0):
+    """camera on a circle of `radius` around the origin in the XZ plane, looking at the origin"""
+    x, z = radius * math.sin(angle), radius * math.cos(angle)
+    pitch = -math.atan2(height, radius)
+    return pose((x, height, z), yaw=angle, pitch=pitch)
+
+
+def translate_local(cam, dx=0.0, dy=0.0, dz=0.0):
+    """move a camera-to-world matrix along its own axes (stereo eye offsets)"""
+    m = np.asarray(cam, np.float32).reshape(4, 4).copy()     # m[c] = column c
+    m[3, :3] = m[3, :3] + dx * m[0, :3] + dy * m[1, :3] + dz * m[2, :3]
+    return m.reshape(16)
+
+
+def camera_from_vr_json(path, raise_by=1.5):
+    """default desktop camera when only a *_vr.json exists: floorMat raised 1.5 along its Y
+    (app.cpp:486-497; vrconfig.cpp:31-35 reads the JSON row-major)"""
+    fm = np.array(json.load(open(path))["floorMat"], np.float32)       # rows
+    cam = fm.copy()
+    cam[:3, 3] = cam[:3, 3] + cam[:3, :3] @ np.array([0.0, raise_by, 0.0], np.float32)
+    return cam.T.reshape(16).copy()

@@ -1,0 +1,643 @@
+// msplat_device.hip -- context management + C-ABI entry points of libmsplat.so that touch the GPU.
+// Host-only scene code (Ply / GaussianCloud / matrices) lives in msplat_host.cpp.
+//
+// Drop-in boundary: include/msplat.h (replaces SplatRenderer::Init/Sort/Render,
+// /root/reference/src/splatrenderer.cpp:50-343).  There is NO CPU fallback: without a HIP device
+// msplat_create fails with MSPLAT_ERR_NO_DEVICE.
+#include "msplat_kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/msplat.h"
+
+using namespace msplat;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct msplat_ctx {
+    msplat_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // cloud
+    uint64_t N = 0;
+    bool full_sh = false;
+    bool has_cloud = false;
+    bool has_sort = false;
+    Buf pos4;       // float4[N]  (x, y, z, 1)            -- the reference's posVec (splatrenderer.cpp:106-111)
+    Buf recs;       // padded AoS: 16 (full SH) or 7 float4 per splat, reference float offsets preserved
+    // sort state
+    Buf keyA, keyB, valA, valB;   // uint32[N]; final sorted result in keyA/valA
+    Buf hist;       // uint32[256 * hist_stride]
+    uint32_t hist_stride = 0;
+    Buf totals;     // uint32[256]
+    Buf counters;   // uint32[8]: 0=V, 1=D, 2=overflow, 3=drawn
+    // render state
+    Buf rec2d;      // float4[3*N]
+    Buf rect;       // uint32[N]
+    Buf tile_count; // uint32[65536]
+    Buf tile_start; // uint32[65537]
+    Buf hist1;      // uint32[256 * hist1_stride]
+    uint32_t hist1_stride = 0;
+    Buf pairsA, pairsB;   // uint32[pair_cap]
+    uint64_t pair_cap = 0;
+    Buf hist2;      // uint32[256 * hist2_stride]
+    uint32_t hist2_stride = 0;
+    Buf fb;         // internal framebuffer for host-output renders
+    // band
+    int row_mod = 1, row_rem = 0;
+    // last frame
+    FrameParams last_fp{};
+    bool has_render = false;
+    // timing
+    hipEvent_t ev[8]{};
+    bool ev_ok = false;
+    bool ev_sort_valid = false, ev_render_valid = false;
+
+    uint64_t device_bytes = 0;
+};
+
+namespace {
+
+int fail(msplat_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail((c), MSPLAT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                      \
+    } while (0)
+
+int buf_alloc(msplat_ctx* c, Buf& b, size_t bytes)
+{
+    if (b.p && b.bytes >= bytes) return MSPLAT_OK;
+    if (b.p) {
+        (void)hipFree(b.p);
+        c->device_bytes -= b.bytes;
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    c->device_bytes += bytes;
+    return MSPLAT_OK;
+}
+
+void buf_free(msplat_ctx* c, Buf& b)
+{
+    if (b.p) {
+        (void)hipFree(b.p);
+        c->device_bytes -= b.bytes;
+    }
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+int grid_for(uint32_t nchunks)
+{
+    // grid-stride kernels: enough workgroups to fill 256 CUs x 8, never more than the chunk count
+    const uint32_t cap = 256u * 8u;
+    return (int)std::max(1u, std::min(nchunks, cap));
+}
+
+// host matrix helpers (implemented in msplat_host.cpp)
+}  // namespace
+
+extern "C" {
+
+const char* msplat_version_string(void) { return "msplat 0.1 (gfx950, HIP)"; }
+
+const char* msplat_last_error(const msplat_ctx* ctx)
+{
+    if (ctx) return ctx->err.c_str();
+    return g_last_error.c_str();
+}
+
+int msplat_create(msplat_ctx** out, const msplat_config* cfg)
+{
+    if (!out) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: out is NULL");
+    *out = nullptr;
+    msplat_config c{};
+    c.struct_size = sizeof(msplat_config);
+    c.t_epsilon = -1.0f;
+    if (cfg) {
+        if (cfg->struct_size != sizeof(msplat_config))
+            return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: config struct_size %u != %zu",
+                        cfg->struct_size, sizeof(msplat_config));
+        c = *cfg;
+    }
+    if (c.fb_format != MSPLAT_FB_RGBA32F && c.fb_format != MSPLAT_FB_RGBA16F)
+        return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: bad fb_format %d", c.fb_format);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, MSPLAT_ERR_NO_DEVICE, "msplat_create: no HIP device (%s); there is no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (c.device < 0 || c.device >= ndev)
+        return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: device %d out of range [0,%d)", c.device, ndev);
+    msplat_ctx* ctx = new msplat_ctx;
+    ctx->cfg = c;
+    ctx->device = c.device;
+    if (ctx->cfg.t_epsilon < 0.0f) ctx->cfg.t_epsilon = 1.0f / 16384.0f;
+    e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, MSPLAT_ERR_NO_DEVICE, "hipSetDevice(%d): %s", c.device, hipGetErrorString(e));
+    }
+    if (c.stream) {
+        ctx->stream = (hipStream_t)c.stream;
+    } else {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return fail(nullptr, MSPLAT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
+        ctx->own_stream = true;
+    }
+    if (c.enable_timing) {
+        bool ok = true;
+        for (auto& ev : ctx->ev) ok = ok && (hipEventCreate(&ev) == hipSuccess);
+        ctx->ev_ok = ok;
+    }
+    int rc = buf_alloc(ctx, ctx->totals, 256 * sizeof(uint32_t));
+    if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->counters, 8 * sizeof(uint32_t));
+    if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_count, 65536 * sizeof(uint32_t));
+    if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_start, 65537 * sizeof(uint32_t));
+    if (rc == MSPLAT_OK && hipMemsetAsync(ctx->counters.p, 0, 8 * sizeof(uint32_t), ctx->stream) != hipSuccess)
+        rc = MSPLAT_ERR_HIP;
+    if (rc != MSPLAT_OK) {
+        std::string msg = ctx->err;
+        msplat_destroy(ctx);
+        g_last_error = msg;
+        return rc;
+    }
+    *out = ctx;
+    return MSPLAT_OK;
+}
+
+void msplat_destroy(msplat_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    Buf* all[] = {&ctx->pos4, &ctx->recs, &ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist,
+                  &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->tile_count, &ctx->tile_start,
+                  &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb};
+    for (Buf* b : all) buf_free(ctx, *b);
+    if (ctx->ev_ok)
+        for (auto& ev : ctx->ev) (void)hipEventDestroy(ev);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int msplat_synchronize(msplat_ctx* ctx)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MSPLAT_OK;
+}
+
+static int ensure_pair_capacity(msplat_ctx* ctx, uint64_t cap)
+{
+    if (cap > 0x7FFFFFFFull) cap = 0x7FFFFFFFull;
+    if (ctx->pair_cap >= cap && ctx->pairsA.p) return MSPLAT_OK;
+    int rc = buf_alloc(ctx, ctx->pairsA, cap * sizeof(uint32_t));
+    if (rc) return rc;
+    rc = buf_alloc(ctx, ctx->pairsB, cap * sizeof(uint32_t));
+    if (rc) return rc;
+    ctx->hist2_stride = div_up(cap, kSortChunk);
+    rc = buf_alloc(ctx, ctx->hist2, (size_t)256 * ctx->hist2_stride * sizeof(uint32_t));
+    if (rc) return rc;
+    ctx->pair_cap = cap;
+    return MSPLAT_OK;
+}
+
+int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t stride_bytes,
+                        const msplat_attr_offsets* off, int full_sh)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if ((!aos && n) || !off) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_upload_cloud: NULL argument");
+    if (n > (1ull << 24))
+        return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "msplat_upload_cloud: %llu splats > 2^24 (rank field is 24 bit)",
+                    (unsigned long long)n);
+    if (stride_bytes % 4 != 0) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "stride must be a multiple of 4");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->has_cloud = false;
+    ctx->has_sort = false;
+    ctx->has_render = false;
+    ctx->N = n;
+    ctx->full_sh = full_sh != 0;
+    const int F4 = ctx->full_sh ? 16 : 7;
+    const size_t alloc_n = std::max<uint64_t>(n, 1);
+    int rc;
+    if ((rc = buf_alloc(ctx, ctx->pos4, alloc_n * 16))) return rc;
+    if ((rc = buf_alloc(ctx, ctx->recs, alloc_n * F4 * 16))) return rc;
+    if ((rc = buf_alloc(ctx, ctx->keyA, alloc_n * 4))) return rc;
+    if ((rc = buf_alloc(ctx, ctx->keyB, alloc_n * 4))) return rc;
+    if ((rc = buf_alloc(ctx, ctx->valA, alloc_n * 4))) return rc;
+    if ((rc = buf_alloc(ctx, ctx->valB, alloc_n * 4))) return rc;
+    ctx->hist_stride = std::max(1u, div_up(n, kSortChunk));
+    if ((rc = buf_alloc(ctx, ctx->hist, (size_t)256 * ctx->hist_stride * 4))) return rc;
+    if ((rc = buf_alloc(ctx, ctx->rec2d, alloc_n * 48))) return rc;
+    if ((rc = buf_alloc(ctx, ctx->rect, alloc_n * 4))) return rc;
+    ctx->hist1_stride = std::max(1u, div_up(n, kBinChunk));
+    if ((rc = buf_alloc(ctx, ctx->hist1, (size_t)256 * ctx->hist1_stride * 4))) return rc;
+    uint64_t cap = ctx->cfg.pair_capacity ? ctx->cfg.pair_capacity
+                                          : std::max<uint64_t>(1ull << 22, std::min<uint64_t>(32 * n, 1ull << 30));
+    if ((rc = ensure_pair_capacity(ctx, cap))) return rc;
+
+    // repack: reference AoS (100 B / 244 B, arbitrary offsets) -> 16-byte aligned padded records with the
+    // reference's float order (gaussiancloud.cpp:32-56), plus the vec4(x,y,z,1) array of splatrenderer.cpp:106-111
+    const size_t chunk = 1u << 18;
+    std::vector<float> stage_rec(chunk * F4 * 4);
+    std::vector<float> stage_pos(chunk * 4);
+    const uint32_t src_off_base[7] = {off->pos_with_alpha, off->r_sh0, off->g_sh0, off->b_sh0,
+                                      off->cov3_col0, off->cov3_col1, off->cov3_col2};
+    const uint32_t src_off_full[9] = {off->r_sh1, off->r_sh2, off->r_sh3, off->g_sh1, off->g_sh2, off->g_sh3,
+                                      off->b_sh1, off->b_sh2, off->b_sh3};
+    const uint32_t max_need = ctx->full_sh ? 16 : 12;
+    for (int k = 0; k < 7; ++k)
+        if (src_off_base[k] + (k < 4 ? 16u : 12u) > stride_bytes)
+            return fail(ctx, MSPLAT_ERR_INVALID_ARG, "attribute offset %u beyond stride %u", src_off_base[k], stride_bytes);
+    if (ctx->full_sh)
+        for (int k = 0; k < 9; ++k)
+            if (src_off_full[k] + 16u > stride_bytes)
+                return fail(ctx, MSPLAT_ERR_INVALID_ARG, "attribute offset %u beyond stride %u", src_off_full[k], stride_bytes);
+    (void)max_need;
+    const uint8_t* src = static_cast<const uint8_t*>(aos);
+    for (uint64_t base = 0; base < n; base += chunk) {
+        const size_t cnt = (size_t)std::min<uint64_t>(chunk, n - base);
+        for (size_t j = 0; j < cnt; ++j) {
+            const uint8_t* rec = src + (base + j) * stride_bytes;
+            float* d = stage_rec.data() + j * F4 * 4;
+            std::memcpy(d + 0, rec + off->pos_with_alpha, 16);
+            std::memcpy(d + 4, rec + off->r_sh0, 16);
+            std::memcpy(d + 8, rec + off->g_sh0, 16);
+            std::memcpy(d + 12, rec + off->b_sh0, 16);
+            std::memcpy(d + 16, rec + off->cov3_col0, 12);
+            std::memcpy(d + 19, rec + off->cov3_col1, 12);
+            std::memcpy(d + 22, rec + off->cov3_col2, 12);
+            if (ctx->full_sh) {
+                for (int k = 0; k < 9; ++k) std::memcpy(d + 25 + 4 * k, rec + src_off_full[k], 16);
+                d[61] = d[62] = d[63] = 0.0f;
+            } else {
+                d[25] = d[26] = d[27] = 0.0f;
+            }
+            float* p = stage_pos.data() + j * 4;
+            p[0] = d[0]; p[1] = d[1]; p[2] = d[2]; p[3] = 1.0f;
+        }
+        HIP_TRY(ctx, hipMemcpy((char*)ctx->recs.p + base * F4 * 16, stage_rec.data(), cnt * F4 * 16, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy((char*)ctx->pos4.p + base * 16, stage_pos.data(), cnt * 16, hipMemcpyHostToDevice));
+    }
+    ctx->has_cloud = true;
+    return MSPLAT_OK;
+}
+
+int msplat_set_band(msplat_ctx* ctx, int32_t row_mod, int32_t row_rem)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if (row_mod < 1 || row_rem < 0 || row_rem >= row_mod)
+        return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_set_band: need row_mod >= 1 and 0 <= row_rem < row_mod");
+    ctx->row_mod = row_mod;
+    ctx->row_rem = row_rem;
+    return MSPLAT_OK;
+}
+
+static int make_frame_params(msplat_ctx* ctx, const float cameraMat[16], const float projMat[16],
+                             const float viewport[4], const float nearFar[2], FrameParams& fp)
+{
+    if (!cameraMat || !projMat || !viewport || !nearFar)
+        return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL matrix/viewport argument");
+    std::memset(&fp, 0, sizeof(fp));
+    msplat_mat4_inverse(cameraMat, fp.view);               // splatrenderer.cpp:161 / :327
+    msplat_mat4_mul(projMat, fp.view, fp.mvp);             // splatrenderer.cpp:175
+    std::memcpy(fp.proj, projMat, 16 * sizeof(float));
+    fp.eye[0] = cameraMat[12]; fp.eye[1] = cameraMat[13]; fp.eye[2] = cameraMat[14];   // :328
+    fp.W = viewport[2];
+    fp.H = viewport[3];
+    fp.zn = nearFar[0];
+    fp.zf = nearFar[1];
+    fp.X0 = viewport[0] * (0.00001f * nearFar[0]);         // splat_vert.glsl:160
+    fp.Y0 = viewport[1];
+    fp.width = (int)viewport[2];
+    fp.height = (int)viewport[3];
+    if (fp.width < 1 || fp.height < 1 || fp.width > 4096 || fp.height > 4096)
+        return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "viewport %dx%d outside [1,4096]^2 (256x256 tiles of 16 px)",
+                    fp.width, fp.height);
+    fp.tiles_x = (fp.width + kTile - 1) / kTile;
+    const int rows_full = (fp.height + kTile - 1) / kTile;
+    fp.row_mod = ctx->row_mod;
+    fp.row_rem = ctx->row_rem;
+    // owned rows: vy*mod + rem < rows_full
+    fp.tiles_y = (rows_full > ctx->row_rem) ? (rows_full - ctx->row_rem + ctx->row_mod - 1) / ctx->row_mod : 0;
+    fp.full_sh = ctx->full_sh ? 1 : 0;
+    fp.srgb = ctx->cfg.srgb ? 1 : 0;
+    fp.t_eps = ctx->cfg.t_epsilon;
+    return MSPLAT_OK;
+}
+
+int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[16],
+                const float viewport[4], const float nearFar[2])
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if (!ctx->has_cloud) return fail(ctx, MSPLAT_ERR_NO_CLOUD, "msplat_sort: no cloud uploaded");
+    FrameParams fp;
+    int rc = make_frame_params(ctx, cameraMat, projMat, viewport, nearFar, fp);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint32_t N = (uint32_t)ctx->N;
+    uint32_t* counters = (uint32_t*)ctx->counters.p;
+    uint32_t* d_V = counters + 0;
+    uint32_t* hist = (uint32_t*)ctx->hist.p;
+    uint32_t* totals = (uint32_t*)ctx->totals.p;
+    const float4* pos = (const float4*)ctx->pos4.p;
+    uint32_t *kA = (uint32_t*)ctx->keyA.p, *kB = (uint32_t*)ctx->keyB.p;
+    uint32_t *vA = (uint32_t*)ctx->valA.p, *vB = (uint32_t*)ctx->valB.p;
+    const int grid = grid_for(div_up(N, kSortChunk));
+
+    if (ctx->ev_ok) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
+    // pass 0: cull + key fused into the first radix pass (presort_compute.glsl + byte 0 of the sort)
+    hipLaunchKernelGGL(radix_upsweep<MODE_CULL>, dim3(grid), dim3(kThreads), 0, s, nullptr, pos, nullptr, N, N, 0,
+                       hist, ctx->hist_stride, fp);
+    hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, hist, ctx->hist_stride, nullptr, N, N,
+                       (uint32_t)kSortChunk, totals);
+    hipLaunchKernelGGL((radix_downsweep<MODE_CULL, true>), dim3(grid), dim3(kThreads), 0, s, nullptr, nullptr, pos,
+                       nullptr, N, N, 0, hist, ctx->hist_stride, totals, kB, vB, d_V, fp);
+    // passes 1..3 on the V survivors (V stays on the device; splatrenderer.cpp:195-204's readback is gone)
+    for (int pass = 1; pass < 4; ++pass) {
+        uint32_t* kin = (pass & 1) ? kB : kA;
+        uint32_t* vin = (pass & 1) ? vB : vA;
+        uint32_t* kout = (pass & 1) ? kA : kB;
+        uint32_t* vout = (pass & 1) ? vA : vB;
+        hipLaunchKernelGGL(radix_upsweep<MODE_KEYS>, dim3(grid), dim3(kThreads), 0, s, kin, nullptr, d_V, 0u, N,
+                           pass * 8, hist, ctx->hist_stride, fp);
+        hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, hist, ctx->hist_stride, d_V, 0u, N,
+                           (uint32_t)kSortChunk, totals);
+        hipLaunchKernelGGL((radix_downsweep<MODE_KEYS, true>), dim3(grid), dim3(kThreads), 0, s, kin, vin, nullptr,
+                           d_V, 0u, N, pass * 8, hist, ctx->hist_stride, totals, kout, vout, nullptr, fp);
+    }
+    if (ctx->ev_ok) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
+        ctx->ev_sort_valid = true;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->has_sort = true;
+    return MSPLAT_OK;
+}
+
+static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, size_t pitch)
+{
+    hipStream_t s = ctx->stream;
+    const uint32_t N = (uint32_t)ctx->N;
+    uint32_t* counters = (uint32_t*)ctx->counters.p;
+    uint32_t *d_V = counters + 0, *d_D = counters + 1, *d_overflow = counters + 2, *d_drawn = counters + 3;
+    const int ntiles = fp.tiles_x * fp.tiles_y;
+    const uint32_t cap = (uint32_t)ctx->pair_cap;
+
+    if (ctx->ev_ok) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->tile_count.p, 0, (size_t)std::max(ntiles, 1) * sizeof(uint32_t), s));
+    HIP_TRY(ctx, hipMemsetAsync(d_D, 0, 3 * sizeof(uint32_t), s));
+    const int pgrid = std::max(1u, div_up(N, kThreads));
+    if (ctx->full_sh)
+        hipLaunchKernelGGL(project_kernel<true>, dim3(pgrid), dim3(kThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
+                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
+                           (uint32_t*)ctx->tile_count.p, d_drawn);
+    else
+        hipLaunchKernelGGL(project_kernel<false>, dim3(pgrid), dim3(kThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
+                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
+                           (uint32_t*)ctx->tile_count.p, d_drawn);
+    if (ctx->ev_ok) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
+
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)ctx->tile_count.p, ntiles,
+                       (uint32_t*)ctx->tile_start.p, d_D, cap, d_overflow);
+    // pass 1: stable partition by tile column, enumerated from the rank-ordered rectangles
+    const int g1 = grid_for(div_up(N, kBinChunk));
+    hipLaunchKernelGGL(bin1_upsweep, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
+                       (uint32_t*)ctx->hist1.p, ctx->hist1_stride);
+    hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V,
+                       0u, N, (uint32_t)kBinChunk, (uint32_t*)ctx->totals.p);
+    hipLaunchKernelGGL(bin1_downsweep, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
+                       (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)ctx->totals.p,
+                       (uint32_t*)ctx->pairsA.p, cap, fp.tiles_x);
+    // pass 2: stable partition by tile row (one generic radix pass on the top byte)
+    const int g2 = grid_for(div_up(cap, kSortChunk));
+    hipLaunchKernelGGL(radix_upsweep<MODE_PAIR>, dim3(g2), dim3(kThreads), 0, s, (const uint32_t*)ctx->pairsA.p,
+                       nullptr, d_D, 0u, cap, 24, (uint32_t*)ctx->hist2.p, ctx->hist2_stride, fp);
+    hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, (uint32_t*)ctx->hist2.p, ctx->hist2_stride, d_D,
+                       0u, cap, (uint32_t)kSortChunk, (uint32_t*)ctx->totals.p);
+    hipLaunchKernelGGL((radix_downsweep<MODE_PAIR, false>), dim3(g2), dim3(kThreads), 0, s,
+                       (const uint32_t*)ctx->pairsA.p, nullptr, nullptr, d_D, 0u, cap, 24,
+                       (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)ctx->totals.p,
+                       (uint32_t*)ctx->pairsB.p, nullptr, nullptr, fp);
+    if (ctx->ev_ok) HIP_TRY(ctx, hipEventRecord(ctx->ev[4], s));
+
+    if (ntiles > 0) {
+        if (ctx->cfg.fb_format == MSPLAT_FB_RGBA16F)
+            hipLaunchKernelGGL(composite_kernel<true>, dim3(ntiles), dim3(kThreads), 0, s,
+                               (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
+                               (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap);
+        else
+            hipLaunchKernelGGL(composite_kernel<false>, dim3(ntiles), dim3(kThreads), 0, s,
+                               (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
+                               (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap);
+    }
+    if (ctx->ev_ok) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));
+        ctx->ev_render_valid = true;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return MSPLAT_OK;
+}
+
+int msplat_render(msplat_ctx* ctx, const float cameraMat[16], const float projMat[16],
+                  const float viewport[4], const float nearFar[2],
+                  void* rgba, uint64_t pitch_bytes, int out_is_device)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if (!ctx->has_cloud) return fail(ctx, MSPLAT_ERR_NO_CLOUD, "msplat_render: no cloud uploaded");
+    if (!ctx->has_sort) return fail(ctx, MSPLAT_ERR_NO_SORT, "msplat_render: msplat_sort has not been called");
+    if (!rgba) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_render: rgba is NULL");
+    FrameParams fp;
+    int rc = make_frame_params(ctx, cameraMat, projMat, viewport, nearFar, fp);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bpp = ctx->cfg.fb_format == MSPLAT_FB_RGBA16F ? 8 : 16;
+    const size_t tight = (size_t)fp.width * bpp;
+    if (pitch_bytes == 0) pitch_bytes = tight;
+    if (pitch_bytes < tight || pitch_bytes % bpp != 0)
+        return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_render: pitch %llu too small / misaligned for width %d",
+                    (unsigned long long)pitch_bytes, fp.width);
+    ctx->last_fp = fp;
+
+    if (out_is_device) {
+        rc = launch_render(ctx, fp, rgba, pitch_bytes);
+        if (rc) return rc;
+        ctx->has_render = true;
+        return MSPLAT_OK;
+    }
+    // host output: render into an internal device framebuffer, copy back, grow the pair buffer on overflow
+    if ((rc = buf_alloc(ctx, ctx->fb, tight * fp.height))) return rc;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        if (ctx->row_mod > 1) HIP_TRY(ctx, hipMemsetAsync(ctx->fb.p, 0, tight * fp.height, ctx->stream));
+        rc = launch_render(ctx, fp, ctx->fb.p, tight);
+        if (rc) return rc;
+        uint32_t cnt[4];
+        HIP_TRY(ctx, hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (cnt[2] == 0) {
+            HIP_TRY(ctx, hipMemcpy2D(rgba, pitch_bytes, ctx->fb.p, tight, tight, fp.height, hipMemcpyDeviceToHost));
+            ctx->has_render = true;
+            return MSPLAT_OK;
+        }
+        // overflow: cnt[2] holds the required pair count
+        const uint64_t need = (uint64_t)cnt[2] + (cnt[2] >> 2) + 1024;
+        if (ctx->cfg.pair_capacity != 0 || need > 0x7FFFFFFFull)
+            return fail(ctx, MSPLAT_ERR_PAIR_OVERFLOW, "pair buffer too small: need %u, capacity %llu", cnt[2],
+                        (unsigned long long)ctx->pair_cap);
+        if ((rc = ensure_pair_capacity(ctx, need))) return rc;
+    }
+    return fail(ctx, MSPLAT_ERR_PAIR_OVERFLOW, "pair buffer could not be grown");
+}
+
+int msplat_sort_count(msplat_ctx* ctx, uint32_t* v)
+{
+    if (!ctx || !v) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
+    if (!ctx->has_sort) return fail(ctx, MSPLAT_ERR_NO_SORT, "no sort yet");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(v, ctx->counters.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MSPLAT_OK;
+}
+
+static int copy_sorted(msplat_ctx* ctx, const Buf& src, uint32_t* dst, uint32_t cap)
+{
+    uint32_t v = 0;
+    int rc = msplat_sort_count(ctx, &v);
+    if (rc) return rc;
+    if (!dst && v) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "dst is NULL");
+    if (cap < v) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "capacity %u < sort count %u", cap, v);
+    if (v) HIP_TRY(ctx, hipMemcpy(dst, src.p, (size_t)v * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return MSPLAT_OK;
+}
+
+int msplat_get_sorted_indices(msplat_ctx* ctx, uint32_t* dst, uint32_t cap)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    return copy_sorted(ctx, ctx->valA, dst, cap);
+}
+
+int msplat_get_sorted_keys(msplat_ctx* ctx, uint32_t* dst, uint32_t cap)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    return copy_sorted(ctx, ctx->keyA, dst, cap);
+}
+
+int msplat_get_stats(msplat_ctx* ctx, msplat_stats* out)
+{
+    if (!ctx || !out) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memset(out, 0, sizeof(*out));
+    out->num_splats = ctx->N;
+    out->sort_count = ctx->has_sort ? cnt[0] : 0;
+    out->pairs = ctx->has_render ? cnt[1] : 0;
+    out->drawn = ctx->has_render ? cnt[3] : 0;
+    out->tiles_x = ctx->last_fp.tiles_x;
+    out->tiles_y = ctx->last_fp.tiles_y;
+    out->width = ctx->last_fp.width;
+    out->height = ctx->last_fp.height;
+    out->pair_capacity = ctx->pair_cap;
+    out->device_bytes = ctx->device_bytes;
+    if (ctx->has_render && cnt[2] != 0)
+        return fail(ctx, MSPLAT_ERR_PAIR_OVERFLOW, "last render overflowed the pair buffer: need %u, capacity %llu",
+                    cnt[2], (unsigned long long)ctx->pair_cap);
+    return MSPLAT_OK;
+}
+
+int msplat_get_timings(msplat_ctx* ctx, msplat_timings* out)
+{
+    if (!ctx || !out) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
+    std::memset(out, 0, sizeof(*out));
+    if (!ctx->ev_ok) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "context created without enable_timing");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ev_sort_valid) HIP_TRY(ctx, hipEventElapsedTime(&out->sort_total, ctx->ev[0], ctx->ev[1]));
+    if (ctx->ev_render_valid) {
+        HIP_TRY(ctx, hipEventElapsedTime(&out->render_total, ctx->ev[2], ctx->ev[5]));
+        HIP_TRY(ctx, hipEventElapsedTime(&out->project, ctx->ev[2], ctx->ev[3]));
+        HIP_TRY(ctx, hipEventElapsedTime(&out->binning, ctx->ev[3], ctx->ev[4]));
+        HIP_TRY(ctx, hipEventElapsedTime(&out->composite, ctx->ev[4], ctx->ev[5]));
+    }
+    return MSPLAT_OK;
+}
+
+int msplat_debug_get_projected(msplat_ctx* ctx, float* rec12, uint32_t* rect, uint32_t cap)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if (!ctx->has_render) return fail(ctx, MSPLAT_ERR_NO_SORT, "no render yet");
+    uint32_t v = 0;
+    int rc = msplat_sort_count(ctx, &v);
+    if (rc) return rc;
+    if (cap < v) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "capacity %u < sort count %u", cap, v);
+    if (v && rec12) HIP_TRY(ctx, hipMemcpy(rec12, ctx->rec2d.p, (size_t)v * 48, hipMemcpyDeviceToHost));
+    if (v && rect) HIP_TRY(ctx, hipMemcpy(rect, ctx->rect.p, (size_t)v * 4, hipMemcpyDeviceToHost));
+    return MSPLAT_OK;
+}
+
+int msplat_debug_get_tile_lists(msplat_ctx* ctx, uint32_t* tile_start, uint32_t tile_cap,
+                                uint32_t* pairs, uint64_t pair_cap)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if (!ctx->has_render) return fail(ctx, MSPLAT_ERR_NO_SORT, "no render yet");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t ntiles = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y);
+    if (tile_cap < ntiles + 1) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile capacity too small");
+    if (tile_start) HIP_TRY(ctx, hipMemcpy(tile_start, ctx->tile_start.p, (size_t)(ntiles + 1) * 4, hipMemcpyDeviceToHost));
+    uint32_t cnt[4];
+    HIP_TRY(ctx, hipMemcpy(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
+    const uint64_t d = std::min<uint64_t>(cnt[1], ctx->pair_cap);
+    if (pairs) {
+        if (pair_cap < d) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "pair capacity too small");
+        if (d) HIP_TRY(ctx, hipMemcpy(pairs, ctx->pairsB.p, d * 4, hipMemcpyDeviceToHost));
+    }
+    return MSPLAT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,678 @@
+// msplat_kernels.hip.h -- hand-written CDNA4 (gfx950, wave64) kernels of the splat hot path.
+//
+// Replaces (not ports) the reference's GL pipeline:
+//   shader/presort_compute.glsl + shader/multi_radixsort*.glsl  -> radix_* (cull fused in pass 0)
+//   shader/splat_vert.glsl + shader/splat_geom.glsl             -> project_kernel
+//   GL rasteriser + shader/splat_frag.glsl + ROP blend          -> bin1_*/radix_*<MODE_PAIR> + composite_kernel
+//
+// Design notes: everything is HBM/LDS/VALU work -- no MFMA anywhere.
+// Compiled with -ffp-contract=off: an FMA happens only where __builtin_fmaf is written.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// The key / reject arithmetic must execute exactly as written (bit-parity with the oracle):
+// no implicit FMA contraction anywhere in this file (the build also passes -ffp-contract=off).
+#pragma clang fp contract(off)
+
+namespace msplat {
+
+constexpr int kThreads = 256;            // 4 wave64 per workgroup
+constexpr int kSortItems = 8;            // keys per thread per chunk
+constexpr int kSortChunk = kThreads * kSortItems;   // 2048 keys per chunk
+constexpr int kBinChunk = 1024;          // draw-order ranks per chunk in the tile-column partition
+constexpr int kTile = 16;                // 16x16 pixel tiles
+constexpr uint32_t kRectEmpty = 0x000000FFu;   // tx0=255 > tx1=0
+constexpr uint32_t kRankMask = 0x00FFFFFFu;
+
+enum { MODE_KEYS = 0, MODE_CULL = 1, MODE_PAIR = 2 };
+
+// Per-frame constants, passed by value (lives in SGPRs / kernarg segment).
+struct FrameParams {
+    float mvp[16];     // projMat * inverse(cameraMat)            (splatrenderer.cpp:161,175)
+    float view[16];    // inverse(cameraMat)                      (splatrenderer.cpp:327)
+    float proj[16];
+    float eye[3];      // cameraMat[3].xyz                        (splatrenderer.cpp:328)
+    float W, H, X0, Y0, zn, zf;
+    float t_eps;
+    int width, height;
+    int tiles_x, tiles_y;       // tiles_y = number of OWNED tile rows (band mode) else ceil(H/16)
+    int row_mod, row_rem;       // owned tile rows: ty = vy * row_mod + row_rem
+    int full_sh, srgb;
+};
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+
+// inclusive scan of one uint32 per thread across a 256-thread workgroup.
+__device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* s_tmp4, uint32_t& total)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    if (lane == 63) s_tmp4[w] = v;
+    __syncthreads();
+    uint32_t off = 0;
+    total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t s = s_tmp4[k];
+        if (k < w) off += s;
+        total += s;
+    }
+    __syncthreads();
+    return v + off;
+}
+
+// presort_compute.glsl:38-55.  Operation order identical to oracle/msplat_oracle.c (orc_cull_key)
+// so that keys and the visible set are bit-exact.
+__device__ __forceinline__ bool cull_key(const float4 p, const FrameParams& fp, uint32_t& key)
+{
+    const float* m = fp.mvp;
+    float px = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m[0], p.x), __fmul_rn(m[4], p.y)), __fmul_rn(m[8], p.z)), m[12]);
+    float py = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m[1], p.x), __fmul_rn(m[5], p.y)), __fmul_rn(m[9], p.z)), m[13]);
+    float pw = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m[3], p.x), __fmul_rn(m[7], p.y)), __fmul_rn(m[11], p.z)), m[15]);
+    float depth = pw;
+    float xx = __fdiv_rn(px, depth);
+    float yy = __fdiv_rn(py, depth);
+    const float CLIP = 1.5f;
+    if (depth > 0.0f && xx < CLIP && xx > -CLIP && yy < CLIP && yy > -CLIP) {
+        float f = __fmul_rn(__fdiv_rn(depth, fp.zf), 4294967296.0f);
+        uint32_t q = (f >= 4294967296.0f) ? 0xFFFFFFFFu : (uint32_t)f;
+        key = 0xFFFFFFFFu - q;
+        return true;
+    }
+    return false;
+}
+
+template <int MODE>
+__device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift)
+{
+    if (MODE == MODE_PAIR) return key >> 24;
+    return (key >> shift) & 255u;
+}
+
+// ------------------------------------------------------------------------------------------
+// 8-bit-digit stable LSD radix pass: upsweep (per-chunk histograms), scan, downsweep (rank+scatter)
+//   MODE_KEYS : keys from a buffer, n = *d_n
+//   MODE_CULL : pass 0 -- keys computed on the fly from positions (fused presort), value = index,
+//               culled splats are neither counted nor scattered (ordered compaction for free)
+//   MODE_PAIR : key-only words (ty<<24 | rank), digit = top byte
+// hist layout: hist[digit * hist_stride + chunk]
+// ------------------------------------------------------------------------------------------
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __restrict__ keys,
+                                                          const float4* __restrict__ pos,
+                                                          const uint32_t* __restrict__ d_n, uint32_t n_static,
+                                                          uint32_t n_cap, int shift,
+                                                          uint32_t* __restrict__ hist, uint32_t hist_stride,
+                                                          FrameParams fp)
+{
+    __shared__ uint32_t s_hist[256];
+    uint32_t n = d_n ? *d_n : n_static;
+    if (n > n_cap) n = n_cap;
+    const uint32_t nchunks = (n + kSortChunk - 1) / kSortChunk;
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        s_hist[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t base = chunk * kSortChunk;
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r) {
+            const uint32_t i = base + r * kThreads + threadIdx.x;
+            if (i < n) {
+                uint32_t key;
+                bool ok = true;
+                if (MODE == MODE_CULL) ok = cull_key(pos[i], fp, key);
+                else key = keys[i];
+                if (ok) atomicAdd(&s_hist[digit_of<MODE>(key, shift)], 1u);
+            }
+        }
+        __syncthreads();
+        hist[(size_t)threadIdx.x * hist_stride + chunk] = s_hist[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// one workgroup per digit: exclusive scan of that digit's row over the active chunks; row total -> totals
+__global__ __launch_bounds__(kThreads) void radix_scan(uint32_t* __restrict__ hist, uint32_t hist_stride,
+                                                       const uint32_t* __restrict__ d_n, uint32_t n_static,
+                                                       uint32_t n_cap, uint32_t chunk_size,
+                                                       uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t s_tmp[4];
+    uint32_t n = d_n ? *d_n : n_static;
+    if (n > n_cap) n = n_cap;
+    const uint32_t nchunks = (n + chunk_size - 1) / chunk_size;
+    uint32_t* row = hist + (size_t)blockIdx.x * hist_stride;
+    uint32_t running = 0;
+    for (uint32_t base = 0; base < nchunks; base += kThreads) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = (i < nchunks) ? row[i] : 0u;
+        uint32_t total;
+        const uint32_t incl = block_incl_scan(v, s_tmp, total);
+        if (i < nchunks) row[i] = running + incl - v;
+        running += total;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = running;
+}
+
+template <int MODE, bool HAS_VALUES>
+__global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __restrict__ keys_in,
+                                                            const uint32_t* __restrict__ vals_in,
+                                                            const float4* __restrict__ pos,
+                                                            const uint32_t* __restrict__ d_n, uint32_t n_static,
+                                                            uint32_t n_cap, int shift,
+                                                            const uint32_t* __restrict__ hist, uint32_t hist_stride,
+                                                            const uint32_t* __restrict__ totals,
+                                                            uint32_t* __restrict__ keys_out,
+                                                            uint32_t* __restrict__ vals_out,
+                                                            uint32_t* __restrict__ d_count_out,
+                                                            FrameParams fp)
+{
+    __shared__ uint32_t s_cnt[4][256];   // per-wave digit counters, then per-wave scatter bases
+    __shared__ uint32_t s_base[256];     // exclusive scan of the digit totals
+    __shared__ uint32_t s_tmp[4];
+
+    uint32_t n = d_n ? *d_n : n_static;
+    if (n > n_cap) n = n_cap;
+    const uint32_t nchunks = (n + kSortChunk - 1) / kSortChunk;
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+
+    {
+        const uint32_t t = totals[threadIdx.x];
+        uint32_t tot;
+        const uint32_t incl = block_incl_scan(t, s_tmp, tot);
+        s_base[threadIdx.x] = incl - t;
+        if (d_count_out != nullptr && blockIdx.x == 0 && threadIdx.x == 255) *d_count_out = incl;
+    }
+    __syncthreads();
+
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
+        __syncthreads();
+
+        uint32_t key[kSortItems];
+        uint32_t val[kSortItems];
+        uint32_t lrank[kSortItems];
+        bool valid[kSortItems];
+        // wave w owns the contiguous sub-chunk [w*64*ITEMS, (w+1)*64*ITEMS): keeps the sort stable
+        const uint32_t base = chunk * kSortChunk + (uint32_t)w * (64 * kSortItems);
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r) {
+            const uint32_t i = base + r * 64 + lane;
+            valid[r] = i < n;
+            key[r] = 0;
+            val[r] = 0;
+            if (valid[r]) {
+                if (MODE == MODE_CULL) {
+                    valid[r] = cull_key(pos[i], fp, key[r]);
+                    val[r] = i;
+                } else {
+                    key[r] = keys_in[i];
+                    if (HAS_VALUES) val[r] = vals_in[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r) {
+            const uint32_t d = digit_of<MODE>(key[r], shift);
+            uint64_t m = __ballot(valid[r]);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            uint32_t prev = 0;
+            if (valid[r]) prev = s_cnt[w][d];
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t rk = __popcll(m & lt_mask);
+            const uint32_t cnt = __popcll(m);
+            lrank[r] = prev + rk;
+            if (valid[r] && rk == 0) s_cnt[w][d] = prev + cnt;
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        {
+            const int d = threadIdx.x;
+            const uint32_t g = s_base[d] + hist[(size_t)d * hist_stride + chunk];
+            const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d];
+            s_cnt[0][d] = g;
+            s_cnt[1][d] = g + c0;
+            s_cnt[2][d] = g + c0 + c1;
+            s_cnt[3][d] = g + c0 + c1 + c2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r) {
+            if (valid[r]) {
+                const uint32_t d = digit_of<MODE>(key[r], shift);
+                const uint32_t dst = s_cnt[w][d] + lrank[r];
+                keys_out[dst] = key[r];
+                if (HAS_VALUES) vals_out[dst] = val[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// project: vertex + geometry stage for the splats in draw order (one thread per rank)
+//   splat_vert.glsl:153-222 (+ SH :51-127, sRGB :129-151), splat_geom.glsl:22-54
+// Writes a 48-byte record per rank, a packed tile rectangle, and counts pairs per tile.
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float srgb_to_linear(float s)
+{
+    if (s <= 0.04045f) return s / 12.92f;
+    return powf((s + 0.055f) / 1.055f, 2.4f);
+}
+
+template <bool FULL_SH>
+__global__ __launch_bounds__(kThreads) void project_kernel(const uint32_t* __restrict__ sorted_idx,
+                                                           const uint32_t* __restrict__ d_V,
+                                                           const float4* __restrict__ recs,
+                                                           FrameParams fp,
+                                                           float4* __restrict__ out_rec,
+                                                           uint32_t* __restrict__ out_rect,
+                                                           uint32_t* __restrict__ tile_count,
+                                                           uint32_t* __restrict__ d_drawn)
+{
+    constexpr int F4 = FULL_SH ? 16 : 7;
+    const uint32_t V = *d_V;
+    const uint32_t r = blockIdx.x * kThreads + threadIdx.x;
+    if (r >= V) return;
+    const uint32_t i = sorted_idx[r];
+    const float4* src = recs + (size_t)i * F4;
+    float f[F4 * 4];
+#pragma unroll
+    for (int k = 0; k < F4; ++k) {
+        const float4 v = src[k];
+        f[4 * k + 0] = v.x; f[4 * k + 1] = v.y; f[4 * k + 2] = v.z; f[4 * k + 3] = v.w;
+    }
+    const float x = f[0], y = f[1], z = f[2], alpha = f[3];
+    const float* vm = fp.view;
+    const float* pm = fp.proj;
+
+    // t = viewMat * vec4(pos, 1)   -- same op order as the oracle (reject tests must not flip)
+    float t[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        t[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(vm[c], x), __fmul_rn(vm[4 + c], y)), __fmul_rn(vm[8 + c], z)), vm[12 + c]);
+    float p4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        p4[c] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(pm[c], t[0]), __fmul_rn(pm[4 + c], t[1])), __fmul_rn(pm[8 + c], t[2])), __fmul_rn(pm[12 + c], t[3]));
+    const float ndcx = __fdiv_rn(p4[0], p4[3]);
+    const float ndcy = __fdiv_rn(p4[1], p4[3]);
+    const float ndcz = __fdiv_rn(p4[2], p4[3]);
+
+    bool reject = (ndcz < 0.25f) || (ndcx > 2.0f) || (ndcx < -2.0f) || (ndcy > 2.0f) || (ndcy < -2.0f);
+    if (!(ndcz <= 1.0f)) reject = true;     // far-plane clip of the whole quad / NaN
+    if (!(p4[3] > 0.0f)) reject = true;
+
+    const float WIDTH = fp.W, HEIGHT = fp.H;
+    const float px = __fmul_rn(0.5f, __fadd_rn(__fadd_rn(WIDTH, __fmul_rn(ndcx, WIDTH)), __fmul_rn(2.0f, fp.X0)));
+    const float py = __fmul_rn(0.5f, __fadd_rn(__fadd_rn(HEIGHT, __fmul_rn(ndcy, HEIGHT)), __fmul_rn(2.0f, fp.Y0)));
+
+    // Jacobian rows (splat_vert.glsl:170-181); third row only feeds dropped terms
+    const float SX = pm[0], SY = pm[5];
+    const float tz = t[2];
+    const float tzSq = tz * tz;
+    const float jsx = -(SX * WIDTH) / (2.0f * tz);
+    const float jsy = -(SY * HEIGHT) / (2.0f * tz);
+    const float jtx = (SX * t[0] * WIDTH) / (2.0f * tzSq);
+    const float jty = (SY * t[1] * HEIGHT) / (2.0f * tzSq);
+    // M = [J0;J1] * mat3(viewMat):  M[r][k] = J[r][0]*W[0][k] + J[r][1]*W[1][k] + J[r][2]*W[2][k]
+    // with W[row][col] = vm[col*4 + row]
+    float M0[3], M1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        M0[k] = jsx * vm[k * 4 + 0] + jtx * vm[k * 4 + 2];
+        M1[k] = jsy * vm[k * 4 + 1] + jty * vm[k * 4 + 2];
+    }
+    // Sigma columns: col0 = f[16..18], col1 = f[19..21], col2 = f[22..24];  S[row][col] = f[16 + col*3 + row]
+    float A0[3], A1[3];   // A = M * Sigma
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        A0[c] = M0[0] * f[16 + c * 3 + 0] + M0[1] * f[16 + c * 3 + 1] + M0[2] * f[16 + c * 3 + 2];
+        A1[c] = M1[0] * f[16 + c * 3 + 0] + M1[1] * f[16 + c * 3 + 1] + M1[2] * f[16 + c * 3 + 2];
+    }
+    const float m00 = (A0[0] * M0[0] + A0[1] * M0[1] + A0[2] * M0[2]) + 0.3f;
+    const float m10 = (A0[0] * M1[0] + A0[1] * M1[1] + A0[2] * M1[2]);   // row 0, col 1
+    const float m01 = (A1[0] * M0[0] + A1[1] * M0[1] + A1[2] * M0[2]);   // row 1, col 0
+    const float m11 = (A1[0] * M1[0] + A1[1] * M1[1] + A1[2] * M1[2]) + 0.3f;
+    const float det = m00 * m11 - m01 * m10;
+    const float i00 = m11 / det;
+    const float i01 = -m01 / det;
+    const float i10 = -m10 / det;
+    const float i11 = m00 / det;
+
+    // colour: 0.5 + SH(v), no clamp (splat_vert.glsl:51-127,206-207)
+    const float dx = x - fp.eye[0], dy = y - fp.eye[1], dz = z - fp.eye[2];
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float vx = dx / len, vy = dy / len, vz = dz / len;
+    float b[FULL_SH ? 16 : 4];
+    b[0] = 0.28209479177387814f;
+    const float k1 = 0.4886025119029199f;
+    b[1] = -k1 * vy;
+    b[2] = k1 * vz;
+    b[3] = -k1 * vx;
+    float rgb[3];
+    if (FULL_SH) {
+        const float vx2 = vx * vx, vy2 = vy * vy, vz2 = vz * vz;
+        const float k2 = 1.0925484305920792f, k3 = 0.31539156525252005f, k4 = 0.5462742152960396f;
+        b[4] = k2 * vy * vx;
+        b[5] = -k2 * vy * vz;
+        b[6] = k3 * (3.0f * vz2 - 1.0f);
+        b[7] = -k2 * vx * vz;
+        b[8] = k4 * (vx2 - vy2);
+        const float k5 = 0.5900435899266435f, k6 = 2.8906114426405543f, k7 = 0.4570457994644658f;
+        const float k8 = 0.37317633259011546f, k9 = 1.4453057213202771f;
+        b[9] = -k5 * vy * (3.0f * vx2 - vy2);
+        b[10] = k6 * vy * vx * vz;
+        b[11] = -k7 * vy * (5.0f * vz2 - 1.0f);
+        b[12] = k8 * vz * (5.0f * vz2 - 3.0f);
+        b[13] = -k7 * vx * (5.0f * vz2 - 1.0f);
+        b[14] = k9 * vz * (vx2 - vy2);
+        b[15] = -k5 * vx * (vx2 - 3.0f * vy2);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            // channel c: sh0 at floats 4+4c.., sh1..3 at floats 25+12c..
+            float s = b[0] * f[4 + 4 * c];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) s = s + b[k] * f[4 + 4 * c + k];
+#pragma unroll
+            for (int k = 4; k < 16; ++k) s = s + b[k] * f[25 + 12 * c + (k - 4)];
+            rgb[c] = 0.5f + s;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float s = b[0] * f[4 + 4 * c];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) s = s + b[k] * f[4 + 4 * c + k];
+            rgb[c] = 0.5f + s;
+        }
+    }
+    if (fp.srgb) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[c] = srgb_to_linear(rgb[c]);
+    }
+
+    // footprint: w = alpha*exp(-q/2) > 1/256  <=>  q < 2 ln(256 alpha) =: rho2 (splat_frag.glsl:37-40).
+    // The 3.5-sigma quad of splat_geom.glsl:56-106 always contains it (rho <= 3.33), so the discard
+    // test alone defines coverage.
+    uint32_t rect = kRectEmpty;
+    const float rho2 = 2.0f * logf(256.0f * alpha);
+    if (!(rho2 > 0.0f)) reject = true;                      // alpha <= 1/256 (or NaN): never visible
+    if (!(det > 0.0f) || !(m00 > 0.0f) || !(m11 > 0.0f)) reject = true;   // degenerate/NaN covariance
+    if (!reject) {
+        const float ex = sqrtf(rho2 * m00) * 1.0001f + 0.01f;
+        const float ey = sqrtf(rho2 * m11) * 1.0001f + 0.01f;
+        float x0f = ceilf(px - ex - 0.5f), x1f = floorf(px + ex - 0.5f);
+        float y0f = ceilf(py - ey - 0.5f), y1f = floorf(py + ey - 0.5f);
+        x0f = fmaxf(x0f, 0.0f);
+        y0f = fmaxf(y0f, 0.0f);
+        x1f = fminf(x1f, (float)(fp.width - 1));
+        y1f = fminf(y1f, (float)(fp.height - 1));
+        if (x0f <= x1f && y0f <= y1f) {
+            const int tx0 = (int)x0f / kTile, tx1 = (int)x1f / kTile;
+            int ty0 = (int)y0f / kTile, ty1 = (int)y1f / kTile;
+            // band mode: keep only owned tile rows, renumbered vy = (ty - rem) / mod
+            if (fp.row_mod > 1) {
+                int a = ty0 - fp.row_rem, bq = ty1 - fp.row_rem;
+                // ceil(a/mod) for possibly negative a
+                ty0 = (a >= 0) ? (a + fp.row_mod - 1) / fp.row_mod : 0;
+                ty1 = (bq >= 0) ? bq / fp.row_mod : -1;
+            }
+            if (ty0 <= ty1) {
+                rect = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
+                for (int ty = ty0; ty <= ty1; ++ty)
+                    for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&tile_count[ty * fp.tiles_x + tx], 1u);
+                atomicAdd(d_drawn, 1u);
+            }
+        }
+    }
+
+    // record: w(dx,dy) = exp2(A dx^2 + B dx dy + C dy^2 + log2 alpha)
+    const float kk = -0.5f * 1.44269504088896340736f;
+    float4 r0, r1, r2;
+    r0.x = px; r0.y = py; r0.z = kk * i00; r0.w = kk * (i01 + i10);
+    r1.x = kk * i11; r1.y = log2f(alpha); r1.z = rgb[0]; r1.w = rgb[1];
+    r2.x = rgb[2]; r2.y = alpha; r2.z = 0.0f; r2.w = 0.0f;
+    out_rec[(size_t)r * 3 + 0] = r0;
+    out_rec[(size_t)r * 3 + 1] = r1;
+    out_rec[(size_t)r * 3 + 2] = r2;
+    out_rect[r] = rect;
+}
+
+// exclusive scan of the per-tile pair counts (<= 65536 tiles) -> tile_start[ntiles+1]; D -> d_D
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ tile_count, int ntiles,
+                                                         uint32_t* __restrict__ tile_start,
+                                                         uint32_t* __restrict__ d_D, uint32_t cap,
+                                                         uint32_t* __restrict__ d_overflow)
+{
+    __shared__ uint32_t s_wave[16];
+    const int per = (ntiles + 1023) / 1024;
+    const int begin = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (int k = 0; k < per; ++k) {
+        const int i = begin + k;
+        if (i < ntiles) sum += tile_count[i];
+    }
+    // block exclusive scan over 1024 threads (16 waves)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t v = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    if (lane == 63) s_wave[w] = v;
+    __syncthreads();
+    uint32_t off = 0, total = 0;
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t s = s_wave[k];
+        if (k < w) off += s;
+        total += s;
+    }
+    uint32_t run = off + v - sum;
+    for (int k = 0; k < per; ++k) {
+        const int i = begin + k;
+        if (i < ntiles) {
+            tile_start[i] = run;
+            run += tile_count[i];
+        }
+    }
+    if (threadIdx.x == 0) {
+        tile_start[ntiles] = total;
+        *d_D = total;
+        if (total > cap) *d_overflow = total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// tile binning, pass 1: stable partition of (splat,tile) pairs by tile COLUMN, enumerated on the
+// fly from the rank-ordered rectangles ("bin-parallel": thread tx owns column tx and walks the
+// chunk's rectangles in rank order, so stability needs no ranking or atomics).
+// Output word = (row << 24) | rank;  pass 2 is radix_*<MODE_PAIR> on the row byte.
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restrict__ rect,
+                                                         const uint32_t* __restrict__ d_V,
+                                                         uint32_t* __restrict__ hist, uint32_t hist_stride)
+{
+    __shared__ uint32_t s_diff[kThreads + 1];
+    __shared__ uint32_t s_tmp[4];
+    const uint32_t V = *d_V;
+    const uint32_t nchunks = (V + kBinChunk - 1) / kBinChunk;
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        s_diff[threadIdx.x] = 0;
+        if (threadIdx.x == 0) s_diff[kThreads] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kBinChunk / kThreads; ++k) {
+            const uint32_t r = chunk * kBinChunk + k * kThreads + threadIdx.x;
+            if (r < V) {
+                const uint32_t rc = rect[r];
+                const uint32_t tx0 = rc & 255u, ty0 = (rc >> 8) & 255u, tx1 = (rc >> 16) & 255u, ty1 = rc >> 24;
+                if (tx0 <= tx1) {
+                    const uint32_t rows = ty1 - ty0 + 1u;
+                    atomicAdd(&s_diff[tx0], rows);
+                    atomicAdd(&s_diff[tx1 + 1u], 0u - rows);
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t total;
+        const uint32_t incl = block_incl_scan(s_diff[threadIdx.x], s_tmp, total);   // wraps mod 2^32: exact
+        hist[(size_t)threadIdx.x * hist_stride + chunk] = incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __restrict__ rect,
+                                                           const uint32_t* __restrict__ d_V,
+                                                           const uint32_t* __restrict__ hist, uint32_t hist_stride,
+                                                           const uint32_t* __restrict__ totals,
+                                                           uint32_t* __restrict__ pairs_out, uint32_t cap,
+                                                           int tiles_x)
+{
+    __shared__ uint32_t s_rect[kBinChunk];
+    __shared__ uint32_t s_base[kThreads];
+    __shared__ uint32_t s_tmp[4];
+    const uint32_t V = *d_V;
+    const uint32_t nchunks = (V + kBinChunk - 1) / kBinChunk;
+    {
+        const uint32_t t = totals[threadIdx.x];
+        uint32_t tot;
+        const uint32_t incl = block_incl_scan(t, s_tmp, tot);
+        s_base[threadIdx.x] = incl - t;
+    }
+    __syncthreads();
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const uint32_t rbase = chunk * kBinChunk;
+#pragma unroll
+        for (int k = 0; k < kBinChunk / kThreads; ++k) {
+            const uint32_t j = k * kThreads + threadIdx.x;
+            s_rect[j] = (rbase + j < V) ? rect[rbase + j] : kRectEmpty;
+        }
+        __syncthreads();
+        const uint32_t tx = threadIdx.x;
+        if ((int)tx < tiles_x) {
+            uint32_t cursor = s_base[tx] + hist[(size_t)tx * hist_stride + chunk];
+            const uint32_t cnt = min((uint32_t)kBinChunk, V - rbase);
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const uint32_t rc = s_rect[j];
+                const uint32_t tx0 = rc & 255u, tx1 = (rc >> 16) & 255u;
+                if (tx >= tx0 && tx <= tx1) {
+                    const uint32_t ty0 = (rc >> 8) & 255u, ty1 = rc >> 24;
+                    const uint32_t rank = rbase + j;
+                    for (uint32_t ty = ty0; ty <= ty1; ++ty) {
+                        if (cursor < cap) pairs_out[cursor] = (ty << 24) | rank;
+                        ++cursor;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// composite: one 16x16 workgroup per tile, front-to-back over the tile's depth-ordered list
+// (reverse of the reference's back-to-front ROP blend; algebraically identical -- SURVEY 8a-12):
+//   C = sum_i T_i w_i c_i,  T_i = prod_{j nearer}(1 - w_j),  A = 1
+// splat_frag.glsl:18-42 defines w and the discard (w <= 1/256); app.cpp:153-160 the blend/clear.
+// ------------------------------------------------------------------------------------------
+
+template <bool HALF>
+__global__ __launch_bounds__(kThreads) void composite_kernel(const uint32_t* __restrict__ tile_start,
+                                                             const uint32_t* __restrict__ pairs,
+                                                             const float4* __restrict__ rec,
+                                                             void* __restrict__ out, size_t pitch_bytes,
+                                                             FrameParams fp, uint32_t cap)
+{
+    __shared__ float4 s_rec[kThreads * 3];
+    __shared__ int s_alive[2];
+
+    const int tile = blockIdx.x;
+    const int vty = tile / fp.tiles_x;
+    const int tx = tile - vty * fp.tiles_x;
+    const int ty = vty * fp.row_mod + fp.row_rem;
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int x = tx * kTile + lx, y = ty * kTile + ly;
+    const bool inside = (x < fp.width) && (y < fp.height);
+    const float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+
+    uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    if (start > cap) start = cap;
+    if (end > cap) end = cap;
+
+    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    bool done = !inside;
+    if (threadIdx.x < 2) s_alive[threadIdx.x] = 0;
+    __syncthreads();
+
+    int it = 0;
+    for (uint32_t hi = end; hi > start; ++it) {
+        const uint32_t cnt = min((uint32_t)kThreads, hi - start);
+        if (threadIdx.x < cnt) {
+            const uint32_t rank = pairs[hi - 1u - threadIdx.x] & kRankMask;   // j = 0 is the nearest splat
+            const float4* src = rec + (size_t)rank * 3;
+            s_rec[threadIdx.x * 3 + 0] = src[0];
+            s_rec[threadIdx.x * 3 + 1] = src[1];
+            s_rec[threadIdx.x * 3 + 2] = src[2];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_alive[(it + 1) & 1] = 0;
+        if (!done) {
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const float4 a = s_rec[j * 3 + 0];
+                const float4 b = s_rec[j * 3 + 1];
+                const float blue = s_rec[j * 3 + 2].x;
+                const float dx = fx - a.x, dy = fy - a.y;
+                float e = __builtin_fmaf(b.x * dy, dy, b.y);
+                e = __builtin_fmaf(a.w * dx, dy, e);
+                e = __builtin_fmaf(a.z * dx, dx, e);
+                const float w = __builtin_amdgcn_exp2f(e);
+                if (w > (1.0f / 256.0f)) {
+                    const float tw = T * w;
+                    cr = __builtin_fmaf(tw, b.z, cr);
+                    cg = __builtin_fmaf(tw, b.w, cg);
+                    cb = __builtin_fmaf(tw, blue, cb);
+                    T = T - tw;
+                    if (T < fp.t_eps) { done = true; break; }
+                }
+            }
+        }
+        if (!done) s_alive[it & 1] = 1;
+        __syncthreads();
+        if (!s_alive[it & 1]) break;
+        hi -= cnt;
+    }
+
+    if (inside) {
+        char* row = (char*)out + (size_t)y * pitch_bytes;
+        if (HALF) {
+            union { _Float16 h[4]; uint2 u; } pk;
+            pk.h[0] = (_Float16)cr; pk.h[1] = (_Float16)cg; pk.h[2] = (_Float16)cb; pk.h[3] = (_Float16)1.0f;
+            ((uint2*)row)[x] = pk.u;
+        } else {
+            ((float4*)row)[x] = make_float4(cr, cg, cb, 1.0f);
+        }
+    }
+}
+
+}  // namespace msplat

@@ -1,0 +1,156 @@
+"""SplatRenderer: Python mirror of the reference's renderer seam
+(/root/reference/src/splatrenderer.h:23-67): Init(gaussianCloud, isFramebufferSRGBEnabled,
+useRgcSortOverride) -> bool, Sort(cameraMat, projMat, viewport, nearFar), Render(same four).
+The reference renders into the currently bound GL framebuffer; here Render takes/returns an explicit
+RGBA framebuffer.  Everything runs in libmsplat.so's HIP kernels -- there is no CPU path."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from .scene import GaussianCloud
+
+
+def _m(a, n):
+    a = np.ascontiguousarray(np.asarray(a, np.float32).reshape(-1))
+    assert a.shape[0] == n, "expected %d floats" % n
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class SplatRenderer:
+    def __init__(self, device=0, fb_format="fp32", t_epsilon=-1.0, pair_capacity=0, stream=None,
+                 enable_timing=False):
+        self.numBlocksPerWorkgroup = 1024      # accepted and ignored (splatrenderer.h:39)
+        self._lib = _capi.lib()
+        self._ctx = None
+        self._device = device
+        self._fb_format = {"fp32": _capi.FB_RGBA32F, "fp16": _capi.FB_RGBA16F}[fb_format]
+        self._t_eps = t_epsilon
+        self._pair_cap = pair_capacity
+        self._stream = stream
+        self._timing = enable_timing
+        self._n = 0
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        ctx, self._ctx = getattr(self, "_ctx", None), None
+        if ctx:
+            self._lib.msplat_destroy(ctx)
+
+    # -- reference surface ------------------------------------------------------------------
+    def Init(self, gaussianCloud, isFramebufferSRGBEnabled=False, useRgcSortOverride=False):
+        """splatrenderer.cpp:50-151.  Returns False (error text via last_error()) on failure, like the reference."""
+        del useRgcSortOverride   # one HIP sort replaces both GL sorters
+        self.close()
+        cfg = _capi.Config()
+        cfg.struct_size = C.sizeof(_capi.Config)
+        cfg.device = self._device
+        cfg.fb_format = self._fb_format
+        cfg.srgb = 1 if isFramebufferSRGBEnabled else 0
+        cfg.t_epsilon = self._t_eps
+        cfg.pair_capacity = self._pair_cap
+        cfg.stream = self._stream
+        cfg.enable_timing = 1 if self._timing else 0
+        h = C.c_void_p()
+        rc = self._lib.msplat_create(C.byref(h), C.byref(cfg))
+        if rc != _capi.OK:
+            self._err = self._lib.msplat_last_error(None).decode()
+            return False
+        self._ctx = h
+        if isinstance(gaussianCloud, GaussianCloud):
+            rc = self._lib.msplat_upload_gaussian_cloud(self._ctx, gaussianCloud.handle)
+            self._n = gaussianCloud.GetNumGaussians()
+        else:   # (N, 25|61) float32 array in the reference AoS layout
+            aos = np.ascontiguousarray(gaussianCloud, np.float32)
+            full = aos.shape[1] == 61
+            assert aos.shape[1] in (25, 61)
+            off = _capi.AttrOffsets(0, 16, 32, 48, 64, 76, 88, 100, 116, 132, 148, 164, 180, 196, 212, 228)
+            rc = self._lib.msplat_upload_cloud(self._ctx, aos.ctypes.data, aos.shape[0], aos.shape[1] * 4,
+                                               C.byref(off), 1 if full else 0)
+            self._n = aos.shape[0]
+        if rc != _capi.OK:
+            self._err = self._lib.msplat_last_error(self._ctx).decode()
+            return False
+        return True
+
+    def last_error(self):
+        if self._ctx:
+            return self._lib.msplat_last_error(self._ctx).decode()
+        return getattr(self, "_err", "")
+
+    def Sort(self, cameraMat, projMat, viewport, nearFar):
+        """splatrenderer.cpp:153-312"""
+        _, c = _m(cameraMat, 16); _, p = _m(projMat, 16); _, v = _m(viewport, 4); _, nf = _m(nearFar, 2)
+        _capi.check(self._ctx, self._lib.msplat_sort(self._ctx, c, p, v, nf))
+
+    def Render(self, cameraMat, projMat, viewport, nearFar, out=None, out_ptr=None, pitch_bytes=0):
+        """splatrenderer.cpp:315-343 + the GL pipeline behind it.
+        out=None      -> returns a new (H, W, 4) numpy array (float32 or float16), row 0 = GL bottom row
+        out=ndarray   -> filled in place
+        out_ptr=int   -> device pointer (e.g. torch tensor .data_ptr()); asynchronous on the stream"""
+        _, c = _m(cameraMat, 16); _, p = _m(projMat, 16); vp, v = _m(viewport, 4); _, nf = _m(nearFar, 2)
+        if out_ptr is not None:
+            _capi.check(self._ctx, self._lib.msplat_render(self._ctx, c, p, v, nf, C.c_void_p(out_ptr),
+                                                           pitch_bytes, 1))
+            return None
+        W, H = int(vp[2]), int(vp[3])
+        dt = np.float16 if self._fb_format == _capi.FB_RGBA16F else np.float32
+        if out is None:
+            out = np.zeros((H, W, 4), dt)
+        assert out.dtype == dt and out.shape == (H, W, 4) and out.flags["C_CONTIGUOUS"]
+        _capi.check(self._ctx, self._lib.msplat_render(self._ctx, c, p, v, nf, out.ctypes.data, 0, 0))
+        return out
+
+    # -- extensions -------------------------------------------------------------------------
+    def set_band(self, row_mod, row_rem):
+        _capi.check(self._ctx, self._lib.msplat_set_band(self._ctx, row_mod, row_rem))
+
+    def synchronize(self):
+        _capi.check(self._ctx, self._lib.msplat_synchronize(self._ctx))
+
+    def sort_count(self):
+        v = C.c_uint32()
+        _capi.check(self._ctx, self._lib.msplat_sort_count(self._ctx, C.byref(v)))
+        return v.value
+
+    def sorted_indices(self):
+        out = np.empty(max(self._n, 1), np.uint32)
+        _capi.check(self._ctx, self._lib.msplat_get_sorted_indices(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                                   out.shape[0]))
+        return out[:self.sort_count()].copy()
+
+    def sorted_keys(self):
+        out = np.empty(max(self._n, 1), np.uint32)
+        _capi.check(self._ctx, self._lib.msplat_get_sorted_keys(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                                out.shape[0]))
+        return out[:self.sort_count()].copy()
+
+    def stats(self):
+        s = _capi.Stats()
+        _capi.check(self._ctx, self._lib.msplat_get_stats(self._ctx, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in _capi.Stats._fields_}
+
+    def timings(self):
+        t = _capi.Timings()
+        _capi.check(self._ctx, self._lib.msplat_get_timings(self._ctx, C.byref(t)))
+        return {k: getattr(t, k) for k in ("sort_total", "render_total", "project", "binning", "composite")}
+
+    def debug_projected(self):
+        v = self.sort_count()
+        rec = np.zeros((max(v, 1), 12), np.float32)
+        rect = np.zeros(max(v, 1), np.uint32)
+        _capi.check(self._ctx, self._lib.msplat_debug_get_projected(
+            self._ctx, rec.ctypes.data_as(C.POINTER(C.c_float)), rect.ctypes.data_as(C.POINTER(C.c_uint32)), rec.shape[0]))
+        return rec[:v], rect[:v]
+
+    def debug_tile_lists(self):
+        st = self.stats()
+        nt = st["tiles_x"] * st["tiles_y"]
+        ts = np.zeros(nt + 1, np.uint32)
+        pairs = np.zeros(max(int(st["pairs"]), 1), np.uint32)
+        _capi.check(self._ctx, self._lib.msplat_debug_get_tile_lists(
+            self._ctx, ts.ctypes.data_as(C.POINTER(C.c_uint32)), ts.shape[0],
+            pairs.ctypes.data_as(C.POINTER(C.c_uint32)), pairs.shape[0]))
+        return ts, pairs[:int(st["pairs"])]

@@ -1,0 +1,353 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, stage by stage.
+
+Tolerances, stated once:
+  keys, visible set, sorted permutation, tile lists ........ exact
+  projected centre ......................................... <= 1e-3 px
+  conic / colour ........................................... rel 1e-4 (abs floor 1e-6)
+  fp32 framebuffer ......................................... >= 99.9 % of values within 1e-4,
+                                                             mean |diff| <= 1e-4, max |diff| <= 2e-2
+     (one discard-threshold flip at w ~ 1/256 is worth <= |c|/256 ~ 4e-3 * |c|; colours are
+      unclamped SH so |c| can exceed 1; early termination adds <= t_eps * |c|)
+  alpha channel ............................................ == 1 within 1e-5
+  fp16 framebuffer ......................................... vs fp32 oracle: 2e-3 + 1 fp16 ulp
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from splatapult_amd import SplatRenderer, camera
+from tests import scenes
+
+pytestmark = pytest.mark.gpu
+
+KK = -0.5 * 1.4426950408889634
+
+
+def make_renderer(cloud, srgb=False, **kw):
+    r = SplatRenderer(device=0, **kw)
+    assert r.Init(cloud, srgb, False), r.last_error()
+    return r
+
+
+def check_image(img, ref, max_abs=2e-2, mean_abs=1e-4, frac=0.999, tol=1e-4):
+    assert img.shape == ref.shape
+    d = np.abs(img.astype(np.float64) - ref.astype(np.float64))
+    rgb = d[..., :3]
+    assert np.isfinite(img).all()
+    within = (rgb <= tol).mean()
+    assert within >= frac, "only %.5f of values within %g (max %.3g)" % (within, tol, rgb.max())
+    assert rgb.mean() <= mean_abs, "mean |diff| %.3g" % rgb.mean()
+    assert rgb.max() <= max_abs, "max |diff| %.3g" % rgb.max()
+    assert np.abs(img[..., 3].astype(np.float64) - 1.0).max() <= 1e-5
+
+
+def run_frame(cloud, view, full_sh=True, srgb=False, **kw):
+    cam, proj, vp, nf = view
+    r = make_renderer(cloud, srgb=srgb, **kw)
+    r.Sort(cam, proj, vp, nf)
+    img = r.Render(cam, proj, vp, nf)
+    ref = orc.render_frame(cloud.as_array(), full_sh, cam, proj, vp, nf, srgb=srgb, nthreads=8, want_splats=True)
+    return r, img, ref
+
+
+# ------------------------------------------------------------------------------------------------
+# stage 1: cull + key + sort
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,seed", [(1, 1), (63, 2), (2048, 3), (2049, 4), (50000, 5)])
+def test_sort_matches_oracle_exactly(n, seed):
+    cloud = scenes.synth_cloud(n, seed)
+    cam, proj, vp, nf = scenes.default_view(640, 480)
+    r = make_renderer(cloud)
+    r.Sort(cam, proj, vp, nf)
+    aos = cloud.as_array()
+    mvp = orc.mat4_mul(proj, orc.mat4_inverse(cam))
+    keys, idx = orc.presort(aos, mvp, nf[1])
+    keys, idx = orc.sort(keys, idx)
+    assert r.sort_count() == keys.shape[0]
+    np.testing.assert_array_equal(r.sorted_keys(), keys)
+    np.testing.assert_array_equal(r.sorted_indices(), idx)
+
+
+def test_sort_hard_cases_and_ties():
+    a = scenes.hard_attrs()
+    cloud = scenes.cloud_from_attrs(a)
+    for yaw in (0.0, 0.7, 3.0):
+        cam, proj, vp, nf = scenes.default_view(800, 600, yaw=yaw)
+        r = make_renderer(cloud)
+        r.Sort(cam, proj, vp, nf)
+        mvp = orc.mat4_mul(proj, orc.mat4_inverse(cam))
+        keys, idx = orc.sort(*orc.presort(cloud.as_array(), mvp, nf[1]))
+        assert 0 < keys.shape[0] < a["xyz"].shape[0]         # something culled, something kept
+        np.testing.assert_array_equal(r.sorted_keys(), keys)
+        np.testing.assert_array_equal(r.sorted_indices(), idx)   # includes the equal-key tie rule
+
+
+def test_sort_everything_culled_and_empty_cloud():
+    cloud = scenes.synth_cloud(500, 9)
+    cam, proj, vp, nf = scenes.default_view(320, 240, z=7.0, yaw=np.pi)   # looking away
+    r = make_renderer(cloud)
+    r.Sort(cam, proj, vp, nf)
+    assert r.sort_count() == 0
+    img = r.Render(cam, proj, vp, nf)
+    assert (img[..., :3] == 0).all() and (img[..., 3] == 1).all()
+    empty = np.zeros((0, 61), np.float32)
+    r2 = SplatRenderer()
+    assert r2.Init(empty)
+    r2.Sort(cam, proj, vp, nf)
+    assert r2.sort_count() == 0
+    img = r2.Render(cam, proj, vp, nf)
+    assert (img[..., :3] == 0).all() and (img[..., 3] == 1).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# stage 2: projection
+# ------------------------------------------------------------------------------------------------
+
+def _check_projection(r, ref, W, H):
+    rec, rect = r.debug_projected()
+    sp = ref["splats"]
+    assert rec.shape[0] == sp.shape[0]
+    tx0, ty0, tx1, ty1 = rect & 255, (rect >> 8) & 255, (rect >> 16) & 255, rect >> 24
+    drawn = tx0 <= tx1
+    # a drawn splat is never one the geometry stage rejected
+    assert not (drawn & (sp["reject"] != 0)).any()
+    ok = sp["reject"] == 0
+    np.testing.assert_allclose(rec[ok, 0], sp["px"][ok], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(rec[ok, 1], sp["py"][ok], atol=1e-3, rtol=0)
+    inv = sp["inv"][ok]
+    exp_conic = np.stack([KK * inv[:, 0], KK * (inv[:, 1] + inv[:, 2]), KK * inv[:, 3]], axis=1)
+    np.testing.assert_allclose(rec[ok, 2:5], exp_conic, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(rec[ok, 6:9], sp["rgb"][ok], rtol=1e-4, atol=2e-6)
+    np.testing.assert_array_equal(rec[ok, 9], sp["alpha"][ok])
+    # footprint: every pixel with w > 1/256 lies within rho*sqrt(cov_xx) of the centre
+    alpha = sp["alpha"].astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rho2 = 2.0 * np.log(256.0 * alpha)
+    vis = ok & (rho2 > 0)
+    ex = np.sqrt(np.maximum(rho2, 0) * sp["cov"][:, 0])
+    ey = np.sqrt(np.maximum(rho2, 0) * sp["cov"][:, 3])
+    x0 = np.ceil(sp["px"] - ex - 0.5); x1 = np.floor(sp["px"] + ex - 0.5)
+    y0 = np.ceil(sp["py"] - ey - 0.5); y1 = np.floor(sp["py"] + ey - 0.5)
+    onscreen = vis & (x1 >= 0) & (y1 >= 0) & (x0 <= W - 1) & (y0 <= H - 1) & (x0 <= x1) & (y0 <= y1)
+    # anything the oracle can light up must be drawn ...
+    assert drawn[onscreen].all()
+    xs0 = np.clip(x0, 0, W - 1) // 16; xs1 = np.clip(x1, 0, W - 1) // 16
+    ys0 = np.clip(y0, 0, H - 1) // 16; ys1 = np.clip(y1, 0, H - 1) // 16
+    m = onscreen
+    assert (tx0[m] <= xs0[m]).all() and (tx1[m] >= xs1[m]).all()
+    assert (ty0[m] <= ys0[m]).all() and (ty1[m] >= ys1[m]).all()
+    # ... and the rectangle is tight to within one tile
+    assert (xs0[m] - tx0[m] <= 1).all() and (tx1[m] - xs1[m] <= 1).all()
+    assert (ys0[m] - ty0[m] <= 1).all() and (ty1[m] - ys1[m] <= 1).all()
+    return rect
+
+
+@pytest.mark.parametrize("full_sh", [True, False])
+def test_projection_matches_oracle(full_sh):
+    cloud = scenes.synth_cloud(6000, 21, full_sh=full_sh, log_scale_mean=-3.2)
+    view = scenes.default_view(640, 360, yaw=0.4, pitch=-0.1, x=3.0)
+    r, img, ref = run_frame(cloud, view, full_sh=full_sh)
+    _check_projection(r, ref, 640, 360)
+
+
+def test_projection_hard_cases():
+    cloud = scenes.cloud_from_attrs(scenes.hard_attrs())
+    view = scenes.default_view(800, 600)
+    r, img, ref = run_frame(cloud, view)
+    _check_projection(r, ref, 800, 600)
+    st = r.stats()
+    assert st["drawn"] < st["sort_count"]          # guard band / near plane / alpha rejects exist
+
+
+# ------------------------------------------------------------------------------------------------
+# stage 3: tile lists (binning must reproduce the draw order inside every tile, exactly)
+# ------------------------------------------------------------------------------------------------
+
+def _expected_tile_lists(rect, tiles_x, tiles_y):
+    lists = [[] for _ in range(tiles_x * tiles_y)]
+    for rank, rc in enumerate(rect.tolist()):
+        tx0, ty0, tx1, ty1 = rc & 255, (rc >> 8) & 255, (rc >> 16) & 255, rc >> 24
+        if tx0 > tx1:
+            continue
+        for ty in range(ty0, ty1 + 1):
+            for tx in range(tx0, tx1 + 1):
+                lists[ty * tiles_x + tx].append(rank)
+    return lists
+
+
+@pytest.mark.parametrize("W,H", [(640, 360), (333, 211), (16, 16)])
+def test_tile_lists_exact(W, H):
+    cloud = scenes.cloud_from_attrs(scenes.hard_attrs(2500, 5))
+    view = scenes.default_view(W, H)
+    r, img, ref = run_frame(cloud, view)
+    rec, rect = r.debug_projected()
+    st = r.stats()
+    ts, pairs = r.debug_tile_lists()
+    exp = _expected_tile_lists(rect, st["tiles_x"], st["tiles_y"])
+    assert st["pairs"] == sum(len(e) for e in exp)
+    assert ts[-1] == st["pairs"]
+    for t, e in enumerate(exp):
+        got = pairs[ts[t]:ts[t + 1]] & 0xFFFFFF
+        assert got.tolist() == e, "tile %d" % t
+
+
+# ------------------------------------------------------------------------------------------------
+# stage 4: framebuffer
+# ------------------------------------------------------------------------------------------------
+
+def test_image_test_ply_config1(golden_dir):
+    """BASELINE config 1: data/test.ply, 640x480, --nosh, camera from test_vr.json"""
+    import os
+    from splatapult_amd import GaussianCloud
+    gc = GaussianCloud(GaussianCloud.Options(False, False))
+    assert gc.ImportPly(os.path.join(golden_dir, "test.ply"))
+    cam = camera.camera_from_vr_json(os.path.join(golden_dir, "test_vr.json"))
+    W, H = 640, 480
+    view = (cam, camera.perspective(camera.FOVY, W / H), [0, 0, W, H], scenes.NF)
+    r, img, ref = run_frame(gc, view, full_sh=False)
+    assert ref["V"] == 16
+    np.testing.assert_array_equal(r.sorted_indices(), ref["sorted_idx"])
+    check_image(img, ref["image"])
+    assert img[..., :3].max() > 0.9
+
+
+@pytest.mark.parametrize("n,W,H,seed,full_sh", [(3000, 320, 240, 31, True), (20000, 640, 360, 32, True),
+                                               (20000, 500, 301, 33, False)])
+def test_image_matches_oracle(n, W, H, seed, full_sh):
+    cloud = scenes.synth_cloud(n, seed, full_sh=full_sh, log_scale_mean=-3.3)
+    view = scenes.default_view(W, H, yaw=0.2)
+    r, img, ref = run_frame(cloud, view, full_sh=full_sh)
+    check_image(img, ref["image"])
+
+
+def test_image_exact_mode_no_early_termination():
+    """t_epsilon = 0: no early-out; the only differences left are fp32 association + exp ulps"""
+    cloud = scenes.synth_cloud(8000, 41, log_scale_mean=-3.0)
+    view = scenes.default_view(400, 300)
+    r, img, ref = run_frame(cloud, view, t_epsilon=0.0)
+    check_image(img, ref["image"], mean_abs=2e-5)
+
+
+def test_image_hard_cases():
+    cloud = scenes.cloud_from_attrs(scenes.hard_attrs())
+    for yaw, z in ((0.0, 7.0), (0.9, 3.0)):
+        view = scenes.default_view(640, 480, yaw=yaw, z=z)
+        r, img, ref = run_frame(cloud, view)
+        check_image(img, ref["image"])
+
+
+def test_image_srgb_flag():
+    cloud = scenes.synth_cloud(4000, 51, log_scale_mean=-3.0)
+    view = scenes.default_view(320, 240)
+    r, img, ref = run_frame(cloud, view, srgb=True)
+    ok = np.isfinite(ref["image"]).all(axis=-1)          # pow() of a negative colour is NaN in both
+    assert ok.mean() > 0.5
+    d = np.abs(img[ok] - ref["image"][ok])
+    assert (d[..., :3] <= 1e-4).mean() >= 0.999 and d[..., :3].max() <= 2e-2
+
+
+def test_two_views_share_one_sort():
+    """XR contract (app.cpp:603-607): Sort with view 0 only, Render both eyes"""
+    cloud = scenes.synth_cloud(10000, 61, log_scale_mean=-3.2)
+    W, H = 504, 560
+    cam0 = camera.pose((0.0, 0.0, 7.0))
+    eyes = [camera.translate_local(cam0, dx=-0.032), camera.translate_local(cam0, dx=+0.032)]
+    projs = [camera.create_projection(-1.0, 0.8, 0.95, -0.95), camera.create_projection(-0.8, 1.0, 0.95, -0.95)]
+    vp, nf = [0, 0, W, H], scenes.NF
+    r = make_renderer(cloud)
+    r.Sort(eyes[0], projs[0], vp, nf)
+    for e in range(2):
+        img = r.Render(eyes[e], projs[e], vp, nf)
+        ref = orc.render_frame(cloud.as_array(), True, eyes[0], projs[0], vp, nf, render_cam=eyes[e],
+                               render_proj=projs[e], nthreads=8)
+        check_image(img, ref["image"])
+
+
+def test_fp16_framebuffer():
+    cloud = scenes.synth_cloud(8000, 71, log_scale_mean=-3.2)
+    view = scenes.default_view(320, 240)
+    cam, proj, vp, nf = view
+    r = make_renderer(cloud, fb_format="fp16")
+    r.Sort(cam, proj, vp, nf)
+    img = r.Render(cam, proj, vp, nf)
+    assert img.dtype == np.float16
+    ref = orc.render_frame(cloud.as_array(), True, cam, proj, vp, nf, nthreads=8)["image"]
+    ulp = np.abs(ref) * 2.0 ** -10
+    d = np.abs(img.astype(np.float32) - ref)
+    assert ((d <= 2e-3 + ulp) | (d <= 2e-2)).all()
+    assert (d <= 2e-3 + ulp).mean() > 0.999
+    assert (img[..., 3] == 1).all()
+
+
+def test_row_bands_reassemble_bit_exact():
+    """multi-GPU sharding: interleaved tile rows rendered by separate contexts == single-context image"""
+    cloud = scenes.synth_cloud(12000, 81, log_scale_mean=-3.2)
+    view = scenes.default_view(640, 360, yaw=0.3)
+    cam, proj, vp, nf = view
+    r = make_renderer(cloud)
+    r.Sort(cam, proj, vp, nf)
+    full = r.Render(cam, proj, vp, nf)
+    for G in (2, 3, 8):
+        acc = np.zeros_like(full)
+        for g in range(G):
+            rb = make_renderer(cloud)
+            rb.set_band(G, g)
+            rb.Sort(cam, proj, vp, nf)
+            part = rb.Render(cam, proj, vp, nf)
+            rows = np.arange(360) // 16 % G == g
+            assert (part[~rows] == 0).all()
+            acc[rows] = part[rows]
+        np.testing.assert_array_equal(acc, full)
+
+
+def test_render_before_sort_and_bad_viewport_errors():
+    from splatapult_amd import MsplatError
+    cloud = scenes.synth_cloud(10, 1)
+    cam, proj, vp, nf = scenes.default_view(64, 64)
+    r = make_renderer(cloud)
+    with pytest.raises(MsplatError):
+        r.Render(cam, proj, vp, nf)
+    with pytest.raises(MsplatError):
+        r.Sort(cam, proj, [0, 0, 5000, 100], nf)
+
+
+# ------------------------------------------------------------------------------------------------
+# full size (BASELINE config 2): exact sort parity + size-independent properties
+# ------------------------------------------------------------------------------------------------
+
+def test_full_size_config2_sort_and_properties():
+    n, W, H = 1_000_000, 1920, 1080
+    cloud = scenes.synth_cloud(n, 0x5EED1234)
+    cam, proj, vp, nf = scenes.default_view(W, H, z=7.0)
+    r = make_renderer(cloud)
+    r.Sort(cam, proj, vp, nf)
+    aos = cloud.as_array()
+    mvp = orc.mat4_mul(proj, orc.mat4_inverse(cam))
+    keys, idx = orc.sort(*orc.presort(aos, mvp, nf[1]))
+    gk, gi = r.sorted_keys(), r.sorted_indices()
+    np.testing.assert_array_equal(gk, keys)
+    np.testing.assert_array_equal(gi, idx)
+    assert (np.diff(gk.astype(np.int64)) >= 0).all()              # sortedness
+    assert np.unique(gi).shape[0] == gi.shape[0]                  # a permutation of the visible set
+    img = r.Render(cam, proj, vp, nf)
+    st = r.stats()
+    assert st["sort_count"] == keys.shape[0] and st["pairs"] > st["drawn"] > 0
+    assert np.isfinite(img).all() and (img[..., 3] == 1).all()
+    # idempotence: rendering again from the same sort is bit-identical
+    np.testing.assert_array_equal(r.Render(cam, proj, vp, nf), img)
+    # linearity in colour is not available (SH offsets), but the image must be invariant to splat order
+    # in the cloud when no keys tie: render a shuffled copy
+    ts, pairs = r.debug_tile_lists()
+    assert (np.diff(ts.astype(np.int64)) >= 0).all() and ts[-1] == st["pairs"]
+    # every tile list is strictly increasing in rank (draw order preserved inside tiles)
+    ranks = (pairs & 0xFFFFFF).astype(np.int64)
+    d = np.diff(ranks)
+    starts = ts[1:-1][(ts[1:-1] > 0) & (ts[1:-1] < ranks.shape[0])]
+    d[starts - 1] = 1
+    assert (d > 0).all()
+    # bounded oracle comparison: a 256x256 window of the full frame
+    ref = orc.render_frame(aos, True, cam, proj, vp, nf, nthreads=8, want_image=False, want_splats=True)
+    y0, y1 = 412, 668
+    win = orc.composite(ref["splats"], W, H, nthreads=8, row0=y0, row1=y1)
+    check_image(img[y0:y1], win[y0:y1])

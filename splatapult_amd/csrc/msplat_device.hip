@@ -47,12 +47,12 @@ struct msplat_ctx {
     Buf keyA, keyB, valA, valB;   // uint32[N]; final sorted result in keyA/valA
     Buf hist;       // uint32[256 * hist_stride]
     uint32_t hist_stride = 0;
-    Buf totals;     // uint32[256]
+    Buf totals;     // uint32[256]  digit totals of the current radix pass (rows in binning pass 2)
+    Buf totals1;    // uint32[256]  column totals of binning pass 1
     Buf counters;   // uint32[8]: 0=V, 1=D, 2=overflow, 3=drawn
     // render state
     Buf rec2d;      // float4[3*N]
     Buf rect;       // uint32[N]
-    Buf tile_count; // uint32[65536]
     Buf tile_start; // uint32[65537]
     Buf hist1;      // uint32[256 * hist1_stride]
     uint32_t hist1_stride = 0;
@@ -192,7 +192,7 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
     }
     int rc = buf_alloc(ctx, ctx->totals, 256 * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->counters, 8 * sizeof(uint32_t));
-    if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_count, 65536 * sizeof(uint32_t));
+    if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->totals1, 256 * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_start, 65537 * sizeof(uint32_t));
     if (rc == MSPLAT_OK && hipMemsetAsync(ctx->counters.p, 0, 8 * sizeof(uint32_t), ctx->stream) != hipSuccess)
         rc = MSPLAT_ERR_HIP;
@@ -212,7 +212,7 @@ void msplat_destroy(msplat_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     Buf* all[] = {&ctx->pos4, &ctx->recs, &ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist,
-                  &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->tile_count, &ctx->tile_start,
+                  &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->totals1, &ctx->tile_start,
                   &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb};
     for (Buf* b : all) buf_free(ctx, *b);
     if (ctx->ev_ok)
@@ -396,7 +396,7 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
     hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, hist, ctx->hist_stride, nullptr, N, N,
                        (uint32_t)kSortChunk, totals);
     hipLaunchKernelGGL((radix_downsweep<MODE_CULL, true>), dim3(grid), dim3(kThreads), 0, s, nullptr, nullptr, pos,
-                       nullptr, N, N, 0, hist, ctx->hist_stride, totals, kB, vB, d_V, fp);
+                       nullptr, N, N, 0, hist, ctx->hist_stride, totals, kB, vB, d_V, nullptr, fp);
     // passes 1..3 on the V survivors (V stays on the device; splatrenderer.cpp:195-204's readback is gone)
     for (int pass = 1; pass < 4; ++pass) {
         uint32_t* kin = (pass & 1) ? kB : kA;
@@ -408,7 +408,7 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
         hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, hist, ctx->hist_stride, d_V, 0u, N,
                            (uint32_t)kSortChunk, totals);
         hipLaunchKernelGGL((radix_downsweep<MODE_KEYS, true>), dim3(grid), dim3(kThreads), 0, s, kin, vin, nullptr,
-                           d_V, 0u, N, pass * 8, hist, ctx->hist_stride, totals, kout, vout, nullptr, fp);
+                           d_V, 0u, N, pass * 8, hist, ctx->hist_stride, totals, kout, vout, nullptr, nullptr, fp);
     }
     if (ctx->ev_ok) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
@@ -429,40 +429,40 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const uint32_t cap = (uint32_t)ctx->pair_cap;
 
     if (ctx->ev_ok) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->tile_count.p, 0, (size_t)std::max(ntiles, 1) * sizeof(uint32_t), s));
     HIP_TRY(ctx, hipMemsetAsync(d_D, 0, 3 * sizeof(uint32_t), s));
     const int pgrid = std::max(1u, div_up(N, kThreads));
     if (ctx->full_sh)
         hipLaunchKernelGGL(project_kernel<true>, dim3(pgrid), dim3(kThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
-                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
-                           (uint32_t*)ctx->tile_count.p, d_drawn);
+                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, d_drawn);
     else
         hipLaunchKernelGGL(project_kernel<false>, dim3(pgrid), dim3(kThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
-                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
-                           (uint32_t*)ctx->tile_count.p, d_drawn);
+                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, d_drawn);
     if (ctx->ev_ok) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
 
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)ctx->tile_count.p, ntiles,
-                       (uint32_t*)ctx->tile_start.p, d_D, cap, d_overflow);
     // pass 1: stable partition by tile column, enumerated from the rank-ordered rectangles
+    uint32_t* totals1 = (uint32_t*)ctx->totals1.p;
+    uint32_t* totals2 = (uint32_t*)ctx->totals.p;
     const int g1 = grid_for(div_up(N, kBinChunk));
     hipLaunchKernelGGL(bin1_upsweep, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
                        (uint32_t*)ctx->hist1.p, ctx->hist1_stride);
     hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V,
-                       0u, N, (uint32_t)kBinChunk, (uint32_t*)ctx->totals.p);
+                       0u, N, (uint32_t)kBinChunk, totals1);
     hipLaunchKernelGGL(bin1_downsweep, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
-                       (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)ctx->totals.p,
-                       (uint32_t*)ctx->pairsA.p, cap, fp.tiles_x);
-    // pass 2: stable partition by tile row (one generic radix pass on the top byte)
+                       (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,
+                       (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow);
+    // pass 2: stable partition by tile row (one generic radix pass on the top byte); words become (tx<<24)|rank
     const int g2 = grid_for(div_up(cap, kSortChunk));
     hipLaunchKernelGGL(radix_upsweep<MODE_PAIR>, dim3(g2), dim3(kThreads), 0, s, (const uint32_t*)ctx->pairsA.p,
                        nullptr, d_D, 0u, cap, 24, (uint32_t*)ctx->hist2.p, ctx->hist2_stride, fp);
     hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, (uint32_t*)ctx->hist2.p, ctx->hist2_stride, d_D,
-                       0u, cap, (uint32_t)kSortChunk, (uint32_t*)ctx->totals.p);
+                       0u, cap, (uint32_t)kSortChunk, totals2);
     hipLaunchKernelGGL((radix_downsweep<MODE_PAIR, false>), dim3(g2), dim3(kThreads), 0, s,
                        (const uint32_t*)ctx->pairsA.p, nullptr, nullptr, d_D, 0u, cap, 24,
-                       (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)ctx->totals.p,
-                       (uint32_t*)ctx->pairsB.p, nullptr, nullptr, fp);
+                       (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
+                       (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1, fp);
+    hipLaunchKernelGGL(tile_start_kernel, dim3(std::max(1, (ntiles + kThreads) / kThreads)), dim3(kThreads), 0, s,
+                       (const uint32_t*)ctx->pairsB.p, (const uint32_t*)totals2, d_D, cap, fp.tiles_x, ntiles,
+                       (uint32_t*)ctx->tile_start.p);
     if (ctx->ev_ok) HIP_TRY(ctx, hipEventRecord(ctx->ev[4], s));
 
     if (ntiles > 0) {

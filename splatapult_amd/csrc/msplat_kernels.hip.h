@@ -174,8 +174,10 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
                                                             uint32_t* __restrict__ keys_out,
                                                             uint32_t* __restrict__ vals_out,
                                                             uint32_t* __restrict__ d_count_out,
+                                                            const uint32_t* __restrict__ col_totals,
                                                             FrameParams fp)
 {
+    __shared__ uint32_t s_col[MODE == MODE_PAIR ? 256 : 1];   // MODE_PAIR: first input position of each column
     __shared__ uint32_t s_cnt[4][256];   // per-wave digit counters, then per-wave scatter bases
     __shared__ uint32_t s_base[256];     // exclusive scan of the digit totals
     __shared__ uint32_t s_tmp[4];
@@ -193,6 +195,12 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
         const uint32_t incl = block_incl_scan(t, s_tmp, tot);
         s_base[threadIdx.x] = incl - t;
         if (d_count_out != nullptr && blockIdx.x == 0 && threadIdx.x == 255) *d_count_out = incl;
+    }
+    if (MODE == MODE_PAIR) {
+        const uint32_t t = col_totals[threadIdx.x];
+        uint32_t tot;
+        const uint32_t incl = block_incl_scan(t, s_tmp, tot);
+        s_col[threadIdx.x] = incl - t;
     }
     __syncthreads();
 
@@ -258,7 +266,20 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
             if (valid[r]) {
                 const uint32_t d = digit_of<MODE>(key[r], shift);
                 const uint32_t dst = s_cnt[w][d] + lrank[r];
-                keys_out[dst] = key[r];
+                uint32_t kout = key[r];
+                if (MODE == MODE_PAIR) {
+                    // input is ordered by (column, rank): recover the column from the input position and
+                    // store (tx << 24) | rank, so each row of the result is ascending (tile_start_kernel)
+                    const uint32_t i = base + r * 64 + lane;
+                    uint32_t lo = 0, hi = 255;            // last c with s_col[c] <= i
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        const uint32_t mid = (lo + hi + 1u) >> 1;
+                        if (s_col[mid] <= i) lo = mid; else hi = mid - 1u;
+                    }
+                    kout = (lo << 24) | (key[r] & kRankMask);
+                }
+                keys_out[dst] = kout;
                 if (HAS_VALUES) vals_out[dst] = val[r];
             }
         }
@@ -285,7 +306,6 @@ __global__ __launch_bounds__(kThreads) void project_kernel(const uint32_t* __res
                                                            FrameParams fp,
                                                            float4* __restrict__ out_rec,
                                                            uint32_t* __restrict__ out_rect,
-                                                           uint32_t* __restrict__ tile_count,
                                                            uint32_t* __restrict__ d_drawn)
 {
     constexpr int F4 = FULL_SH ? 16 : 7;
@@ -438,9 +458,7 @@ __global__ __launch_bounds__(kThreads) void project_kernel(const uint32_t* __res
             }
             if (ty0 <= ty1) {
                 rect = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
-                for (int ty = ty0; ty <= ty1; ++ty)
-                    for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&tile_count[ty * fp.tiles_x + tx], 1u);
-                atomicAdd(d_drawn, 1u);
+                atomicAdd(d_drawn, 1u);      // wave-aggregated by the compiler: one atomic per wave
             }
         }
     }
@@ -457,57 +475,22 @@ __global__ __launch_bounds__(kThreads) void project_kernel(const uint32_t* __res
     out_rect[r] = rect;
 }
 
-// exclusive scan of the per-tile pair counts (<= 65536 tiles) -> tile_start[ntiles+1]; D -> d_D
-__global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ tile_count, int ntiles,
-                                                         uint32_t* __restrict__ tile_start,
-                                                         uint32_t* __restrict__ d_D, uint32_t cap,
-                                                         uint32_t* __restrict__ d_overflow)
-{
-    __shared__ uint32_t s_wave[16];
-    const int per = (ntiles + 1023) / 1024;
-    const int begin = threadIdx.x * per;
-    uint32_t sum = 0;
-    for (int k = 0; k < per; ++k) {
-        const int i = begin + k;
-        if (i < ntiles) sum += tile_count[i];
-    }
-    // block exclusive scan over 1024 threads (16 waves)
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t v = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    if (lane == 63) s_wave[w] = v;
-    __syncthreads();
-    uint32_t off = 0, total = 0;
-    for (int k = 0; k < 16; ++k) {
-        const uint32_t s = s_wave[k];
-        if (k < w) off += s;
-        total += s;
-    }
-    uint32_t run = off + v - sum;
-    for (int k = 0; k < per; ++k) {
-        const int i = begin + k;
-        if (i < ntiles) {
-            tile_start[i] = run;
-            run += tile_count[i];
-        }
-    }
-    if (threadIdx.x == 0) {
-        tile_start[ntiles] = total;
-        *d_D = total;
-        if (total > cap) *d_overflow = total;
-    }
-}
+// ------------------------------------------------------------------------------------------
+// tile binning.  The splats are already in global depth order (rank).  Two STABLE partitions of the
+// (splat, tile) pairs -- first by tile column, then by tile row -- leave every tile's list in
+// draw order without ever sorting on depth again:
+//   pass 1 (bin1_*):  pairs are enumerated on the fly from the rank-ordered rectangles and
+//                     partitioned by column tx;       word = (row << 24) | rank
+//   pass 2 (radix_*<MODE_PAIR>): partition by the row byte; the downsweep rewrites the word to
+//                     (tx << 24) | rank (tx recovered from the input position), so that inside a
+//                     row the words are ascending and tile_start_kernel can binary-search them.
+// ------------------------------------------------------------------------------------------
 
-// ------------------------------------------------------------------------------------------
-// tile binning, pass 1: stable partition of (splat,tile) pairs by tile COLUMN, enumerated on the
-// fly from the rank-ordered rectangles ("bin-parallel": thread tx owns column tx and walks the
-// chunk's rectangles in rank order, so stability needs no ranking or atomics).
-// Output word = (row << 24) | rank;  pass 2 is radix_*<MODE_PAIR> on the row byte.
-// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rect_width(uint32_t rc)
+{
+    const uint32_t tx0 = rc & 255u, tx1 = (rc >> 16) & 255u;
+    return tx0 <= tx1 ? tx1 - tx0 + 1u : 0u;
+}
 
 __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restrict__ rect,
                                                          const uint32_t* __restrict__ d_V,
@@ -528,6 +511,7 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
                 const uint32_t rc = rect[r];
                 const uint32_t tx0 = rc & 255u, ty0 = (rc >> 8) & 255u, tx1 = (rc >> 16) & 255u, ty1 = rc >> 24;
                 if (tx0 <= tx1) {
+                    // pairs per column = sum of row counts of the rectangles covering it: difference array
                     const uint32_t rows = ty1 - ty0 + 1u;
                     atomicAdd(&s_diff[tx0], rows);
                     atomicAdd(&s_diff[tx1 + 1u], 0u - rows);
@@ -542,52 +526,166 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
     }
 }
 
+// Splat-parallel stable partition by column.  Items = (rank, column) "column pairs" in (rank, tx)
+// order, weight = number of tile rows; wave w takes a contiguous quarter of the chunk's items, so
+// (wave, round, lane) order == item order.  Ranking inside a wave: ballot-match on the column byte,
+// weighted prefix from 9 ballots over the bits of the weight (rows <= 256).
 __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __restrict__ rect,
                                                            const uint32_t* __restrict__ d_V,
                                                            const uint32_t* __restrict__ hist, uint32_t hist_stride,
                                                            const uint32_t* __restrict__ totals,
                                                            uint32_t* __restrict__ pairs_out, uint32_t cap,
-                                                           int tiles_x)
+                                                           uint32_t* __restrict__ d_D,
+                                                           uint32_t* __restrict__ d_overflow)
 {
+    constexpr int PER = kBinChunk / kThreads;          // rectangles per thread (blocked)
+    __shared__ uint32_t s_off[kBinChunk + 1];          // exclusive scan of the rectangle widths
     __shared__ uint32_t s_rect[kBinChunk];
+    __shared__ uint32_t s_cnt[4][256];                 // per-wave column weights, then per-wave cursors
     __shared__ uint32_t s_base[kThreads];
     __shared__ uint32_t s_tmp[4];
     const uint32_t V = *d_V;
     const uint32_t nchunks = (V + kBinChunk - 1) / kBinChunk;
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
     {
         const uint32_t t = totals[threadIdx.x];
         uint32_t tot;
         const uint32_t incl = block_incl_scan(t, s_tmp, tot);
         s_base[threadIdx.x] = incl - t;
+        if (blockIdx.x == 0 && threadIdx.x == 255) {
+            *d_D = incl;
+            if (incl > cap) *d_overflow = incl;
+        }
     }
     __syncthreads();
+
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const uint32_t rbase = chunk * kBinChunk;
+        uint32_t rc[PER], woff[PER], wsum = 0;
 #pragma unroll
-        for (int k = 0; k < kBinChunk / kThreads; ++k) {
-            const uint32_t j = k * kThreads + threadIdx.x;
-            s_rect[j] = (rbase + j < V) ? rect[rbase + j] : kRectEmpty;
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t r = rbase + threadIdx.x * PER + k;
+            rc[k] = (r < V) ? rect[r] : kRectEmpty;
+            woff[k] = wsum;
+            wsum += rect_width(rc[k]);
+        }
+        uint32_t M;
+        const uint32_t incl = block_incl_scan(wsum, s_tmp, M);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            s_off[threadIdx.x * PER + k] = incl - wsum + woff[k];
+            s_rect[threadIdx.x * PER + k] = rc[k];
+        }
+        if (threadIdx.x == 0) s_off[kBinChunk] = M;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
+        __syncthreads();
+
+        const uint32_t per_wave = (((M + 3u) >> 2) + 63u) & ~63u;    // multiple of 64
+        const uint32_t wbeg = (uint32_t)w * per_wave;
+        const uint32_t wend = min(M, wbeg + per_wave);
+
+        // item k -> (owner rectangle j, column tx, rows, first row)
+        auto locate = [&](uint32_t k, uint32_t& tx, uint32_t& rows, uint32_t& ty0, uint32_t& rank) {
+            uint32_t lo = 0, hi = kBinChunk - 1;      // last j with s_off[j] <= k (1024 candidates: 10 steps)
+#pragma unroll
+            for (int s = 0; s < 10; ++s) {
+                const uint32_t mid = (lo + hi + 1u) >> 1;
+                if (s_off[mid] <= k) lo = mid; else hi = mid - 1u;
+            }
+            const uint32_t r = s_rect[lo];
+            tx = (r & 255u) + (k - s_off[lo]);
+            ty0 = (r >> 8) & 255u;
+            rows = (r >> 24) - ty0 + 1u;
+            rank = rbase + lo;
+        };
+
+        // pass A: column weights per wave
+        for (uint32_t k = wbeg + lane; k < wend; k += 64) {
+            uint32_t tx, rows, ty0, rank;
+            locate(k, tx, rows, ty0, rank);
+            atomicAdd(&s_cnt[w][tx], rows);
         }
         __syncthreads();
-        const uint32_t tx = threadIdx.x;
-        if ((int)tx < tiles_x) {
-            uint32_t cursor = s_base[tx] + hist[(size_t)tx * hist_stride + chunk];
-            const uint32_t cnt = min((uint32_t)kBinChunk, V - rbase);
-            for (uint32_t j = 0; j < cnt; ++j) {
-                const uint32_t rc = s_rect[j];
-                const uint32_t tx0 = rc & 255u, tx1 = (rc >> 16) & 255u;
-                if (tx >= tx0 && tx <= tx1) {
-                    const uint32_t ty0 = (rc >> 8) & 255u, ty1 = rc >> 24;
-                    const uint32_t rank = rbase + j;
-                    for (uint32_t ty = ty0; ty <= ty1; ++ty) {
-                        if (cursor < cap) pairs_out[cursor] = (ty << 24) | rank;
-                        ++cursor;
-                    }
-                }
+        {
+            const int d = threadIdx.x;
+            const uint32_t g = s_base[d] + hist[(size_t)d * hist_stride + chunk];
+            const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d];
+            s_cnt[0][d] = g;
+            s_cnt[1][d] = g + c0;
+            s_cnt[2][d] = g + c0 + c1;
+            s_cnt[3][d] = g + c0 + c1 + c2;
+        }
+        __syncthreads();
+
+        // pass B: rank inside the wave, advance the wave's column cursors, emit the words
+        for (uint32_t kb = wbeg; kb < wend; kb += 64) {          // wave-uniform trip count
+            const uint32_t k = kb + lane;
+            const bool valid = k < wend;
+            uint32_t tx = 0, rows = 0, ty0 = 0, rank = 0;
+            if (valid) locate(k, tx, rows, ty0, rank);
+            uint64_t m = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (tx >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            uint32_t pre = 0, tot = 0;
+#pragma unroll
+            for (int b = 0; b < 9; ++b) {
+                const uint64_t bal = __ballot(valid && ((rows >> b) & 1u)) & m;
+                pre += (uint32_t)__popcll(bal & lt_mask) << b;
+                tot += (uint32_t)__popcll(bal) << b;
+            }
+            uint32_t prev = 0;
+            if (valid) prev = s_cnt[w][tx];
+            __builtin_amdgcn_wave_barrier();
+            if (valid && (m & lt_mask) == 0) s_cnt[w][tx] = prev + tot;
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                const uint32_t pos = prev + pre;
+                for (uint32_t q = 0; q < rows; ++q)
+                    if (pos + q < cap) pairs_out[pos + q] = ((ty0 + q) << 24) | rank;
             }
         }
         __syncthreads();
     }
+}
+
+// per tile: first position of its list in the final pair array.  The array is sorted by (row, word)
+// with word = (tx << 24) | rank, so inside row vty the words are ascending: lower_bound(tx << 24).
+__global__ __launch_bounds__(kThreads) void tile_start_kernel(const uint32_t* __restrict__ pairs,
+                                                              const uint32_t* __restrict__ row_totals,
+                                                              const uint32_t* __restrict__ d_D, uint32_t cap,
+                                                              int tiles_x, int ntiles,
+                                                              uint32_t* __restrict__ tile_start)
+{
+    __shared__ uint32_t s_row[kThreads + 1];
+    __shared__ uint32_t s_tmp[4];
+    {
+        const uint32_t t = row_totals[threadIdx.x];
+        uint32_t tot;
+        const uint32_t incl = block_incl_scan(t, s_tmp, tot);
+        s_row[threadIdx.x] = incl - t;
+        if (threadIdx.x == 255) s_row[256] = incl;
+    }
+    __syncthreads();
+    const uint32_t D = min(*d_D, cap);
+    const int tile = blockIdx.x * kThreads + threadIdx.x;
+    if (tile == 0) tile_start[ntiles] = D;
+    if (tile >= ntiles) return;
+    const int vty = tile / tiles_x;
+    const uint32_t tx = (uint32_t)(tile - vty * tiles_x);
+    uint32_t lo = min(s_row[vty], D), hi = min(s_row[vty + 1], D);
+    const uint32_t key = tx << 24;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pairs[mid] < key) lo = mid + 1u; else hi = mid;
+    }
+    tile_start[tile] = lo;
 }
 
 // ------------------------------------------------------------------------------------------

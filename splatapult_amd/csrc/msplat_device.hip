@@ -42,7 +42,7 @@ struct msplat_ctx {
     bool has_cloud = false;
     bool has_sort = false;
     Buf pos4;       // float4[N]  (x, y, z, 1)            -- the reference's posVec (splatrenderer.cpp:106-111)
-    Buf recs;       // padded AoS: 16 (full SH) or 7 float4 per splat, reference float offsets preserved
+    Buf recs;       // padded AoS: 16 (full SH) or 8 float4 per splat, reference float offsets preserved
     // sort state
     Buf keyA, keyB, valA, valB;   // uint32[N]; final sorted result in keyA/valA
     Buf hist;       // uint32[256 * hist_stride]
@@ -260,7 +260,7 @@ int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t s
     ctx->has_render = false;
     ctx->N = n;
     ctx->full_sh = full_sh != 0;
-    const int F4 = ctx->full_sh ? 16 : 7;
+    const int F4 = ctx->full_sh ? 16 : 8;
     const size_t alloc_n = std::max<uint64_t>(n, 1);
     int rc;
     if ((rc = buf_alloc(ctx, ctx->pos4, alloc_n * 16))) return rc;
@@ -314,7 +314,7 @@ int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t s
                 for (int k = 0; k < 9; ++k) std::memcpy(d + 25 + 4 * k, rec + src_off_full[k], 16);
                 d[61] = d[62] = d[63] = 0.0f;
             } else {
-                d[25] = d[26] = d[27] = 0.0f;
+                for (int k = 25; k < 32; ++k) d[k] = 0.0f;
             }
             float* p = stage_pos.data() + j * 4;
             p[0] = d[0]; p[1] = d[1]; p[2] = d[2]; p[3] = 1.0f;
@@ -424,19 +424,19 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     hipStream_t s = ctx->stream;
     const uint32_t N = (uint32_t)ctx->N;
     uint32_t* counters = (uint32_t*)ctx->counters.p;
-    uint32_t *d_V = counters + 0, *d_D = counters + 1, *d_overflow = counters + 2, *d_drawn = counters + 3;
+    uint32_t *d_V = counters + 0, *d_D = counters + 1, *d_overflow = counters + 2;
     const int ntiles = fp.tiles_x * fp.tiles_y;
     const uint32_t cap = (uint32_t)ctx->pair_cap;
 
     if (ctx->ev_ok) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
-    HIP_TRY(ctx, hipMemsetAsync(d_D, 0, 3 * sizeof(uint32_t), s));
-    const int pgrid = std::max(1u, div_up(N, kThreads));
+    HIP_TRY(ctx, hipMemsetAsync(d_D, 0, 2 * sizeof(uint32_t), s));
+    const int pgrid = std::max(1u, div_up(N, kProjThreads));
     if (ctx->full_sh)
-        hipLaunchKernelGGL(project_kernel<true>, dim3(pgrid), dim3(kThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
-                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, d_drawn);
+        hipLaunchKernelGGL(project_kernel<true>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
+                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p);
     else
-        hipLaunchKernelGGL(project_kernel<false>, dim3(pgrid), dim3(kThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
-                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, d_drawn);
+        hipLaunchKernelGGL(project_kernel<false>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
+                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p);
     if (ctx->ev_ok) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
 
     // pass 1: stable partition by tile column, enumerated from the rank-ordered rectangles
@@ -571,6 +571,12 @@ int msplat_get_stats(msplat_ctx* ctx, msplat_stats* out)
     if (!ctx || !out) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     uint32_t cnt[4] = {0, 0, 0, 0};
+    if (ctx->has_render) {   // "drawn" is a statistic only: counted on demand, not in the frame
+        uint32_t* counters = (uint32_t*)ctx->counters.p;
+        HIP_TRY(ctx, hipMemsetAsync(counters + 3, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(count_drawn_kernel, dim3(256), dim3(kThreads), 0, ctx->stream, (const uint32_t*)ctx->rect.p,
+                           counters + 0, counters + 3);
+    }
     HIP_TRY(ctx, hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     std::memset(out, 0, sizeof(*out));

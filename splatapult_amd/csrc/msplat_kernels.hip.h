@@ -299,27 +299,53 @@ __device__ __forceinline__ float srgb_to_linear(float s)
     return powf((s + 0.055f) / 1.055f, 2.4f);
 }
 
+constexpr int kProjThreads = 64;          // one wave per workgroup: wave-private LDS staging, no block barriers
+
 template <bool FULL_SH>
-__global__ __launch_bounds__(kThreads) void project_kernel(const uint32_t* __restrict__ sorted_idx,
-                                                           const uint32_t* __restrict__ d_V,
-                                                           const float4* __restrict__ recs,
-                                                           FrameParams fp,
-                                                           float4* __restrict__ out_rec,
-                                                           uint32_t* __restrict__ out_rect,
-                                                           uint32_t* __restrict__ d_drawn)
+__global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* __restrict__ sorted_idx,
+                                                               const uint32_t* __restrict__ d_V,
+                                                               const float4* __restrict__ recs,
+                                                               FrameParams fp,
+                                                               float4* __restrict__ out_rec,
+                                                               uint32_t* __restrict__ out_rect)
 {
-    constexpr int F4 = FULL_SH ? 16 : 7;
+    // Records are 256 B (full SH) or 128 B (base) and line aligned.  The gather by sorted index is
+    // done cooperatively: F4 consecutive lanes fetch one whole record (coalesced 256/128 B), the wave
+    // stages 64 records in LDS, then every lane reads its own record back (stride 68/36 dwords keeps
+    // the ds_read_b128 accesses conflict free).
+    constexpr int F4 = FULL_SH ? 16 : 8;
+    constexpr int RPI = 64 / F4;              // records fetched per wave-wide load instruction
+    constexpr int STRIDE = F4 * 4 + 4;        // dwords
+    __shared__ __attribute__((aligned(16))) float s_stage[64 * STRIDE];
     const uint32_t V = *d_V;
-    const uint32_t r = blockIdx.x * kThreads + threadIdx.x;
-    if (r >= V) return;
-    const uint32_t i = sorted_idx[r];
-    const float4* src = recs + (size_t)i * F4;
+    const int lane = threadIdx.x;
+    if (blockIdx.x * kProjThreads >= V) return;
+    const uint32_t r = blockIdx.x * kProjThreads + lane;
+    const bool valid = r < V;
+    const uint32_t i = valid ? sorted_idx[r] : 0u;
+    {
+        const int sub = lane % F4;
+        float4 tmp[F4];
+#pragma unroll
+        for (int it = 0; it < F4; ++it) {
+            const int owner = it * RPI + lane / F4;
+            const uint32_t oi = __shfl(i, owner, 64);
+            tmp[it] = recs[(size_t)oi * F4 + sub];
+        }
+#pragma unroll
+        for (int it = 0; it < F4; ++it) {
+            const int owner = it * RPI + lane / F4;
+            *reinterpret_cast<float4*>(&s_stage[owner * STRIDE + sub * 4]) = tmp[it];
+        }
+    }
+    __syncthreads();
     float f[F4 * 4];
 #pragma unroll
     for (int k = 0; k < F4; ++k) {
-        const float4 v = src[k];
+        const float4 v = *reinterpret_cast<const float4*>(&s_stage[lane * STRIDE + k * 4]);
         f[4 * k + 0] = v.x; f[4 * k + 1] = v.y; f[4 * k + 2] = v.z; f[4 * k + 3] = v.w;
     }
+    if (!valid) return;
     const float x = f[0], y = f[1], z = f[2], alpha = f[3];
     const float* vm = fp.view;
     const float* pm = fp.proj;
@@ -458,7 +484,6 @@ __global__ __launch_bounds__(kThreads) void project_kernel(const uint32_t* __res
             }
             if (ty0 <= ty1) {
                 rect = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
-                atomicAdd(d_drawn, 1u);      // wave-aggregated by the compiler: one atomic per wave
             }
         }
     }
@@ -475,6 +500,26 @@ __global__ __launch_bounds__(kThreads) void project_kernel(const uint32_t* __res
     out_rect[r] = rect;
 }
 
+__device__ __forceinline__ uint32_t rect_width(uint32_t rc)
+{
+    const uint32_t tx0 = rc & 255u, tx1 = (rc >> 16) & 255u;
+    return tx0 <= tx1 ? tx1 - tx0 + 1u : 0u;
+}
+
+// statistics only (msplat_get_stats): number of splats with a non-empty tile rectangle
+__global__ __launch_bounds__(kThreads) void count_drawn_kernel(const uint32_t* __restrict__ rect,
+                                                               const uint32_t* __restrict__ d_V,
+                                                               uint32_t* __restrict__ d_drawn)
+{
+    const uint32_t V = *d_V;
+    uint32_t c = 0;
+    for (uint32_t r = blockIdx.x * kThreads + threadIdx.x; r < V; r += gridDim.x * kThreads)
+        c += rect_width(rect[r]) != 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(d_drawn, c);
+}
+
 // ------------------------------------------------------------------------------------------
 // tile binning.  The splats are already in global depth order (rank).  Two STABLE partitions of the
 // (splat, tile) pairs -- first by tile column, then by tile row -- leave every tile's list in
@@ -485,12 +530,6 @@ __global__ __launch_bounds__(kThreads) void project_kernel(const uint32_t* __res
 //                     (tx << 24) | rank (tx recovered from the input position), so that inside a
 //                     row the words are ascending and tile_start_kernel can binary-search them.
 // ------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ uint32_t rect_width(uint32_t rc)
-{
-    const uint32_t tx0 = rc & 255u, tx1 = (rc >> 16) & 255u;
-    return tx0 <= tx1 ? tx1 - tx0 + 1u : 0u;
-}
 
 __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restrict__ rect,
                                                          const uint32_t* __restrict__ d_V,

@@ -467,11 +467,11 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
 
     if (ntiles > 0) {
         if (ctx->cfg.fb_format == MSPLAT_FB_RGBA16F)
-            hipLaunchKernelGGL(composite_kernel<true>, dim3(ntiles), dim3(kThreads), 0, s,
+            hipLaunchKernelGGL(composite_kernel<true>, dim3(ntiles), dim3(kCompThreads), 0, s,
                                (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
                                (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap);
         else
-            hipLaunchKernelGGL(composite_kernel<false>, dim3(ntiles), dim3(kThreads), 0, s,
+            hipLaunchKernelGGL(composite_kernel<false>, dim3(ntiles), dim3(kCompThreads), 0, s,
                                (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
                                (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap);
     }

@@ -463,9 +463,10 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
     const float rho2 = 2.0f * logf(256.0f * alpha);
     if (!(rho2 > 0.0f)) reject = true;                      // alpha <= 1/256 (or NaN): never visible
     if (!(det > 0.0f) || !(m00 > 0.0f) || !(m11 > 0.0f)) reject = true;   // degenerate/NaN covariance
+    float ex = 0.0f, ey = 0.0f;       // conservative half extents of the footprint (pixels)
     if (!reject) {
-        const float ex = sqrtf(rho2 * m00) * 1.0001f + 0.01f;
-        const float ey = sqrtf(rho2 * m11) * 1.0001f + 0.01f;
+        ex = sqrtf(rho2 * m00) * 1.0001f + 0.01f;
+        ey = sqrtf(rho2 * m11) * 1.0001f + 0.01f;
         float x0f = ceilf(px - ex - 0.5f), x1f = floorf(px + ex - 0.5f);
         float y0f = ceilf(py - ey - 0.5f), y1f = floorf(py + ey - 0.5f);
         x0f = fmaxf(x0f, 0.0f);
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
     float4 r0, r1, r2;
     r0.x = px; r0.y = py; r0.z = kk * i00; r0.w = kk * (i01 + i10);
     r1.x = kk * i11; r1.y = log2f(alpha); r1.z = rgb[0]; r1.w = rgb[1];
-    r2.x = rgb[2]; r2.y = alpha; r2.z = 0.0f; r2.w = 0.0f;
+    r2.x = rgb[2]; r2.y = alpha; r2.z = ex; r2.w = ey;
     out_rec[(size_t)r * 3 + 0] = r0;
     out_rec[(size_t)r * 3 + 1] = r1;
     out_rec[(size_t)r * 3 + 2] = r2;
@@ -734,80 +735,124 @@ __global__ __launch_bounds__(kThreads) void tile_start_kernel(const uint32_t* __
 // splat_frag.glsl:18-42 defines w and the discard (w <= 1/256); app.cpp:153-160 the blend/clear.
 // ------------------------------------------------------------------------------------------
 
+constexpr int kCompThreads = 64;   // one wave per 16x16 tile, 4 pixels (one per 16x4 strip) per lane
+
 template <bool HALF>
-__global__ __launch_bounds__(kThreads) void composite_kernel(const uint32_t* __restrict__ tile_start,
-                                                             const uint32_t* __restrict__ pairs,
-                                                             const float4* __restrict__ rec,
-                                                             void* __restrict__ out, size_t pitch_bytes,
-                                                             FrameParams fp, uint32_t cap)
+__global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t* __restrict__ tile_start,
+                                                                 const uint32_t* __restrict__ pairs,
+                                                                 const float4* __restrict__ rec,
+                                                                 void* __restrict__ out, size_t pitch_bytes,
+                                                                 FrameParams fp, uint32_t cap)
 {
-    __shared__ float4 s_rec[kThreads * 3];
-    __shared__ int s_alive[2];
+    // Lane (lx, ly) owns pixels (x0+lx, y0 + 4k + ly), k = 0..3: strip k is the 16x4 pixel block of
+    // rows 4k..4k+3.  Per splat the exponent is split into a part shared by the four strips and a
+    // 2-FMA part per strip; strips the splat's y-range cannot reach, or whose 64 pixels are all
+    // saturated, are skipped with scalar branches.
+    __shared__ float4 s_rec[kCompThreads * 3];
 
     const int tile = blockIdx.x;
     const int vty = tile / fp.tiles_x;
     const int tx = tile - vty * fp.tiles_x;
     const int ty = vty * fp.row_mod + fp.row_rem;
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int x = tx * kTile + lx, y = ty * kTile + ly;
-    const bool inside = (x < fp.width) && (y < fp.height);
-    const float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+    const int lane = threadIdx.x;
+    const int lx = lane & 15, ly = lane >> 4;
+    const int x = tx * kTile + lx, ybase = ty * kTile + ly;
+    const float fx = (float)x + 0.5f;
+    const float fy0 = (float)ybase + 0.5f;
+    const float tile_y0 = (float)(ty * kTile);
 
     uint32_t start = tile_start[tile], end = tile_start[tile + 1];
     if (start > cap) start = cap;
     if (end > cap) end = cap;
 
-    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    bool done = !inside;
-    if (threadIdx.x < 2) s_alive[threadIdx.x] = 0;
-    __syncthreads();
+    float T[4], cr[4], cg[4], cb[4];
+    bool inside[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        T[k] = 1.0f; cr[k] = 0.0f; cg[k] = 0.0f; cb[k] = 0.0f;
+        inside[k] = (x < fp.width) && (ybase + 4 * k < fp.height);
+    }
+    uint32_t alive = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) alive |= (__ballot(inside[k]) != 0ull) ? (1u << k) : 0u;
 
-    int it = 0;
-    for (uint32_t hi = end; hi > start; ++it) {
-        const uint32_t cnt = min((uint32_t)kThreads, hi - start);
-        if (threadIdx.x < cnt) {
-            const uint32_t rank = pairs[hi - 1u - threadIdx.x] & kRankMask;   // j = 0 is the nearest splat
-            const float4* src = rec + (size_t)rank * 3;
-            s_rec[threadIdx.x * 3 + 0] = src[0];
-            s_rec[threadIdx.x * 3 + 1] = src[1];
-            s_rec[threadIdx.x * 3 + 2] = src[2];
+    // software pipeline: the next batch's records are fetched while the current one is composited
+    uint32_t hi = end;
+    uint32_t cnt = min((uint32_t)kCompThreads, hi - start);
+    float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
+    if (hi > start && lane < (int)cnt) {
+        const uint32_t rank = pairs[hi - 1u - lane] & kRankMask;       // j = 0 is the nearest splat
+        const float4* src = rec + (size_t)rank * 3;
+        p0 = src[0]; p1 = src[1]; p2 = src[2];
+    }
+    while (hi > start && alive != 0u) {
+        // stage: record + the strips (bit k) its y-range [py - ey, py + ey] can reach in this tile
+        {
+            uint32_t strips = 0;
+            const float ylo = p0.y - p2.w, yhi = p0.y + p2.w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (yhi >= tile_y0 + 4.0f * k + 0.5f && ylo <= tile_y0 + 4.0f * k + 3.5f) strips |= 1u << k;
+            p2.y = __uint_as_float(strips);
+            s_rec[lane * 3 + 0] = p0;
+            s_rec[lane * 3 + 1] = p1;
+            s_rec[lane * 3 + 2] = p2;
         }
+        const uint32_t cur = cnt;
+        hi -= cnt;
         __syncthreads();
-        if (threadIdx.x == 0) s_alive[(it + 1) & 1] = 0;
-        if (!done) {
-            for (uint32_t j = 0; j < cnt; ++j) {
-                const float4 a = s_rec[j * 3 + 0];
-                const float4 b = s_rec[j * 3 + 1];
-                const float blue = s_rec[j * 3 + 2].x;
-                const float dx = fx - a.x, dy = fy - a.y;
-                float e = __builtin_fmaf(b.x * dy, dy, b.y);
-                e = __builtin_fmaf(a.w * dx, dy, e);
-                e = __builtin_fmaf(a.z * dx, dx, e);
-                const float w = __builtin_amdgcn_exp2f(e);
-                if (w > (1.0f / 256.0f)) {
-                    const float tw = T * w;
-                    cr = __builtin_fmaf(tw, b.z, cr);
-                    cg = __builtin_fmaf(tw, b.w, cg);
-                    cb = __builtin_fmaf(tw, blue, cb);
-                    T = T - tw;
-                    if (T < fp.t_eps) { done = true; break; }
+        cnt = min((uint32_t)kCompThreads, hi - start);
+        if (hi > start && lane < (int)cnt) {
+            const uint32_t rank = pairs[hi - 1u - lane] & kRankMask;
+            const float4* src = rec + (size_t)rank * 3;
+            p0 = src[0]; p1 = src[1]; p2 = src[2];
+        }
+        for (uint32_t j = 0; j < cur; ++j) {
+            const float4 c = s_rec[j * 3 + 2];
+            const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(c.y)) & alive;
+            if (m == 0u) continue;
+            const float4 a = s_rec[j * 3 + 0];     // px, py, A, B
+            const float4 b = s_rec[j * 3 + 1];     // C, log2(alpha), r, g
+            const float dx = fx - a.x;
+            const float base = __builtin_fmaf(a.z * dx, dx, b.y);
+            const float lin = a.w * dx;
+            const float dy0 = fy0 - a.y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (m & (1u << k)) {
+                    const float dy = dy0 + 4.0f * k;
+                    const float e = __builtin_fmaf(dy, __builtin_fmaf(b.x, dy, lin), base);
+                    const float w = __builtin_amdgcn_exp2f(e);
+                    if (w > (1.0f / 256.0f)) {                 // splat_frag.glsl:37-40 discard
+                        const float tw = T[k] * w;
+                        cr[k] = __builtin_fmaf(tw, b.z, cr[k]);
+                        cg[k] = __builtin_fmaf(tw, b.w, cg[k]);
+                        cb[k] = __builtin_fmaf(tw, c.x, cb[k]);
+                        T[k] = T[k] - tw;
+                    }
                 }
             }
         }
-        if (!done) s_alive[it & 1] = 1;
+        // strips whose 64 pixels are all saturated (or outside the image) are finished
+        uint32_t na = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            na |= (__ballot(inside[k] && T[k] >= fp.t_eps) != 0ull) ? (1u << k) : 0u;
+        alive = na;
         __syncthreads();
-        if (!s_alive[it & 1]) break;
-        hi -= cnt;
     }
 
-    if (inside) {
-        char* row = (char*)out + (size_t)y * pitch_bytes;
-        if (HALF) {
-            union { _Float16 h[4]; uint2 u; } pk;
-            pk.h[0] = (_Float16)cr; pk.h[1] = (_Float16)cg; pk.h[2] = (_Float16)cb; pk.h[3] = (_Float16)1.0f;
-            ((uint2*)row)[x] = pk.u;
-        } else {
-            ((float4*)row)[x] = make_float4(cr, cg, cb, 1.0f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (inside[k]) {
+            char* row = (char*)out + (size_t)(ybase + 4 * k) * pitch_bytes;
+            if (HALF) {
+                union { _Float16 h[4]; uint2 u; } pk;
+                pk.h[0] = (_Float16)cr[k]; pk.h[1] = (_Float16)cg[k]; pk.h[2] = (_Float16)cb[k]; pk.h[3] = (_Float16)1.0f;
+                ((uint2*)row)[x] = pk.u;
+            } else {
+                ((float4*)row)[x] = make_float4(cr[k], cg[k], cb[k], 1.0f);
+            }
         }
     }
 }

@@ -107,27 +107,19 @@ def main():
             return [c]
         return [camera.translate_local(c, dx=-0.032), camera.translate_local(c, dx=+0.032)]
 
-    # gather plumbing: rank g owns tile rows g, g+G, ... ; bands are padded to the same row count
+    # the only exchange step: gather each rank's tile rows to rank 0 (splatapult_amd/dist.py)
+    gathers = None
     if world > 1:
-        max_rows = (tiles_y + world - 1) // world
-        send = [torch.zeros((max_rows, 16, W, 4), dtype=fdt, device=dev) for _ in range(views)]
-        recv = [[torch.zeros((max_rows, 16, W, 4), dtype=fdt, device=dev) for _ in range(world)]
-                for _ in range(views)] if rank == 0 else None
-        final = [torch.zeros((tiles_y, 16, W, 4), dtype=fdt, device=dev) for _ in range(views)] if rank == 0 else None
+        from splatapult_amd.dist import BandGather
+        gathers = [BandGather(tiles_y, W, fdt, dev, rank, world) for _ in range(views)]
 
     def frame(step):
         cams = cams_for(step)
         r.Sort(cams[0], projs[0], vp, nf)                      # sort once with view 0 (app.cpp:603-606)
         for v in range(views):
             r.Render(cams[v], projs[v], vp, nf, out_ptr=fbs[v].data_ptr(), pitch_bytes=W * bpp)
-            if world > 1:
-                mine = fbs[v].view(tiles_y, 16, W, 4)[rank::world]
-                send[v][:mine.shape[0]].copy_(mine)
-                dist.gather(send[v], recv[v] if rank == 0 else None, dst=0)
-                if rank == 0:
-                    for g in range(world):
-                        rows = final[v][g::world]
-                        rows.copy_(recv[v][g][:rows.shape[0]])
+            if gathers is not None:
+                gathers[v](fbs[v])
 
     def sync_all():
         torch.cuda.synchronize(dev)

@@ -1,0 +1,87 @@
+#!/usr/bin/env python
+"""Regenerates the golden fixtures under tests/golden/ (data only: inputs + expected outputs).
+
+    python tests/golden/make_golden.py
+
+The reference's hot path (GLSL shaders behind an OpenGL driver) cannot run in the build container
+and the reference ships no tests or golden vectors, so the expected outputs here come
+from this repo's CPU oracle (oracle/msplat_oracle.c) -- PARITY UNPINNED for the shader arithmetic.
+What IS pinned against the real reference:
+  * test.ply / test_vr.json are the reference's own data files (data/test.ply, data/test_vr.json);
+  * the PLY vertex block and property offsets in test_ply_cfg1.npz are read with the reference's own
+    parser (oracle/_ref/libref_ply.so, built from /root/reference/src/ply.cpp).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as orc  # noqa: E402
+from splatapult_amd import camera, synthetic  # noqa: E402
+from tests import scenes  # noqa: E402
+
+PLY_NAMES = (["x", "y", "z", "opacity"] + ["f_dc_%d" % i for i in range(3)] + ["f_rest_%d" % i for i in range(45)] +
+             ["scale_%d" % i for i in range(3)] + ["rot_%d" % i for i in range(4)])
+
+
+def attrs_from_ref_ply(path):
+    cnt, vs, props, raw = orc.ref_ply_read(path, PLY_NAMES)
+    v = raw.reshape(cnt, vs).view(np.float32)
+
+    def c(n):
+        return v[:, props[n][2] // 4].copy()
+    a = dict(xyz=np.stack([c("x"), c("y"), c("z")], 1), f_dc=np.stack([c("f_dc_%d" % i) for i in range(3)], 1),
+             f_rest=np.stack([c("f_rest_%d" % i) for i in range(45)], 1), opacity=c("opacity"),
+             log_scale=np.stack([c("scale_%d" % i) for i in range(3)], 1),
+             rot=np.stack([c("rot_%d" % i) for i in range(4)], 1))
+    return a, cnt, vs, {k: list(map(int, p)) for k, p in props.items()}
+
+
+def frame(aos, full_sh, cam, proj, W, H, **kw):
+    res = orc.render_frame(aos, full_sh, cam, proj, [0, 0, W, H], scenes.NF, want_splats=True, **kw)
+    sp = res["splats"]
+    return dict(V=np.int64(res["V"]), sorted_idx=res["sorted_idx"], sorted_keys=res["sorted_keys"],
+                px=sp["px"], py=sp["py"], cov=sp["cov"], inv=sp["inv"], rgb=sp["rgb"], alpha=sp["alpha"],
+                reject=sp["reject"], image=res["image"])
+
+
+def main():
+    assert orc.ref_ply_lib() is not None, "build oracle/_ref first (make -C oracle) -- needs /root/reference"
+    # ---- config 1: the reference's only fixture --------------------------------------------
+    a, cnt, vs, props = attrs_from_ref_ply(os.path.join(HERE, "test.ply"))
+    W, H = 640, 480
+    cam = camera.camera_from_vr_json(os.path.join(HERE, "test_vr.json"))
+    proj = orc.perspective(np.float32(camera.FOVY), W / H, camera.Z_NEAR, camera.Z_FAR)
+    aos = orc.build_cloud(a["xyz"], a["f_dc"], a["f_rest"], a["opacity"], a["log_scale"], a["rot"], False)
+    out = frame(aos, False, cam, proj, W, H)
+    np.savez_compressed(os.path.join(HERE, "test_ply_cfg1.npz"), vertex_count=cnt, vertex_size=vs,
+                        prop_names=np.array(sorted(props)), prop_offsets=np.array([props[k][2] for k in sorted(props)]),
+                        aos_nosh=aos, aos_sh=orc.build_cloud(a["xyz"], a["f_dc"], a["f_rest"], a["opacity"],
+                                                             a["log_scale"], a["rot"], True),
+                        cam=cam, proj=proj, W=W, H=H, **{"exp_" + k: v for k, v in out.items()})
+    # ---- synthetic scenes (seeded, small) ----------------------------------------------------
+    for name, attrs, (W, H), view in (
+            ("synth_sh3", synthetic.generate(2000, seed=101, log_scale_mean=-3.2), (192, 144), dict(yaw=0.3, x=1.0)),
+            ("synth_hard", scenes.hard_attrs(1500, seed=202), (200, 150), dict()),
+    ):
+        aos = orc.build_cloud(attrs["xyz"], attrs["f_dc"], attrs["f_rest"], attrs["opacity"], attrs["log_scale"],
+                              attrs["rot"], True)
+        cam, proj, vp, nf = scenes.default_view(W, H, **view)
+        out = frame(aos, True, cam, proj, W, H)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), cam=cam, proj=proj, W=W, H=H,
+                            **{"in_" + k: v for k, v in attrs.items()}, **{"exp_" + k: v for k, v in out.items()})
+    # ---- generator known answers (language-independent spec) ----------------------
+    g = synthetic.generate(4, seed=synthetic.SEED_1M)
+    json.dump({k: np.asarray(v, np.float64).round(7).tolist() for k, v in g.items() if v is not None},
+              open(os.path.join(HERE, "generator_kat.json"), "w"), indent=0)
+    for f in sorted(os.listdir(HERE)):
+        print("%-24s %8d B" % (f, os.path.getsize(os.path.join(HERE, f))))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+"""CPU tests of the C-ABI boundary: the shared library loads, exports every symbol include/msplat.h
+declares, fails loudly without a GPU (no CPU fallback), and the product never touches oracle/."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from splatapult_amd import SplatRenderer, _capi
+from tests.conftest import ROOT, has_gpu
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "msplat.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(msplat_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = C.CDLL(_capi.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), "libmsplat.so does not export " + n
+    bound = {n for n, _, _ in _capi.SYMBOLS}
+    assert set(names) == bound, "ctypes binding and header disagree: %s" % (set(names) ^ bound)
+
+
+def test_signatures_are_plain_c_no_framework_types():
+    src = open(os.path.join(ROOT, "include", "msplat.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    assert "torch" not in code and "std::" not in code and "glm" not in code and "hipStream" not in code
+    assert 'extern "C"' in code
+
+
+def test_version_and_struct_sizes():
+    L = _capi.lib()
+    assert b"msplat" in L.msplat_version_string()
+    assert C.sizeof(_capi.Config) == 48 and C.sizeof(_capi.AttrOffsets) == 64
+    assert C.sizeof(_capi.Stats) == 56 and C.sizeof(_capi.Timings) == 32
+
+
+@pytest.mark.skipif(has_gpu(), reason="a GPU is present")
+def test_create_fails_loudly_without_a_gpu():
+    L = _capi.lib()
+    h = C.c_void_p()
+    rc = L.msplat_create(C.byref(h), None)
+    assert rc == _capi.ERR_NO_DEVICE and not h.value
+    msg = L.msplat_last_error(None).decode()
+    assert "no HIP device" in msg and "no CPU fallback" in msg
+    r = SplatRenderer()
+    import numpy as np
+    assert r.Init(np.zeros((4, 61), np.float32)) is False          # Init -> false after logging, like the reference
+    assert "no CPU fallback" in r.last_error()
+
+
+def test_bad_arguments_are_rejected_without_a_context():
+    L = _capi.lib()
+    assert L.msplat_create(None, None) == _capi.ERR_INVALID_ARG
+    cfg = _capi.Config()
+    cfg.struct_size = 7
+    h = C.c_void_p()
+    assert L.msplat_create(C.byref(h), C.byref(cfg)) == _capi.ERR_INVALID_ARG
+    assert L.msplat_sort(None, None, None, None, None) == _capi.ERR_INVALID_ARG
+    assert L.msplat_render(None, None, None, None, None, None, 0, 0) == _capi.ERR_INVALID_ARG
+    assert L.msplat_cloud_import_ply(None, b"x") == _capi.ERR_INVALID_ARG
+    L.msplat_destroy(None)
+    L.msplat_cloud_destroy(None)
+
+
+def test_product_never_imports_or_links_the_oracle():
+    pkg = os.path.join(ROOT, "splatapult_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                code = "\n".join(l for l in text.splitlines()
+                                 if not l.strip().startswith(("#", "//", "*", '"""')) and "oracle is test" not in l)
+                assert "import oracle" not in code and "from oracle" not in code and "liboracle" not in code, f
+    # and the shared library has no dependency on it
+    import subprocess
+    out = subprocess.run(["ldd", _capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "torch" not in out

@@ -1,0 +1,202 @@
+"""CPU tests of the host side of the boundary: Ply / GaussianCloud re-implementation against the
+REAL reference parser (oracle/_ref, built from /root/reference/src/ply.cpp) and the oracle's
+load-time math, plus the matrix helpers and the synthetic generator."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from splatapult_amd import GaussianCloud, _capi, camera, synthetic
+from tests.golden.make_golden import PLY_NAMES
+
+import ctypes as C
+
+needs_ref = pytest.mark.skipif(orc.ref_ply_lib() is None, reason="oracle/_ref not built (no reference checkout)")
+
+
+def write(path, header_lines, payload=b""):
+    with open(path, "wb") as f:
+        f.write(("\n".join(header_lines) + "\n").encode())
+        f.write(payload)
+
+
+def our_parse(path, full_sh=True):
+    gc = GaussianCloud(GaussianCloud.Options(full_sh, full_sh))
+    return gc.ImportPly(path), gc
+
+
+# ---- Ply parser vs the reference's own parser -------------------------------------------------
+
+@needs_ref
+def test_test_ply_offsets_match_reference_parser(golden_dir):
+    cnt, vs, props, raw = orc.ref_ply_read(os.path.join(golden_dir, "test.ply"), PLY_NAMES + ["nx", "ny", "nz"])
+    assert cnt == 16 and vs == 248
+    assert props["x"][2] == 0 and props["f_dc_0"][2] == 24 and props["f_rest_44"][2] == 212
+    assert props["opacity"][2] == 216 and props["scale_0"][2] == 220 and props["rot_0"][2] == 232
+    g = np.load(os.path.join(golden_dir, "test_ply_cfg1.npz"))
+    assert int(g["vertex_count"]) == cnt and int(g["vertex_size"]) == vs
+
+
+@needs_ref
+def test_import_ply_equals_reference_parse_plus_oracle_math(golden_dir, tmp_path):
+    """ImportPly == (reference Ply::Parse) o (oracle restatement of gaussiancloud.cpp:254-361), bit for bit"""
+    a = synthetic.generate(300, seed=5)
+    path = str(tmp_path / "s.ply")
+    synthetic.write_ply(path, a)
+    for p, full in ((os.path.join(golden_dir, "test.ply"), True), (path, True), (path, False)):
+        cnt, vs, props, raw = orc.ref_ply_read(p, PLY_NAMES)
+        v = raw.reshape(cnt, vs).view(np.float32)
+
+        def c(n):
+            return v[:, props[n][2] // 4]
+        exp = orc.build_cloud(np.stack([c("x"), c("y"), c("z")], 1), np.stack([c("f_dc_%d" % i) for i in range(3)], 1),
+                              np.stack([c("f_rest_%d" % i) for i in range(45)], 1), c("opacity"),
+                              np.stack([c("scale_%d" % i) for i in range(3)], 1),
+                              np.stack([c("rot_%d" % i) for i in range(4)], 1), full)
+        ok, gc = our_parse(p, full)
+        assert ok and gc.GetNumGaussians() == cnt and gc.HasFullSH() == full
+        assert gc.GetStride() == (244 if full else 100) and gc.GetTotalSize() == cnt * gc.GetStride()
+        np.testing.assert_array_equal(gc.as_array(), exp)
+
+
+@needs_ref
+def test_header_variants_accept_reject_like_reference(tmp_path):
+    """comments, type aliases, odd property sets, malformed headers: same verdict as the reference parser"""
+    pay = np.arange(12, dtype="<f4").tobytes()
+    cases = {
+        "ok_comments": (["ply", "comment hello", "format binary_little_endian 1.0", "comment x", "element vertex 3",
+                         "property float x", "comment mid", "property float32 y", "property float z",
+                         "property float opacity", "end_header"], pay),
+        "ok_mixed_types": (["ply", "format binary_little_endian 1.0", "element vertex 1", "property uchar a",
+                            "property int16 b", "property double c", "property uint d", "property float x",
+                            "end_header"], bytes(19)),
+        "bad_magic": (["plx", "format binary_little_endian 1.0", "element vertex 0", "end_header"], b""),
+        "big_endian": (["ply", "format binary_big_endian 1.0", "element vertex 0", "end_header"], b""),
+        "ascii": (["ply", "format ascii 1.0", "element vertex 0", "end_header"], b""),
+        "no_element": (["ply", "format binary_little_endian 1.0", "property float x", "end_header"], b""),
+        "element_face": (["ply", "format binary_little_endian 1.0", "element face 3", "end_header"], b""),
+        "list_property": (["ply", "format binary_little_endian 1.0", "element vertex 1",
+                           "property list uchar int vertex_indices", "end_header"], b""),
+        "bad_type": (["ply", "format binary_little_endian 1.0", "element vertex 1", "property half x", "end_header"], b""),
+        "not_property": (["ply", "format binary_little_endian 1.0", "element vertex 1", "element face 2",
+                          "end_header"], b""),
+        "truncated_header": (["ply", "format binary_little_endian 1.0", "element vertex 1", "property float x"], b""),
+        "empty": ([], b""),
+        "zero_vertices": (["ply", "format binary_little_endian 1.0", "element vertex 0", "property float x",
+                           "end_header"], b""),
+    }
+    L = _capi.lib()
+    for name, (hdr, payload) in cases.items():
+        p = str(tmp_path / (name + ".ply"))
+        write(p, hdr, payload)
+        ref = orc.ref_ply_read(p, ["x", "y", "z", "a", "b", "c", "d", "opacity"])
+        ok, gc = our_parse(p)
+        assert ok == (ref is not None), name
+        if ref is not None:
+            assert gc.GetNumGaussians() == ref[0], name
+    # offsets of the mixed-type header accumulate exactly like the reference's (ply.cpp:106-112)
+    ref = orc.ref_ply_read(str(tmp_path / "ok_mixed_types.ply"), ["a", "b", "c", "d", "x"])
+    assert {k: v[2] for k, v in ref[2].items()} == {"a": 0, "b": 1, "c": 3, "d": 11, "x": 15} and ref[1] == 19
+    del L
+
+
+def test_missing_file_and_missing_f_rest(tmp_path):
+    ok, _ = our_parse(str(tmp_path / "nope.ply"))
+    assert not ok                                              # gaussiancloud.cpp:143-147: false after logging
+    a = synthetic.generate(10, seed=1, full_sh=False)
+    p = str(tmp_path / "nosh.ply")
+    synthetic.write_ply(p, a)
+    ok, gc = our_parse(p, full_sh=True)                        # f_rest missing -> silently SH0 (:188-205)
+    assert ok and not gc.HasFullSH() and gc.GetStride() == 100
+    arr = gc.as_array()
+    np.testing.assert_array_equal(arr[:, 5:8], 0)              # r_sh0 = (f_dc_0, 0, 0, 0)  (:316-332)
+
+
+def test_attribute_offsets_are_the_reference_layout(golden_dir):
+    ok, gc = our_parse(os.path.join(golden_dir, "test.ply"), True)
+    off = gc.GetAttribOffsets()
+    got = [getattr(off, n) for n, _ in _capi.AttrOffsets._fields_]
+    # BaseGaussianData / FullGaussianData, gaussiancloud.cpp:32-56
+    assert got == [0, 16, 32, 48, 64, 76, 88, 100, 116, 132, 148, 164, 180, 196, 212, 228]
+
+
+def test_config1_cloud_matches_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "test_ply_cfg1.npz"))
+    ok, gc = our_parse(os.path.join(golden_dir, "test.ply"), False)
+    np.testing.assert_array_equal(gc.as_array(), g["aos_nosh"])
+    ok, gc = our_parse(os.path.join(golden_dir, "test.ply"), True)
+    np.testing.assert_array_equal(gc.as_array(), g["aos_sh"])
+    # sigma^2 = 0.0025, alpha = 1, f_dc = +-1.77245
+    arr = g["aos_nosh"]
+    np.testing.assert_allclose(arr[:, [16, 20, 24]], 0.0025, rtol=1e-5)
+    assert (arr[:, 3] == 1.0).all()
+
+
+def test_export_roundtrip(tmp_path):
+    cloud = synthetic.make_cloud(200, seed=9)
+    p = str(tmp_path / "out.ply")
+    assert cloud.ExportPly(p)
+    ok, back = our_parse(p, True)
+    assert ok and back.GetNumGaussians() == 200 and back.HasFullSH()
+    a, b = cloud.as_array(), back.as_array()
+    np.testing.assert_allclose(b[:, :3], a[:, :3], rtol=0, atol=0)             # positions
+    np.testing.assert_allclose(b[:, 3], a[:, 3], rtol=2e-5)                    # alpha through logit/sigmoid
+    np.testing.assert_array_equal(b[:, 4:16], a[:, 4:16])                      # SH copied coefficient by coefficient
+    np.testing.assert_array_equal(b[:, 25:61], a[:, 25:61])
+    np.testing.assert_allclose(b[:, 16:25], a[:, 16:25], rtol=2e-3, atol=1e-7)  # covariance via eigen-decomposition
+
+
+def test_debug_cloud_and_prune():
+    gc = GaussianCloud()
+    gc.InitDebugCloud()
+    assert gc.GetNumGaussians() == 16 and gc.GetStride() == 244 and not gc.HasFullSH()   # gaussiancloud.cpp:509-511
+    a = gc.as_array()
+    np.testing.assert_allclose(a[:5, 0], [0.2, 0.4, 0.6, 0.8, 1.0], rtol=1e-6)
+    assert (a[:, 3] == 1).all() and np.allclose(a[:, 16], 0.005)
+    gc.PruneSplats([0.0, 0.0, 0.0], 4)
+    assert gc.GetNumGaussians() == 4
+    d = np.linalg.norm(gc.as_array()[:, :3], axis=1)
+    assert (np.diff(d) >= 0).all() and d[0] == 0.0
+    gc.PruneSplats([0, 0, 0], 100)                 # no-op when asking for more than there are
+    assert gc.GetNumGaussians() == 4
+
+
+def test_host_matrices_equal_oracle_bit_for_bit():
+    L = _capi.lib()
+    rng = np.random.default_rng(4)
+    f = C.POINTER(C.c_float)
+    for _ in range(50):
+        m = camera.pose(rng.normal(size=3) * 5, rng.uniform(-3, 3), rng.uniform(-1, 1))
+        out = np.zeros(16, np.float32)
+        L.msplat_mat4_inverse(m.ctypes.data_as(f), out.ctypes.data_as(f))
+        np.testing.assert_array_equal(out, orc.mat4_inverse(m))
+        p = camera.perspective(camera.FOVY, rng.uniform(0.5, 2.5))
+        out2 = np.zeros(16, np.float32)
+        L.msplat_mat4_mul(p.ctypes.data_as(f), out.ctypes.data_as(f), out2.ctypes.data_as(f))
+        np.testing.assert_array_equal(out2, orc.mat4_mul(p, out))
+    np.testing.assert_array_equal(camera.perspective(camera.FOVY, 16 / 9),
+                                  orc.perspective(np.float32(camera.FOVY), 16 / 9, 0.1, 1000.0))
+    np.testing.assert_array_equal(camera.create_projection(-1.0, 0.8, 0.95, -0.95),
+                                  orc.create_projection(-1.0, 0.8, 0.95, -0.95, 0.1, 1000.0))
+
+
+def test_vr_json_camera(golden_dir):
+    cam = camera.camera_from_vr_json(os.path.join(golden_dir, "test_vr.json"))
+    np.testing.assert_allclose(cam[12:15], [-1.0419, -0.4425, -0.9787], atol=2e-4)
+    assert cam[15] == 1.0
+
+
+def test_generator_known_answers(golden_dir):
+    kat = json.load(open(os.path.join(golden_dir, "generator_kat.json")))
+    g = synthetic.generate(4, seed=synthetic.SEED_1M)
+    for k, v in kat.items():
+        np.testing.assert_allclose(np.asarray(g[k], np.float64), np.array(v), atol=2e-7)
+    # counter-based: any sub-range reproduces the same splats
+    big = synthetic.generate(1000, seed=77, chunk=128)
+    again = synthetic.generate(1000, seed=77, chunk=1000)
+    for k in big:
+        np.testing.assert_array_equal(big[k], again[k])
+    assert abs(float(np.linalg.norm(big["rot"], axis=1).mean()) - 1.0) < 1e-6
+    assert np.abs(big["xyz"]).max() <= 6.0

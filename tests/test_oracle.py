@@ -1,0 +1,171 @@
+"""CPU tests of the oracle itself (no GPU): the C restatement against (a) the hand-derived sanity
+values of SURVEY.md 8c for the reference's only fixture, (b) the committed golden vectors,
+(c) the independent numpy restatement.  The shader arithmetic is PARITY UNPINNED (no runnable
+reference); these tests pin the oracle against everything that exists."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as npo
+from oracle import oracle as orc
+from splatapult_amd import camera, synthetic
+from tests import scenes
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_config1_matches_survey_sanity_values(golden_dir):
+    """values computed independently (fp64) for data/test.ply at 640x480"""
+    g = load(golden_dir, "test_ply_cfg1.npz")
+    res = orc.render_frame(g["aos_nosh"], False, g["cam"], g["proj"], [0, 0, 640, 480], scenes.NF, want_splats=True)
+    assert res["V"] == 16
+    sp = {int(s["index"]): s for s in res["splats"]}
+    keys = dict(zip(res["sorted_idx"].tolist(), res["sorted_keys"].tolist()))
+    assert abs(sp[15]["depth"] - 1.4776) < 2e-4 and abs(sp[0]["depth"] - 1.6048) < 2e-4
+    assert abs(sp[15]["px"] - 303.64) < 0.02 and abs(sp[15]["py"] - 148.76) < 0.02
+    assert abs(sp[0]["px"] - 253.99) < 0.02 and abs(sp[0]["py"] - 133.44) < 0.02
+    np.testing.assert_allclose(sp[15]["cov"], [385.0, 1.7, 1.7, 394.2], atol=0.06)
+    # low key bits may move under fp32 (the survey used fp64 matrices): compare the top 20 bits
+    assert abs(keys[15] - 4288620871) < 4096 and abs(keys[0] - 4288074552) < 4096
+    # axis gizmo: 5 red, 5 green, 5 blue, 1 white, all alpha 1
+    rgb = np.stack([sp[i]["rgb"] for i in range(16)])
+    np.testing.assert_allclose(rgb[0:5], [[1, 0, 0]] * 5, atol=1e-6)
+    np.testing.assert_allclose(rgb[5:10], [[0, 1, 0]] * 5, atol=1e-6)
+    np.testing.assert_allclose(rgb[10:15], [[0, 0, 1]] * 5, atol=1e-6)
+    np.testing.assert_allclose(rgb[15], [1, 1, 1], atol=1e-6)
+    assert all(sp[i]["alpha"] == 1.0 for i in range(16))
+    assert (res["image"][..., 3] == 1).all()
+
+
+@pytest.mark.parametrize("name,full_sh", [("synth_sh3.npz", True), ("synth_hard.npz", True)])
+def test_oracle_reproduces_golden(golden_dir, name, full_sh):
+    g = load(golden_dir, name)
+    aos = orc.build_cloud(g["in_xyz"], g["in_f_dc"], g["in_f_rest"], g["in_opacity"], g["in_log_scale"], g["in_rot"],
+                          full_sh)
+    W, H = int(g["W"]), int(g["H"])
+    res = orc.render_frame(aos, full_sh, g["cam"], g["proj"], [0, 0, W, H], scenes.NF, want_splats=True, nthreads=4)
+    assert res["V"] == int(g["exp_V"])
+    np.testing.assert_array_equal(res["sorted_idx"], g["exp_sorted_idx"])
+    np.testing.assert_array_equal(res["sorted_keys"], g["exp_sorted_keys"])
+    np.testing.assert_allclose(res["splats"]["px"], g["exp_px"], atol=1e-4)
+    np.testing.assert_array_equal(res["splats"]["reject"], g["exp_reject"])
+    np.testing.assert_allclose(res["image"], g["exp_image"], atol=1e-6)
+
+
+def test_config1_golden(golden_dir):
+    g = load(golden_dir, "test_ply_cfg1.npz")
+    res = orc.render_frame(g["aos_nosh"], False, g["cam"], g["proj"], [0, 0, 640, 480], scenes.NF)
+    np.testing.assert_array_equal(res["sorted_idx"], g["exp_sorted_idx"])
+    np.testing.assert_array_equal(res["sorted_keys"], g["exp_sorted_keys"])
+    np.testing.assert_allclose(res["image"], g["exp_image"], atol=1e-6)
+
+
+def test_c_oracle_agrees_with_numpy_restatement():
+    a = scenes.hard_attrs(400, seed=3)
+    aos = orc.build_cloud(a["xyz"], a["f_dc"], a["f_rest"], a["opacity"], a["log_scale"], a["rot"], True)
+    aos_np = npo.build_cloud(a["xyz"], a["f_dc"], a["f_rest"], a["opacity"], a["log_scale"], a["rot"], True)
+    np.testing.assert_allclose(aos, aos_np, rtol=1e-5, atol=1e-7)     # einsum summation order differs
+    W, H = 96, 64
+    cam, proj, vp, nf = scenes.default_view(W, H, yaw=0.2)
+    view = orc.mat4_inverse(cam)
+    mvp = orc.mat4_mul(proj, view)
+    vis, key = npo.cull_keys(aos[:, :3], mvp, nf[1])
+    ck, ci = orc.presort(aos, mvp, nf[1])
+    np.testing.assert_array_equal(np.nonzero(vis)[0], ci)          # visible set: exact
+    np.testing.assert_array_equal(key[vis], ck)                    # keys: exact
+    res = orc.render_frame(aos, True, cam, proj, vp, nf, want_splats=True)
+    pr = npo.project(aos, res["sorted_idx"], True, False, view, proj, vp, nf, cam[12:15])
+    sp = res["splats"]
+    ok = sp["reject"] == 0
+    np.testing.assert_array_equal(pr["reject"], sp["reject"] != 0)
+    np.testing.assert_allclose(pr["px"][ok], sp["px"][ok], atol=1e-3)
+    np.testing.assert_allclose(pr["py"][ok], sp["py"][ok], atol=1e-3)
+    np.testing.assert_allclose(pr["inv"][ok], sp["inv"][ok], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(pr["rgb"][ok], sp["rgb"][ok], rtol=1e-4, atol=2e-6)
+    img = npo.composite({k: (v[ok] if hasattr(v, "shape") else v) for k, v in
+                         dict(px=sp["px"], py=sp["py"], inv=sp["inv"], rgb=sp["rgb"], alpha=sp["alpha"],
+                              reject=sp["reject"]).items()}, W, H)
+    d = np.abs(img - res["image"])
+    assert d.max() < 5e-3 and (d < 1e-5).mean() > 0.999
+
+
+def test_sort_is_stable_and_ascending():
+    rng = np.random.default_rng(1)
+    keys = rng.integers(0, 50, 5000).astype(np.uint32) << np.uint32(13)     # many ties
+    idx = np.arange(5000, dtype=np.uint32)
+    k, i = orc.sort(keys, idx)
+    order = np.argsort(keys, kind="stable")
+    np.testing.assert_array_equal(i, order.astype(np.uint32))
+    np.testing.assert_array_equal(k, keys[order])
+
+
+def test_key_quantisation_edges():
+    """key = keyMax - uint((depth/far) * keyMax) with float(keyMax) == 2^32 (presort_compute.glsl:53)"""
+    mvp = np.eye(4, dtype=np.float32).T.reshape(16).copy()
+    mvp[11] = 1.0   # p.w = z + 1 ... use identity-ish: w = z*1 + 1
+    import ctypes as C
+    L = orc.lib()
+
+    def key_of(z, far=1000.0):
+        xyz = np.array([0.0, 0.0, z], np.float32)
+        out = C.c_uint32()
+        ok = L.orc_cull_key(xyz.ctypes.data_as(C.POINTER(C.c_float)), mvp.ctypes.data_as(C.POINTER(C.c_float)),
+                            far, C.byref(out))
+        return ok, out.value
+    ok, k = key_of(499.0)       # depth 500 = far/2 -> q = 2^31
+    assert ok and k == 0xFFFFFFFF - 2 ** 31
+    ok, k = key_of(999.0)       # depth == far -> saturates (undefined in GLSL; far-clipped anyway)
+    assert ok and k == 0
+    ok, k = key_of(5000.0)
+    assert ok and k == 0
+    ok, _ = key_of(-1.0)        # depth 0: culled (depth > 0 is strict)
+    assert not ok
+    ok, _ = key_of(-3.0)
+    assert not ok
+    ok, k = key_of(0.5)         # depth 1.5: truncation, <= 24 significant bits
+    q = 0xFFFFFFFF - k
+    assert ok and q == int(np.float32(np.float32(1.5) / np.float32(1000.0)) * np.float32(4294967296.0))
+
+
+def test_fp32_blend_close_to_fp64():
+    """calibrates the framebuffer tolerance: literal fp32 back-to-front vs fp64 accumulation"""
+    cloud = synthetic.make_cloud(3000, seed=12, log_scale_mean=-3.0)
+    cam, proj, vp, nf = scenes.default_view(160, 120)
+    res = orc.render_frame(cloud.as_array(), True, cam, proj, vp, nf, want_splats=True)
+    img64 = orc.composite_f64(res["splats"], 160, 120, nthreads=2)
+    d = np.abs(res["image"] - img64)
+    assert d.max() < 5e-3            # a handful of threshold flips at w ~ 1/256
+    assert np.median(d) < 1e-6
+
+
+def test_composite_threads_and_row_windows_are_identical():
+    cloud = synthetic.make_cloud(2000, seed=13, log_scale_mean=-3.0)
+    cam, proj, vp, nf = scenes.default_view(128, 96)
+    res = orc.render_frame(cloud.as_array(), True, cam, proj, vp, nf, want_splats=True)
+    a = orc.composite(res["splats"], 128, 96, nthreads=1)
+    b = orc.composite(res["splats"], 128, 96, nthreads=5)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, res["image"])
+    win = orc.composite(res["splats"], 128, 96, nthreads=3, row0=20, row1=50)
+    np.testing.assert_array_equal(win[20:50], a[20:50])
+
+
+def test_matrix_helpers_closed_forms():
+    m = camera.pose((1.0, -2.0, 3.5), yaw=0.7, pitch=-0.3)
+    inv = orc.mat4_inverse(m)
+    prod = orc.mat4_mul(m, inv).reshape(4, 4)
+    np.testing.assert_allclose(prod, np.eye(4), atol=2e-6)
+    np.testing.assert_allclose(inv.reshape(4, 4).T, np.linalg.inv(m.reshape(4, 4).T.astype(np.float64)), atol=1e-6)
+    p = orc.perspective(np.float32(camera.FOVY), 16 / 9, 0.1, 1000.0).reshape(4, 4)
+    t = np.tan(np.float32(camera.FOVY) / 2)
+    assert abs(p[0][0] - 1 / (16 / 9 * t)) < 1e-6 and abs(p[1][1] - 1 / t) < 1e-6 and p[2][3] == -1
+    assert abs(p[2][2] + 1000.1 / 999.9) < 1e-6 and abs(p[3][2] + 200.0 / 999.9) < 1e-6
+    # CreateProjection, symmetric case == perspective with the same tangents except the z rows (util.cpp:457-479)
+    c = orc.create_projection(-0.5, 0.5, 0.4, -0.4, 0.1, 1000.0).reshape(4, 4)
+    assert abs(c[0][0] - 2.0) < 1e-6 and abs(c[1][1] - 2.5) < 1e-6 and c[2][0] == 0 and c[2][1] == 0
+    assert abs(c[2][2] + (1000.0 + 0.1) / (1000.0 - 0.1)) < 1e-6 and c[2][3] == -1
+    c2 = orc.create_projection(-1.0, 0.8, 0.95, -0.95, 0.1, 1000.0).reshape(4, 4)
+    assert abs(c2[2][0] - (0.8 - 1.0) / 1.8) < 1e-6

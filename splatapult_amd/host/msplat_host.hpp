@@ -1,0 +1,132 @@
+// msplat_host.hpp -- C++ drop-in shim: the reference's SplatRenderer class surface
+// (/root/reference/src/splatrenderer.h:23-67) on top of the C ABI in include/msplat.h.
+//
+//   bool Init(std::shared_ptr<GaussianCloud>, bool isFramebufferSRGBEnabled, bool useRgcSortOverride);
+//   void Sort  (cameraMat, projMat, viewport, nearFar);
+//   void Render(cameraMat, projMat, viewport, nearFar);
+//
+// Matrix/vector arguments are templated on anything that is laid out like glm's types (a mat4 is
+// 16 contiguous column-major floats, vec4/vec2 are 4/2 floats): glm::mat4, glm::vec4, glm::vec2 or
+// the msplat::mat4/vec4/vec2 PODs below all work unchanged, so App::Render's two call sites
+// (app.cpp:603-607, :1067-1068) compile as they are.
+//
+// The reference draws into "whatever GL framebuffer is bound"; here the target is explicit:
+// SetRenderTarget(ptr, pitch, isDevice) once (or per frame), then Render writes RGBA32F/16F rows,
+// row 0 = GL bottom row, alpha = 1.
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+
+#include "../../include/msplat.h"
+#include "gaussian_scene.hpp"
+
+namespace msplat {
+struct mat4 { float m[16]; };   // column-major, m[col*4 + row]
+struct vec4 { float v[4]; };
+struct vec2 { float v[2]; };
+}  // namespace msplat
+
+class SplatRenderer
+{
+public:
+    SplatRenderer() = default;
+    ~SplatRenderer() { msplat_destroy(ctx); }
+    SplatRenderer(const SplatRenderer&) = delete;
+    SplatRenderer& operator=(const SplatRenderer&) = delete;
+
+    // optional, before Init: device ordinal, framebuffer format (MSPLAT_FB_*), stream (hipStream_t)
+    void Configure(int device, int fbFormat, void* stream = nullptr, float tEpsilon = -1.0f)
+    {
+        cfg.device = device;
+        cfg.fb_format = fbFormat;
+        cfg.stream = stream;
+        cfg.t_epsilon = tEpsilon;
+    }
+
+    // splatrenderer.cpp:50-151.  false after logging on failure.  The cloud is copied to the device and
+    // not retained; useRgcSortOverride is accepted and ignored (one HIP sort replaces both GL sorters).
+    bool Init(std::shared_ptr<GaussianCloud> gaussianCloud, bool isFramebufferSRGBEnabledIn, bool useRgcSortOverrideIn)
+    {
+        (void)useRgcSortOverrideIn;
+        msplat_destroy(ctx);
+        ctx = nullptr;
+        cfg.struct_size = sizeof(cfg);
+        cfg.srgb = isFramebufferSRGBEnabledIn ? 1 : 0;
+        if (msplat_create(&ctx, &cfg) != MSPLAT_OK) {
+            std::fprintf(stderr, "[msplat][E] %s\n", msplat_last_error(nullptr));
+            return false;
+        }
+        msplat_attr_offsets off{};
+        off.pos_with_alpha = (uint32_t)gaussianCloud->GetPosWithAlphaAttrib().offset;
+        off.r_sh0 = (uint32_t)gaussianCloud->GetR_SH0Attrib().offset;
+        off.g_sh0 = (uint32_t)gaussianCloud->GetG_SH0Attrib().offset;
+        off.b_sh0 = (uint32_t)gaussianCloud->GetB_SH0Attrib().offset;
+        off.cov3_col0 = (uint32_t)gaussianCloud->GetCov3_Col0Attrib().offset;
+        off.cov3_col1 = (uint32_t)gaussianCloud->GetCov3_Col1Attrib().offset;
+        off.cov3_col2 = (uint32_t)gaussianCloud->GetCov3_Col2Attrib().offset;
+        if (gaussianCloud->HasFullSH()) {
+            off.r_sh1 = (uint32_t)gaussianCloud->GetR_SH1Attrib().offset;
+            off.r_sh2 = (uint32_t)gaussianCloud->GetR_SH2Attrib().offset;
+            off.r_sh3 = (uint32_t)gaussianCloud->GetR_SH3Attrib().offset;
+            off.g_sh1 = (uint32_t)gaussianCloud->GetG_SH1Attrib().offset;
+            off.g_sh2 = (uint32_t)gaussianCloud->GetG_SH2Attrib().offset;
+            off.g_sh3 = (uint32_t)gaussianCloud->GetG_SH3Attrib().offset;
+            off.b_sh1 = (uint32_t)gaussianCloud->GetB_SH1Attrib().offset;
+            off.b_sh2 = (uint32_t)gaussianCloud->GetB_SH2Attrib().offset;
+            off.b_sh3 = (uint32_t)gaussianCloud->GetB_SH3Attrib().offset;
+        }
+        if (msplat_upload_cloud(ctx, gaussianCloud->GetRawDataPtr(), gaussianCloud->GetNumGaussians(),
+                                (uint32_t)gaussianCloud->GetStride(), &off, gaussianCloud->HasFullSH() ? 1 : 0) != MSPLAT_OK) {
+            std::fprintf(stderr, "[msplat][E] %s\n", msplat_last_error(ctx));
+            return false;
+        }
+        return true;
+    }
+
+    // splatrenderer.cpp:153-312
+    template <class Mat4, class Vec4, class Vec2>
+    void Sort(const Mat4& cameraMat, const Mat4& projMat, const Vec4& viewport, const Vec2& nearFar)
+    {
+        static_assert(sizeof(Mat4) == 64 && sizeof(Vec4) == 16 && sizeof(Vec2) == 8, "glm-compatible layout expected");
+        if (msplat_sort(ctx, reinterpret_cast<const float*>(&cameraMat), reinterpret_cast<const float*>(&projMat),
+                        reinterpret_cast<const float*>(&viewport), reinterpret_cast<const float*>(&nearFar)) != MSPLAT_OK)
+            std::fprintf(stderr, "[msplat][E] Sort: %s\n", msplat_last_error(ctx));     // void, like the reference
+    }
+
+    // splatrenderer.cpp:315-343 (+ the GL pipeline behind glDrawElements)
+    template <class Mat4, class Vec4, class Vec2>
+    void Render(const Mat4& cameraMat, const Mat4& projMat, const Vec4& viewport, const Vec2& nearFar)
+    {
+        static_assert(sizeof(Mat4) == 64 && sizeof(Vec4) == 16 && sizeof(Vec2) == 8, "glm-compatible layout expected");
+        if (!target) {
+            std::fprintf(stderr, "[msplat][E] Render: no render target set (SetRenderTarget)\n");
+            return;
+        }
+        if (msplat_render(ctx, reinterpret_cast<const float*>(&cameraMat), reinterpret_cast<const float*>(&projMat),
+                          reinterpret_cast<const float*>(&viewport), reinterpret_cast<const float*>(&nearFar), target,
+                          targetPitch, targetIsDevice ? 1 : 0) != MSPLAT_OK)
+            std::fprintf(stderr, "[msplat][E] Render: %s\n", msplat_last_error(ctx));
+    }
+
+    // replaces "the currently bound GL framebuffer" (app.cpp:1000-1035)
+    void SetRenderTarget(void* rgba, uint64_t pitchBytes, bool isDevicePointer)
+    {
+        target = rgba;
+        targetPitch = pitchBytes;
+        targetIsDevice = isDevicePointer;
+    }
+
+    msplat_ctx* GetContext() { return ctx; }
+
+public:
+    uint32_t numBlocksPerWorkgroup = 1024;   // accepted and ignored (splatrenderer.h:39)
+
+protected:
+    msplat_ctx* ctx = nullptr;
+    msplat_config cfg{sizeof(msplat_config), 0, MSPLAT_FB_RGBA32F, 0, -1.0f, 0, nullptr, 0, 0};
+    void* target = nullptr;
+    uint64_t targetPitch = 0;
+    bool targetIsDevice = false;
+};

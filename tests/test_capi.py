@@ -81,3 +81,17 @@ def test_product_never_imports_or_links_the_oracle():
     import subprocess
     out = subprocess.run(["ldd", _capi.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out and "torch" not in out
+
+
+def test_cpp_shim_compiles_with_plain_gxx(tmp_path):
+    """the SplatRenderer/GaussianCloud C++ surface (splatapult_amd/host/msplat_host.hpp) needs only g++ + the C ABI"""
+    import subprocess
+    exe = str(tmp_path / "example_render")
+    libdir = os.path.dirname(_capi.LIB_PATH)
+    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", "-I", ROOT, os.path.join(ROOT, "splatapult_amd", "host", "example_render.cpp"),
+           "-L", libdir, "-lmsplat", "-Wl,-rpath," + libdir, "-o", exe]
+    subprocess.run(cmd, check=True, cwd=ROOT)
+    if not has_gpu():
+        p = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "test.ply"), str(tmp_path / "o.f32"), "64", "48"],
+                           capture_output=True, text=True)
+        assert p.returncode == 1 and "no CPU fallback" in p.stderr

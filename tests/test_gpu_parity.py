@@ -351,3 +351,27 @@ def test_full_size_config2_sort_and_properties():
     y0, y1 = 412, 668
     win = orc.composite(ref["splats"], W, H, nthreads=8, row0=y0, row1=y1)
     check_image(img[y0:y1], win[y0:y1])
+
+
+def test_cpp_shim_renders_like_the_python_mirror(tmp_path, golden_dir):
+    """C++ drop-in surface (msplat_host.hpp: GaussianCloud::ImportPly -> SplatRenderer::Init/Sort/Render)"""
+    import os
+    import subprocess
+    from splatapult_amd import GaussianCloud, _capi
+    from tests.conftest import ROOT
+    exe = str(tmp_path / "example_render")
+    libdir = os.path.dirname(_capi.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-I", ROOT, os.path.join(ROOT, "splatapult_amd", "host", "example_render.cpp"),
+                    "-L", libdir, "-lmsplat", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    W, H = 320, 200
+    out = str(tmp_path / "o.f32")
+    ply = os.path.join(golden_dir, "test.ply")
+    subprocess.run([exe, ply, out, str(W), str(H)], check=True)
+    img = np.fromfile(out, np.float32).reshape(H, W, 4)
+    gc = GaussianCloud()
+    assert gc.ImportPly(ply)
+    cam = camera.pose((0.0, 0.0, 5.0))
+    proj = camera.perspective(np.float32(45.0 * 3.14159265358979 / 180.0), W / H)
+    ref = orc.render_frame(gc.as_array(), True, cam, proj, [0, 0, W, H], scenes.NF)
+    check_image(img, ref["image"])
+    assert img[..., :3].max() > 0.5

@@ -50,7 +50,9 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="CPU baseline frames (0 = auto, about 10-30 s)")
-    ap.add_argument("--profile-frames", type=int, default=20, help="extra frames timed per stage with hipEvents")
+    ap.add_argument("--profile-frames", type=int, default=8, help="extra frames (outside the timed region) for V/D statistics")
+    ap.add_argument("--timing-stride", type=int, default=8,
+                    help="record per-stage hipEvents on every n-th frame of the timed region (0 = never)")
     args = ap.parse_args()
 
     import torch
@@ -84,7 +86,7 @@ def main():
     # hand-off and torch.cuda.synchronize all order correctly with the HIP kernels
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    r = SplatRenderer(device=local_rank, fb_format=wl["fb"], stream=stream.cuda_stream, enable_timing=True)
+    r = SplatRenderer(device=local_rank, fb_format=wl["fb"], stream=stream.cuda_stream, enable_timing=args.timing_stride)
     if not r.Init(cloud, False, False):
         raise SystemExit("Init failed: " + r.last_error())
     if world > 1:
@@ -140,16 +142,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-stage hipEvent timing + V/D, on extra frames outside the timed region (each read synchronises)
+    # per-stage / per-kernel times: hipEvents recorded on the launch stream on every `timing_stride`-th
+    # frame INSIDE the timed region (the markers cost a few us each, hence sampled); averaged here
     prof = dict(sort_total=0.0, render_total=0.0, project=0.0, binning=0.0, composite=0.0)
+    if args.timing_stride > 0:
+        prof = r.timings()
+    # V / D statistics on a few extra frames outside the timed region (each read synchronises)
     Vs, Ds, drawn = [], [], []
-    pf = max(1, args.profile_frames)
-    for s in range(pf):
+    for s in range(max(1, args.profile_frames)):
         frame(args.warmup + args.steps + s)
-        tm = r.timings()
         st = r.stats()
-        for k in prof:
-            prof[k] += tm[k] / pf
         Vs.append(st["sort_count"]); Ds.append(st["pairs"]); drawn.append(st["drawn"])
     st = r.stats()
     V, D = float(np.mean(Vs)), float(np.mean(Ds))

@@ -57,7 +57,8 @@ typedef struct msplat_config {
                                /* negative = library default (2^-14)                         */
     uint64_t pair_capacity;    /* max (splat,tile) pairs per render; 0 = auto (grows)        */
     void* stream;              /* hipStream_t to launch on; NULL = library-owned stream      */
-    int32_t enable_timing;     /* record hipEvents per stage (msplat_get_timings)            */
+    int32_t enable_timing;     /* n > 0: record per-stage hipEvents on every n-th sort/render */
+                               /* (msplat_get_timings averages them); 0 = never             */
     int32_t reserved;
 } msplat_config;
 
@@ -92,7 +93,7 @@ typedef struct msplat_timings {
     float project;             /* vertex+geometry stage equivalent                           */
     float binning;             /* tile lists (count, scan, two stable partition passes)      */
     float composite;           /* fragment+blend equivalent (the dominant kernel)            */
-    float reserved[3];
+    float reserved[3];         /* [0] = number of frames averaged                            */
 } msplat_timings;
 
 /* ---- context ---------------------------------------------------------------------------- */
@@ -153,6 +154,10 @@ int msplat_debug_get_projected(msplat_ctx* ctx, float* rec12, uint32_t* rect, ui
 /* tile_start has tiles_x*tiles_y+1 entries; pairs[k] & 0xFFFFFF = draw-order rank */
 int msplat_debug_get_tile_lists(msplat_ctx* ctx, uint32_t* tile_start, uint32_t tile_cap,
                                 uint32_t* pairs, uint64_t pair_cap);
+
+/* per tile {100 MHz ticks spent, splats composited, batches fetched, list length}; only when the
+ * context was created with MSPLAT_TILE_PROBE=1 in the environment (performance analysis) */
+int msplat_debug_get_tile_probe(msplat_ctx* ctx, uint32_t* dst4, uint32_t tile_cap);
 
 /* ---- scene data: GaussianCloud / Ply surface (gaussiancloud.h:17-91, ply.h:19-46) -------- */
 /* replaces GaussianCloud::GaussianCloud(Options{importFullSH}) */

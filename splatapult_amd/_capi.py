@@ -62,6 +62,7 @@ SYMBOLS = [
     ("msplat_get_timings", C.c_int, [C.c_void_p, C.POINTER(Timings)]),
     ("msplat_debug_get_projected", C.c_int, [C.c_void_p, _F16, _U32P, C.c_uint32]),
     ("msplat_debug_get_tile_lists", C.c_int, [C.c_void_p, _U32P, C.c_uint32, _U32P, C.c_uint64]),
+    ("msplat_debug_get_tile_probe", C.c_int, [C.c_void_p, _U32P, C.c_uint32]),
     ("msplat_cloud_create", C.c_void_p, [C.c_int]),
     ("msplat_cloud_destroy", None, [C.c_void_p]),
     ("msplat_cloud_import_ply", C.c_int, [C.c_void_p, C.c_char_p]),

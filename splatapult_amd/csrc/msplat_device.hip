@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -49,11 +50,12 @@ struct msplat_ctx {
     uint32_t hist_stride = 0;
     Buf totals;     // uint32[256]  digit totals of the current radix pass (rows in binning pass 2)
     Buf totals1;    // uint32[256]  column totals of binning pass 1
-    Buf counters;   // uint32[8]: 0=V, 1=D, 2=overflow, 3=drawn
+    Buf counters;   // uint32[8]: 0=V, 1=D, 2=overflow, 3=compositor tile queue, 4=drawn
     // render state
     Buf rec2d;      // float4[3*N]
     Buf rect;       // uint32[N]
     Buf tile_start; // uint32[65537]
+    Buf tile_order; // uint32[65536] tiles by descending list length
     Buf hist1;      // uint32[256 * hist1_stride]
     uint32_t hist1_stride = 0;
     Buf pairsA, pairsB;   // uint32[pair_cap]
@@ -61,16 +63,24 @@ struct msplat_ctx {
     Buf hist2;      // uint32[256 * hist2_stride]
     uint32_t hist2_stride = 0;
     Buf fb;         // internal framebuffer for host-output renders
+    Buf probe;      // uint32[4*tiles] per-tile compositor probe (only when MSPLAT_TILE_PROBE=1)
     // band
     int row_mod = 1, row_rem = 0;
     // last frame
     FrameParams last_fp{};
     bool has_render = false;
     // timing
-    hipEvent_t ev[8]{};
+    // per-stage hipEvent sets, recorded on every `timing_stride`-th call so that the event markers
+    // (a few us of pipeline bubble each) do not perturb a throughput run; averaged by msplat_get_timings
+    static constexpr int kEvSets = 32;
+    hipEvent_t ev[kEvSets][6]{};
     bool ev_ok = false;
-    bool ev_sort_valid = false, ev_render_valid = false;
+    int timing_stride = 1;
+    uint64_t sort_calls = 0, render_calls = 0;
+    uint32_t sort_sets = 0, render_sets = 0;      // sets recorded since the last msplat_get_timings
+    int cur_render_set = -1;
 
+    int comp_waves = 6144;      // compositor grid (persistent waves); MSPLAT_COMP_WAVES overrides
     uint64_t device_bytes = 0;
 };
 
@@ -185,15 +195,20 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         }
         ctx->own_stream = true;
     }
-    if (c.enable_timing) {
+    if (c.enable_timing > 0) {
         bool ok = true;
-        for (auto& ev : ctx->ev) ok = ok && (hipEventCreate(&ev) == hipSuccess);
+        for (auto& set : ctx->ev)
+            for (auto& ev : set) ok = ok && (hipEventCreate(&ev) == hipSuccess);
         ctx->ev_ok = ok;
+        ctx->timing_stride = c.enable_timing;
     }
     int rc = buf_alloc(ctx, ctx->totals, 256 * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->counters, 8 * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->totals1, 256 * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_start, 65537 * sizeof(uint32_t));
+    if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_order, 65536 * sizeof(uint32_t));
+    if (getenv("MSPLAT_COMP_WAVES")) ctx->comp_waves = std::max(64, atoi(getenv("MSPLAT_COMP_WAVES")));
+    if (rc == MSPLAT_OK && getenv("MSPLAT_TILE_PROBE") != nullptr) rc = buf_alloc(ctx, ctx->probe, 65536 * 4 * sizeof(uint32_t));
     if (rc == MSPLAT_OK && hipMemsetAsync(ctx->counters.p, 0, 8 * sizeof(uint32_t), ctx->stream) != hipSuccess)
         rc = MSPLAT_ERR_HIP;
     if (rc != MSPLAT_OK) {
@@ -212,11 +227,12 @@ void msplat_destroy(msplat_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     Buf* all[] = {&ctx->pos4, &ctx->recs, &ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist,
-                  &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->totals1, &ctx->tile_start,
-                  &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb};
+                  &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->totals1, &ctx->tile_start, &ctx->tile_order,
+                  &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe};
     for (Buf* b : all) buf_free(ctx, *b);
     if (ctx->ev_ok)
-        for (auto& ev : ctx->ev) (void)hipEventDestroy(ev);
+        for (auto& set : ctx->ev)
+            for (auto& ev : set) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -389,7 +405,9 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
     uint32_t *vA = (uint32_t*)ctx->valA.p, *vB = (uint32_t*)ctx->valB.p;
     const int grid = grid_for(div_up(N, kSortChunk));
 
-    if (ctx->ev_ok) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
+    const bool timed = ctx->ev_ok && (ctx->sort_calls++ % ctx->timing_stride) == 0;
+    const int tset = (int)(ctx->sort_sets % msplat_ctx::kEvSets);
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][0], s));
     // pass 0: cull + key fused into the first radix pass (presort_compute.glsl + byte 0 of the sort)
     hipLaunchKernelGGL(radix_upsweep<MODE_CULL>, dim3(grid), dim3(kThreads), 0, s, nullptr, pos, nullptr, N, N, 0,
                        hist, ctx->hist_stride, fp);
@@ -410,9 +428,9 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
         hipLaunchKernelGGL((radix_downsweep<MODE_KEYS, true>), dim3(grid), dim3(kThreads), 0, s, kin, vin, nullptr,
                            d_V, 0u, N, pass * 8, hist, ctx->hist_stride, totals, kout, vout, nullptr, nullptr, fp);
     }
-    if (ctx->ev_ok) {
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
-        ctx->ev_sort_valid = true;
+    if (timed) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][1], s));
+        ctx->sort_sets++;
     }
     HIP_TRY(ctx, hipGetLastError());
     ctx->has_sort = true;
@@ -424,12 +442,14 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     hipStream_t s = ctx->stream;
     const uint32_t N = (uint32_t)ctx->N;
     uint32_t* counters = (uint32_t*)ctx->counters.p;
-    uint32_t *d_V = counters + 0, *d_D = counters + 1, *d_overflow = counters + 2;
+    uint32_t *d_V = counters + 0, *d_D = counters + 1, *d_overflow = counters + 2, *d_queue = counters + 3;
     const int ntiles = fp.tiles_x * fp.tiles_y;
     const uint32_t cap = (uint32_t)ctx->pair_cap;
 
-    if (ctx->ev_ok) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
-    HIP_TRY(ctx, hipMemsetAsync(d_D, 0, 2 * sizeof(uint32_t), s));
+    const bool timed = ctx->ev_ok && (ctx->render_calls++ % ctx->timing_stride) == 0;
+    const int tset = (int)(ctx->render_sets % msplat_ctx::kEvSets);
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][2], s));
+    HIP_TRY(ctx, hipMemsetAsync(d_D, 0, 3 * sizeof(uint32_t), s));      // D, overflow, tile queue
     const int pgrid = std::max(1u, div_up(N, kProjThreads));
     if (ctx->full_sh)
         hipLaunchKernelGGL(project_kernel<true>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
@@ -437,7 +457,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     else
         hipLaunchKernelGGL(project_kernel<false>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
                            (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p);
-    if (ctx->ev_ok) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][3], s));
 
     // pass 1: stable partition by tile column, enumerated from the rank-ordered rectangles
     uint32_t* totals1 = (uint32_t*)ctx->totals1.p;
@@ -463,21 +483,27 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     hipLaunchKernelGGL(tile_start_kernel, dim3(std::max(1, (ntiles + kThreads) / kThreads)), dim3(kThreads), 0, s,
                        (const uint32_t*)ctx->pairsB.p, (const uint32_t*)totals2, d_D, cap, fp.tiles_x, ntiles,
                        (uint32_t*)ctx->tile_start.p);
-    if (ctx->ev_ok) HIP_TRY(ctx, hipEventRecord(ctx->ev[4], s));
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)ctx->tile_start.p, ntiles,
+                       (uint32_t*)ctx->tile_order.p, getenv("MSPLAT_COMP_ORDER") ? atoi(getenv("MSPLAT_COMP_ORDER")) : 0);
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][4], s));
 
+    // experiment knob: extra dynamic LDS per workgroup caps the compositor's occupancy
+    const size_t comp_lds = getenv("MSPLAT_COMP_LDS") ? (size_t)atoi(getenv("MSPLAT_COMP_LDS")) : 0;
+    // persistent compositor: at most 6 waves per SIMD (256 CUs x 4 SIMDs), never more than tiles
+    const int cgrid = std::min(ntiles, ctx->comp_waves);
     if (ntiles > 0) {
         if (ctx->cfg.fb_format == MSPLAT_FB_RGBA16F)
-            hipLaunchKernelGGL(composite_kernel<true>, dim3(ntiles), dim3(kCompThreads), 0, s,
+            hipLaunchKernelGGL(composite_kernel<true>, dim3(cgrid), dim3(kCompThreads), comp_lds, s,
                                (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
-                               (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap);
+                               (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap, (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles, (uint32_t*)ctx->probe.p);
         else
-            hipLaunchKernelGGL(composite_kernel<false>, dim3(ntiles), dim3(kCompThreads), 0, s,
+            hipLaunchKernelGGL(composite_kernel<false>, dim3(cgrid), dim3(kCompThreads), comp_lds, s,
                                (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
-                               (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap);
+                               (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap, (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles, (uint32_t*)ctx->probe.p);
     }
-    if (ctx->ev_ok) {
-        HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));
-        ctx->ev_render_valid = true;
+    if (timed) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][5], s));
+        ctx->render_sets++;
     }
     HIP_TRY(ctx, hipGetLastError());
     return MSPLAT_OK;
@@ -570,12 +596,12 @@ int msplat_get_stats(msplat_ctx* ctx, msplat_stats* out)
 {
     if (!ctx || !out) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    uint32_t cnt[4] = {0, 0, 0, 0};
+    uint32_t cnt[5] = {0, 0, 0, 0, 0};
     if (ctx->has_render) {   // "drawn" is a statistic only: counted on demand, not in the frame
         uint32_t* counters = (uint32_t*)ctx->counters.p;
-        HIP_TRY(ctx, hipMemsetAsync(counters + 3, 0, sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(counters + 4, 0, sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(count_drawn_kernel, dim3(256), dim3(kThreads), 0, ctx->stream, (const uint32_t*)ctx->rect.p,
-                           counters + 0, counters + 3);
+                           counters + 0, counters + 4);
     }
     HIP_TRY(ctx, hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -583,7 +609,7 @@ int msplat_get_stats(msplat_ctx* ctx, msplat_stats* out)
     out->num_splats = ctx->N;
     out->sort_count = ctx->has_sort ? cnt[0] : 0;
     out->pairs = ctx->has_render ? cnt[1] : 0;
-    out->drawn = ctx->has_render ? cnt[3] : 0;
+    out->drawn = ctx->has_render ? cnt[4] : 0;
     out->tiles_x = ctx->last_fp.tiles_x;
     out->tiles_y = ctx->last_fp.tiles_y;
     out->width = ctx->last_fp.width;
@@ -603,13 +629,25 @@ int msplat_get_timings(msplat_ctx* ctx, msplat_timings* out)
     if (!ctx->ev_ok) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "context created without enable_timing");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->ev_sort_valid) HIP_TRY(ctx, hipEventElapsedTime(&out->sort_total, ctx->ev[0], ctx->ev[1]));
-    if (ctx->ev_render_valid) {
-        HIP_TRY(ctx, hipEventElapsedTime(&out->render_total, ctx->ev[2], ctx->ev[5]));
-        HIP_TRY(ctx, hipEventElapsedTime(&out->project, ctx->ev[2], ctx->ev[3]));
-        HIP_TRY(ctx, hipEventElapsedTime(&out->binning, ctx->ev[3], ctx->ev[4]));
-        HIP_TRY(ctx, hipEventElapsedTime(&out->composite, ctx->ev[4], ctx->ev[5]));
+    // average over the sets recorded since the previous call (at most the kEvSets most recent)
+    const uint32_t ns = std::min<uint32_t>(ctx->sort_sets, msplat_ctx::kEvSets);
+    for (uint32_t k = 0; k < ns; ++k) {
+        float t = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->ev[k][0], ctx->ev[k][1]));
+        out->sort_total += t / ns;
     }
+    const uint32_t nr = std::min<uint32_t>(ctx->render_sets, msplat_ctx::kEvSets);
+    for (uint32_t k = 0; k < nr; ++k) {
+        float a = 0, b = 0, c = 0, d = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev[k][2], ctx->ev[k][5]));
+        HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev[k][2], ctx->ev[k][3]));
+        HIP_TRY(ctx, hipEventElapsedTime(&c, ctx->ev[k][3], ctx->ev[k][4]));
+        HIP_TRY(ctx, hipEventElapsedTime(&d, ctx->ev[k][4], ctx->ev[k][5]));
+        out->render_total += a / nr; out->project += b / nr; out->binning += c / nr; out->composite += d / nr;
+    }
+    out->reserved[0] = (float)nr;       // number of frames averaged
+    ctx->sort_sets = 0;
+    ctx->render_sets = 0;
     return MSPLAT_OK;
 }
 
@@ -623,6 +661,19 @@ int msplat_debug_get_projected(msplat_ctx* ctx, float* rec12, uint32_t* rect, ui
     if (cap < v) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "capacity %u < sort count %u", cap, v);
     if (v && rec12) HIP_TRY(ctx, hipMemcpy(rec12, ctx->rec2d.p, (size_t)v * 48, hipMemcpyDeviceToHost));
     if (v && rect) HIP_TRY(ctx, hipMemcpy(rect, ctx->rect.p, (size_t)v * 4, hipMemcpyDeviceToHost));
+    return MSPLAT_OK;
+}
+
+int msplat_debug_get_tile_probe(msplat_ctx* ctx, uint32_t* dst, uint32_t tile_cap)
+{
+    if (!ctx || !dst) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
+    if (!ctx->probe.p) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile probe not enabled (set MSPLAT_TILE_PROBE=1 before msplat_create)");
+    if (!ctx->has_render) return fail(ctx, MSPLAT_ERR_NO_SORT, "no render yet");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t ntiles = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y);
+    if (tile_cap < ntiles) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile capacity too small");
+    HIP_TRY(ctx, hipMemcpy(dst, ctx->probe.p, (size_t)ntiles * 16, hipMemcpyDeviceToHost));
     return MSPLAT_OK;
 }
 

@@ -19,7 +19,7 @@
 namespace msplat {
 
 constexpr int kThreads = 256;            // 4 wave64 per workgroup
-constexpr int kSortItems = 8;            // keys per thread per chunk
+constexpr int kSortItems = 8;            // keys per thread per chunk (4 measured no faster, 2026-r1)
 constexpr int kSortChunk = kThreads * kSortItems;   // 2048 keys per chunk
 constexpr int kBinChunk = 1024;          // draw-order ranks per chunk in the tile-column partition
 constexpr int kTile = 16;                // 16x16 pixel tiles
@@ -68,6 +68,17 @@ __device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* s_tmp4
     }
     __syncthreads();
     return v + off;
+}
+
+// Workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md; speed only, never correctness).
+// Remap so that each XCD processes a CONTIGUOUS range of chunks.  Measured r1: using it for the
+// scatter kernels (radix/bin1 downsweep) was 5-15 % SLOWER than the plain round-robin mapping, so it
+// is currently unused there.
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t n)
+{
+    const uint32_t q = n >> 3, r = n & 7u, xcd = b & 7u, idx = b >> 3;
+    const uint32_t base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + idx;
 }
 
 // presort_compute.glsl:38-55.  Operation order identical to oracle/msplat_oracle.c (orc_cull_key)
@@ -728,6 +739,47 @@ __global__ __launch_bounds__(kThreads) void tile_start_kernel(const uint32_t* __
     tile_start[tile] = lo;
 }
 
+// tiles ordered by descending list length (counting sort on len/16): the compositor's waves pull tiles
+// from this list through an atomic queue, heaviest first (longest-processing-time-first scheduling)
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ tile_start, int ntiles,
+                                                          uint32_t* __restrict__ order, int mode)
+{
+    if (mode != 0) {   // experiment: 1 = identity, 2 = strided
+        for (int i = threadIdx.x; i < ntiles; i += 1024)
+            order[i] = mode == 1 ? (uint32_t)i : (uint32_t)(((uint64_t)i * 5043u) % (uint32_t)ntiles);
+        return;
+    }
+    __shared__ uint32_t s_cnt[256];
+    __shared__ uint32_t s_off[256];
+    if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntiles; i += 1024) {
+        const uint32_t len = tile_start[i + 1] - tile_start[i];
+        atomicAdd(&s_cnt[255u - min(len >> 4, 255u)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {          // one wave scans the 256 buckets (4 per lane)
+        uint32_t c[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c[k] = s_cnt[threadIdx.x * 4 + k]; sum += c[k]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t t = __shfl_up(incl, d, 64);
+            if ((int)threadIdx.x >= d) incl += t;
+        }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s_off[threadIdx.x * 4 + k] = run; run += c[k]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntiles; i += 1024) {
+        const uint32_t len = tile_start[i + 1] - tile_start[i];
+        const uint32_t pos = atomicAdd(&s_off[255u - min(len >> 4, 255u)], 1u);
+        order[pos] = (uint32_t)i;      // order inside a bucket is irrelevant (tiles are independent)
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // composite: one 16x16 workgroup per tile, front-to-back over the tile's depth-ordered list
 // (reverse of the reference's back-to-front ROP blend; algebraically identical -- SURVEY 8a-12):
@@ -742,15 +794,23 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
                                                                  const uint32_t* __restrict__ pairs,
                                                                  const float4* __restrict__ rec,
                                                                  void* __restrict__ out, size_t pitch_bytes,
-                                                                 FrameParams fp, uint32_t cap)
+                                                                 FrameParams fp, uint32_t cap,
+                                                                 const uint32_t* __restrict__ order,
+                                                                 uint32_t* __restrict__ queue, uint32_t ntiles,
+                                                                 uint32_t* __restrict__ probe)
 {
     // Lane (lx, ly) owns pixels (x0+lx, y0 + 4k + ly), k = 0..3: strip k is the 16x4 pixel block of
     // rows 4k..4k+3.  Per splat the exponent is split into a part shared by the four strips and a
     // 2-FMA part per strip; strips the splat's y-range cannot reach, or whose 64 pixels are all
     // saturated, are skipped with scalar branches.
-    __shared__ float4 s_rec[kCompThreads * 3];
+    __shared__ float4 s_rec[(kCompThreads + 1) * 3];
 
-    const int tile = blockIdx.x;
+    // Persistent waves + dynamic queue: per-tile work varies by >10x (list length, early saturation),
+    // so tiles are pulled heaviest-first from `order` instead of being bound to a workgroup index.
+    // The first tile of every wave is static (its workgroup index): same-address atomics are served
+    // at only ~8 ns each, so thousands of waves pulling at launch would queue up for tens of us.
+    for (uint32_t qpos = blockIdx.x; qpos < ntiles;) {
+    const int tile = (int)order[qpos];
     const int vty = tile / fp.tiles_x;
     const int tx = tile - vty * fp.tiles_x;
     const int ty = vty * fp.row_mod + fp.row_rem;
@@ -765,96 +825,170 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
     if (start > cap) start = cap;
     if (end > cap) end = cap;
 
-    float T[4], cr[4], cg[4], cb[4];
+    // Accumulators are kept as strip PAIRS (0,1) and (2,3): gfx950 executes a plain wave64 fp32 VALU
+    // op in ~4 cycles but a packed v_pk_{fma,mul,add}_f32 does two per lane in the same slot (measured:
+    // SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.4 cycles), and this kernel is VALU bound.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f T[2], cr[2], cg[2], cb[2];
     bool inside[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        T[k] = 1.0f; cr[k] = 0.0f; cg[k] = 0.0f; cb[k] = 0.0f;
-        inside[k] = (x < fp.width) && (ybase + 4 * k < fp.height);
+    for (int h = 0; h < 2; ++h) {
+        T[h] = (v2f){1.0f, 1.0f};
+        cr[h] = (v2f){0.0f, 0.0f}; cg[h] = (v2f){0.0f, 0.0f}; cb[h] = (v2f){0.0f, 0.0f};
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) inside[k] = (x < fp.width) && (ybase + 4 * k < fp.height);
+    const v2f fyp[2] = {(v2f){fy0, fy0 + 4.0f}, (v2f){fy0 + 8.0f, fy0 + 12.0f}};
     uint32_t alive = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) alive |= (__ballot(inside[k]) != 0ull) ? (1u << k) : 0u;
 
-    // software pipeline: the next batch's records are fetched while the current one is composited
-    uint32_t hi = end;
-    uint32_t cnt = min((uint32_t)kCompThreads, hi - start);
+    // Three-stage software pipeline over batches of 64 list entries (nearest first):
+    //   ranks of batch b+2 and records of batch b+1 are in flight while batch b is composited,
+    // so a tile whose entries are mostly culled pays one memory latency per batch instead of two
+    // dependent ones (that latency chain, not ALU work, is the critical path of the long tiles).
+    uint32_t hiA = end;                                        // entries [start, hiA) not yet rank-loaded
+    uint32_t cntA = min((uint32_t)kCompThreads, hiA - start);  // batch whose ranks are in rankA
+    uint32_t rankA = 0;
+    if (lane < (int)cntA) rankA = pairs[hiA - 1u - lane] & kRankMask;     // j = 0 is the nearest splat
+    hiA -= cntA;
+    uint32_t cnt = cntA;                                       // batch whose records are in p0..p2
     float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
-    if (hi > start && lane < (int)cnt) {
-        const uint32_t rank = pairs[hi - 1u - lane] & kRankMask;       // j = 0 is the nearest splat
-        const float4* src = rec + (size_t)rank * 3;
+    if (lane < (int)cnt) {
+        const float4* src = rec + (size_t)rankA * 3;
         p0 = src[0]; p1 = src[1]; p2 = src[2];
     }
-    while (hi > start && alive != 0u) {
+    cntA = min((uint32_t)kCompThreads, hiA - start);
+    if (lane < (int)cntA) rankA = pairs[hiA - 1u - lane] & kRankMask;
+    hiA -= cntA;
+    const uint64_t probe_t0 = probe ? clock64() : 0ull;
+    uint32_t probe_n = 0, probe_batches = 0;
+    uint64_t probe_inner = 0;
+    while (cnt != 0u && alive != 0u) {
         // stage: record + the strips (bit k) its y-range [py - ey, py + ey] can reach in this tile
+        // stage only the splats whose y-range reaches a strip that is still live, compacted in list
+        // order (near to far).  The CU has ONE scalar unit for its four SIMDs, so the inner loop is
+        // written to need almost no scalar work: a plain counted loop, strips handled by VALU predicates.
+        uint32_t n;
         {
-            uint32_t strips = 0;
             const float ylo = p0.y - p2.w, yhi = p0.y + p2.w;
+            bool rel = false;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (yhi >= tile_y0 + 4.0f * k + 0.5f && ylo <= tile_y0 + 4.0f * k + 3.5f) strips |= 1u << k;
-            p2.y = __uint_as_float(strips);
-            s_rec[lane * 3 + 0] = p0;
-            s_rec[lane * 3 + 1] = p1;
-            s_rec[lane * 3 + 2] = p2;
-        }
-        const uint32_t cur = cnt;
-        hi -= cnt;
-        __syncthreads();
-        cnt = min((uint32_t)kCompThreads, hi - start);
-        if (hi > start && lane < (int)cnt) {
-            const uint32_t rank = pairs[hi - 1u - lane] & kRankMask;
-            const float4* src = rec + (size_t)rank * 3;
-            p0 = src[0]; p1 = src[1]; p2 = src[2];
-        }
-        for (uint32_t j = 0; j < cur; ++j) {
-            const float4 c = s_rec[j * 3 + 2];
-            const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(c.y)) & alive;
-            if (m == 0u) continue;
-            const float4 a = s_rec[j * 3 + 0];     // px, py, A, B
-            const float4 b = s_rec[j * 3 + 1];     // C, log2(alpha), r, g
-            const float dx = fx - a.x;
-            const float base = __builtin_fmaf(a.z * dx, dx, b.y);
-            const float lin = a.w * dx;
-            const float dy0 = fy0 - a.y;
+                rel = rel || ((alive & (1u << k)) && yhi >= tile_y0 + 4.0f * k + 0.5f && ylo <= tile_y0 + 4.0f * k + 3.5f);
+            rel = rel && lane < (int)cnt;
+            if (rel) {
+                // exact footprint-vs-tile test (the list was built from bounding rectangles): the exponent
+                // e(d) is a concave quadratic, so unless the centre lies inside the tile's box of pixel
+                // centres its maximum over the box is on one of the four edges (1-D maximiser, clamped)
+                const float X0 = (float)(tx * kTile) + 0.5f, X1 = X0 + (float)(kTile - 1);
+                const float Y0 = tile_y0 + 0.5f, Y1 = Y0 + (float)(kTile - 1);
+                const float qa = p0.z, qb = p0.w, qc = p1.x, la = p1.y;
+                const float dxl = X0 - p0.x, dxh = X1 - p0.x, dyl = Y0 - p0.y, dyh = Y1 - p0.y;
+                if (!(dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f)) {
+                    float emax = -1e30f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (m & (1u << k)) {
-                    const float dy = dy0 + 4.0f * k;
-                    const float e = __builtin_fmaf(dy, __builtin_fmaf(b.x, dy, lin), base);
-                    const float w = __builtin_amdgcn_exp2f(e);
-                    if (w > (1.0f / 256.0f)) {                 // splat_frag.glsl:37-40 discard
-                        const float tw = T[k] * w;
-                        cr[k] = __builtin_fmaf(tw, b.z, cr[k]);
-                        cg[k] = __builtin_fmaf(tw, b.w, cg[k]);
-                        cb[k] = __builtin_fmaf(tw, c.x, cb[k]);
-                        T[k] = T[k] - tw;
+                    for (int s = 0; s < 2; ++s) {
+                        const float dx = s ? dxh : dxl;                      // vertical edges
+                        const float dy = fminf(fmaxf(-qb * dx / (2.0f * qc), dyl), dyh);
+                        emax = fmaxf(emax, (qc * dy + qb * dx) * dy + qa * dx * dx + la);
+                        const float ey = s ? dyh : dyl;                      // horizontal edges
+                        const float ex = fminf(fmaxf(-qb * ey / (2.0f * qa), dxl), dxh);
+                        emax = fmaxf(emax, (qa * ex + qb * ey) * ex + qc * ey * ey + la);
                     }
+                    rel = emax > -8.05f;
                 }
             }
+            const uint64_t relmask = __ballot(rel);
+            n = (uint32_t)__popcll(relmask);
+            if (rel) {
+                const int slot = __popcll(relmask & ((1ull << lane) - 1ull));
+                s_rec[slot * 3 + 0] = p0;
+                s_rec[slot * 3 + 1] = p1;
+                s_rec[slot * 3 + 2] = p2;
+            }
         }
+        __syncthreads();
+        cnt = cntA;
+        if (lane < (int)cnt) {
+            const float4* src = rec + (size_t)rankA * 3;
+            p0 = src[0]; p1 = src[1]; p2 = src[2];
+        }
+        cntA = min((uint32_t)kCompThreads, hiA - start);
+        if (lane < (int)cntA) rankA = pairs[hiA - 1u - lane] & kRankMask;
+        hiA -= cntA;
+        probe_n += n;
+        ++probe_batches;
+        const uint64_t probe_t1 = probe ? clock64() : 0ull;
+        if (n != 0u) {
+            float4 a = s_rec[0];          // px, py, A, B
+            float4 b = s_rec[1];          // C, log2(alpha), r, g
+            float blue = s_rec[2].x;
+#pragma unroll 2
+            for (uint32_t j = 0; j < n; ++j) {
+                // next record (slot n is a harmless over-read inside the 65-slot array)
+                const float4 na = s_rec[(j + 1) * 3 + 0];
+                const float4 nb = s_rec[(j + 1) * 3 + 1];
+                const float nblue = s_rec[(j + 1) * 3 + 2].x;
+                const float dx = fx - a.x;
+                const float base = __builtin_fmaf(a.z * dx, dx, b.y);
+                const float lin = a.w * dx;
+                const v2f vbase = (v2f){base, base}, vlin = (v2f){lin, lin}, vC = (v2f){b.x, b.x};
+                const v2f vpy = (v2f){a.y, a.y};
+                const v2f vr = (v2f){b.z, b.z}, vg = (v2f){b.w, b.w}, vb = (v2f){blue, blue};
+                // Branch-free on purpose: the strips are independent dependency chains inside one basic
+                // block, so the in-order wave can overlap them.  w = 0 where the fragment shader discards.
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const v2f dy = fyp[h] - vpy;
+                    const v2f e = __builtin_elementwise_fma(dy, __builtin_elementwise_fma(vC, dy, vlin), vbase);
+                    // splat_frag.glsl:37-40 discard: w = exp2(e) > 1/256  <=>  e > -8
+                    v2f w;
+                    w.x = (e.x > -8.0f) ? __builtin_amdgcn_exp2f(e.x) : 0.0f;
+                    w.y = (e.y > -8.0f) ? __builtin_amdgcn_exp2f(e.y) : 0.0f;
+                    const v2f tw = T[h] * w;
+                    cr[h] = __builtin_elementwise_fma(tw, vr, cr[h]);
+                    cg[h] = __builtin_elementwise_fma(tw, vg, cg[h]);
+                    cb[h] = __builtin_elementwise_fma(tw, vb, cb[h]);
+                    T[h] = T[h] - tw;
+                }
+                a = na; b = nb; blue = nblue;
+            }
+        }
+        if (probe) probe_inner += clock64() - probe_t1;
         // strips whose 64 pixels are all saturated (or outside the image) are finished
         uint32_t na = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            na |= (__ballot(inside[k] && T[k] >= fp.t_eps) != 0ull) ? (1u << k) : 0u;
+            na |= (__ballot(inside[k] && T[k >> 1][k & 1] >= fp.t_eps) != 0ull) ? (1u << k) : 0u;
         alive = na;
         __syncthreads();
     }
 
+    if (probe != nullptr && lane == 0) {
+        probe[tile * 4 + 0] = (uint32_t)(clock64() - probe_t0);        // shader clocks, whole tile
+        probe[tile * 4 + 1] = probe_n;          // splats composited (after culling / saturation)
+        probe[tile * 4 + 2] = probe_batches;    // batches of 64 list entries fetched
+        probe[tile * 4 + 3] = (uint32_t)probe_inner;   // shader clocks spent in the inner loops
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (inside[k]) {
             char* row = (char*)out + (size_t)(ybase + 4 * k) * pitch_bytes;
             if (HALF) {
                 union { _Float16 h[4]; uint2 u; } pk;
-                pk.h[0] = (_Float16)cr[k]; pk.h[1] = (_Float16)cg[k]; pk.h[2] = (_Float16)cb[k]; pk.h[3] = (_Float16)1.0f;
+                pk.h[0] = (_Float16)cr[k >> 1][k & 1]; pk.h[1] = (_Float16)cg[k >> 1][k & 1]; pk.h[2] = (_Float16)cb[k >> 1][k & 1]; pk.h[3] = (_Float16)1.0f;
                 ((uint2*)row)[x] = pk.u;
             } else {
-                ((float4*)row)[x] = make_float4(cr[k], cg[k], cb[k], 1.0f);
+                ((float4*)row)[x] = make_float4(cr[k >> 1][k & 1], cg[k >> 1][k & 1], cb[k >> 1][k & 1], 1.0f);
             }
         }
     }
+    __syncthreads();      // s_rec is reused by the next tile
+    uint32_t nq = 0;
+    if (threadIdx.x == 0) nq = atomicAdd(queue, 1u);
+    qpos = gridDim.x + __builtin_amdgcn_readfirstlane(nq);
+    }   // persistent tile loop
 }
 
 }  // namespace msplat

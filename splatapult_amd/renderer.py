@@ -52,7 +52,7 @@ class SplatRenderer:
         cfg.t_epsilon = self._t_eps
         cfg.pair_capacity = self._pair_cap
         cfg.stream = self._stream
-        cfg.enable_timing = 1 if self._timing else 0
+        cfg.enable_timing = int(self._timing)
         h = C.c_void_p()
         rc = self._lib.msplat_create(C.byref(h), C.byref(cfg))
         if rc != _capi.OK:
@@ -144,6 +144,14 @@ class SplatRenderer:
         _capi.check(self._ctx, self._lib.msplat_debug_get_projected(
             self._ctx, rec.ctypes.data_as(C.POINTER(C.c_float)), rect.ctypes.data_as(C.POINTER(C.c_uint32)), rec.shape[0]))
         return rec[:v], rect[:v]
+
+    def debug_tile_probe(self):
+        st = self.stats()
+        nt = st["tiles_x"] * st["tiles_y"]
+        out = np.zeros((max(nt, 1), 4), np.uint32)
+        _capi.check(self._ctx, self._lib.msplat_debug_get_tile_probe(
+            self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.shape[0]))
+        return out[:nt]
 
     def debug_tile_lists(self):
         st = self.stats()

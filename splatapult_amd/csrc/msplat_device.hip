@@ -80,6 +80,7 @@ struct msplat_ctx {
     uint32_t sort_sets = 0, render_sets = 0;      // sets recorded since the last msplat_get_timings
     int cur_render_set = -1;
 
+    bool atomic_rank = true;    // LDS atomics hand out ranks in lane order (probed at create)
     int comp_waves = 6144;      // compositor grid (persistent waves); MSPLAT_COMP_WAVES overrides
     uint64_t device_bytes = 0;
 };
@@ -211,6 +212,16 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
     if (rc == MSPLAT_OK && getenv("MSPLAT_TILE_PROBE") != nullptr) rc = buf_alloc(ctx, ctx->probe, 65536 * 4 * sizeof(uint32_t));
     if (rc == MSPLAT_OK && hipMemsetAsync(ctx->counters.p, 0, 8 * sizeof(uint32_t), ctx->stream) != hipSuccess)
         rc = MSPLAT_ERR_HIP;
+    if (rc == MSPLAT_OK) {
+        // feature probe: stable ranks straight from LDS atomics need lane-ordered ds_add_rtn
+        uint32_t* bad = (uint32_t*)ctx->counters.p + 7;
+        hipLaunchKernelGGL(lds_atomic_order_probe, dim3(64), dim3(kThreads), 0, ctx->stream, bad);
+        uint32_t hbad = 1;
+        if (hipMemcpyAsync(&hbad, bad, sizeof(hbad), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = fail(ctx, MSPLAT_ERR_HIP, "LDS atomic order probe failed to run");
+        ctx->atomic_rank = (hbad == 0) && getenv("MSPLAT_BALLOT_RANK") == nullptr;
+    }
     if (rc != MSPLAT_OK) {
         std::string msg = ctx->err;
         msplat_destroy(ctx);
@@ -253,7 +264,7 @@ static int ensure_pair_capacity(msplat_ctx* ctx, uint64_t cap)
     if (rc) return rc;
     rc = buf_alloc(ctx, ctx->pairsB, cap * sizeof(uint32_t));
     if (rc) return rc;
-    ctx->hist2_stride = div_up(cap, kSortChunk);
+    ctx->hist2_stride = div_up(cap, kPairChunk);
     rc = buf_alloc(ctx, ctx->hist2, (size_t)256 * ctx->hist2_stride * sizeof(uint32_t));
     if (rc) return rc;
     ctx->pair_cap = cap;
@@ -413,8 +424,12 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
                        hist, ctx->hist_stride, fp);
     hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, hist, ctx->hist_stride, nullptr, N, N,
                        (uint32_t)kSortChunk, totals);
-    hipLaunchKernelGGL((radix_downsweep<MODE_CULL, true>), dim3(grid), dim3(kThreads), 0, s, nullptr, nullptr, pos,
-                       nullptr, N, N, 0, hist, ctx->hist_stride, totals, kB, vB, d_V, nullptr, fp);
+    if (ctx->atomic_rank)
+        hipLaunchKernelGGL((radix_downsweep<MODE_CULL, true, true>), dim3(grid), dim3(kThreads), 0, s, nullptr, nullptr, pos,
+                           nullptr, N, N, 0, hist, ctx->hist_stride, totals, kB, vB, d_V, nullptr, fp);
+    else
+        hipLaunchKernelGGL((radix_downsweep<MODE_CULL, true, false>), dim3(grid), dim3(kThreads), 0, s, nullptr, nullptr, pos,
+                           nullptr, N, N, 0, hist, ctx->hist_stride, totals, kB, vB, d_V, nullptr, fp);
     // passes 1..3 on the V survivors (V stays on the device; splatrenderer.cpp:195-204's readback is gone)
     for (int pass = 1; pass < 4; ++pass) {
         uint32_t* kin = (pass & 1) ? kB : kA;
@@ -425,8 +440,12 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
                            pass * 8, hist, ctx->hist_stride, fp);
         hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, hist, ctx->hist_stride, d_V, 0u, N,
                            (uint32_t)kSortChunk, totals);
-        hipLaunchKernelGGL((radix_downsweep<MODE_KEYS, true>), dim3(grid), dim3(kThreads), 0, s, kin, vin, nullptr,
-                           d_V, 0u, N, pass * 8, hist, ctx->hist_stride, totals, kout, vout, nullptr, nullptr, fp);
+        if (ctx->atomic_rank)
+            hipLaunchKernelGGL((radix_downsweep<MODE_KEYS, true, true>), dim3(grid), dim3(kThreads), 0, s, kin, vin, nullptr,
+                               d_V, 0u, N, pass * 8, hist, ctx->hist_stride, totals, kout, vout, nullptr, nullptr, fp);
+        else
+            hipLaunchKernelGGL((radix_downsweep<MODE_KEYS, true, false>), dim3(grid), dim3(kThreads), 0, s, kin, vin, nullptr,
+                               d_V, 0u, N, pass * 8, hist, ctx->hist_stride, totals, kout, vout, nullptr, nullptr, fp);
     }
     if (timed) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][1], s));
@@ -467,19 +486,30 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                        (uint32_t*)ctx->hist1.p, ctx->hist1_stride);
     hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V,
                        0u, N, (uint32_t)kBinChunk, totals1);
-    hipLaunchKernelGGL(bin1_downsweep, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
-                       (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,
-                       (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow);
+    if (ctx->atomic_rank)
+        hipLaunchKernelGGL(bin1_downsweep<true>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
+                           (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,
+                           (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow);
+    else
+        hipLaunchKernelGGL(bin1_downsweep<false>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
+                           (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,
+                           (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow);
     // pass 2: stable partition by tile row (one generic radix pass on the top byte); words become (tx<<24)|rank
-    const int g2 = grid_for(div_up(cap, kSortChunk));
+    const int g2 = grid_for(div_up(cap, kPairChunk));
     hipLaunchKernelGGL(radix_upsweep<MODE_PAIR>, dim3(g2), dim3(kThreads), 0, s, (const uint32_t*)ctx->pairsA.p,
                        nullptr, d_D, 0u, cap, 24, (uint32_t*)ctx->hist2.p, ctx->hist2_stride, fp);
     hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, (uint32_t*)ctx->hist2.p, ctx->hist2_stride, d_D,
-                       0u, cap, (uint32_t)kSortChunk, totals2);
-    hipLaunchKernelGGL((radix_downsweep<MODE_PAIR, false>), dim3(g2), dim3(kThreads), 0, s,
-                       (const uint32_t*)ctx->pairsA.p, nullptr, nullptr, d_D, 0u, cap, 24,
-                       (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
-                       (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1, fp);
+                       0u, cap, (uint32_t)kPairChunk, totals2);
+    if (ctx->atomic_rank)
+        hipLaunchKernelGGL((radix_downsweep<MODE_PAIR, false, true>), dim3(g2), dim3(kThreads), 0, s,
+                           (const uint32_t*)ctx->pairsA.p, nullptr, nullptr, d_D, 0u, cap, 24,
+                           (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
+                           (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1, fp);
+    else
+        hipLaunchKernelGGL((radix_downsweep<MODE_PAIR, false, false>), dim3(g2), dim3(kThreads), 0, s,
+                           (const uint32_t*)ctx->pairsA.p, nullptr, nullptr, d_D, 0u, cap, 24,
+                           (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
+                           (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1, fp);
     hipLaunchKernelGGL(tile_start_kernel, dim3(std::max(1, (ntiles + kThreads) / kThreads)), dim3(kThreads), 0, s,
                        (const uint32_t*)ctx->pairsB.p, (const uint32_t*)totals2, d_D, cap, fp.tiles_x, ntiles,
                        (uint32_t*)ctx->tile_start.p);

@@ -21,6 +21,9 @@ namespace msplat {
 constexpr int kThreads = 256;            // 4 wave64 per workgroup
 constexpr int kSortItems = 8;            // keys per thread per chunk (4 measured no faster, 2026-r1)
 constexpr int kSortChunk = kThreads * kSortItems;   // 2048 keys per chunk
+constexpr int kPairItems = 16;           // binning pass 2 moves 7x more words: bigger chunks, longer runs
+constexpr int kPairChunk = kThreads * kPairItems;   // 4096 words per chunk
+template <int MODE> struct RadixCfg { static constexpr int ITEMS = (MODE == 2) ? kPairItems : kSortItems; static constexpr int CHUNK = kThreads * ITEMS; };
 constexpr int kBinChunk = 1024;          // draw-order ranks per chunk in the tile-column partition
 constexpr int kTile = 16;                // 16x16 pixel tiles
 constexpr uint32_t kRectEmpty = 0x000000FFu;   // tx0=255 > tx1=0
@@ -109,6 +112,41 @@ __device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift)
     return (key >> shift) & 255u;
 }
 
+// Self-test for the ATOMIC_RANK paths: every lane adds 1 to a per-wave LDS counter selected by a
+// pseudo-random digit; bad[0] counts lanes whose returned value is not "number of lower lanes (and
+// earlier rounds) with the same digit".  Run once per context; a non-zero result selects the ballot paths.
+__global__ __launch_bounds__(kThreads) void lds_atomic_order_probe(uint32_t* __restrict__ bad)
+{
+    __shared__ uint32_t s_c[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t errs = 0;
+    for (int mod = 1; mod <= 256; mod = mod * 3 + 1) {          // 1, 4, 13, 40, 121 distinct digits
+        for (int q = 0; q < 4; ++q) s_c[q][threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t expect_base[1];
+        (void)expect_base;
+        for (int r = 0; r < 8; ++r) {
+            uint32_t h = (uint32_t)(threadIdx.x * 2654435761u) ^ (uint32_t)(r * 40503u + blockIdx.x * 977u + mod);
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            const uint32_t d = (h % (uint32_t)mod) * (mod == 13 ? 32u : 1u) % 256u;    // mod 13: same-bank strides
+            uint64_t m = ~0ull;
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            const uint32_t before = s_c[w][d];
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t got = atomicAdd(&s_c[w][d], 1u);
+            __builtin_amdgcn_wave_barrier();
+            if (got != before + (uint32_t)__popcll(m & lt)) ++errs;
+        }
+        __syncthreads();
+    }
+    if (errs) atomicAdd(bad, errs);
+}
+
 // ------------------------------------------------------------------------------------------
 // 8-bit-digit stable LSD radix pass: upsweep (per-chunk histograms), scan, downsweep (rank+scatter)
 //   MODE_KEYS : keys from a buffer, n = *d_n
@@ -126,16 +164,18 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
                                                           uint32_t* __restrict__ hist, uint32_t hist_stride,
                                                           FrameParams fp)
 {
+    constexpr int ITEMS = RadixCfg<MODE>::ITEMS;
+    constexpr int CHUNK = RadixCfg<MODE>::CHUNK;
     __shared__ uint32_t s_hist[256];
     uint32_t n = d_n ? *d_n : n_static;
     if (n > n_cap) n = n_cap;
-    const uint32_t nchunks = (n + kSortChunk - 1) / kSortChunk;
+    const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         s_hist[threadIdx.x] = 0;
         __syncthreads();
-        const uint32_t base = chunk * kSortChunk;
+        const uint32_t base = chunk * CHUNK;
 #pragma unroll
-        for (int r = 0; r < kSortItems; ++r) {
+        for (int r = 0; r < ITEMS; ++r) {
             const uint32_t i = base + r * kThreads + threadIdx.x;
             if (i < n) {
                 uint32_t key;
@@ -174,7 +214,7 @@ __global__ __launch_bounds__(kThreads) void radix_scan(uint32_t* __restrict__ hi
     if (threadIdx.x == 0) totals[blockIdx.x] = running;
 }
 
-template <int MODE, bool HAS_VALUES>
+template <int MODE, bool HAS_VALUES, bool ATOMIC_RANK>
 __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __restrict__ keys_in,
                                                             const uint32_t* __restrict__ vals_in,
                                                             const float4* __restrict__ pos,
@@ -188,14 +228,20 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
                                                             const uint32_t* __restrict__ col_totals,
                                                             FrameParams fp)
 {
+    constexpr int ITEMS = RadixCfg<MODE>::ITEMS;
+    constexpr int CHUNK = RadixCfg<MODE>::CHUNK;
     __shared__ uint32_t s_col[MODE == MODE_PAIR ? 256 : 1];   // MODE_PAIR: first input position of each column
     __shared__ uint32_t s_cnt[4][256];   // per-wave digit counters, then per-wave scatter bases
     __shared__ uint32_t s_base[256];     // exclusive scan of the digit totals
+    __shared__ uint32_t s_gdelta[256];   // global position minus chunk-local position, per digit
+    __shared__ uint32_t s_keys[CHUNK];
+    __shared__ uint32_t s_vals[HAS_VALUES ? CHUNK : 1];
+    __shared__ uint8_t s_dig[CHUNK];
     __shared__ uint32_t s_tmp[4];
 
     uint32_t n = d_n ? *d_n : n_static;
     if (n > n_cap) n = n_cap;
-    const uint32_t nchunks = (n + kSortChunk - 1) / kSortChunk;
+    const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -220,14 +266,14 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
         for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
         __syncthreads();
 
-        uint32_t key[kSortItems];
-        uint32_t val[kSortItems];
-        uint32_t lrank[kSortItems];
-        bool valid[kSortItems];
+        uint32_t key[ITEMS];
+        uint32_t val[ITEMS];
+        uint32_t lrank[ITEMS];
+        bool valid[ITEMS];
         // wave w owns the contiguous sub-chunk [w*64*ITEMS, (w+1)*64*ITEMS): keeps the sort stable
-        const uint32_t base = chunk * kSortChunk + (uint32_t)w * (64 * kSortItems);
+        const uint32_t base = chunk * CHUNK + (uint32_t)w * (64 * ITEMS);
 #pragma unroll
-        for (int r = 0; r < kSortItems; ++r) {
+        for (int r = 0; r < ITEMS; ++r) {
             const uint32_t i = base + r * 64 + lane;
             valid[r] = i < n;
             key[r] = 0;
@@ -243,55 +289,90 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
             }
         }
 #pragma unroll
-        for (int r = 0; r < kSortItems; ++r) {
+        for (int r = 0; r < ITEMS; ++r) {
             const uint32_t d = digit_of<MODE>(key[r], shift);
-            uint64_t m = __ballot(valid[r]);
+            if (ATOMIC_RANK) {
+                // ds_add_rtn_u32 serves the lanes of one wave instruction in ascending lane order and a
+                // wave's DS instructions in program order (verified at context creation by
+                // lds_atomic_order_probe; if the probe ever fails the ballot path below is used), so the
+                // returned value IS the stable local rank: 1 LDS op instead of ~45 VALU ops per key.
+                lrank[r] = 0;
+                if (valid[r]) lrank[r] = atomicAdd(&s_cnt[w][d], 1u);
+            } else {
+                uint64_t m = __ballot(valid[r]);
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const uint64_t bal = __ballot(bit);
-                m &= bit ? bal : ~bal;
+                for (int b = 0; b < 8; ++b) {
+                    const bool bit = (d >> b) & 1u;
+                    const uint64_t bal = __ballot(bit);
+                    m &= bit ? bal : ~bal;
+                }
+                uint32_t prev = 0;
+                if (valid[r]) prev = s_cnt[w][d];
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t rk = __popcll(m & lt_mask);
+                const uint32_t cnt = __popcll(m);
+                lrank[r] = prev + rk;
+                if (valid[r] && rk == 0) s_cnt[w][d] = prev + cnt;
+                __builtin_amdgcn_wave_barrier();
             }
-            uint32_t prev = 0;
-            if (valid[r]) prev = s_cnt[w][d];
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t rk = __popcll(m & lt_mask);
-            const uint32_t cnt = __popcll(m);
-            lrank[r] = prev + rk;
-            if (valid[r] && rk == 0) s_cnt[w][d] = prev + cnt;
-            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
+        // Local sort through LDS, then a coalesced write-out: position p of the chunk's digit-sorted
+        // order goes to p + s_gdelta[digit], so neighbouring threads write neighbouring words of a
+        // digit run (direct scattering cost 1.8-2.4x write amplification in 32-byte partial lines).
+        uint32_t chunk_count;
         {
             const int d = threadIdx.x;
-            const uint32_t g = s_base[d] + hist[(size_t)d * hist_stride + chunk];
-            const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d];
-            s_cnt[0][d] = g;
-            s_cnt[1][d] = g + c0;
-            s_cnt[2][d] = g + c0 + c1;
-            s_cnt[3][d] = g + c0 + c1 + c2;
+            const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d], c3 = s_cnt[3][d];
+            const uint32_t tot = c0 + c1 + c2 + c3;
+            const uint32_t incl = block_incl_scan(tot, s_tmp, chunk_count);
+            const uint32_t excl = incl - tot;
+            s_cnt[0][d] = excl;
+            s_cnt[1][d] = excl + c0;
+            s_cnt[2][d] = excl + c0 + c1;
+            s_cnt[3][d] = excl + c0 + c1 + c2;
+            s_gdelta[d] = s_base[d] + hist[(size_t)d * hist_stride + chunk] - excl;
         }
         __syncthreads();
+        uint32_t wave_col = 0;
+        if (MODE == MODE_PAIR) {       // column of the wave's first input position: last c with s_col[c] <= base
+            uint32_t lo = 0, hi = 255;
 #pragma unroll
-        for (int r = 0; r < kSortItems; ++r) {
+            for (int s = 0; s < 8; ++s) {
+                const uint32_t mid = (lo + hi + 1u) >> 1;
+                if (s_col[mid] <= base) lo = mid; else hi = mid - 1u;
+            }
+            wave_col = lo;
+        }
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
             if (valid[r]) {
                 const uint32_t d = digit_of<MODE>(key[r], shift);
-                const uint32_t dst = s_cnt[w][d] + lrank[r];
+                const uint32_t p = s_cnt[w][d] + lrank[r];
                 uint32_t kout = key[r];
                 if (MODE == MODE_PAIR) {
                     // input is ordered by (column, rank): recover the column from the input position and
-                    // store (tx << 24) | rank, so each row of the result is ascending (tile_start_kernel)
+                    // store (tx << 24) | rank, so each row of the result is ascending (tile_start_kernel).
+                    // The wave's positions are consecutive and a column holds ~D/tiles_x words, so almost
+                    // every wave sits inside one column: search once per wave, then walk.
                     const uint32_t i = base + r * 64 + lane;
-                    uint32_t lo = 0, hi = 255;            // last c with s_col[c] <= i
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) {
-                        const uint32_t mid = (lo + hi + 1u) >> 1;
-                        if (s_col[mid] <= i) lo = mid; else hi = mid - 1u;
-                    }
-                    kout = (lo << 24) | (key[r] & kRankMask);
+                    uint32_t c = wave_col;
+                    while (c < 255u && s_col[c + 1u] <= i) ++c;       // rarely iterates
+                    kout = (c << 24) | (key[r] & kRankMask);
                 }
-                keys_out[dst] = kout;
-                if (HAS_VALUES) vals_out[dst] = val[r];
+                s_keys[p] = kout;
+                s_dig[p] = (uint8_t)d;
+                if (HAS_VALUES) s_vals[p] = val[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const uint32_t p = k * kThreads + threadIdx.x;
+            if (p < chunk_count) {
+                const uint32_t dst = p + s_gdelta[s_dig[p]];
+                keys_out[dst] = s_keys[p];
+                if (HAS_VALUES) vals_out[dst] = s_vals[p];
             }
         }
         __syncthreads();
@@ -581,6 +662,7 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
 // order, weight = number of tile rows; wave w takes a contiguous quarter of the chunk's items, so
 // (wave, round, lane) order == item order.  Ranking inside a wave: ballot-match on the column byte,
 // weighted prefix from 9 ballots over the bits of the weight (rows <= 256).
+template <bool ATOMIC_RANK>
 __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __restrict__ rect,
                                                            const uint32_t* __restrict__ d_V,
                                                            const uint32_t* __restrict__ hist, uint32_t hist_stride,
@@ -677,27 +759,33 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
             const bool valid = k < wend;
             uint32_t tx = 0, rows = 0, ty0 = 0, rank = 0;
             if (valid) locate(k, tx, rows, ty0, rank);
-            uint64_t m = __ballot(valid);
+            uint32_t pos = 0;
+            if (ATOMIC_RANK) {
+                // weighted stable rank straight from the LDS atomic (lane-ordered, see radix_downsweep)
+                if (valid) pos = atomicAdd(&s_cnt[w][tx], rows);
+            } else {
+                uint64_t m = __ballot(valid);
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (tx >> b) & 1u;
-                const uint64_t bal = __ballot(bit);
-                m &= bit ? bal : ~bal;
-            }
-            uint32_t pre = 0, tot = 0;
+                for (int b = 0; b < 8; ++b) {
+                    const bool bit = (tx >> b) & 1u;
+                    const uint64_t bal = __ballot(bit);
+                    m &= bit ? bal : ~bal;
+                }
+                uint32_t pre = 0, tot = 0;
 #pragma unroll
-            for (int b = 0; b < 9; ++b) {
-                const uint64_t bal = __ballot(valid && ((rows >> b) & 1u)) & m;
-                pre += (uint32_t)__popcll(bal & lt_mask) << b;
-                tot += (uint32_t)__popcll(bal) << b;
+                for (int b = 0; b < 9; ++b) {
+                    const uint64_t bal = __ballot(valid && ((rows >> b) & 1u)) & m;
+                    pre += (uint32_t)__popcll(bal & lt_mask) << b;
+                    tot += (uint32_t)__popcll(bal) << b;
+                }
+                uint32_t prev = 0;
+                if (valid) prev = s_cnt[w][tx];
+                __builtin_amdgcn_wave_barrier();
+                if (valid && (m & lt_mask) == 0) s_cnt[w][tx] = prev + tot;
+                __builtin_amdgcn_wave_barrier();
+                pos = prev + pre;
             }
-            uint32_t prev = 0;
-            if (valid) prev = s_cnt[w][tx];
-            __builtin_amdgcn_wave_barrier();
-            if (valid && (m & lt_mask) == 0) s_cnt[w][tx] = prev + tot;
-            __builtin_amdgcn_wave_barrier();
             if (valid) {
-                const uint32_t pos = prev + pre;
                 for (uint32_t q = 0; q < rows; ++q)
                     if (pos + q < cap) pairs_out[pos + q] = ((ty0 + q) << 24) | rank;
             }

@@ -92,8 +92,10 @@ def main():
     if world > 1:
         r.set_band(world, rank)
 
-    tiles_y = (H + 15) // 16
-    Hpad = tiles_y * 16
+    from splatapult_amd import _capi
+    TILE = _capi.lib().msplat_tile_size()
+    tiles_y = (H + TILE - 1) // TILE
+    Hpad = tiles_y * TILE
     fdt = torch.float16 if wl["fb"] == "fp16" else torch.float32
     bpp = 8 if wl["fb"] == "fp16" else 16
     fbs = [torch.zeros((Hpad, W, 4), dtype=fdt, device=dev) for _ in range(views)]
@@ -113,7 +115,7 @@ def main():
     gathers = None
     if world > 1:
         from splatapult_amd.dist import BandGather
-        gathers = [BandGather(tiles_y, W, fdt, dev, rank, world) for _ in range(views)]
+        gathers = [BandGather(tiles_y, W, fdt, dev, rank, world, tile=TILE) for _ in range(views)]
 
     def frame(step):
         cams = cams_for(step)

@@ -33,7 +33,7 @@ enum {
     MSPLAT_ERR_HIP = -3,           /* a HIP call failed; see msplat_last_error               */
     MSPLAT_ERR_NO_CLOUD = -4,      /* sort/render before upload                              */
     MSPLAT_ERR_NO_SORT = -5,       /* render before sort                                     */
-    MSPLAT_ERR_UNSUPPORTED = -6,   /* e.g. viewport larger than 4096x4096                    */
+    MSPLAT_ERR_UNSUPPORTED = -6,   /* e.g. viewport larger than 8192x8192                    */
     MSPLAT_ERR_PAIR_OVERFLOW = -7, /* (splat,tile) pair buffer too small and could not grow  */
     MSPLAT_ERR_IO = -8             /* PLY open/parse failure                                 */
 };
@@ -102,6 +102,8 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg);
 void msplat_destroy(msplat_ctx* ctx);
 const char* msplat_last_error(const msplat_ctx* ctx);   /* ctx may be NULL: global last error */
 const char* msplat_version_string(void);
+/* edge of the square screen bins (pixels) that tile lists and msplat_set_band rows refer to */
+int msplat_tile_size(void);
 
 /* replaces SplatRenderer::Init + BuildVertexArrayObject (splatrenderer.cpp:50-151,345-391):
  * copies the interleaved cloud to the device (the caller may free it afterwards, as the
@@ -110,7 +112,8 @@ int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t s
                         const msplat_attr_offsets* off, int full_sh);
 
 /* Multi-GPU tile-row sharding (no reference counterpart).  Restricts this
- * context to tile rows t with t % row_mod == row_rem (16-pixel rows, row 0 = GL bottom).
+ * context to tile rows t with t % row_mod == row_rem (rows of msplat_tile_size() pixels, row 0 = GL
+ * bottom).
  * row_mod = 1 (default) = whole image.  The framebuffer handed to msplat_render is always the
  * full W x H image; only rows owned by the band are written. */
 int msplat_set_band(msplat_ctx* ctx, int32_t row_mod, int32_t row_rem);

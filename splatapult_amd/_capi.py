@@ -50,6 +50,7 @@ SYMBOLS = [
     ("msplat_destroy", None, [C.c_void_p]),
     ("msplat_last_error", C.c_char_p, [C.c_void_p]),
     ("msplat_version_string", C.c_char_p, []),
+    ("msplat_tile_size", C.c_int, []),
     ("msplat_upload_cloud", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(AttrOffsets), C.c_int]),
     ("msplat_set_band", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     ("msplat_sort", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16]),

@@ -149,6 +149,8 @@ extern "C" {
 
 const char* msplat_version_string(void) { return "msplat 0.1 (gfx950, HIP)"; }
 
+int msplat_tile_size(void) { return kBin; }
+
 const char* msplat_last_error(const msplat_ctx* ctx)
 {
     if (ctx) return ctx->err.c_str();
@@ -381,11 +383,11 @@ static int make_frame_params(msplat_ctx* ctx, const float cameraMat[16], const f
     fp.Y0 = viewport[1];
     fp.width = (int)viewport[2];
     fp.height = (int)viewport[3];
-    if (fp.width < 1 || fp.height < 1 || fp.width > 4096 || fp.height > 4096)
-        return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "viewport %dx%d outside [1,4096]^2 (256x256 tiles of 16 px)",
+    if (fp.width < 1 || fp.height < 1 || fp.width > 8192 || fp.height > 8192)
+        return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "viewport %dx%d outside [1,8192]^2 (256x256 bins of 32 px)",
                     fp.width, fp.height);
-    fp.tiles_x = (fp.width + kTile - 1) / kTile;
-    const int rows_full = (fp.height + kTile - 1) / kTile;
+    fp.tiles_x = (fp.width + kBin - 1) / kBin;
+    const int rows_full = (fp.height + kBin - 1) / kBin;
     fp.row_mod = ctx->row_mod;
     fp.row_rem = ctx->row_rem;
     // owned rows: vy*mod + rem < rows_full
@@ -520,16 +522,16 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     // experiment knob: extra dynamic LDS per workgroup caps the compositor's occupancy
     const size_t comp_lds = getenv("MSPLAT_COMP_LDS") ? (size_t)atoi(getenv("MSPLAT_COMP_LDS")) : 0;
     // persistent compositor: at most 6 waves per SIMD (256 CUs x 4 SIMDs), never more than tiles
-    const int cgrid = std::min(ntiles, ctx->comp_waves);
+    const int cgrid = std::min(ntiles * 4, ctx->comp_waves);     // work items = (bin, quadrant)
     if (ntiles > 0) {
         if (ctx->cfg.fb_format == MSPLAT_FB_RGBA16F)
             hipLaunchKernelGGL(composite_kernel<true>, dim3(cgrid), dim3(kCompThreads), comp_lds, s,
                                (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
-                               (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap, (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles, (uint32_t*)ctx->probe.p);
+                               (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap, (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u, (uint32_t*)ctx->probe.p);
         else
             hipLaunchKernelGGL(composite_kernel<false>, dim3(cgrid), dim3(kCompThreads), comp_lds, s,
                                (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
-                               (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap, (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles, (uint32_t*)ctx->probe.p);
+                               (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap, (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u, (uint32_t*)ctx->probe.p);
     }
     if (timed) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][5], s));
@@ -701,7 +703,7 @@ int msplat_debug_get_tile_probe(msplat_ctx* ctx, uint32_t* dst, uint32_t tile_ca
     if (!ctx->has_render) return fail(ctx, MSPLAT_ERR_NO_SORT, "no render yet");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t ntiles = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y);
+    const uint32_t ntiles = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y) * 4u;   // (bin, quadrant) items
     if (tile_cap < ntiles) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile capacity too small");
     HIP_TRY(ctx, hipMemcpy(dst, ctx->probe.p, (size_t)ntiles * 16, hipMemcpyDeviceToHost));
     return MSPLAT_OK;

@@ -25,7 +25,9 @@ constexpr int kPairItems = 16;           // binning pass 2 moves 7x more words: 
 constexpr int kPairChunk = kThreads * kPairItems;   // 4096 words per chunk
 template <int MODE> struct RadixCfg { static constexpr int ITEMS = (MODE == 2) ? kPairItems : kSortItems; static constexpr int CHUNK = kThreads * ITEMS; };
 constexpr int kBinChunk = 1024;          // draw-order ranks per chunk in the tile-column partition
-constexpr int kTile = 16;                // 16x16 pixel tiles
+constexpr int kTile = 16;                // one compositor wave owns a 16x16 pixel tile ...
+constexpr int kBin = 32;                 // ... binning works on 32x32 bins (4 tiles share one list, each
+                                         // wave filters it for its own quadrant): 2.2-2.9x fewer pairs
 constexpr uint32_t kRectEmpty = 0x000000FFu;   // tx0=255 > tx1=0
 constexpr uint32_t kRankMask = 0x00FFFFFFu;
 
@@ -566,8 +568,8 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
         x1f = fminf(x1f, (float)(fp.width - 1));
         y1f = fminf(y1f, (float)(fp.height - 1));
         if (x0f <= x1f && y0f <= y1f) {
-            const int tx0 = (int)x0f / kTile, tx1 = (int)x1f / kTile;
-            int ty0 = (int)y0f / kTile, ty1 = (int)y1f / kTile;
+            const int tx0 = (int)x0f / kBin, tx1 = (int)x1f / kBin;
+            int ty0 = (int)y0f / kBin, ty1 = (int)y1f / kBin;
             // band mode: keep only owned tile rows, renumbered vy = (ty - rem) / mod
             if (fp.row_mod > 1) {
                 int a = ty0 - fp.row_rem, bq = ty1 - fp.row_rem;
@@ -897,11 +899,20 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
     // so tiles are pulled heaviest-first from `order` instead of being bound to a workgroup index.
     // The first tile of every wave is static (its workgroup index): same-address atomics are served
     // at only ~8 ns each, so thousands of waves pulling at launch would queue up for tens of us.
+    // Work item = (bin, quadrant): the four 16x16 tiles of a 32x32 bin share the bin's list.
     for (uint32_t qpos = blockIdx.x; qpos < ntiles;) {
-    const int tile = (int)order[qpos];
-    const int vty = tile / fp.tiles_x;
-    const int tx = tile - vty * fp.tiles_x;
-    const int ty = vty * fp.row_mod + fp.row_rem;
+    const int tile = (int)qpos;                       // probe slot
+    const int bin = (int)order[qpos >> 2];
+    const int quad = (int)(qpos & 3u);
+    const int bvy = bin / fp.tiles_x;
+    const int tx = (bin - bvy * fp.tiles_x) * 2 + (quad & 1);
+    const int ty = (bvy * fp.row_mod + fp.row_rem) * 2 + (quad >> 1);
+    if (tx * kTile >= fp.width || ty * kTile >= fp.height) {      // quadrant entirely outside the image
+        uint32_t nq = 0;
+        if (threadIdx.x == 0) nq = atomicAdd(queue, 1u);
+        qpos = gridDim.x + __builtin_amdgcn_readfirstlane(nq);
+        continue;
+    }
     const int lane = threadIdx.x;
     const int lx = lane & 15, ly = lane >> 4;
     const int x = tx * kTile + lx, ybase = ty * kTile + ly;
@@ -909,7 +920,7 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
     const float fy0 = (float)ybase + 0.5f;
     const float tile_y0 = (float)(ty * kTile);
 
-    uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    uint32_t start = tile_start[bin], end = tile_start[bin + 1];
     if (start > cap) start = cap;
     if (end > cap) end = cap;
 

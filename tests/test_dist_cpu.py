@@ -32,13 +32,14 @@ def _worker(rank, world, port, W, H, q):
     cloud = synthetic.make_cloud(1500, seed=5, log_scale_mean=-3.0)
     cam, proj, vp, nf = scenes.default_view(W, H)
     res = orc.render_frame(cloud.as_array(), True, cam, proj, vp, nf, want_image=False, want_splats=True)
-    tiles_y = (H + 15) // 16
-    fb = np.zeros((tiles_y * 16, W, 4), np.float32)
+    T = 32                                   # msplat_tile_size()
+    tiles_y = (H + T - 1) // T
+    fb = np.zeros((tiles_y * T, W, 4), np.float32)
     # this rank "renders" only its own tile rows (rows of tile t with t % world == rank)
     for t in range(rank, tiles_y, world):
-        y0, y1 = t * 16, min(t * 16 + 16, H)
+        y0, y1 = t * T, min(t * T + T, H)
         fb[y0:y1] = orc.composite(res["splats"], W, H, row0=y0, row1=y1)[y0:y1]
-    g = BandGather(tiles_y, W, torch.float32, torch.device("cpu"), rank, world)
+    g = BandGather(tiles_y, W, torch.float32, torch.device("cpu"), rank, world, tile=T)
     out = g(torch.from_numpy(fb))
     if rank == 0:
         full = orc.composite(res["splats"], W, H)
@@ -64,8 +65,8 @@ def _run(world, W, H):
 
 
 def test_two_ranks_reassemble_the_frame_bit_exact():
-    assert _run(2, 160, 120)        # 120 rows = 7.5 tiles: ragged last tile row
+    assert _run(2, 160, 120)        # 120 rows = 3.75 tiles: ragged last tile row
 
 
 def test_three_ranks_uneven_bands():
-    assert _run(3, 96, 112)         # 7 tile rows over 3 ranks: 3 + 2 + 2
+    assert _run(3, 96, 208)         # 7 tile rows over 3 ranks: 3 + 2 + 2

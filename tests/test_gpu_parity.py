@@ -23,6 +23,11 @@ pytestmark = pytest.mark.gpu
 KK = -0.5 * 1.4426950408889634
 
 
+def bin_px():
+    from splatapult_amd import _capi
+    return _capi.lib().msplat_tile_size()
+
+
 def make_renderer(cloud, srgb=False, **kw):
     r = SplatRenderer(device=0, **kw)
     assert r.Init(cloud, srgb, False), r.last_error()
@@ -132,8 +137,9 @@ def _check_projection(r, ref, W, H):
     onscreen = vis & (x1 >= 0) & (y1 >= 0) & (x0 <= W - 1) & (y0 <= H - 1) & (x0 <= x1) & (y0 <= y1)
     # anything the oracle can light up must be drawn ...
     assert drawn[onscreen].all()
-    xs0 = np.clip(x0, 0, W - 1) // 16; xs1 = np.clip(x1, 0, W - 1) // 16
-    ys0 = np.clip(y0, 0, H - 1) // 16; ys1 = np.clip(y1, 0, H - 1) // 16
+    B = bin_px()
+    xs0 = np.clip(x0, 0, W - 1) // B; xs1 = np.clip(x1, 0, W - 1) // B
+    ys0 = np.clip(y0, 0, H - 1) // B; ys1 = np.clip(y1, 0, H - 1) // B
     m = onscreen
     assert (tx0[m] <= xs0[m]).all() and (tx1[m] >= xs1[m]).all()
     assert (ty0[m] <= ys0[m]).all() and (ty1[m] >= ys1[m]).all()
@@ -295,7 +301,7 @@ def test_row_bands_reassemble_bit_exact():
             rb.set_band(G, g)
             rb.Sort(cam, proj, vp, nf)
             part = rb.Render(cam, proj, vp, nf)
-            rows = np.arange(360) // 16 % G == g
+            rows = np.arange(360) // bin_px() % G == g
             assert (part[~rows] == 0).all()
             acc[rows] = part[rows]
         np.testing.assert_array_equal(acc, full)
@@ -309,7 +315,7 @@ def test_render_before_sort_and_bad_viewport_errors():
     with pytest.raises(MsplatError):
         r.Render(cam, proj, vp, nf)
     with pytest.raises(MsplatError):
-        r.Sort(cam, proj, [0, 0, 5000, 100], nf)
+        r.Sort(cam, proj, [0, 0, 9000, 100], nf)
 
 
 # ------------------------------------------------------------------------------------------------

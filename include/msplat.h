@@ -78,11 +78,13 @@ typedef struct msplat_stats {
     uint64_t num_splats;       /* N                                                          */
     uint32_t sort_count;       /* V: splats that survived the presort cull (sortCount)       */
     uint32_t drawn;            /* splats that passed the geometry-stage guard band           */
-    uint64_t pairs;            /* D: (splat, tile) pairs of the last render                  */
+    uint64_t pairs;            /* (splat, bin) pairs actually binned (bins of msplat_tile_size()) */
     uint32_t tiles_x, tiles_y;
     uint32_t width, height;
     uint64_t pair_capacity;
     uint64_t device_bytes;     /* device memory held by the context                          */
+    uint64_t pairs_tile16;     /* (splat, 16x16 tile) pairs covered by the footprints: the D */
+                               /* of the algorithmic byte count               */
 } msplat_stats;
 
 typedef struct msplat_timings {
@@ -93,7 +95,8 @@ typedef struct msplat_timings {
     float project;             /* vertex+geometry stage equivalent                           */
     float binning;             /* tile lists (count, scan, two stable partition passes)      */
     float composite;           /* fragment+blend equivalent (the dominant kernel)            */
-    float reserved[3];         /* [0] = number of frames averaged                            */
+    float reserved[3];         /* [0] = frames averaged, [1] = compositor KERNEL time (exact    */
+                               /* dispatch begin/end events), [2] = launches in that average   */
 } msplat_timings;
 
 /* ---- context ---------------------------------------------------------------------------- */

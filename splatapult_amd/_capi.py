@@ -34,7 +34,7 @@ class Stats(C.Structure):
     _fields_ = [("num_splats", C.c_uint64), ("sort_count", C.c_uint32), ("drawn", C.c_uint32),
                 ("pairs", C.c_uint64), ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32),
                 ("width", C.c_uint32), ("height", C.c_uint32), ("pair_capacity", C.c_uint64),
-                ("device_bytes", C.c_uint64)]
+                ("device_bytes", C.c_uint64), ("pairs_tile16", C.c_uint64)]
 
 
 class Timings(C.Structure):

@@ -6,6 +6,8 @@
 // msplat_create fails with MSPLAT_ERR_NO_DEVICE.
 #include "msplat_kernels.hip.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -50,7 +52,7 @@ struct msplat_ctx {
     uint32_t hist_stride = 0;
     Buf totals;     // uint32[256]  digit totals of the current radix pass (rows in binning pass 2)
     Buf totals1;    // uint32[256]  column totals of binning pass 1
-    Buf counters;   // uint32[8]: 0=V, 1=D, 2=overflow, 3=compositor tile queue, 4=drawn
+    Buf counters;   // uint32[16]: 0=V, 1=D, 2=overflow, 3=compositor tile queue, 4=drawn, 6..7=pairs16 (u64), 8=probe
     // render state
     Buf rec2d;      // float4[3*N]
     Buf rect;       // uint32[N]
@@ -73,12 +75,14 @@ struct msplat_ctx {
     // per-stage hipEvent sets, recorded on every `timing_stride`-th call so that the event markers
     // (a few us of pipeline bubble each) do not perturb a throughput run; averaged by msplat_get_timings
     static constexpr int kEvSets = 32;
-    hipEvent_t ev[kEvSets][6]{};
+    hipEvent_t ev[kEvSets][8]{};   // [6],[7] = exact dispatch start/stop of the compositor (hipExtLaunchKernelGGL)
     bool ev_ok = false;
     int timing_stride = 1;
     uint64_t sort_calls = 0, render_calls = 0;
     uint32_t sort_sets = 0, render_sets = 0;      // sets recorded since the last msplat_get_timings
     int cur_render_set = -1;
+    bool comp_kernel_timed = false;
+    uint32_t comp_kernel_sets_mask = 0;
 
     bool atomic_rank = true;    // LDS atomics hand out ranks in lane order (probed at create)
     int comp_waves = 6144;      // compositor grid (persistent waves); MSPLAT_COMP_WAVES overrides
@@ -206,17 +210,17 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         ctx->timing_stride = c.enable_timing;
     }
     int rc = buf_alloc(ctx, ctx->totals, 256 * sizeof(uint32_t));
-    if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->counters, 8 * sizeof(uint32_t));
+    if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->counters, 16 * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->totals1, 256 * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_start, 65537 * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_order, 65536 * sizeof(uint32_t));
     if (getenv("MSPLAT_COMP_WAVES")) ctx->comp_waves = std::max(64, atoi(getenv("MSPLAT_COMP_WAVES")));
     if (rc == MSPLAT_OK && getenv("MSPLAT_TILE_PROBE") != nullptr) rc = buf_alloc(ctx, ctx->probe, 65536 * 4 * sizeof(uint32_t));
-    if (rc == MSPLAT_OK && hipMemsetAsync(ctx->counters.p, 0, 8 * sizeof(uint32_t), ctx->stream) != hipSuccess)
+    if (rc == MSPLAT_OK && hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(uint32_t), ctx->stream) != hipSuccess)
         rc = MSPLAT_ERR_HIP;
     if (rc == MSPLAT_OK) {
         // feature probe: stable ranks straight from LDS atomics need lane-ordered ds_add_rtn
-        uint32_t* bad = (uint32_t*)ctx->counters.p + 7;
+        uint32_t* bad = (uint32_t*)ctx->counters.p + 8;
         hipLaunchKernelGGL(lds_atomic_order_probe, dim3(64), dim3(kThreads), 0, ctx->stream, bad);
         uint32_t hbad = 1;
         if (hipMemcpyAsync(&hbad, bad, sizeof(hbad), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -524,17 +528,28 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     // persistent compositor: at most 6 waves per SIMD (256 CUs x 4 SIMDs), never more than tiles
     const int cgrid = std::min(ntiles * 4, ctx->comp_waves);     // work items = (bin, quadrant)
     if (ntiles > 0) {
+        // on sampled frames the dominant kernel gets exact dispatch begin/end events (the plain stream
+        // markers around the stages can be processed while the previous kernel is still draining)
+        hipEvent_t e0 = timed ? ctx->ev[tset][6] : nullptr, e1 = timed ? ctx->ev[tset][7] : nullptr;
         if (ctx->cfg.fb_format == MSPLAT_FB_RGBA16F)
-            hipLaunchKernelGGL(composite_kernel<true>, dim3(cgrid), dim3(kCompThreads), comp_lds, s,
-                               (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
-                               (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap, (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u, (uint32_t*)ctx->probe.p);
+            hipExtLaunchKernelGGL(composite_kernel<true>, dim3(cgrid), dim3(kCompThreads), comp_lds, s, e0, e1, 0,
+                                  (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
+                                  (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap,
+                                  (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u,
+                                  (uint32_t*)ctx->probe.p);
         else
-            hipLaunchKernelGGL(composite_kernel<false>, dim3(cgrid), dim3(kCompThreads), comp_lds, s,
-                               (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
-                               (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap, (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u, (uint32_t*)ctx->probe.p);
+            hipExtLaunchKernelGGL(composite_kernel<false>, dim3(cgrid), dim3(kCompThreads), comp_lds, s, e0, e1, 0,
+                                  (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
+                                  (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap,
+                                  (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u,
+                                  (uint32_t*)ctx->probe.p);
+        ctx->comp_kernel_timed = timed;
+    } else {
+        ctx->comp_kernel_timed = false;
     }
     if (timed) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][5], s));
+        if (ctx->comp_kernel_timed) ctx->comp_kernel_sets_mask |= 1u << tset; else ctx->comp_kernel_sets_mask &= ~(1u << tset);
         ctx->render_sets++;
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -628,12 +643,14 @@ int msplat_get_stats(msplat_ctx* ctx, msplat_stats* out)
 {
     if (!ctx || !out) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    uint32_t cnt[5] = {0, 0, 0, 0, 0};
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (ctx->has_render) {   // "drawn" is a statistic only: counted on demand, not in the frame
         uint32_t* counters = (uint32_t*)ctx->counters.p;
-        HIP_TRY(ctx, hipMemsetAsync(counters + 4, 0, sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(counters + 4, 0, 4 * sizeof(uint32_t), ctx->stream));
+        // counters + 6 is 8-byte aligned: the 64-bit pair count lives in words 6..7
         hipLaunchKernelGGL(count_drawn_kernel, dim3(256), dim3(kThreads), 0, ctx->stream, (const uint32_t*)ctx->rect.p,
-                           counters + 0, counters + 4);
+                           (const float4*)ctx->rec2d.p, counters + 0, ctx->last_fp, counters + 4,
+                           (unsigned long long*)(counters + 6));
     }
     HIP_TRY(ctx, hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -642,6 +659,7 @@ int msplat_get_stats(msplat_ctx* ctx, msplat_stats* out)
     out->sort_count = ctx->has_sort ? cnt[0] : 0;
     out->pairs = ctx->has_render ? cnt[1] : 0;
     out->drawn = ctx->has_render ? cnt[4] : 0;
+    out->pairs_tile16 = ctx->has_render ? ((uint64_t)cnt[7] << 32 | cnt[6]) : 0;
     out->tiles_x = ctx->last_fp.tiles_x;
     out->tiles_y = ctx->last_fp.tiles_y;
     out->width = ctx->last_fp.width;
@@ -676,7 +694,14 @@ int msplat_get_timings(msplat_ctx* ctx, msplat_timings* out)
         HIP_TRY(ctx, hipEventElapsedTime(&c, ctx->ev[k][3], ctx->ev[k][4]));
         HIP_TRY(ctx, hipEventElapsedTime(&d, ctx->ev[k][4], ctx->ev[k][5]));
         out->render_total += a / nr; out->project += b / nr; out->binning += c / nr; out->composite += d / nr;
+        if (ctx->comp_kernel_sets_mask & (1u << k)) {
+            float e = 0;
+            HIP_TRY(ctx, hipEventElapsedTime(&e, ctx->ev[k][6], ctx->ev[k][7]));
+            out->reserved[1] += e;       // summed here, averaged below
+            out->reserved[2] += 1.0f;
+        }
     }
+    if (out->reserved[2] > 0.0f) out->reserved[1] /= out->reserved[2];
     out->reserved[0] = (float)nr;       // number of frames averaged
     ctx->sort_sets = 0;
     ctx->render_sets = 0;

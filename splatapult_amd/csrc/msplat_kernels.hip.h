@@ -601,18 +601,38 @@ __device__ __forceinline__ uint32_t rect_width(uint32_t rc)
     return tx0 <= tx1 ? tx1 - tx0 + 1u : 0u;
 }
 
-// statistics only (msplat_get_stats): number of splats with a non-empty tile rectangle
+// statistics only (msplat_get_stats): number of splats with a non-empty rectangle, and the number of
+// (splat, 16x16 tile) pairs their footprints cover (the "D" of the algorithmic byte count)
 __global__ __launch_bounds__(kThreads) void count_drawn_kernel(const uint32_t* __restrict__ rect,
-                                                               const uint32_t* __restrict__ d_V,
-                                                               uint32_t* __restrict__ d_drawn)
+                                                               const float4* __restrict__ rec,
+                                                               const uint32_t* __restrict__ d_V, FrameParams fp,
+                                                               uint32_t* __restrict__ d_drawn,
+                                                               unsigned long long* __restrict__ d_pairs16)
 {
     const uint32_t V = *d_V;
     uint32_t c = 0;
-    for (uint32_t r = blockIdx.x * kThreads + threadIdx.x; r < V; r += gridDim.x * kThreads)
-        c += rect_width(rect[r]) != 0u;
+    unsigned long long p16 = 0;
+    for (uint32_t r = blockIdx.x * kThreads + threadIdx.x; r < V; r += gridDim.x * kThreads) {
+        if (rect_width(rect[r]) == 0u) continue;
+        ++c;
+        const float4 a = rec[(size_t)r * 3 + 0], q = rec[(size_t)r * 3 + 2];      // px, py ... ex, ey
+        const float x0 = fmaxf(ceilf(a.x - q.z - 0.5f), 0.0f), x1 = fminf(floorf(a.x + q.z - 0.5f), (float)(fp.width - 1));
+        const float y0 = fmaxf(ceilf(a.y - q.w - 0.5f), 0.0f), y1 = fminf(floorf(a.y + q.w - 0.5f), (float)(fp.height - 1));
+        if (x0 <= x1 && y0 <= y1) {
+            int ty0 = (int)y0 / kTile, ty1 = (int)y1 / kTile, rows = 0;
+            for (int ty = ty0; ty <= ty1; ++ty) rows += ((ty / (kBin / kTile)) % fp.row_mod) == fp.row_rem;
+            p16 += (unsigned long long)((int)x1 / kTile - (int)x0 / kTile + 1) * (unsigned long long)rows;
+        }
+    }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(d_drawn, c);
+    for (int d = 32; d >= 1; d >>= 1) {
+        c += __shfl_down(c, d, 64);
+        p16 += __shfl_down(p16, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && c) {
+        atomicAdd(d_drawn, c);
+        atomicAdd(d_pairs16, p16);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -135,7 +135,10 @@ class SplatRenderer:
     def timings(self):
         t = _capi.Timings()
         _capi.check(self._ctx, self._lib.msplat_get_timings(self._ctx, C.byref(t)))
-        return {k: getattr(t, k) for k in ("sort_total", "render_total", "project", "binning", "composite")}
+        d = {k: getattr(t, k) for k in ("sort_total", "render_total", "project", "binning", "composite")}
+        d["frames_averaged"] = t.reserved[0]
+        d["composite_kernel"] = t.reserved[1]      # exact dispatch begin/end of composite_kernel
+        return d
 
     def debug_projected(self):
         v = self.sort_count()

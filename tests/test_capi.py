@@ -37,7 +37,7 @@ def test_version_and_struct_sizes():
     L = _capi.lib()
     assert b"msplat" in L.msplat_version_string()
     assert C.sizeof(_capi.Config) == 48 and C.sizeof(_capi.AttrOffsets) == 64
-    assert C.sizeof(_capi.Stats) == 56 and C.sizeof(_capi.Timings) == 32
+    assert C.sizeof(_capi.Stats) == 64 and C.sizeof(_capi.Timings) == 32
 
 
 @pytest.mark.skipif(has_gpu(), reason="a GPU is present")

@@ -174,6 +174,18 @@ def main():
     comp_ms = prof.get("composite_kernel", 0.0) or prof["composite"]   # exact kernel begin/end events
     comp_s = comp_ms * 1e-3
     achieved = B_comp / comp_s if comp_s > 0 else 0.0
+    # HBM traffic of the dominant kernel comes from a SEPARATE rocprofv3 --pmc run (tools_pmc_traffic.sh:
+    # FETCH_SIZE / WRITE_SIZE in their own passes, gfx950 x2 correction on FETCH_SIZE); the committed
+    # summary is only quoted for the workload it was measured on
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.workload)
+    if world == 1 and os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = "msplat::composite_kernel<%s>" % ("true" if wl["fb"] == "fp16" else "false")
+            traffic = tj[key]["hbm_bytes_per_launch_corrected"]
+        except (KeyError, ValueError):
+            traffic = None
 
     out = {
         "metric": "frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -188,7 +200,9 @@ def main():
         "frame_algorithmic_GB": B_frame / 1e9,
         "frame_hbm_frac": (B_frame / (elapsed / args.steps)) / HBM_PEAK / world,
         "roofline": {"kernel": "composite_kernel", "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+                     "traffic_source": "profiles/r01_pmc_traffic_%s.json (rocprofv3 --pmc, bytes per launch)" % args.workload if traffic else None,
+                     "algorithmic_bytes_per_launch": B_comp,
                      "avg_launch_ms": comp_ms,
                      "note": "composite is VALU/LDS bound (exp + blend per pixel-splat); HBM fraction is honest-but-low"},
     }

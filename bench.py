@@ -70,10 +70,18 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
     if rank == 0:
         graft.build()
+    # MSPLAT_BENCH_ONE_DEVICE=1: debug aid for 1-GPU boxes -- every rank uses device 0 and the gather
+    # runs over gloo; it exercises the N > 1 control flow (bands, gather, max-over-ranks timing), not xGMI.
+    one_dev = os.environ.get("MSPLAT_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         dist.barrier()
 
     wl = WORKLOADS[args.workload]

@@ -474,7 +474,6 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const bool timed = ctx->ev_ok && (ctx->render_calls++ % ctx->timing_stride) == 0;
     const int tset = (int)(ctx->render_sets % msplat_ctx::kEvSets);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][2], s));
-    HIP_TRY(ctx, hipMemsetAsync(d_D, 0, 3 * sizeof(uint32_t), s));      // D, overflow, tile queue
     const int pgrid = std::max(1u, div_up(N, kProjThreads));
     if (ctx->full_sh)
         hipLaunchKernelGGL(project_kernel<true>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
@@ -489,7 +488,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     uint32_t* totals2 = (uint32_t*)ctx->totals.p;
     const int g1 = grid_for(div_up(N, kBinChunk));
     hipLaunchKernelGGL(bin1_upsweep, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
-                       (uint32_t*)ctx->hist1.p, ctx->hist1_stride);
+                       (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_overflow);
     hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V,
                        0u, N, (uint32_t)kBinChunk, totals1);
     if (ctx->atomic_rank)
@@ -520,11 +519,9 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                        (const uint32_t*)ctx->pairsB.p, (const uint32_t*)totals2, d_D, cap, fp.tiles_x, ntiles,
                        (uint32_t*)ctx->tile_start.p);
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)ctx->tile_start.p, ntiles,
-                       (uint32_t*)ctx->tile_order.p, getenv("MSPLAT_COMP_ORDER") ? atoi(getenv("MSPLAT_COMP_ORDER")) : 0);
+                       (uint32_t*)ctx->tile_order.p, d_queue);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][4], s));
 
-    // experiment knob: extra dynamic LDS per workgroup caps the compositor's occupancy
-    const size_t comp_lds = getenv("MSPLAT_COMP_LDS") ? (size_t)atoi(getenv("MSPLAT_COMP_LDS")) : 0;
     // persistent compositor: at most 6 waves per SIMD (256 CUs x 4 SIMDs), never more than tiles
     const int cgrid = std::min(ntiles * 4, ctx->comp_waves);     // work items = (bin, quadrant)
     if (ntiles > 0) {
@@ -532,13 +529,13 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         // markers around the stages can be processed while the previous kernel is still draining)
         hipEvent_t e0 = timed ? ctx->ev[tset][6] : nullptr, e1 = timed ? ctx->ev[tset][7] : nullptr;
         if (ctx->cfg.fb_format == MSPLAT_FB_RGBA16F)
-            hipExtLaunchKernelGGL(composite_kernel<true>, dim3(cgrid), dim3(kCompThreads), comp_lds, s, e0, e1, 0,
+            hipExtLaunchKernelGGL(composite_kernel<true>, dim3(cgrid), dim3(kCompThreads), 0, s, e0, e1, 0,
                                   (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
                                   (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap,
                                   (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u,
                                   (uint32_t*)ctx->probe.p);
         else
-            hipExtLaunchKernelGGL(composite_kernel<false>, dim3(cgrid), dim3(kCompThreads), comp_lds, s, e0, e1, 0,
+            hipExtLaunchKernelGGL(composite_kernel<false>, dim3(cgrid), dim3(kCompThreads), 0, s, e0, e1, 0,
                                   (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
                                   (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap,
                                   (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u,

@@ -648,8 +648,11 @@ __global__ __launch_bounds__(kThreads) void count_drawn_kernel(const uint32_t* _
 
 __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restrict__ rect,
                                                          const uint32_t* __restrict__ d_V,
-                                                         uint32_t* __restrict__ hist, uint32_t hist_stride)
+                                                         uint32_t* __restrict__ hist, uint32_t hist_stride,
+                                                         uint32_t* __restrict__ d_overflow)
 {
+    // per-frame reset of the sticky overflow flag (set later in the frame by bin1_downsweep): saves a memset launch
+    if (blockIdx.x == 0 && threadIdx.x == 0) *d_overflow = 0u;
     __shared__ uint32_t s_diff[kThreads + 1];
     __shared__ uint32_t s_tmp[4];
     const uint32_t V = *d_V;
@@ -852,13 +855,11 @@ __global__ __launch_bounds__(kThreads) void tile_start_kernel(const uint32_t* __
 // tiles ordered by descending list length (counting sort on len/16): the compositor's waves pull tiles
 // from this list through an atomic queue, heaviest first (longest-processing-time-first scheduling)
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ tile_start, int ntiles,
-                                                          uint32_t* __restrict__ order, int mode)
+                                                          uint32_t* __restrict__ order,
+                                                          uint32_t* __restrict__ queue)
 {
-    if (mode != 0) {   // experiment: 1 = identity, 2 = strided
-        for (int i = threadIdx.x; i < ntiles; i += 1024)
-            order[i] = mode == 1 ? (uint32_t)i : (uint32_t)(((uint64_t)i * 5043u) % (uint32_t)ntiles);
-        return;
-    }
+    if (threadIdx.x == 0) *queue = 0u;      // the compositor's work queue starts empty every frame
+
     __shared__ uint32_t s_cnt[256];
     __shared__ uint32_t s_off[256];
     if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;

@@ -114,6 +114,28 @@ int msplat_tile_size(void);
 int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t stride_bytes,
                         const msplat_attr_offsets* off, int full_sh);
 
+/* GPU ingest: GaussianCloud::ImportPly's per-vertex math (gaussiancloud.cpp:254-361:
+ * sigmoid(opacity), exp(scale), quaternion -> R S S^T R^T, SH repack) as a HIP kernel over the raw PLY
+ * vertex block, building the renderer's device cloud directly.  Byte offsets of the float properties inside
+ * one vertex; -1 = property absent (reads as 0, like BinaryAttribute::Read).  f_rest is optional: if any
+ * is absent, or full_sh == 0, the cloud is SH degree 0 (gaussiancloud.cpp:188-205). */
+typedef struct msplat_ply_layout {
+    uint32_t vertex_size;
+    int32_t x, y, z;
+    int32_t f_dc[3];
+    int32_t f_rest[45];
+    int32_t opacity;
+    int32_t scale[3];
+    int32_t rot[4];
+} msplat_ply_layout;
+int msplat_upload_ply_vertices(msplat_ctx* ctx, const void* vertices, uint64_t n,
+                               const msplat_ply_layout* layout, int full_sh);
+/* Ply::Parse (ply.cpp:72-87) on the host + msplat_upload_ply_vertices: replaces
+ * GaussianCloud::ImportPly + SplatRenderer::Init for callers that do not need the host-side cloud */
+int msplat_upload_ply(msplat_ctx* ctx, const char* path, int import_full_sh);
+/* the device cloud in the reference's interleaved layout (100 B / 244 B records); parity tests */
+int msplat_download_cloud(msplat_ctx* ctx, void* aos_out, uint64_t cap_bytes);
+
 /* Multi-GPU tile-row sharding (no reference counterpart).  Restricts this
  * context to tile rows t with t % row_mod == row_rem (rows of msplat_tile_size() pixels, row 0 = GL
  * bottom).

@@ -30,6 +30,12 @@ class AttrOffsets(C.Structure):
                  "r_sh1", "r_sh2", "r_sh3", "g_sh1", "g_sh2", "g_sh3", "b_sh1", "b_sh2", "b_sh3")]
 
 
+class PlyLayout(C.Structure):
+    _fields_ = [("vertex_size", C.c_uint32), ("x", C.c_int32), ("y", C.c_int32), ("z", C.c_int32),
+                ("f_dc", C.c_int32 * 3), ("f_rest", C.c_int32 * 45), ("opacity", C.c_int32),
+                ("scale", C.c_int32 * 3), ("rot", C.c_int32 * 4)]
+
+
 class Stats(C.Structure):
     _fields_ = [("num_splats", C.c_uint64), ("sort_count", C.c_uint32), ("drawn", C.c_uint32),
                 ("pairs", C.c_uint64), ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32),
@@ -52,6 +58,9 @@ SYMBOLS = [
     ("msplat_version_string", C.c_char_p, []),
     ("msplat_tile_size", C.c_int, []),
     ("msplat_upload_cloud", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(AttrOffsets), C.c_int]),
+    ("msplat_upload_ply_vertices", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(PlyLayout), C.c_int]),
+    ("msplat_upload_ply", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    ("msplat_download_cloud", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     ("msplat_set_band", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     ("msplat_sort", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16]),
     ("msplat_render", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16, C.c_void_p, C.c_uint64, C.c_int]),

@@ -277,22 +277,18 @@ static int ensure_pair_capacity(msplat_ctx* ctx, uint64_t cap)
     return MSPLAT_OK;
 }
 
-int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t stride_bytes,
-                        const msplat_attr_offsets* off, int full_sh)
+// (re)allocates every per-cloud device buffer for n splats; leaves the context without a cloud
+static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh)
 {
-    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
-    if ((!aos && n) || !off) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_upload_cloud: NULL argument");
     if (n > (1ull << 24))
-        return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "msplat_upload_cloud: %llu splats > 2^24 (rank field is 24 bit)",
-                    (unsigned long long)n);
-    if (stride_bytes % 4 != 0) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "stride must be a multiple of 4");
+        return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "%llu splats > 2^24 (rank field is 24 bit)", (unsigned long long)n);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->has_cloud = false;
     ctx->has_sort = false;
     ctx->has_render = false;
     ctx->N = n;
-    ctx->full_sh = full_sh != 0;
+    ctx->full_sh = full_sh;
     const int F4 = ctx->full_sh ? 16 : 8;
     const size_t alloc_n = std::max<uint64_t>(n, 1);
     int rc;
@@ -310,7 +306,18 @@ int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t s
     if ((rc = buf_alloc(ctx, ctx->hist1, (size_t)256 * ctx->hist1_stride * 4))) return rc;
     uint64_t cap = ctx->cfg.pair_capacity ? ctx->cfg.pair_capacity
                                           : std::max<uint64_t>(1ull << 22, std::min<uint64_t>(32 * n, 1ull << 30));
-    if ((rc = ensure_pair_capacity(ctx, cap))) return rc;
+    return ensure_pair_capacity(ctx, cap);
+}
+
+int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t stride_bytes,
+                        const msplat_attr_offsets* off, int full_sh)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if ((!aos && n) || !off) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_upload_cloud: NULL argument");
+    if (stride_bytes % 4 != 0) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "stride must be a multiple of 4");
+    int rc = prepare_cloud_buffers(ctx, n, full_sh != 0);
+    if (rc) return rc;
+    const int F4 = ctx->full_sh ? 16 : 8;
 
     // repack: reference AoS (100 B / 244 B, arbitrary offsets) -> 16-byte aligned padded records with the
     // reference's float order (gaussiancloud.cpp:32-56), plus the vec4(x,y,z,1) array of splatrenderer.cpp:106-111
@@ -356,6 +363,78 @@ int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t s
         HIP_TRY(ctx, hipMemcpy((char*)ctx->pos4.p + base * 16, stage_pos.data(), cnt * 16, hipMemcpyHostToDevice));
     }
     ctx->has_cloud = true;
+    return MSPLAT_OK;
+}
+
+
+// GPU ingest: GaussianCloud::ImportPly's per-vertex math (gaussiancloud.cpp:254-361) as a HIP kernel over
+// the raw PLY vertex block -- SURVEY.md 8f-1.  `vertices` is host memory (n * layout->vertex_size bytes).
+int msplat_upload_ply_vertices(msplat_ctx* ctx, const void* vertices, uint64_t n, const msplat_ply_layout* layout,
+                               int full_sh)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if ((!vertices && n) || !layout) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_upload_ply_vertices: NULL argument");
+    const uint32_t vs = layout->vertex_size;
+    if (vs == 0 || vs % 4 != 0 || vs > 1024)
+        return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "vertex size %u must be a multiple of 4 in (0, 1024]", vs);
+    const int32_t* offs = &layout->x;
+    constexpr int kProps = 3 + 3 + 45 + 1 + 3 + 4;     // x y z, f_dc, f_rest, opacity, scale, rot
+    static_assert(sizeof(msplat_ply_layout) == 4 + 4 * kProps, "msplat_ply_layout must be packed int32s");
+    for (int k = 0; k < kProps; ++k)
+        if (offs[k] >= 0 && ((uint32_t)offs[k] + 4u > vs || offs[k] % 4 != 0))
+            return fail(ctx, MSPLAT_ERR_INVALID_ARG, "property offset %d outside / misaligned in a %u-byte vertex", offs[k], vs);
+    bool has_rest = true;
+    for (int k = 0; k < 45; ++k) has_rest = has_rest && layout->f_rest[k] >= 0;
+    const bool full = full_sh != 0 && has_rest;      // f_rest is optional (gaussiancloud.cpp:188-205)
+    int rc = prepare_cloud_buffers(ctx, n, full);
+    if (rc) return rc;
+    if (n) {
+        Buf raw;
+        if ((rc = buf_alloc(ctx, raw, (size_t)n * vs + 16))) return rc;
+        hipError_t e = hipMemcpyAsync(raw.p, vertices, (size_t)n * vs, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            const int grid = (int)div_up(n, 64);
+            const size_t lds = (size_t)64 * vs + 16;
+            PlyLayout kl;
+            static_assert(sizeof(PlyLayout) == sizeof(msplat_ply_layout), "layout mirror out of sync");
+            std::memcpy(&kl, layout, sizeof(kl));
+            if (full)
+                hipLaunchKernelGGL(ingest_kernel<true>, dim3(grid), dim3(64), lds, ctx->stream, (const char*)raw.p, n,
+                                   kl, (float4*)ctx->pos4.p, (float4*)ctx->recs.p);
+            else
+                hipLaunchKernelGGL(ingest_kernel<false>, dim3(grid), dim3(64), lds, ctx->stream, (const char*)raw.p, n,
+                                   kl, (float4*)ctx->pos4.p, (float4*)ctx->recs.p);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        buf_free(ctx, raw);
+        if (e != hipSuccess) return fail(ctx, MSPLAT_ERR_HIP, "GPU ingest failed: %s", hipGetErrorString(e));
+    }
+    ctx->has_cloud = true;
+    return MSPLAT_OK;
+}
+
+// device cloud -> reference AoS layout (100 B / 244 B records, gaussiancloud.cpp:32-56); parity tests
+int msplat_download_cloud(msplat_ctx* ctx, void* aos_out, uint64_t cap_bytes)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if (!ctx->has_cloud) return fail(ctx, MSPLAT_ERR_NO_CLOUD, "no cloud uploaded");
+    const int F4 = ctx->full_sh ? 16 : 8;
+    const size_t rec_floats = ctx->full_sh ? 61 : 25;
+    if (cap_bytes < ctx->N * rec_floats * 4) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "output buffer too small");
+    if (ctx->N == 0) return MSPLAT_OK;
+    if (!aos_out) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "aos_out is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t chunk = 1u << 18;
+    std::vector<float> stage(chunk * F4 * 4);
+    float* dst = static_cast<float*>(aos_out);
+    for (uint64_t base = 0; base < ctx->N; base += chunk) {
+        const size_t cnt = (size_t)std::min<uint64_t>(chunk, ctx->N - base);
+        HIP_TRY(ctx, hipMemcpy(stage.data(), (const char*)ctx->recs.p + base * F4 * 16, cnt * F4 * 16, hipMemcpyDeviceToHost));
+        for (size_t j = 0; j < cnt; ++j)
+            std::memcpy(dst + (base + j) * rec_floats, stage.data() + j * F4 * 4, rec_floats * 4);
+    }
     return MSPLAT_OK;
 }
 

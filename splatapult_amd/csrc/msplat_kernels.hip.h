@@ -382,6 +382,97 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
 }
 
 // ------------------------------------------------------------------------------------------
+// GPU ingest: GaussianCloud::ImportPly's per-vertex lambda (gaussiancloud.cpp:254-361)
+//   alpha = 1/(1+exp(-opacity)), scale = exp(log scale), Sigma = R S S^T R^T from the normalised quaternion,
+//   SH repack -- written straight into the renderer's device layout (pos4 + padded records).
+// One wave per 64 vertices: their bytes are contiguous in the PLY vertex block, so the wave copies the span
+// with coalesced 16-byte loads into LDS and every lane then picks its properties out of its own vertex.
+// Same operation order as the host code (splatapult_amd/host/gaussian_scene.cpp), contraction off.
+// ------------------------------------------------------------------------------------------
+struct PlyLayout {             // mirrors msplat_ply_layout (include/msplat.h)
+    uint32_t vertex_size;
+    int32_t x, y, z;
+    int32_t f_dc[3];
+    int32_t f_rest[45];
+    int32_t opacity;
+    int32_t scale[3];
+    int32_t rot[4];
+};
+
+template <bool FULL_SH>
+__global__ __launch_bounds__(64) void ingest_kernel(const char* __restrict__ raw, uint64_t n, PlyLayout L,
+                                                    float4* __restrict__ pos4, float4* __restrict__ recs)
+{
+    extern __shared__ __attribute__((aligned(16))) char s_raw[];
+    constexpr int F4 = FULL_SH ? 16 : 8;
+    const int lane = threadIdx.x;
+    const uint32_t vs = L.vertex_size;
+    const uint64_t v0 = (uint64_t)blockIdx.x * 64u;
+    const uint64_t byte0 = v0 * vs;
+    const uint64_t total = n * (uint64_t)vs;
+    const uint32_t span = (uint32_t)min((uint64_t)64u * vs, total - byte0);      // multiple of 4
+    for (uint32_t off = lane * 16u; off < span; off += 64u * 16u) {
+        if (off + 16u <= span) {
+            *reinterpret_cast<float4*>(s_raw + off) = *reinterpret_cast<const float4*>(raw + byte0 + off);
+        } else {
+            for (uint32_t o = off; o < span; o += 4u)
+                *reinterpret_cast<float*>(s_raw + o) = *reinterpret_cast<const float*>(raw + byte0 + o);
+        }
+    }
+    __syncthreads();
+    const uint64_t i = v0 + lane;
+    if (i >= n) return;
+    const char* v = s_raw + (size_t)lane * vs;
+    auto rd = [&](int32_t off) -> float { return off >= 0 ? *reinterpret_cast<const float*>(v + off) : 0.0f; };
+
+    float f[F4 * 4];
+#pragma unroll
+    for (int k = 0; k < F4 * 4; ++k) f[k] = 0.0f;
+    f[0] = rd(L.x); f[1] = rd(L.y); f[2] = rd(L.z);
+    f[3] = 1.0f / (1.0f + expf(-rd(L.opacity)));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        f[4 + 4 * c] = rd(L.f_dc[c]);
+        if constexpr (FULL_SH) {
+#pragma unroll
+            for (int k = 1; k < 4; ++k) f[4 + 4 * c + k] = rd(L.f_rest[c * 15 + k - 1]);
+#pragma unroll
+            for (int k = 4; k < 16; ++k) f[25 + 12 * c + (k - 4)] = rd(L.f_rest[c * 15 + k - 1]);
+        }
+    }
+    const float s0 = expf(rd(L.scale[0])), s1 = expf(rd(L.scale[1])), s2 = expf(rd(L.scale[2]));
+    float w = rd(L.rot[0]), x = rd(L.rot[1]), y = rd(L.rot[2]), z = rd(L.rot[3]);
+    const float len = sqrtf((w * w + x * x) + (y * y + z * z));
+    if (len <= 0.0f) { w = 1.0f; x = 0.0f; y = 0.0f; z = 0.0f; }
+    else { const float inv = 1.0f / len; w *= inv; x *= inv; y *= inv; z *= inv; }
+    const float xx = x * x, yy = y * y, zz = z * z, xz = x * z, xy = x * y, yz = y * z;
+    const float wx = w * x, wy = w * y, wz = w * z;
+    // R[c][r], column-major like the host code
+    const float R[9] = {1.0f - 2.0f * (yy + zz), 2.0f * (xy + wz),        2.0f * (xz - wy),
+                        2.0f * (xy - wz),        1.0f - 2.0f * (xx + zz), 2.0f * (yz + wx),
+                        2.0f * (xz + wy),        2.0f * (yz - wx),        1.0f - 2.0f * (xx + yy)};
+    const float sc[3] = {s0, s1, s2};
+    float B[9];      // (R S) S^T : column c scaled by s_c twice (the zero terms of the 3x3 products add exactly)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) B[c * 3 + r] = (R[c * 3 + r] * sc[c]) * sc[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            // V[c][r] = B[0][r]*Rt[c][0] + B[1][r]*Rt[c][1] + B[2][r]*Rt[c][2],  Rt[c][k] = R[k][c]
+            float s = B[0 * 3 + r] * R[0 * 3 + c];
+            s = s + B[1 * 3 + r] * R[1 * 3 + c];
+            s = s + B[2 * 3 + r] * R[2 * 3 + c];
+            f[16 + c * 3 + r] = s;
+        }
+    pos4[i] = make_float4(f[0], f[1], f[2], 1.0f);
+#pragma unroll
+    for (int k = 0; k < F4; ++k) recs[i * F4 + k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
+}
+
+// ------------------------------------------------------------------------------------------
 // project: vertex + geometry stage for the splats in draw order (one thread per rank)
 //   splat_vert.glsl:153-222 (+ SH :51-127, sRGB :129-151), splat_geom.glsl:22-54
 // Writes a 48-byte record per rank, a packed tile rectangle, and counts pairs per tile.
@@ -509,7 +600,7 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
     b[2] = k1 * vz;
     b[3] = -k1 * vx;
     float rgb[3];
-    if (FULL_SH) {
+    if constexpr (FULL_SH) {
         const float vx2 = vx * vx, vy2 = vy * vy, vz2 = vz * vz;
         const float k2 = 1.0925484305920792f, k3 = 0.31539156525252005f, k4 = 0.5462742152960396f;
         b[4] = k2 * vy * vx;

@@ -629,6 +629,35 @@ int msplat_upload_gaussian_cloud(msplat_ctx* ctx, const msplat_cloud* c)
                                c->gc.HasFullSH() ? 1 : 0);
 }
 
+int msplat_upload_ply(msplat_ctx* ctx, const char* path, int import_full_sh)
+{
+    if (!ctx || !path) return MSPLAT_ERR_INVALID_ARG;
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) {
+        LogE("failed to open %s\n", path);
+        return MSPLAT_ERR_IO;
+    }
+    Ply ply;
+    if (!ply.Parse(f)) {
+        LogE("Error parsing ply file \"%s\"\n", path);
+        return MSPLAT_ERR_IO;
+    }
+    msplat_ply_layout L;
+    L.vertex_size = (uint32_t)ply.GetVertexSize();
+    auto off = [&](const std::string& name) -> int32_t {
+        BinaryAttribute a;
+        if (!ply.GetProperty(name, a) || a.type != BinaryAttribute::Type::Float) return -1;
+        return (int32_t)a.offset;
+    };
+    L.x = off("x"); L.y = off("y"); L.z = off("z");
+    for (int i = 0; i < 3; ++i) L.f_dc[i] = off("f_dc_" + std::to_string(i));
+    for (int i = 0; i < 45; ++i) L.f_rest[i] = off("f_rest_" + std::to_string(i));
+    L.opacity = off("opacity");
+    for (int i = 0; i < 3; ++i) L.scale[i] = off("scale_" + std::to_string(i));
+    for (int i = 0; i < 4; ++i) L.rot[i] = off("rot_" + std::to_string(i));
+    return msplat_upload_ply_vertices(ctx, ply.GetRawData(), ply.GetVertexCount(), &L, import_full_sh);
+}
+
 // ---- matrices (glm closed forms; used by Sort/Render exactly as splatrenderer.cpp:161,175,327) ----
 
 void msplat_mat4_mul(const float a[16], const float b[16], float out[16])

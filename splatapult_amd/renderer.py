@@ -75,6 +75,43 @@ class SplatRenderer:
             return False
         return True
 
+    def _create(self, isFramebufferSRGBEnabled):
+        self.close()
+        cfg = _capi.Config()
+        cfg.struct_size = C.sizeof(_capi.Config)
+        cfg.device = self._device
+        cfg.fb_format = self._fb_format
+        cfg.srgb = 1 if isFramebufferSRGBEnabled else 0
+        cfg.t_epsilon = self._t_eps
+        cfg.pair_capacity = self._pair_cap
+        cfg.stream = self._stream
+        cfg.enable_timing = int(self._timing)
+        h = C.c_void_p()
+        rc = self._lib.msplat_create(C.byref(h), C.byref(cfg))
+        if rc != _capi.OK:
+            self._err = self._lib.msplat_last_error(None).decode()
+            return False
+        self._ctx = h
+        return True
+
+    def InitFromPly(self, plyFilename, importFullSH=True, isFramebufferSRGBEnabled=False):
+        """GPU ingest (SURVEY.md 8f-1): Ply::Parse on the host, then GaussianCloud::ImportPly's per-vertex
+        math (gaussiancloud.cpp:254-361) as a HIP kernel straight into the renderer's device layout."""
+        if not self._create(isFramebufferSRGBEnabled):
+            return False
+        rc = self._lib.msplat_upload_ply(self._ctx, str(plyFilename).encode(), 1 if importFullSH else 0)
+        if rc != _capi.OK:
+            self._err = self._lib.msplat_last_error(self._ctx).decode() or "PLY open/parse failure"
+            return False
+        self._n = self.stats()["num_splats"]
+        return True
+
+    def download_cloud(self, full_sh):
+        """device cloud as (N, 25|61) float32 in the reference record layout (parity tests)"""
+        out = np.zeros((max(self._n, 1), 61 if full_sh else 25), np.float32)
+        _capi.check(self._ctx, self._lib.msplat_download_cloud(self._ctx, out.ctypes.data, out.nbytes))
+        return out[:self._n]
+
     def last_error(self):
         if self._ctx:
             return self._lib.msplat_last_error(self._ctx).decode()

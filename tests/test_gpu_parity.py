@@ -381,3 +381,52 @@ def test_cpp_shim_renders_like_the_python_mirror(tmp_path, golden_dir):
     ref = orc.render_frame(gc.as_array(), True, cam, proj, [0, 0, W, H], scenes.NF)
     check_image(img, ref["image"])
     assert img[..., :3].max() > 0.5
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU ingest: ImportPly's per-vertex math as a HIP kernel
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,full_sh", [(1, True), (63, True), (64, False), (5000, True), (5000, False)])
+def test_gpu_ingest_matches_host_import(tmp_path, n, full_sh):
+    """device cloud built by ingest_kernel == GaussianCloud::ImportPly (host) == oracle load-time math.
+    Tolerance: alpha rel 1e-6, covariance 3e-6 of the splat's largest entry (device expf / sqrt vs glibc
+    differ by <= 1 ulp); positions and SH coefficients are copies: exact."""
+    from splatapult_amd import GaussianCloud, synthetic
+    a = synthetic.generate(n, seed=1000 + n, full_sh=True)
+    path = str(tmp_path / "in.ply")
+    synthetic.write_ply(path, a)
+    host = GaussianCloud(GaussianCloud.Options(full_sh, full_sh))
+    assert host.ImportPly(path)
+    r = SplatRenderer()
+    assert r.InitFromPly(path, importFullSH=full_sh), r.last_error()
+    dev = r.download_cloud(full_sh)
+    ref = host.as_array()
+    assert dev.shape == ref.shape
+    np.testing.assert_array_equal(dev[:, :3], ref[:, :3])
+    np.testing.assert_array_equal(dev[:, 4:16], ref[:, 4:16])
+    if full_sh:
+        np.testing.assert_array_equal(dev[:, 25:], ref[:, 25:])
+    np.testing.assert_allclose(dev[:, 3], ref[:, 3], rtol=1e-6)
+    # covariance: relative to the splat's own scale (off-diagonals are differences of near-equal products)
+    scale = np.abs(ref[:, 16:25]).max(axis=1, keepdims=True)
+    assert (np.abs(dev[:, 16:25] - ref[:, 16:25]) <= 3e-6 * scale).all()
+    # and the ingested cloud renders like the host-built one
+    cam, proj, vp, nf = scenes.default_view(256, 160)
+    r.Sort(cam, proj, vp, nf)
+    img = r.Render(cam, proj, vp, nf)
+    refimg = orc.render_frame(ref, full_sh, cam, proj, vp, nf)["image"]
+    check_image(img, refimg)
+
+
+def test_gpu_ingest_test_ply_and_errors(golden_dir, tmp_path):
+    import os
+    r = SplatRenderer()
+    assert r.InitFromPly(os.path.join(golden_dir, "test.ply"), importFullSH=False)
+    g = np.load(os.path.join(golden_dir, "test_ply_cfg1.npz"))
+    np.testing.assert_allclose(r.download_cloud(False), g["aos_nosh"], rtol=1e-6)
+    assert r.stats()["num_splats"] == 16
+    assert not SplatRenderer().InitFromPly(str(tmp_path / "missing.ply"))           # false after logging
+    bad = tmp_path / "bad.ply"
+    bad.write_bytes(b"ply\nformat ascii 1.0\nelement vertex 0\nend_header\n")
+    assert not SplatRenderer().InitFromPly(str(bad))

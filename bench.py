@@ -98,7 +98,8 @@ def main():
     if not r.Init(cloud, False, False):
         raise SystemExit("Init failed: " + r.last_error())
     if world > 1:
-        r.set_band(world, rank)
+        # mono workloads may also restrict the cull to the band (every Render uses its Sort's camera)
+        r.set_band(world, rank, band_cull=(wl["views"] == 1))
 
     from splatapult_amd import _capi
     TILE = _capi.lib().msplat_tile_size()

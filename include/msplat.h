@@ -142,6 +142,12 @@ int msplat_download_cloud(msplat_ctx* ctx, void* aos_out, uint64_t cap_bytes);
  * row_mod = 1 (default) = whole image.  The framebuffer handed to msplat_render is always the
  * full W x H image; only rows owned by the band are written. */
 int msplat_set_band(msplat_ctx* ctx, int32_t row_mod, int32_t row_rem);
+/* Band-restricted cull: with a band set, msplat_sort additionally drops splats whose
+ * footprint (conservative bound) cannot reach a row owned by this context, so sort / projection / binning
+ * shrink with the number of ranks.  Pixels are unchanged, but msplat_sort_count and the sorted list then
+ * describe the band only, and every msplat_render must use the camera of the preceding msplat_sort
+ * (mono rendering).  Default off; ignored without a band. */
+int msplat_set_band_cull(msplat_ctx* ctx, int enable);
 
 /* replaces SplatRenderer::Sort (splatrenderer.cpp:153-312): cull + depth key
  * (presort_compute.glsl:31-57), stable ascending 32-bit radix sort, sorted index list kept as

@@ -62,6 +62,7 @@ SYMBOLS = [
     ("msplat_upload_ply", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("msplat_download_cloud", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     ("msplat_set_band", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    ("msplat_set_band_cull", C.c_int, [C.c_void_p, C.c_int]),
     ("msplat_sort", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16]),
     ("msplat_render", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16, C.c_void_p, C.c_uint64, C.c_int]),
     ("msplat_synchronize", C.c_int, [C.c_void_p]),

@@ -68,6 +68,7 @@ struct msplat_ctx {
     Buf probe;      // uint32[4*tiles] per-tile compositor probe (only when MSPLAT_TILE_PROBE=1)
     // band
     int row_mod = 1, row_rem = 0;
+    bool band_cull = false;
     // last frame
     FrameParams last_fp{};
     bool has_render = false;
@@ -357,7 +358,9 @@ int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t s
                 for (int k = 25; k < 32; ++k) d[k] = 0.0f;
             }
             float* p = stage_pos.data() + j * 4;
-            p[0] = d[0]; p[1] = d[1]; p[2] = d[2]; p[3] = 1.0f;
+            // .w = rho^2 * trace(Sigma), rho^2 = 2 ln(256 alpha): world-space footprint bound for the band cull
+            const float rho2 = 2.0f * std::log(256.0f * d[3]);
+            p[0] = d[0]; p[1] = d[1]; p[2] = d[2]; p[3] = rho2 > 0.0f ? rho2 * (d[16] + d[20] + d[24]) : 0.0f;
         }
         HIP_TRY(ctx, hipMemcpy((char*)ctx->recs.p + base * F4 * 16, stage_rec.data(), cnt * F4 * 16, hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy((char*)ctx->pos4.p + base * 16, stage_pos.data(), cnt * 16, hipMemcpyHostToDevice));
@@ -438,6 +441,13 @@ int msplat_download_cloud(msplat_ctx* ctx, void* aos_out, uint64_t cap_bytes)
     return MSPLAT_OK;
 }
 
+int msplat_set_band_cull(msplat_ctx* ctx, int enable)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    ctx->band_cull = enable != 0;
+    return MSPLAT_OK;
+}
+
 int msplat_set_band(msplat_ctx* ctx, int32_t row_mod, int32_t row_rem)
 {
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
@@ -478,6 +488,11 @@ static int make_frame_params(msplat_ctx* ctx, const float cameraMat[16], const f
     fp.full_sh = ctx->full_sh ? 1 : 0;
     fp.srgb = ctx->cfg.srgb ? 1 : 0;
     fp.t_eps = ctx->cfg.t_epsilon;
+    fp.band_cull = (ctx->band_cull && ctx->row_mod > 1) ? 1 : 0;
+    fp.view_scale2 = 0.0f;
+    for (int c = 0; c < 3; ++c)
+        fp.view_scale2 = std::max(fp.view_scale2, fp.view[c * 4] * fp.view[c * 4] + fp.view[c * 4 + 1] * fp.view[c * 4 + 1] +
+                                                      fp.view[c * 4 + 2] * fp.view[c * 4 + 2]);
     return MSPLAT_OK;
 }
 

@@ -45,6 +45,8 @@ struct FrameParams {
     int tiles_x, tiles_y;       // tiles_y = number of OWNED tile rows (band mode) else ceil(H/16)
     int row_mod, row_rem;       // owned tile rows: ty = vy * row_mod + row_rem
     int full_sh, srgb;
+    int band_cull;              // multi-GPU only: Sort also drops splats that cannot reach an owned bin row
+    float view_scale2;          // largest squared column norm of mat3(view) (1 for a rigid camera)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -99,6 +101,25 @@ __device__ __forceinline__ bool cull_key(const float4 p, const FrameParams& fp, 
     float yy = __fdiv_rn(py, depth);
     const float CLIP = 1.5f;
     if (depth > 0.0f && xx < CLIP && xx > -CLIP && yy < CLIP && yy > -CLIP) {
+        if (fp.band_cull) {
+            // Band-restricted cull (never active on a single GPU, where the reference's cull
+            // must be reproduced exactly).  Conservative bound on the footprint's y half-extent:
+            //   ey^2 = rho^2 (M1 Sigma M1^T + 0.3) <= |J1|^2 |W|^2 * (rho^2 trace Sigma) + 0.3 rho^2_max,
+            // p.w = rho^2 trace(Sigma) precomputed at upload (0 when alpha <= 1/256: never visible).
+            if (!(p.w > 0.0f)) return false;
+            const float* v = fp.view;
+            const float ty = v[1] * p.x + v[5] * p.y + v[9] * p.z + v[13];
+            const float tz = v[2] * p.x + v[6] * p.y + v[10] * p.z + v[14];
+            const float jsy = fp.proj[5] * fp.H / (2.0f * tz);
+            const float j2 = jsy * jsy * (1.0f + (ty * ty) / (tz * tz));
+            const float ey = sqrtf(j2 * fp.view_scale2 * p.w + 3.4f) * 1.001f + 1.5f;
+            const float cy = 0.5f * (fp.H + yy * fp.H) + fp.Y0;
+            const float y0 = fmaxf(cy - ey, 0.0f), y1 = fminf(cy + ey, fp.H - 1.0f);
+            if (!(y0 <= y1)) return false;
+            const int r0 = (int)y0 / kBin, r1 = (int)y1 / kBin;
+            const int first = r0 + ((fp.row_rem - r0 % fp.row_mod) + fp.row_mod) % fp.row_mod;   // first owned row >= r0
+            if (first > r1) return false;
+        }
         float f = __fmul_rn(__fdiv_rn(depth, fp.zf), 4294967296.0f);
         uint32_t q = (f >= 4294967296.0f) ? 0xFFFFFFFFu : (uint32_t)f;
         key = 0xFFFFFFFFu - q;
@@ -467,7 +488,9 @@ __global__ __launch_bounds__(64) void ingest_kernel(const char* __restrict__ raw
             s = s + B[2 * 3 + r] * R[2 * 3 + c];
             f[16 + c * 3 + r] = s;
         }
-    pos4[i] = make_float4(f[0], f[1], f[2], 1.0f);
+    // .w = rho^2 * trace(Sigma), rho^2 = 2 ln(256 alpha): world-space footprint bound for the band cull
+    const float rho2 = 2.0f * logf(256.0f * f[3]);
+    pos4[i] = make_float4(f[0], f[1], f[2], rho2 > 0.0f ? rho2 * (f[16] + f[20] + f[24]) : 0.0f);
 #pragma unroll
     for (int k = 0; k < F4; ++k) recs[i * F4 + k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
 }

@@ -141,8 +141,9 @@ class SplatRenderer:
         return out
 
     # -- extensions -------------------------------------------------------------------------
-    def set_band(self, row_mod, row_rem):
+    def set_band(self, row_mod, row_rem, band_cull=False):
         _capi.check(self._ctx, self._lib.msplat_set_band(self._ctx, row_mod, row_rem))
+        _capi.check(self._ctx, self._lib.msplat_set_band_cull(self._ctx, 1 if band_cull else 0))
 
     def synchronize(self):
         _capi.check(self._ctx, self._lib.msplat_synchronize(self._ctx))

@@ -305,6 +305,20 @@ def test_row_bands_reassemble_bit_exact():
             assert (part[~rows] == 0).all()
             acc[rows] = part[rows]
         np.testing.assert_array_equal(acc, full)
+    # band-restricted cull (Sort drops splats that cannot reach an owned row): same pixels, smaller V
+    G = 4
+    acc = np.zeros_like(full)
+    vs = []
+    for g in range(G):
+        rb = make_renderer(cloud)
+        rb.set_band(G, g, band_cull=True)
+        rb.Sort(cam, proj, vp, nf)
+        vs.append(rb.sort_count())
+        part = rb.Render(cam, proj, vp, nf)
+        rows = np.arange(360) // bin_px() % G == g
+        acc[rows] = part[rows]
+    np.testing.assert_array_equal(acc, full)
+    assert max(vs) < 0.8 * r.sort_count(), (vs, r.sort_count())
 
 
 def test_render_before_sort_and_bad_viewport_errors():

@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--ply", default=None, help="render a real scene instead of the synthetic workload (BASELINE configs[2]: "
+                    "Inria point_cloud.ply); cameras.json next to it (or up to two directories above) is replayed")
+    ap.add_argument("--save-image", default=None, help="write the last frame of rank 0 as PNG")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="CPU baseline frames (0 = auto, about 10-30 s)")
     ap.add_argument("--profile-frames", type=int, default=8, help="extra frames (outside the timed region) for V/D statistics")
@@ -84,10 +87,23 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         dist.barrier()
 
-    wl = WORKLOADS[args.workload]
-    n, W, H, views = wl["n"], wl["W"], wl["H"], wl["views"]
+    wl = dict(WORKLOADS[args.workload])
+    W, H, views = wl["W"], wl["H"], wl["views"]
     t0 = time.time()
-    cloud = synthetic.make_cloud(n, seed=wl["seed"], full_sh=True, pos_sigma=wl["pos_sigma"])
+    scene_cams = None
+    if args.ply:
+        from splatapult_amd import GaussianCloud
+        cloud = GaussianCloud()
+        if not cloud.ImportPly(args.ply):
+            raise SystemExit("cannot import " + args.ply)
+        wl["n"] = cloud.GetNumGaussians()
+        wl["desc"] = "%s (%d splats), %dx%d %s" % (os.path.basename(args.ply), wl["n"], W, H, wl["fb"])
+        cj = camera.find_config_file(args.ply, "cameras.json")          # app.cpp:418-461
+        if cj:
+            scene_cams = [m for m, _ in camera.load_cameras_json(cj)]
+    else:
+        cloud = synthetic.make_cloud(wl["n"], seed=wl["seed"], full_sh=True, pos_sigma=wl["pos_sigma"])
+    n = wl["n"]
     t_gen = time.time() - t0
 
     # a dedicated (non-null) torch stream: libmsplat launches on it, so torch copies, RCCL's stream
@@ -115,7 +131,10 @@ def main():
         projs = [camera.create_projection(-1.0, 0.8, 0.95, -0.95), camera.create_projection(-0.8, 1.0, 0.95, -0.95)]
 
     def cams_for(step):
-        c = camera.orbit(wl["cam_z"], 2.0 * math.pi * (step % 64) / 64.0)
+        if scene_cams:
+            c = scene_cams[step % len(scene_cams)]
+        else:
+            c = camera.orbit(wl["cam_z"], 2.0 * math.pi * (step % 64) / 64.0)
         if views == 1:
             return [c]
         return [camera.translate_local(c, dx=-0.032), camera.translate_local(c, dx=+0.032)]
@@ -199,7 +218,7 @@ def main():
     out = {
         "metric": "frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.ply else "file",
         "gsplats_per_sec": n * fps / 1e9,
         "config": {"workload": wl["desc"], "key": args.workload, "splats": n, "width": W, "height": H,
                    "views": views, "framebuffer": wl["fb"], "sharding": "tile rows, row %% %d == rank" % world,
@@ -219,6 +238,9 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cloud, wl, cams_for, projs, vp, nf, args.cpu_frames)
 
+    if rank == 0 and args.save_image:
+        img = (gathers[0].final.view(Hpad, W, 4) if gathers else fbs[0])[:H].float().cpu().numpy()
+        camera.write_image(args.save_image, img)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

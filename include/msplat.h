@@ -217,6 +217,22 @@ int msplat_cloud_attr_offsets(const msplat_cloud* c, msplat_attr_offsets* out); 
 /* msplat_upload_cloud(ctx, raw, n, stride, offsets, has_full_sh) in one call */
 int msplat_upload_gaussian_cloud(msplat_ctx* ctx, const msplat_cloud* c);
 
+/* ---- scene config files + image output (host only) -------------------------- */
+/* CamerasConfig::ImportJson (camerasconfig.cpp:20-67): cameras.json -> camera-to-world matrices (float[16]
+ * each, column-major, -z forward / +y up) and the two fov angles; count_out = cameras in the file */
+int msplat_cameras_import_json(const char* path, float* mats16_out, float* fovs2_out, uint32_t cap,
+                               uint32_t* count_out);
+/* CamerasConfig::EstimateFloorPlane (camerasconfig.cpp:69-95) */
+int msplat_cameras_floor_plane(const char* path, float normal_out[3], float pos_out[3]);
+/* VrConfig::ImportJson / ExportJson (vrconfig.cpp:20-65): <scene>_vr.json floor matrix */
+int msplat_vrconfig_import_json(const char* path, float floor_mat_out[16]);
+int msplat_vrconfig_export_json(const char* path, const float floor_mat[16]);
+/* FindConfigFile (app.cpp:89-119): looks in the PLY's directory, its parent and grandparent */
+int msplat_find_config_file(const char* ply_path, const char* config_name, char* out, uint32_t cap);
+/* W x H float RGBA framebuffer (row 0 = bottom) -> 8-bit image file, top row first: clamp + round as an RGBA8
+ * target does (the reference's back buffer), optional LinearToSRGB (util.cpp:357-367); ".ppm" or PNG */
+int msplat_write_image(const char* path, const float* rgba, int width, int height, int encode_srgb);
+
 /* ---- host matrix helpers used by the shims (glm closed forms; app.cpp:1042, util.cpp:420) - */
 void msplat_mat4_inverse(const float m[16], float out[16]);
 void msplat_mat4_mul(const float a[16], const float b[16], float out[16]);

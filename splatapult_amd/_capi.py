@@ -88,6 +88,12 @@ SYMBOLS = [
     ("msplat_cloud_has_full_sh", C.c_int, [C.c_void_p]),
     ("msplat_cloud_attr_offsets", C.c_int, [C.c_void_p, C.POINTER(AttrOffsets)]),
     ("msplat_upload_gaussian_cloud", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("msplat_cameras_import_json", C.c_int, [C.c_char_p, _F16, _F16, C.c_uint32, _U32P]),
+    ("msplat_cameras_floor_plane", C.c_int, [C.c_char_p, _F16, _F16]),
+    ("msplat_vrconfig_import_json", C.c_int, [C.c_char_p, _F16]),
+    ("msplat_vrconfig_export_json", C.c_int, [C.c_char_p, _F16]),
+    ("msplat_find_config_file", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32]),
+    ("msplat_write_image", C.c_int, [C.c_char_p, _F16, C.c_int, C.c_int, C.c_int]),
     ("msplat_mat4_inverse", None, [_F16, _F16]),
     ("msplat_mat4_mul", None, [_F16, _F16, _F16]),
     ("msplat_perspective", None, [C.c_float, C.c_float, C.c_float, C.c_float, _F16]),

@@ -57,10 +57,46 @@ def translate_local(cam, dx=0.0, dy=0.0, dz=0.0):
     return m.reshape(16)
 
 
+def load_vr_json(path):
+    """VrConfig::ImportJson (vrconfig.cpp:20-46): floor matrix, float32[16] column-major"""
+    a, p = _out16()
+    rc = _capi.lib().msplat_vrconfig_import_json(str(path).encode(), p)
+    if rc != _capi.OK:
+        raise IOError("cannot read vr config %s" % path)
+    return a
+
+
 def camera_from_vr_json(path, raise_by=1.5):
-    """default desktop camera when only a *_vr.json exists: floorMat raised 1.5 along its Y
-    (app.cpp:486-497; vrconfig.cpp:31-35 reads the JSON row-major)"""
-    fm = np.array(json.load(open(path))["floorMat"], np.float32)       # rows
-    cam = fm.copy()
-    cam[:3, 3] = cam[:3, 3] + cam[:3, :3] @ np.array([0.0, raise_by, 0.0], np.float32)
-    return cam.T.reshape(16).copy()
+    """default desktop camera when only a *_vr.json exists: floorMat raised 1.5 along its Y (app.cpp:486-497)"""
+    cam = load_vr_json(path).reshape(4, 4).copy()            # cam[c] = column c
+    cam[3, :3] = cam[3, :3] + raise_by * cam[1, :3]          # pos += mat3(floorMat) * (0, 1.5, 0)
+    return cam.reshape(16)
+
+
+def load_cameras_json(path):
+    """CamerasConfig::ImportJson (camerasconfig.cpp:20-67): list of (camera-to-world float32[16], fov float32[2])"""
+    L = _capi.lib()
+    n = C.c_uint32()
+    if L.msplat_cameras_import_json(str(path).encode(), None, None, 0, C.byref(n)) != _capi.OK:
+        raise IOError("cannot read cameras config %s" % path)
+    mats = np.zeros((max(n.value, 1), 16), np.float32)
+    fovs = np.zeros((max(n.value, 1), 2), np.float32)
+    L.msplat_cameras_import_json(str(path).encode(), mats.ctypes.data_as(C.POINTER(C.c_float)),
+                                 fovs.ctypes.data_as(C.POINTER(C.c_float)), n.value, C.byref(n))
+    return [(mats[i].copy(), fovs[i].copy()) for i in range(n.value)]
+
+
+def find_config_file(ply_path, name):
+    """FindConfigFile (app.cpp:89-119); returns '' when nothing is found"""
+    buf = C.create_string_buffer(4096)
+    rc = _capi.lib().msplat_find_config_file(str(ply_path).encode(), name.encode(), buf, 4096)
+    return buf.value.decode() if rc == _capi.OK else ""
+
+
+def write_image(path, rgba, encode_srgb=False):
+    """float RGBA framebuffer (row 0 = bottom) -> PNG (or .ppm), 8-bit, top row first"""
+    a = np.ascontiguousarray(rgba, np.float32)
+    rc = _capi.lib().msplat_write_image(str(path).encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[1], a.shape[0],
+                                        1 if encode_srgb else 0)
+    if rc != _capi.OK:
+        raise IOError("cannot write %s" % path)

@@ -86,7 +86,7 @@ struct msplat_ctx {
     uint32_t comp_kernel_sets_mask = 0;
 
     bool atomic_rank = true;    // LDS atomics hand out ranks in lane order (probed at create)
-    int comp_waves = 6144;      // compositor grid (persistent waves); MSPLAT_COMP_WAVES overrides
+    int comp_waves = 8192;      // compositor grid (persistent waves; measured best of 2k..8k); MSPLAT_COMP_WAVES overrides
     uint64_t device_bytes = 0;
 };
 
@@ -616,7 +616,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                        (uint32_t*)ctx->tile_order.p, d_queue);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][4], s));
 
-    // persistent compositor: at most 6 waves per SIMD (256 CUs x 4 SIMDs), never more than tiles
+    // persistent compositor: a fixed pool of waves pulls (bin, quadrant) items; never more waves than items
     const int cgrid = std::min(ntiles * 4, ctx->comp_waves);     // work items = (bin, quadrant)
     if (ntiles > 0) {
         // on sampled frames the dominant kernel gets exact dispatch begin/end events (the plain stream

@@ -188,7 +188,7 @@ class SplatRenderer:
 
     def debug_tile_probe(self):
         st = self.stats()
-        nt = st["tiles_x"] * st["tiles_y"]
+        nt = st["tiles_x"] * st["tiles_y"] * 4        # one slot per (bin, quadrant) work item
         out = np.zeros((max(nt, 1), 4), np.uint32)
         _capi.check(self._ctx, self._lib.msplat_debug_get_tile_probe(
             self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.shape[0]))

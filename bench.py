@@ -202,7 +202,7 @@ def main():
     comp_ms = prof.get("composite_kernel", 0.0) or prof["composite"]   # exact kernel begin/end events
     comp_s = comp_ms * 1e-3
     achieved = B_comp / comp_s if comp_s > 0 else 0.0
-    # HBM traffic of the dominant kernel comes from a SEPARATE rocprofv3 --pmc run (tools_pmc_traffic.sh:
+    # HBM traffic of the dominant kernel comes from a SEPARATE rocprofv3 --pmc run (tools/pmc_traffic.sh:
     # FETCH_SIZE / WRITE_SIZE in their own passes, gfx950 x2 correction on FETCH_SIZE); the committed
     # summary is only quoted for the workload it was measured on
     traffic = None

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools_pmc_traffic.sh <tag>
+# usage (GPU box, repo root): tools/pmc_traffic.sh <tag>
 # Collects HBM traffic of every kernel with rocprofv3 PMC counters, one counter family per pass
 # (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2 -- MI355X_MICROARCH.md), no trace domains mixed in,
 # and writes gpurun_out/pmc_<tag>/traffic.json (+ the raw counter CSVs).

@@ -45,8 +45,8 @@ HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--ply", default=None, help="render a real scene instead of the synthetic workload (BASELINE configs[2]: "
                     "Inria point_cloud.ply); cameras.json next to it (or up to two directories above) is replayed")
@@ -54,6 +54,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="CPU baseline frames (0 = auto, about 10-30 s)")
     ap.add_argument("--profile-frames", type=int, default=8, help="extra frames (outside the timed region) for V/D statistics")
+    ap.add_argument("--prewarm", type=int, default=400, help="untimed frames before the warm-up (runtime pool growth)")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="frames overlapped on the GPU (one context + stream + framebuffer per frame in flight, one shared "
+                         "cloud); 1 = strictly serial frames (latency mode)")
     ap.add_argument("--timing-stride", type=int, default=8,
                     help="record per-stage hipEvents on every n-th frame of the timed region (0 = never)")
     args = ap.parse_args()
@@ -110,7 +114,9 @@ def main():
     # hand-off and torch.cuda.synchronize all order correctly with the HIP kernels
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    r = SplatRenderer(device=local_rank, fb_format=wl["fb"], stream=stream.cuda_stream, enable_timing=args.timing_stride)
+    P = max(1, args.frames_in_flight)
+    r = SplatRenderer(device=local_rank, fb_format=wl["fb"], stream=stream.cuda_stream, enable_timing=args.timing_stride,
+                      frames_in_flight=P)
     if not r.Init(cloud, False, False):
         raise SystemExit("Init failed: " + r.last_error())
     if world > 1:
@@ -123,7 +129,10 @@ def main():
     Hpad = tiles_y * TILE
     fdt = torch.float16 if wl["fb"] == "fp16" else torch.float32
     bpp = 8 if wl["fb"] == "fp16" else 16
-    fbs = [torch.zeros((Hpad, W, 4), dtype=fdt, device=dev) for _ in range(views)]
+    # one framebuffer set per frame in flight
+    fb_sets = [[torch.zeros((Hpad, W, 4), dtype=fdt, device=dev) for _ in range(views)] for _ in range(P)]
+    fbs = fb_sets[0]
+    fb_free = [None] * P      # N > 1: event recorded after the gather that read the slot's framebuffers
     vp, nf = [0, 0, W, H], [camera.Z_NEAR, camera.Z_FAR]
     if views == 1:
         projs = [camera.perspective(camera.FOVY, W / H)]
@@ -146,12 +155,24 @@ def main():
         gathers = [BandGather(tiles_y, W, fdt, dev, rank, world, tile=TILE) for _ in range(views)]
 
     def frame(step):
+        nonlocal fbs
         cams = cams_for(step)
+        if P > 1 and gathers is not None:
+            ev = fb_free[(r.frame_slot + 1) % P]
+            if ev is not None:
+                r.next_frame_wait_event(ev.cuda_event)         # the slot's previous frame has been gathered
         r.Sort(cams[0], projs[0], vp, nf)                      # sort once with view 0 (app.cpp:603-606)
+        fbs = fb_sets[r.frame_slot]
         for v in range(views):
             r.Render(cams[v], projs[v], vp, nf, out_ptr=fbs[v].data_ptr(), pitch_bytes=W * bpp)
             if gathers is not None:
+                if P > 1:
+                    r.wait_on_stream(stream.cuda_stream)       # the gather's stream waits for this frame only
                 gathers[v](fbs[v])
+        if P > 1 and gathers is not None:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            fb_free[r.frame_slot] = ev
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -159,12 +180,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # The HIP runtime grows its per-queue kernarg / signal pools once, a few thousand launches after start-up
+    # (measured: a single 15-40 ms stall around frame 170-210, scratch timeline in DESIGN.md 6): get past it
+    # before the official warm-up so that short --steps runs measure the steady state too.
+    for s in range(args.prewarm):
+        frame(s)
+    sync_all()
     for s in range(args.warmup):
         frame(s)
     sync_all()
     t0 = time.perf_counter()
     for s in range(args.steps):
         frame(args.warmup + s)
+    enqueue = time.perf_counter() - t0        # host time to issue the frames (launch-rate bound check)
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -185,6 +213,16 @@ def main():
         Vs.append(st["sort_count"]); Ds.append(st["pairs_tile16"]); drawn.append(st["drawn"]); Dbin.append(st["pairs"])
     st = r.stats()
     V, D = float(np.mean(Vs)), float(np.mean(Ds))
+    # latency of ONE frame with nothing else in flight (outside the timed region)
+    lat = []
+    for s in range(16 * P):
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        frame(args.warmup + args.steps + 64 + s)
+        torch.cuda.synchronize(dev)
+        lat.append(time.perf_counter() - t1)
+    latency_ms = 1e3 * float(np.median(lat))
+    prof_serial = r.timings() if args.timing_stride > 0 else None     # the same events, frames not overlapped
     if world > 1:
         t = torch.tensor([V, D, prof["composite"]], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -222,9 +260,12 @@ def main():
         "gsplats_per_sec": n * fps / 1e9,
         "config": {"workload": wl["desc"], "key": args.workload, "splats": n, "width": W, "height": H,
                    "views": views, "framebuffer": wl["fb"], "sharding": "tile rows, row %% %d == rank" % world,
+                   "frames_in_flight": P,
                    "visible_V": V, "pairs_D": D_total, "pairs_binned_32px": float(np.mean(Dbin)),
                    "drawn": float(np.mean(drawn))},
         "stages_ms": prof,
+        "single_frame_latency_ms": latency_ms,
+        "host_enqueue_ms_per_frame": 1e3 * enqueue / args.steps,
         "frame_algorithmic_GB": B_frame / 1e9,
         "frame_hbm_frac": (B_frame / (elapsed / args.steps)) / HBM_PEAK / world,
         "roofline": {"kernel": "composite_kernel", "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
@@ -232,7 +273,11 @@ def main():
                      "traffic_source": "profiles/r01_pmc_traffic_%s.json (rocprofv3 --pmc, bytes per launch)" % args.workload if traffic else None,
                      "algorithmic_bytes_per_launch": B_comp,
                      "avg_launch_ms": comp_ms,
-                     "note": "composite is VALU/LDS bound (exp + blend per pixel-splat); HBM fraction is honest-but-low"},
+                     "avg_launch_ms_one_frame_at_a_time": prof_serial["composite_kernel"] if prof_serial else None,
+                     "frac_one_frame_at_a_time": (B_comp / (prof_serial["composite_kernel"] * 1e-3) / HBM_PEAK)
+                     if prof_serial and prof_serial["composite_kernel"] > 0 else None,
+                     "note": "composite is VALU/LDS bound (exp + blend per pixel-splat); HBM fraction is honest-but-low"
+                             + ("; launch duration measured while %d frames share the GPU" % P if P > 1 else "")},
     }
 
     if rank == 0 and not args.no_cpu_baseline:

@@ -59,7 +59,9 @@ typedef struct msplat_config {
     void* stream;              /* hipStream_t to launch on; NULL = library-owned stream      */
     int32_t enable_timing;     /* n > 0: record per-stage hipEvents on every n-th sort/render */
                                /* (msplat_get_timings averages them); 0 = never             */
-    int32_t reserved;
+    int32_t compositor_waves;  /* persistent compositor waves per render; 0 = default (8192, the  */
+                               /* measured best for one frame at a time; the SplatRenderer shims   */
+                               /* use 2048 with frames in flight so that frames share the CUs)     */
 } msplat_config;
 
 /* Byte offsets of the attributes inside one AoS record, i.e. the BinaryAttribute offsets that
@@ -169,6 +171,22 @@ int msplat_render(msplat_ctx* ctx, const float cameraMat[16], const float projMa
 
 /* blocks until everything queued on the context's stream has finished */
 int msplat_synchronize(msplat_ctx* ctx);
+
+/* ---- frames in flight -------------------------------------------------------------------
+ * The reference queues Sort and Render of successive frames on one GL command stream and lets the
+ * driver overlap them.  Here a frame's ~20 launches are a dependent chain on one HIP stream, so the
+ * overlap is made explicit: create one context per frame in flight (each has its own stream and
+ * per-frame buffers), upload the cloud into the first and attach it to the others (no copy), then
+ * issue frame k's Sort + Render(s) on context k % depth.  Results are bit-identical to a single
+ * context.  The C++ / Python SplatRenderer shims do this rotation (SetFramesInFlight). */
+/* `ctx` renders `owner`'s cloud (same device).  A later upload into either context detaches it. */
+int msplat_attach_cloud(msplat_ctx* ctx, msplat_ctx* owner);
+/* makes `stream` (hipStream_t; NULL = default stream) wait, on the device, for everything queued so
+ * far on the context's stream -- e.g. before a collective or a readback of the frame just rendered */
+int msplat_stream_wait(msplat_ctx* ctx, void* stream);
+/* the reverse join: the context's stream waits for `event` (a hipEvent_t the caller recorded, e.g. after
+ * the consumer of a framebuffer that the next frame issued on this context will overwrite) */
+int msplat_wait_event(msplat_ctx* ctx, void* event);
 
 /* sortCount of the last Sort (splatrenderer.cpp:198-199); synchronises */
 int msplat_sort_count(msplat_ctx* ctx, uint32_t* v);

@@ -21,7 +21,7 @@ class MsplatError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("fb_format", C.c_int32),
                 ("srgb", C.c_int32), ("t_epsilon", C.c_float), ("pair_capacity", C.c_uint64),
-                ("stream", C.c_void_p), ("enable_timing", C.c_int32), ("reserved", C.c_int32)]
+                ("stream", C.c_void_p), ("enable_timing", C.c_int32), ("compositor_waves", C.c_int32)]
 
 
 class AttrOffsets(C.Structure):
@@ -66,6 +66,9 @@ SYMBOLS = [
     ("msplat_sort", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16]),
     ("msplat_render", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16, C.c_void_p, C.c_uint64, C.c_int]),
     ("msplat_synchronize", C.c_int, [C.c_void_p]),
+    ("msplat_attach_cloud", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("msplat_stream_wait", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("msplat_wait_event", C.c_int, [C.c_void_p, C.c_void_p]),
     ("msplat_sort_count", C.c_int, [C.c_void_p, _U32P]),
     ("msplat_get_sorted_indices", C.c_int, [C.c_void_p, _U32P, C.c_uint32]),
     ("msplat_get_sorted_keys", C.c_int, [C.c_void_p, _U32P, C.c_uint32]),

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -30,6 +31,20 @@ struct Buf {
     size_t bytes = 0;
 };
 
+// The uploaded cloud (read-only after upload).  Held by shared_ptr so that several contexts -- one per
+// frame in flight, each with its own stream and per-frame buffers -- can render the same cloud
+// (msplat_attach_cloud); a re-upload allocates a new store when the old one is still shared.
+struct CloudStore {
+    int device = 0;
+    Buf pos4, recs;
+    ~CloudStore()
+    {
+        (void)hipSetDevice(device);
+        if (pos4.p) (void)hipFree(pos4.p);
+        if (recs.p) (void)hipFree(recs.p);
+    }
+};
+
 }  // namespace
 
 struct msplat_ctx {
@@ -44,8 +59,10 @@ struct msplat_ctx {
     bool full_sh = false;
     bool has_cloud = false;
     bool has_sort = false;
-    Buf pos4;       // float4[N]  (x, y, z, 1)            -- the reference's posVec (splatrenderer.cpp:106-111)
-    Buf recs;       // padded AoS: 16 (full SH) or 8 float4 per splat, reference float offsets preserved
+    std::shared_ptr<CloudStore> store;   // owns pos4 / recs (possibly shared with other contexts)
+    Buf pos4;       // view: float4[N]  (x, y, z, bound)  -- the reference's posVec (splatrenderer.cpp:106-111)
+    Buf recs;       // view: padded AoS, 16 (full SH) or 8 float4 per splat, reference float offsets preserved
+    hipEvent_t join_ev = nullptr;        // msplat_stream_wait
     // sort state
     Buf keyA, keyB, valA, valB;   // uint32[N]; final sorted result in keyA/valA
     Buf hist;       // uint32[256 * hist_stride]
@@ -215,6 +232,7 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->totals1, 256 * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_start, 65537 * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_order, 65536 * sizeof(uint32_t));
+    if (c.compositor_waves > 0) ctx->comp_waves = std::max(64, (int)c.compositor_waves);
     if (getenv("MSPLAT_COMP_WAVES")) ctx->comp_waves = std::max(64, atoi(getenv("MSPLAT_COMP_WAVES")));
     if (rc == MSPLAT_OK && getenv("MSPLAT_TILE_PROBE") != nullptr) rc = buf_alloc(ctx, ctx->probe, 65536 * 4 * sizeof(uint32_t));
     if (rc == MSPLAT_OK && hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(uint32_t), ctx->stream) != hipSuccess)
@@ -244,7 +262,11 @@ void msplat_destroy(msplat_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    Buf* all[] = {&ctx->pos4, &ctx->recs, &ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist,
+    ctx->pos4 = Buf{};
+    ctx->recs = Buf{};
+    ctx->store.reset();
+    if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
+    Buf* all[] = {&ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist,
                   &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->totals1, &ctx->tile_start, &ctx->tile_order,
                   &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe};
     for (Buf* b : all) buf_free(ctx, *b);
@@ -263,6 +285,48 @@ int msplat_synchronize(msplat_ctx* ctx)
     return MSPLAT_OK;
 }
 
+static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, const std::shared_ptr<CloudStore>& share);
+
+// Frames in flight: `ctx` renders `owner`'s cloud (no copy).  Each context keeps its own stream and
+// per-frame buffers, so consecutive frames issued round-robin over several contexts overlap on the GPU
+// (one frame's latency-bound sort/binning launches fill the gaps of another frame's compositor).
+int msplat_attach_cloud(msplat_ctx* ctx, msplat_ctx* owner)
+{
+    if (!ctx || !owner) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_attach_cloud: NULL argument");
+    if (ctx == owner) return MSPLAT_OK;
+    if (!owner->has_cloud || !owner->store) return fail(ctx, MSPLAT_ERR_NO_CLOUD, "msplat_attach_cloud: owner has no cloud");
+    if (owner->device != ctx->device)
+        return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_attach_cloud: contexts are on different devices (%d, %d)",
+                    ctx->device, owner->device);
+    int rc = prepare_cloud_buffers(ctx, owner->N, owner->full_sh, owner->store);
+    if (rc) return rc;
+    ctx->has_cloud = true;       // uploads are synchronous: the store is complete
+    return MSPLAT_OK;
+}
+
+// Makes `stream` (a hipStream_t, NULL = the legacy default stream) wait for everything enqueued so far on
+// the context's stream, without blocking the host.
+int msplat_stream_wait(msplat_ctx* ctx, void* stream)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if ((hipStream_t)stream == ctx->stream) return MSPLAT_OK;
+    if (!ctx->join_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(ctx->join_ev, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->join_ev, 0));
+    return MSPLAT_OK;
+}
+
+// The context's stream waits for `event` (a hipEvent_t recorded by the caller, e.g. after the consumer of a
+// framebuffer that the next frame on this context will overwrite).
+int msplat_wait_event(msplat_ctx* ctx, void* event)
+{
+    if (!ctx || !event) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_wait_event: NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)event, 0));
+    return MSPLAT_OK;
+}
+
 static int ensure_pair_capacity(msplat_ctx* ctx, uint64_t cap)
 {
     if (cap > 0x7FFFFFFFull) cap = 0x7FFFFFFFull;
@@ -278,8 +342,9 @@ static int ensure_pair_capacity(msplat_ctx* ctx, uint64_t cap)
     return MSPLAT_OK;
 }
 
-// (re)allocates every per-cloud device buffer for n splats; leaves the context without a cloud
-static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh)
+// (re)allocates every per-cloud device buffer for n splats; leaves the context without a cloud.
+// `share` != null: use that store's cloud instead of allocating one (msplat_attach_cloud).
+static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, const std::shared_ptr<CloudStore>& share)
 {
     if (n > (1ull << 24))
         return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "%llu splats > 2^24 (rank field is 24 bit)", (unsigned long long)n);
@@ -293,8 +358,32 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh)
     const int F4 = ctx->full_sh ? 16 : 8;
     const size_t alloc_n = std::max<uint64_t>(n, 1);
     int rc;
-    if ((rc = buf_alloc(ctx, ctx->pos4, alloc_n * 16))) return rc;
-    if ((rc = buf_alloc(ctx, ctx->recs, alloc_n * F4 * 16))) return rc;
+    if (share) {
+        if (ctx->store && ctx->store != share && ctx->store.use_count() == 1)
+            ctx->device_bytes -= ctx->store->pos4.bytes + ctx->store->recs.bytes;
+        ctx->store = share;
+    } else {
+        const size_t need_pos = alloc_n * 16, need_rec = alloc_n * F4 * 16;
+        const bool reuse = ctx->store && ctx->store.use_count() == 1 && ctx->store->pos4.bytes >= need_pos &&
+                           ctx->store->recs.bytes >= need_rec;
+        if (!reuse) {
+            if (ctx->store && ctx->store.use_count() == 1)
+                ctx->device_bytes -= ctx->store->pos4.bytes + ctx->store->recs.bytes;
+            ctx->pos4 = Buf{};
+            ctx->recs = Buf{};
+            ctx->store.reset();
+            auto st = std::make_shared<CloudStore>();
+            st->device = ctx->device;
+            HIP_TRY(ctx, hipMalloc(&st->pos4.p, need_pos));
+            st->pos4.bytes = need_pos;
+            HIP_TRY(ctx, hipMalloc(&st->recs.p, need_rec));
+            st->recs.bytes = need_rec;
+            ctx->device_bytes += need_pos + need_rec;
+            ctx->store = st;
+        }
+    }
+    ctx->pos4 = ctx->store->pos4;
+    ctx->recs = ctx->store->recs;
     if ((rc = buf_alloc(ctx, ctx->keyA, alloc_n * 4))) return rc;
     if ((rc = buf_alloc(ctx, ctx->keyB, alloc_n * 4))) return rc;
     if ((rc = buf_alloc(ctx, ctx->valA, alloc_n * 4))) return rc;
@@ -316,7 +405,7 @@ int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t s
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if ((!aos && n) || !off) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_upload_cloud: NULL argument");
     if (stride_bytes % 4 != 0) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "stride must be a multiple of 4");
-    int rc = prepare_cloud_buffers(ctx, n, full_sh != 0);
+    int rc = prepare_cloud_buffers(ctx, n, full_sh != 0, nullptr);
     if (rc) return rc;
     const int F4 = ctx->full_sh ? 16 : 8;
 
@@ -389,7 +478,7 @@ int msplat_upload_ply_vertices(msplat_ctx* ctx, const void* vertices, uint64_t n
     bool has_rest = true;
     for (int k = 0; k < 45; ++k) has_rest = has_rest && layout->f_rest[k] >= 0;
     const bool full = full_sh != 0 && has_rest;      // f_rest is optional (gaussiancloud.cpp:188-205)
-    int rc = prepare_cloud_buffers(ctx, n, full);
+    int rc = prepare_cloud_buffers(ctx, n, full, nullptr);
     if (rc) return rc;
     if (n) {
         Buf raw;
@@ -618,6 +707,8 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
 
     // persistent compositor: a fixed pool of waves pulls (bin, quadrant) items; never more waves than items
     const int cgrid = std::min(ntiles * 4, ctx->comp_waves);     // work items = (bin, quadrant)
+    // (frames in flight: serialising the compositor launches of the contexts sharing a cloud with an event
+    //  gate was measured r1 -- no gain over letting the hardware queues interleave them, dropped)
     if (ntiles > 0) {
         // on sampled frames the dominant kernel gets exact dispatch begin/end events (the plain stream
         // markers around the stages can be processed while the previous kernel is still draining)

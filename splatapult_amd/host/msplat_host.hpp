@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <memory>
+#include <vector>
 
 #include "../../include/msplat.h"
 #include "gaussian_scene.hpp"
@@ -32,7 +33,7 @@ class SplatRenderer
 {
 public:
     SplatRenderer() = default;
-    ~SplatRenderer() { msplat_destroy(ctx); }
+    ~SplatRenderer() { DestroyContexts(); }
     SplatRenderer(const SplatRenderer&) = delete;
     SplatRenderer& operator=(const SplatRenderer&) = delete;
 
@@ -45,19 +46,38 @@ public:
         cfg.t_epsilon = tEpsilon;
     }
 
+    // optional, before Init: number of frames in flight (default 1).  With depth > 1 every Sort moves on to
+    // the next of `depth` contexts (own stream + per-frame buffers, one shared cloud), so successive frames
+    // overlap on the GPU the way a GL driver overlaps queued frames; the following Render(s) use the context
+    // of the latest Sort.  Each context creates its own stream (a stream given to Configure is only used
+    // with depth 1): use WaitOnStream / Synchronize before consuming a frame, and one render target per
+    // frame in flight.
+    void SetFramesInFlight(int depth) { framesInFlight = depth < 1 ? 1 : depth; }
+
     // splatrenderer.cpp:50-151.  false after logging on failure.  The cloud is copied to the device and
     // not retained; useRgcSortOverride is accepted and ignored (one HIP sort replaces both GL sorters).
     bool Init(std::shared_ptr<GaussianCloud> gaussianCloud, bool isFramebufferSRGBEnabledIn, bool useRgcSortOverrideIn)
     {
         (void)useRgcSortOverrideIn;
-        msplat_destroy(ctx);
-        ctx = nullptr;
+        DestroyContexts();
         cfg.struct_size = sizeof(cfg);
         cfg.srgb = isFramebufferSRGBEnabledIn ? 1 : 0;
-        if (msplat_create(&ctx, &cfg) != MSPLAT_OK) {
-            std::fprintf(stderr, "[msplat][E] %s\n", msplat_last_error(nullptr));
-            return false;
+        msplat_config c = cfg;
+        if (framesInFlight > 1) {
+            c.stream = nullptr;
+            c.compositor_waves = 2048;       // frames share the CUs (measured)
         }
+        for (int k = 0; k < framesInFlight; ++k) {
+            msplat_ctx* h = nullptr;
+            if (msplat_create(&h, &c) != MSPLAT_OK) {
+                std::fprintf(stderr, "[msplat][E] %s\n", msplat_last_error(nullptr));
+                DestroyContexts();
+                return false;
+            }
+            ctxs.push_back(h);
+        }
+        ctx = ctxs[0];
+        cur = framesInFlight - 1;            // the first Sort lands on context 0
         msplat_attr_offsets off{};
         off.pos_with_alpha = (uint32_t)gaussianCloud->GetPosWithAlphaAttrib().offset;
         off.r_sh0 = (uint32_t)gaussianCloud->GetR_SH0Attrib().offset;
@@ -82,6 +102,11 @@ public:
             std::fprintf(stderr, "[msplat][E] %s\n", msplat_last_error(ctx));
             return false;
         }
+        for (size_t k = 1; k < ctxs.size(); ++k)
+            if (msplat_attach_cloud(ctxs[k], ctxs[0]) != MSPLAT_OK) {
+                std::fprintf(stderr, "[msplat][E] %s\n", msplat_last_error(ctxs[k]));
+                return false;
+            }
         return true;
     }
 
@@ -90,6 +115,9 @@ public:
     void Sort(const Mat4& cameraMat, const Mat4& projMat, const Vec4& viewport, const Vec2& nearFar)
     {
         static_assert(sizeof(Mat4) == 64 && sizeof(Vec4) == 16 && sizeof(Vec2) == 8, "glm-compatible layout expected");
+        if (ctxs.empty()) return;
+        cur = (cur + 1) % (int)ctxs.size();
+        ctx = ctxs[cur];
         if (msplat_sort(ctx, reinterpret_cast<const float*>(&cameraMat), reinterpret_cast<const float*>(&projMat),
                         reinterpret_cast<const float*>(&viewport), reinterpret_cast<const float*>(&nearFar)) != MSPLAT_OK)
             std::fprintf(stderr, "[msplat][E] Sort: %s\n", msplat_last_error(ctx));     // void, like the reference
@@ -118,13 +146,42 @@ public:
         targetIsDevice = isDevicePointer;
     }
 
-    msplat_ctx* GetContext() { return ctx; }
+    // blocks until every frame in flight has finished
+    void Synchronize()
+    {
+        for (msplat_ctx* h : ctxs) msplat_synchronize(h);
+    }
+    // device-side join: `stream` (hipStream_t) waits for the frame issued last (the latest Sort's context)
+    void WaitOnStream(void* stream)
+    {
+        if (ctx) msplat_stream_wait(ctx, stream);
+    }
+
+    // reverse join: the context the NEXT Sort will use waits for `event` (hipEvent_t), e.g. recorded after the
+    // consumer of the render target that frame is going to overwrite
+    void NextFrameWaitEvent(void* event)
+    {
+        if (!ctxs.empty()) msplat_wait_event(ctxs[(cur + 1) % (int)ctxs.size()], event);
+    }
+    int GetFrameSlot() const { return cur; }
+
+    msplat_ctx* GetContext() { return ctx; }   // the context of the latest Sort
 
 public:
     uint32_t numBlocksPerWorkgroup = 1024;   // accepted and ignored (splatrenderer.h:39)
 
 protected:
-    msplat_ctx* ctx = nullptr;
+    void DestroyContexts()
+    {
+        for (msplat_ctx* h : ctxs) msplat_destroy(h);
+        ctxs.clear();
+        ctx = nullptr;
+    }
+
+    std::vector<msplat_ctx*> ctxs;       // one per frame in flight; ctxs[0] owns the cloud
+    msplat_ctx* ctx = nullptr;           // == ctxs[cur]
+    int cur = 0;
+    int framesInFlight = 1;
     msplat_config cfg{sizeof(msplat_config), 0, MSPLAT_FB_RGBA32F, 0, -1.0f, 0, nullptr, 0, 0};
     void* target = nullptr;
     uint64_t targetPitch = 0;

@@ -19,10 +19,17 @@ def _m(a, n):
 
 class SplatRenderer:
     def __init__(self, device=0, fb_format="fp32", t_epsilon=-1.0, pair_capacity=0, stream=None,
-                 enable_timing=False):
+                 enable_timing=False, frames_in_flight=1):
+        """frames_in_flight > 1: every Sort moves on to the next of that many contexts (own stream and
+        per-frame buffers, ONE shared cloud -- msplat_attach_cloud), so successive frames overlap on the
+        GPU; Render and the getters use the context of the latest Sort.  `stream` is only used with depth 1;
+        consume a frame after wait_on_stream() / synchronize(), one framebuffer per frame in flight."""
         self.numBlocksPerWorkgroup = 1024      # accepted and ignored (splatrenderer.h:39)
         self._lib = _capi.lib()
         self._ctx = None
+        self._ctxs = []
+        self._cur = 0
+        self._depth = max(1, int(frames_in_flight))
         self._device = device
         self._fb_format = {"fp32": _capi.FB_RGBA32F, "fp16": _capi.FB_RGBA16F}[fb_format]
         self._t_eps = t_epsilon
@@ -35,30 +42,16 @@ class SplatRenderer:
         self.close()
 
     def close(self):
-        ctx, self._ctx = getattr(self, "_ctx", None), None
-        if ctx:
+        ctxs, self._ctxs, self._ctx = getattr(self, "_ctxs", []), [], None
+        for ctx in ctxs:
             self._lib.msplat_destroy(ctx)
 
     # -- reference surface ------------------------------------------------------------------
     def Init(self, gaussianCloud, isFramebufferSRGBEnabled=False, useRgcSortOverride=False):
         """splatrenderer.cpp:50-151.  Returns False (error text via last_error()) on failure, like the reference."""
         del useRgcSortOverride   # one HIP sort replaces both GL sorters
-        self.close()
-        cfg = _capi.Config()
-        cfg.struct_size = C.sizeof(_capi.Config)
-        cfg.device = self._device
-        cfg.fb_format = self._fb_format
-        cfg.srgb = 1 if isFramebufferSRGBEnabled else 0
-        cfg.t_epsilon = self._t_eps
-        cfg.pair_capacity = self._pair_cap
-        cfg.stream = self._stream
-        cfg.enable_timing = int(self._timing)
-        h = C.c_void_p()
-        rc = self._lib.msplat_create(C.byref(h), C.byref(cfg))
-        if rc != _capi.OK:
-            self._err = self._lib.msplat_last_error(None).decode()
+        if not self._create(isFramebufferSRGBEnabled):
             return False
-        self._ctx = h
         if isinstance(gaussianCloud, GaussianCloud):
             rc = self._lib.msplat_upload_gaussian_cloud(self._ctx, gaussianCloud.handle)
             self._n = gaussianCloud.GetNumGaussians()
@@ -73,9 +66,10 @@ class SplatRenderer:
         if rc != _capi.OK:
             self._err = self._lib.msplat_last_error(self._ctx).decode()
             return False
-        return True
+        return self._attach_all()
 
     def _create(self, isFramebufferSRGBEnabled):
+        """one context per frame in flight; context 0 receives the cloud"""
         self.close()
         cfg = _capi.Config()
         cfg.struct_size = C.sizeof(_capi.Config)
@@ -84,14 +78,29 @@ class SplatRenderer:
         cfg.srgb = 1 if isFramebufferSRGBEnabled else 0
         cfg.t_epsilon = self._t_eps
         cfg.pair_capacity = self._pair_cap
-        cfg.stream = self._stream
         cfg.enable_timing = int(self._timing)
-        h = C.c_void_p()
-        rc = self._lib.msplat_create(C.byref(h), C.byref(cfg))
-        if rc != _capi.OK:
-            self._err = self._lib.msplat_last_error(None).decode()
-            return False
-        self._ctx = h
+        cfg.compositor_waves = 0 if self._depth == 1 else 2048     # measured: bench sweep, DESIGN.md 6
+        for k in range(self._depth):
+            if isinstance(self._stream, (list, tuple)):       # one caller-owned stream per frame in flight
+                cfg.stream = self._stream[k]
+            else:
+                cfg.stream = self._stream if self._depth == 1 else None
+            h = C.c_void_p()
+            rc = self._lib.msplat_create(C.byref(h), C.byref(cfg))
+            if rc != _capi.OK:
+                self._err = self._lib.msplat_last_error(None).decode()
+                self.close()
+                return False
+            self._ctxs.append(h)
+        self._ctx = self._ctxs[0]
+        self._cur = self._depth - 1          # the first Sort lands on context 0
+        return True
+
+    def _attach_all(self):
+        for h in self._ctxs[1:]:
+            if self._lib.msplat_attach_cloud(h, self._ctxs[0]) != _capi.OK:
+                self._err = self._lib.msplat_last_error(h).decode()
+                return False
         return True
 
     def InitFromPly(self, plyFilename, importFullSH=True, isFramebufferSRGBEnabled=False):
@@ -104,7 +113,7 @@ class SplatRenderer:
             self._err = self._lib.msplat_last_error(self._ctx).decode() or "PLY open/parse failure"
             return False
         self._n = self.stats()["num_splats"]
-        return True
+        return self._attach_all()
 
     def download_cloud(self, full_sh):
         """device cloud as (N, 25|61) float32 in the reference record layout (parity tests)"""
@@ -120,6 +129,8 @@ class SplatRenderer:
     def Sort(self, cameraMat, projMat, viewport, nearFar):
         """splatrenderer.cpp:153-312"""
         _, c = _m(cameraMat, 16); _, p = _m(projMat, 16); _, v = _m(viewport, 4); _, nf = _m(nearFar, 2)
+        self._cur = (self._cur + 1) % len(self._ctxs)
+        self._ctx = self._ctxs[self._cur]
         _capi.check(self._ctx, self._lib.msplat_sort(self._ctx, c, p, v, nf))
 
     def Render(self, cameraMat, projMat, viewport, nearFar, out=None, out_ptr=None, pitch_bytes=0):
@@ -142,11 +153,34 @@ class SplatRenderer:
 
     # -- extensions -------------------------------------------------------------------------
     def set_band(self, row_mod, row_rem, band_cull=False):
-        _capi.check(self._ctx, self._lib.msplat_set_band(self._ctx, row_mod, row_rem))
-        _capi.check(self._ctx, self._lib.msplat_set_band_cull(self._ctx, 1 if band_cull else 0))
+        for h in self._ctxs:
+            _capi.check(h, self._lib.msplat_set_band(h, row_mod, row_rem))
+            _capi.check(h, self._lib.msplat_set_band_cull(h, 1 if band_cull else 0))
 
     def synchronize(self):
-        _capi.check(self._ctx, self._lib.msplat_synchronize(self._ctx))
+        """blocks until every frame in flight has finished"""
+        for h in self._ctxs:
+            _capi.check(h, self._lib.msplat_synchronize(h))
+
+    def wait_on_stream(self, stream):
+        """device-side join: `stream` (hipStream_t handle, e.g. torch.cuda.Stream.cuda_stream; None or 0 = the
+        default stream) waits for the frame issued last"""
+        _capi.check(self._ctx, self._lib.msplat_stream_wait(self._ctx, C.c_void_p(stream or 0)))
+
+    def next_frame_wait_event(self, event):
+        """the context the NEXT Sort will use waits for `event` (hipEvent_t handle, e.g. torch.cuda.Event
+        .cuda_event recorded after the consumer of the framebuffer that frame is going to overwrite)"""
+        h = self._ctxs[(self._cur + 1) % len(self._ctxs)]
+        _capi.check(h, self._lib.msplat_wait_event(h, C.c_void_p(event)))
+
+    @property
+    def frames_in_flight(self):
+        return self._depth
+
+    @property
+    def frame_slot(self):
+        """index of the context the latest Sort ran on (0 .. frames_in_flight-1)"""
+        return self._cur
 
     def sort_count(self):
         v = C.c_uint32()
@@ -171,11 +205,20 @@ class SplatRenderer:
         return {k: getattr(s, k) for k, _ in _capi.Stats._fields_}
 
     def timings(self):
-        t = _capi.Timings()
-        _capi.check(self._ctx, self._lib.msplat_get_timings(self._ctx, C.byref(t)))
-        d = {k: getattr(t, k) for k in ("sort_total", "render_total", "project", "binning", "composite")}
-        d["frames_averaged"] = t.reserved[0]
-        d["composite_kernel"] = t.reserved[1]      # exact dispatch begin/end of composite_kernel
+        """stage times averaged over the sampled frames of every context (frames in flight)"""
+        keys = ("sort_total", "render_total", "project", "binning", "composite")
+        acc = {k: 0.0 for k in keys + ("composite_kernel",)}
+        frames = 0.0
+        for h in self._ctxs:
+            t = _capi.Timings()
+            _capi.check(h, self._lib.msplat_get_timings(h, C.byref(t)))
+            nf = t.reserved[0]
+            frames += nf
+            for k in keys:
+                acc[k] += getattr(t, k) * nf
+            acc["composite_kernel"] += t.reserved[1] * nf    # exact dispatch begin/end of composite_kernel
+        d = {k: (v / frames if frames > 0 else 0.0) for k, v in acc.items()}
+        d["frames_averaged"] = frames
         return d
 
     def debug_projected(self):

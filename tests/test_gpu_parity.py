@@ -321,6 +321,54 @@ def test_row_bands_reassemble_bit_exact():
     assert max(vs) < 0.8 * r.sort_count(), (vs, r.sort_count())
 
 
+def test_frames_in_flight_bit_identical_to_serial_frames():
+    """frames overlapped on several contexts sharing one cloud (msplat_attach_cloud) == the same frames
+    rendered one after the other on a single context; stereo re-uses the slot of its Sort"""
+    import torch
+    cloud = scenes.synth_cloud(60000, 91, log_scale_mean=-3.4)
+    W, H = 640, 360
+    Hpad = (H + bin_px() - 1) // bin_px() * bin_px()
+    views = [scenes.default_view(W, H, yaw=0.1 * k, x=0.05 * k) for k in range(7)]
+    r1 = make_renderer(cloud)
+    serial = []
+    for cam, proj, vp, nf in views:
+        r1.Sort(cam, proj, vp, nf)
+        serial.append((r1.Render(cam, proj, vp, nf), r1.sort_count(), r1.sorted_indices()))
+    P = 3
+    rp = make_renderer(cloud, frames_in_flight=P)
+    assert rp.frames_in_flight == P
+    dev = torch.device("cuda", 0)
+    fbs = [torch.zeros((Hpad, W, 4), dtype=torch.float32, device=dev) for _ in views]
+    fb2 = [torch.zeros((Hpad, W, 4), dtype=torch.float32, device=dev) for _ in views]
+    torch.cuda.synchronize()
+    slots = []
+    for k, (cam, proj, vp, nf) in enumerate(views):       # nothing synchronises inside this loop
+        rp.Sort(cam, proj, vp, nf)
+        slots.append(rp.frame_slot)
+        rp.Render(cam, proj, vp, nf, out_ptr=fbs[k].data_ptr(), pitch_bytes=W * 16)
+        cam2 = camera.translate_local(cam, dx=0.03)        # second eye, same sort
+        rp.Render(cam2, proj, vp, nf, out_ptr=fb2[k].data_ptr(), pitch_bytes=W * 16)
+    assert slots == [k % P for k in range(len(views))]
+    rp.wait_on_stream(None)                                # device-side join of the last frame ...
+    rp.synchronize()                                       # ... and a host-side wait for all of them
+    for k in range(len(views)):
+        np.testing.assert_array_equal(fbs[k][:H].cpu().numpy(), serial[k][0])
+    # getters refer to the latest Sort's context
+    assert rp.sort_count() == serial[-1][1]
+    np.testing.assert_array_equal(rp.sorted_indices(), serial[-1][2])
+    cam, proj, vp, nf = views[-1]
+    r1.Sort(cam, proj, vp, nf)
+    eye2 = r1.Render(camera.translate_local(cam, dx=0.03), proj, vp, nf)
+    np.testing.assert_array_equal(fb2[-1][:H].cpu().numpy(), eye2)
+    # re-upload into the owner detaches it (new store); the attached contexts keep rendering the old cloud
+    small = scenes.synth_cloud(500, 92)
+    assert rp.Init(small, False, False)
+    rp.Sort(cam, proj, vp, nf)
+    img = rp.Render(cam, proj, vp, nf)
+    ref = orc.render_frame(small.as_array(), True, cam, proj, vp, nf)
+    check_image(img, ref["image"])
+
+
 def test_render_before_sort_and_bad_viewport_errors():
     from splatapult_amd import MsplatError
     cloud = scenes.synth_cloud(10, 1)

@@ -151,6 +151,16 @@ int msplat_set_band(msplat_ctx* ctx, int32_t row_mod, int32_t row_rem);
  * (mono rendering).  Default off; ignored without a band. */
 int msplat_set_band_cull(msplat_ctx* ctx, int enable);
 
+/* Depth-buffer emulation.  The reference enables GL_DEPTH_TEST (app.cpp:163, GL_LESS,
+ * depth writes on).  It is inert on the colour-only --fp16/--fp32 FBO (app.cpp:1027) -- bits = 0, the
+ * default and the configuration every other entry point models -- and live on the default back buffer
+ * (24-bit, sdl_main.cpp:79) and the XR swapchains: there a fragment that survives the discard must also
+ * pass z < depth buffer, so later-drawn splats lose fragments where quantised depths tie or where the
+ * draw order is not the depth order (second eye rendered with the first eye's sort).  bits = 24: 24-bit
+ * unorm depth; 32: float depth.  Renders then walk every tile list in draw order without early
+ * termination (several times slower); meant for diffing against the GL app's output. */
+int msplat_set_depth_test(msplat_ctx* ctx, int depth_bits);
+
 /* replaces SplatRenderer::Sort (splatrenderer.cpp:153-312): cull + depth key
  * (presort_compute.glsl:31-57), stable ascending 32-bit radix sort, sorted index list kept as
  * context state for subsequent renders.  Asynchronous: no host readback (the reference's

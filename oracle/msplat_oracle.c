@@ -557,6 +557,77 @@ void orc_composite(uint32_t v, const orc_splat2d* s, int W, int H, float* rgba,
     g_fragments = frags;
 }
 
+/* Window-space depth of a splat's fragments as an order-preserving uint32.  The quad's four vertices
+ * share the centre's clip z and w (splat_geom.glsl:93-101 offsets x and y only), so every fragment of a
+ * splat has z_ndc = ndc[2]; window z = 0.5 z_ndc + 0.5 (default glDepthRange); a 24-bit buffer stores
+ * round(z_w (2^24 - 1)) (sdl_main.cpp:79 asks for 24 bits), a float buffer the value itself. */
+uint32_t orc_quantise_depth(float ndcz, int depth_bits)
+{
+    float zw = 0.5f * ndcz + 0.5f;
+    if (!(zw >= 0.0f)) return 0u;
+    if (depth_bits == 24) {
+        double q = floor((double)zw * 16777215.0 + 0.5);
+        return q >= 16777215.0 ? 16777215u : (uint32_t)q;
+    }
+    uint32_t u;
+    memcpy(&u, &zw, 4);
+    return u;
+}
+
+/* orc_composite with the depth test the reference leaves enabled (app.cpp:163: glEnable(GL_DEPTH_TEST),
+ * default func GL_LESS, depth writes on, buffer cleared to 1.0 by app.cpp:160): a fragment that survives
+ * the discard is blended only if its depth is LESS than the stored one, and then stores its depth.
+ * Discarded fragments write nothing (splat_frag.glsl:37-40 `discard`). */
+void orc_composite_depth(uint32_t v, const orc_splat2d* s, int W, int H, float* rgba, int depth_bits,
+                         int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > H) nthreads = H;
+    if (H <= 0 || W <= 0) return;
+#pragma omp parallel for schedule(static, 1) num_threads(nthreads)
+    for (int band = 0; band < nthreads; ++band) {
+        const int y0 = (int)(((int64_t)H * band) / nthreads);
+        const int y1 = (int)(((int64_t)H * (band + 1)) / nthreads);
+        uint32_t* zbuf = (uint32_t*)malloc((size_t)(y1 - y0 > 0 ? y1 - y0 : 1) * W * sizeof(uint32_t));
+        for (int y = y0; y < y1; ++y)
+            for (int x = 0; x < W; ++x) {
+                float* d = rgba + ((size_t)y * W + x) * 4;
+                d[0] = 0.0f; d[1] = 0.0f; d[2] = 0.0f; d[3] = 1.0f;
+                zbuf[(size_t)(y - y0) * W + x] = 0xFFFFFFFFu;           /* glClear: depth 1.0 */
+            }
+        for (uint32_t k = 0; k < v; ++k) {
+            const orc_splat2d* g = &s[k];
+            if (g->reject) continue;
+            const uint32_t zq = orc_quantise_depth(g->ndc[2], depth_bits);
+            int xa, xb, ya, yb;
+            pixel_range(g->px, g->hx, W, 0, W, &xa, &xb);
+            pixel_range(g->py, g->hy, H, y0, y1, &ya, &yb);
+            for (int y = ya; y <= yb; ++y) {
+                for (int x = xa; x <= xb; ++x) {
+                    float dx = ((float)x + 0.5f) - g->px;
+                    float dy = ((float)y + 0.5f) - g->py;
+                    float mx = g->inv[0] * dx + g->inv[2] * dy;
+                    float my = g->inv[1] * dx + g->inv[3] * dy;
+                    float q = dx * mx + dy * my;
+                    float e = expf(-0.5f * q);
+                    float sa = g->alpha * e;
+                    if (sa <= (1.0f / 256.0f)) continue;        /* discard: no colour, no depth write */
+                    uint32_t* zb = &zbuf[(size_t)(y - y0) * W + x];
+                    if (!(zq < *zb)) continue;                  /* GL_LESS */
+                    *zb = zq;
+                    float* d = rgba + ((size_t)y * W + x) * 4;
+                    float oma = 1.0f - sa;
+                    d[0] = (sa * g->rgb[0]) + oma * d[0];
+                    d[1] = (sa * g->rgb[1]) + oma * d[1];
+                    d[2] = (sa * g->rgb[2]) + oma * d[2];
+                    d[3] = sa + oma * d[3];
+                }
+            }
+        }
+        free(zbuf);
+    }
+}
+
 void orc_composite_f64(uint32_t v, const orc_splat2d* s, int W, int H, double* rgba, int nthreads)
 {
     if (nthreads < 1) nthreads = 1;

@@ -60,6 +60,9 @@ def lib():
     L.orc_project.argtypes = [C.c_uint32, u32p, fp, C.c_size_t, C.c_int, C.c_int, fp, fp, fp, fp, fp,
                               C.c_void_p]
     L.orc_composite.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int]
+    L.orc_composite_depth.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_int, fp, C.c_int, C.c_int]
+    L.orc_quantise_depth.argtypes = [C.c_float, C.c_int]
+    L.orc_quantise_depth.restype = C.c_uint32
     L.orc_composite_f64.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
     L.orc_render_frame.argtypes = [C.c_size_t, fp, C.c_size_t, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp,
                                    fp, u32p, u32p, C.c_void_p, C.c_int]
@@ -151,6 +154,16 @@ def composite(splats, W, H, nthreads=1, row0=0, row1=None):
     rgba = np.zeros((H, W, 4), np.float32)
     lib().orc_composite(splats.shape[0], splats.ctypes.data, W, H,
                         rgba.ctypes.data_as(C.POINTER(C.c_float)), row0, H if row1 is None else row1, nthreads)
+    return rgba
+
+
+def composite_depth(splats, W, H, depth_bits=24, nthreads=1):
+    """orc_composite with the reference's enabled GL_LESS depth test against an emulated depth buffer"""
+    splats = np.ascontiguousarray(splats)
+    assert splats.dtype == SPLAT2D_DTYPE
+    rgba = np.zeros((H, W, 4), np.float32)
+    lib().orc_composite_depth(splats.shape[0], splats.ctypes.data, W, H,
+                              rgba.ctypes.data_as(C.POINTER(C.c_float)), depth_bits, nthreads)
     return rgba
 
 

@@ -66,6 +66,7 @@ SYMBOLS = [
     ("msplat_sort", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16]),
     ("msplat_render", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16, C.c_void_p, C.c_uint64, C.c_int]),
     ("msplat_synchronize", C.c_int, [C.c_void_p]),
+    ("msplat_set_depth_test", C.c_int, [C.c_void_p, C.c_int]),
     ("msplat_attach_cloud", C.c_int, [C.c_void_p, C.c_void_p]),
     ("msplat_stream_wait", C.c_int, [C.c_void_p, C.c_void_p]),
     ("msplat_wait_event", C.c_int, [C.c_void_p, C.c_void_p]),

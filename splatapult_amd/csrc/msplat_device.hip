@@ -73,6 +73,8 @@ struct msplat_ctx {
     // render state
     Buf rec2d;      // float4[3*N]
     Buf rect;       // uint32[N]
+    Buf zq;         // uint32[N] quantised window depth per rank (only with msplat_set_depth_test)
+    int depth_bits = 0;
     Buf tile_start; // uint32[65537]
     Buf tile_order; // uint32[65536] tiles by descending list length
     Buf hist1;      // uint32[256 * hist1_stride]
@@ -268,7 +270,7 @@ void msplat_destroy(msplat_ctx* ctx)
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
     Buf* all[] = {&ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist,
                   &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->totals1, &ctx->tile_start, &ctx->tile_order,
-                  &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe};
+                  &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe, &ctx->zq};
     for (Buf* b : all) buf_free(ctx, *b);
     if (ctx->ev_ok)
         for (auto& set : ctx->ev)
@@ -286,6 +288,22 @@ int msplat_synchronize(msplat_ctx* ctx)
 }
 
 static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, const std::shared_ptr<CloudStore>& share);
+
+// Emulated depth buffer for subsequent renders (app.cpp:163 enables GL_DEPTH_TEST, which is live
+// on targets with a depth attachment).  bits = 0: colour-only target, the default.
+int msplat_set_depth_test(msplat_ctx* ctx, int depth_bits)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if (depth_bits != 0 && depth_bits != 24 && depth_bits != 32)
+        return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_set_depth_test: depth_bits must be 0, 24 or 32 (got %d)", depth_bits);
+    if (depth_bits != 0) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        int rc = buf_alloc(ctx, ctx->zq, std::max<uint64_t>(ctx->N, 1) * 4);
+        if (rc) return rc;
+    }
+    ctx->depth_bits = depth_bits;
+    return MSPLAT_OK;
+}
 
 // Frames in flight: `ctx` renders `owner`'s cloud (no copy).  Each context keeps its own stream and
 // per-frame buffers, so consecutive frames issued round-robin over several contexts overlap on the GPU
@@ -392,6 +410,7 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
     if ((rc = buf_alloc(ctx, ctx->hist, (size_t)256 * ctx->hist_stride * 4))) return rc;
     if ((rc = buf_alloc(ctx, ctx->rec2d, alloc_n * 48))) return rc;
     if ((rc = buf_alloc(ctx, ctx->rect, alloc_n * 4))) return rc;
+    if (ctx->depth_bits != 0 && (rc = buf_alloc(ctx, ctx->zq, alloc_n * 4))) return rc;
     ctx->hist1_stride = std::max(1u, div_up(n, kBinChunk));
     if ((rc = buf_alloc(ctx, ctx->hist1, (size_t)256 * ctx->hist1_stride * 4))) return rc;
     uint64_t cap = ctx->cfg.pair_capacity ? ctx->cfg.pair_capacity
@@ -578,6 +597,7 @@ static int make_frame_params(msplat_ctx* ctx, const float cameraMat[16], const f
     fp.srgb = ctx->cfg.srgb ? 1 : 0;
     fp.t_eps = ctx->cfg.t_epsilon;
     fp.band_cull = (ctx->band_cull && ctx->row_mod > 1) ? 1 : 0;
+    fp.depth_bits = ctx->depth_bits;
     fp.view_scale2 = 0.0f;
     for (int c = 0; c < 3; ++c)
         fp.view_scale2 = std::max(fp.view_scale2, fp.view[c * 4] * fp.view[c * 4] + fp.view[c * 4 + 1] * fp.view[c * 4 + 1] +
@@ -660,10 +680,12 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const int pgrid = std::max(1u, div_up(N, kProjThreads));
     if (ctx->full_sh)
         hipLaunchKernelGGL(project_kernel<true>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
-                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p);
+                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
+                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr);
     else
         hipLaunchKernelGGL(project_kernel<false>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
-                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p);
+                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
+                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][3], s));
 
     // pass 1: stable partition by tile column, enumerated from the rank-ordered rectangles
@@ -709,7 +731,20 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const int cgrid = std::min(ntiles * 4, ctx->comp_waves);     // work items = (bin, quadrant)
     // (frames in flight: serialising the compositor launches of the contexts sharing a cloud with an event
     //  gate was measured r1 -- no gain over letting the hardware queues interleave them, dropped)
-    if (ntiles > 0) {
+    if (ntiles > 0 && ctx->depth_bits != 0) {
+        // emulated depth buffer: draw-order walk, no early termination
+        if (ctx->cfg.fb_format == MSPLAT_FB_RGBA16F)
+            hipLaunchKernelGGL(composite_depth_kernel<true>, dim3(cgrid), dim3(kCompThreads), 0, s,
+                               (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
+                               (const float4*)ctx->rec2d.p, (const uint32_t*)ctx->zq.p, d_out, pitch, fp, cap,
+                               (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u);
+        else
+            hipLaunchKernelGGL(composite_depth_kernel<false>, dim3(cgrid), dim3(kCompThreads), 0, s,
+                               (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
+                               (const float4*)ctx->rec2d.p, (const uint32_t*)ctx->zq.p, d_out, pitch, fp, cap,
+                               (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u);
+        ctx->comp_kernel_timed = false;
+    } else if (ntiles > 0) {
         // on sampled frames the dominant kernel gets exact dispatch begin/end events (the plain stream
         // markers around the stages can be processed while the previous kernel is still draining)
         hipEvent_t e0 = timed ? ctx->ev[tset][6] : nullptr, e1 = timed ? ctx->ev[tset][7] : nullptr;

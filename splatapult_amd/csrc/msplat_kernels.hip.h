@@ -47,6 +47,7 @@ struct FrameParams {
     int full_sh, srgb;
     int band_cull;              // multi-GPU only: Sort also drops splats that cannot reach an owned bin row
     float view_scale2;          // largest squared column norm of mat3(view) (1 for a rigid camera)
+    int depth_bits;             // 0 = colour-only target (no depth test); 24 / 32 = emulated depth buffer
 };
 
 // ------------------------------------------------------------------------------------------
@@ -507,6 +508,19 @@ __device__ __forceinline__ float srgb_to_linear(float s)
     return powf((s + 0.055f) / 1.055f, 2.4f);
 }
 
+// Window-space depth as an order-preserving uint32: 24-bit unorm like the default back buffer
+// (sdl_main.cpp:79), or the raw bits of the non-negative float for a 32F depth attachment.
+__device__ __forceinline__ uint32_t quantise_depth(float ndcz, int depth_bits)
+{
+    const float zw = __fadd_rn(__fmul_rn(0.5f, ndcz), 0.5f);
+    if (!(zw >= 0.0f)) return 0u;
+    if (depth_bits == 24) {
+        const double q = floor((double)zw * 16777215.0 + 0.5);
+        return q >= 16777215.0 ? 16777215u : (uint32_t)q;
+    }
+    return __float_as_uint(zw);
+}
+
 constexpr int kProjThreads = 64;          // one wave per workgroup: wave-private LDS staging, no block barriers
 
 template <bool FULL_SH>
@@ -515,7 +529,8 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
                                                                const float4* __restrict__ recs,
                                                                FrameParams fp,
                                                                float4* __restrict__ out_rec,
-                                                               uint32_t* __restrict__ out_rect)
+                                                               uint32_t* __restrict__ out_rect,
+                                                               uint32_t* __restrict__ out_zq)
 {
     // Records are 256 B (full SH) or 128 B (base) and line aligned.  The gather by sorted index is
     // done cooperatively: F4 consecutive lanes fetch one whole record (coalesced 256/128 B), the wave
@@ -707,6 +722,9 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
     out_rec[(size_t)r * 3 + 1] = r1;
     out_rec[(size_t)r * 3 + 2] = r2;
     out_rect[r] = rect;
+    // depth-buffer emulation (composite_depth_kernel): the quad's fragments all carry the centre's depth
+    // (splat_geom.glsl:93-101 offsets only x and y); window z = 0.5 ndc.z + 0.5 (default glDepthRange)
+    if (out_zq != nullptr) out_zq[r] = quantise_depth(ndcz, fp.depth_bits);
 }
 
 __device__ __forceinline__ uint32_t rect_width(uint32_t rc)
@@ -1223,6 +1241,135 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
     if (threadIdx.x == 0) nq = atomicAdd(queue, 1u);
     qpos = gridDim.x + __builtin_amdgcn_readfirstlane(nq);
     }   // persistent tile loop
+}
+
+// ------------------------------------------------------------------------------------------
+// composite with an emulated depth buffer.  The reference enables GL_DEPTH_TEST
+// (app.cpp:163, GL_LESS, depth writes on); it is live whenever the target has a depth attachment
+// (default back buffer, XR swapchains) and inert for the colour-only --fp16/--fp32 FBO that the
+// main compositor models.  With a depth buffer a fragment that survives the discard also has to
+// pass z < zbuf and then writes its z: splats whose quantised depths tie, or that are drawn out
+// of depth order (second XR eye re-using the first eye's sort), lose their later fragments.
+// Whether a fragment passes depends on everything drawn BEFORE it, so this variant walks the list
+// in draw order (far to near) with the literal "over" blend and cannot terminate early.
+// ------------------------------------------------------------------------------------------
+template <bool HALF>
+__global__ __launch_bounds__(kCompThreads) void composite_depth_kernel(const uint32_t* __restrict__ tile_start,
+                                                                       const uint32_t* __restrict__ pairs,
+                                                                       const float4* __restrict__ rec,
+                                                                       const uint32_t* __restrict__ zq,
+                                                                       void* __restrict__ out, size_t pitch_bytes,
+                                                                       FrameParams fp, uint32_t cap,
+                                                                       const uint32_t* __restrict__ order,
+                                                                       uint32_t* __restrict__ queue, uint32_t ntiles)
+{
+    __shared__ float4 s_rec[kCompThreads * 3];
+    __shared__ uint32_t s_z[kCompThreads];
+    const int lane = threadIdx.x;
+    const int lx = lane & 15, ly = lane >> 4;
+    for (uint32_t qpos = blockIdx.x; qpos < ntiles;) {
+        const int bin = (int)order[qpos >> 2];
+        const int quad = (int)(qpos & 3u);
+        const int bvy = bin / fp.tiles_x;
+        const int tx = (bin - bvy * fp.tiles_x) * 2 + (quad & 1);
+        const int ty = (bvy * fp.row_mod + fp.row_rem) * 2 + (quad >> 1);
+        if (tx * kTile < fp.width && ty * kTile < fp.height) {
+            const int x = tx * kTile + lx, ybase = ty * kTile + ly;
+            const float fx = (float)x + 0.5f;
+            uint32_t start = tile_start[bin], end = tile_start[bin + 1];
+            if (start > cap) start = cap;
+            if (end > cap) end = cap;
+            float cr[4], cg[4], cb[4];
+            uint32_t zbuf[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { cr[k] = 0.0f; cg[k] = 0.0f; cb[k] = 0.0f; zbuf[k] = 0xFFFFFFFFu; }   // cleared to 1.0
+            const float X0 = (float)(tx * kTile) + 0.5f, X1 = X0 + (float)(kTile - 1);
+            const float Y0 = (float)(ty * kTile) + 0.5f, Y1 = Y0 + (float)(kTile - 1);
+            for (uint32_t base = start; base < end; base += kCompThreads) {      // ascending = draw order
+                const uint32_t cnt = min((uint32_t)kCompThreads, end - base);
+                float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
+                uint32_t z = 0;
+                bool rel = false;
+                if (lane < (int)cnt) {
+                    uint32_t rank = pairs[base + lane] & kRankMask;
+                    // hipcc 7.2 (gfx950) folds "(x & 0xFFFFFF) * 48 + base" in ONE basic block into v_mad_u64_u32
+                    // on the UNMASKED word (mul24 known-bits combine; seen in the ISA, faulted on the GPU): keep
+                    // the masked value opaque.  composite_kernel masks in a different block and is not affected.
+                    asm volatile("" : "+v"(rank));
+                    const float4* src = rec + (size_t)rank * 3;
+                    p0 = src[0]; p1 = src[1]; p2 = src[2];
+                    z = zq[rank];
+                    // same exact footprint-vs-tile test as composite_kernel
+                    const float qa = p0.z, qb = p0.w, qc = p1.x, la = p1.y;
+                    const float dxl = X0 - p0.x, dxh = X1 - p0.x, dyl = Y0 - p0.y, dyh = Y1 - p0.y;
+                    rel = true;
+                    if (!(dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f)) {
+                        float emax = -1e30f;
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const float dx = s ? dxh : dxl;
+                            const float dy = fminf(fmaxf(-qb * dx / (2.0f * qc), dyl), dyh);
+                            emax = fmaxf(emax, (qc * dy + qb * dx) * dy + qa * dx * dx + la);
+                            const float ey = s ? dyh : dyl;
+                            const float ex = fminf(fmaxf(-qb * ey / (2.0f * qa), dxl), dxh);
+                            emax = fmaxf(emax, (qa * ex + qb * ey) * ex + qc * ey * ey + la);
+                        }
+                        rel = emax > -8.05f;
+                    }
+                }
+                const uint64_t relmask = __ballot(rel);
+                const uint32_t n = (uint32_t)__popcll(relmask);
+                if (rel) {
+                    const int slot = __popcll(relmask & ((1ull << lane) - 1ull));     // keeps draw order
+                    s_rec[slot * 3 + 0] = p0;
+                    s_rec[slot * 3 + 1] = p1;
+                    s_rec[slot * 3 + 2] = p2;
+                    s_z[slot] = z;
+                }
+                __syncthreads();
+                for (uint32_t j = 0; j < n; ++j) {
+                    const float4 a = s_rec[j * 3 + 0];      // px, py, A, B
+                    const float4 b = s_rec[j * 3 + 1];      // C, log2(alpha), r, g
+                    const float blue = s_rec[j * 3 + 2].x;
+                    const uint32_t zj = s_z[j];
+                    const float dx = fx - a.x;
+                    const float base_e = __builtin_fmaf(a.z * dx, dx, b.y);
+                    const float lin = a.w * dx;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float dy = ((float)(ybase + 4 * k) + 0.5f) - a.y;
+                        const float e = __builtin_fmaf(dy, __builtin_fmaf(b.x, dy, lin), base_e);
+                        // splat_frag.glsl:37-40 discard, then GL_LESS against the emulated depth buffer
+                        if (e > -8.0f && zj < zbuf[k]) {
+                            const float w = __builtin_amdgcn_exp2f(e);
+                            const float oma = 1.0f - w;
+                            cr[k] = (w * b.z) + oma * cr[k];          // GL_ONE, GL_ONE_MINUS_SRC_ALPHA
+                            cg[k] = (w * b.w) + oma * cg[k];
+                            cb[k] = (w * blue) + oma * cb[k];
+                            zbuf[k] = zj;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (x < fp.width && ybase + 4 * k < fp.height) {
+                    char* row = (char*)out + (size_t)(ybase + 4 * k) * pitch_bytes;
+                    if (HALF) {
+                        union { _Float16 h[4]; uint2 u; } pk;
+                        pk.h[0] = (_Float16)cr[k]; pk.h[1] = (_Float16)cg[k]; pk.h[2] = (_Float16)cb[k]; pk.h[3] = (_Float16)1.0f;
+                        ((uint2*)row)[x] = pk.u;
+                    } else {
+                        ((float4*)row)[x] = make_float4(cr[k], cg[k], cb[k], 1.0f);
+                    }
+                }
+            }
+        }
+        uint32_t nq = 0;
+        if (threadIdx.x == 0) nq = atomicAdd(queue, 1u);
+        qpos = gridDim.x + __builtin_amdgcn_readfirstlane(nq);
+    }
 }
 
 }  // namespace msplat

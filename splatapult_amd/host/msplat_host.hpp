@@ -146,6 +146,12 @@ public:
         targetIsDevice = isDevicePointer;
     }
 
+    // emulated depth buffer for targets that have one in the GL app (app.cpp:163; 24 = default back buffer)
+    void SetDepthTest(int depthBits)
+    {
+        for (msplat_ctx* h : ctxs) msplat_set_depth_test(h, depthBits);
+    }
+
     // blocks until every frame in flight has finished
     void Synchronize()
     {

@@ -157,6 +157,12 @@ class SplatRenderer:
             _capi.check(h, self._lib.msplat_set_band(h, row_mod, row_rem))
             _capi.check(h, self._lib.msplat_set_band_cull(h, 1 if band_cull else 0))
 
+    def set_depth_test(self, depth_bits):
+        """emulated depth buffer: 0 = colour-only target (default), 24 = default back buffer,
+        32 = float depth attachment"""
+        for h in self._ctxs:
+            _capi.check(h, self._lib.msplat_set_depth_test(h, int(depth_bits)))
+
     def synchronize(self):
         """blocks until every frame in flight has finished"""
         for h in self._ctxs:

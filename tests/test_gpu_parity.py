@@ -270,6 +270,61 @@ def test_two_views_share_one_sort():
         check_image(img, ref["image"])
 
 
+# ------------------------------------------------------------------------------------------------
+# depth-buffer emulation: the GL_DEPTH_TEST the reference leaves enabled
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("bits", [24, 32])
+def test_depth_test_emulation_matches_oracle(bits):
+    cloud = scenes.synth_cloud(20000, 101, log_scale_mean=-3.0)
+    W, H = 640, 360
+    cam, proj, vp, nf = scenes.default_view(W, H, yaw=0.2)
+    r = make_renderer(cloud)
+    r.Sort(cam, proj, vp, nf)
+    plain = r.Render(cam, proj, vp, nf)
+    r.set_depth_test(bits)
+    img = r.Render(cam, proj, vp, nf)                      # same sort, depth-tested composite
+    ref = orc.render_frame(cloud.as_array(), True, cam, proj, vp, nf, nthreads=8, want_splats=True)
+    check_image(plain, ref["image"])
+    check_image(img, orc.composite_depth(ref["splats"], W, H, bits, nthreads=8))
+    r.set_depth_test(0)
+    np.testing.assert_array_equal(r.Render(cam, proj, vp, nf), plain)
+    from splatapult_amd import MsplatError
+    with pytest.raises(MsplatError):
+        r.set_depth_test(16)
+
+
+def test_depth_test_second_eye_artifact_and_bands():
+    """the case the flag exists for: the second XR eye is drawn in the FIRST eye's depth order, so GL_LESS
+    rejects fragments of splats that are nearer for eye 0 but farther for eye 1"""
+    cloud = scenes.synth_cloud(15000, 102, log_scale_mean=-2.8)
+    W, H = 504, 560
+    cam0 = camera.pose((0.0, 0.0, 6.0))
+    eye1 = camera.translate_local(camera.pose((0.0, 0.0, 6.0), yaw=0.35), dx=0.4)     # exaggerated second view
+    proj = camera.create_projection(-0.8, 1.0, 0.95, -0.95)
+    vp, nf = [0, 0, W, H], scenes.NF
+    r = make_renderer(cloud)
+    r.set_depth_test(24)
+    r.Sort(cam0, proj, vp, nf)
+    img = r.Render(eye1, proj, vp, nf)
+    ref = orc.render_frame(cloud.as_array(), True, cam0, proj, vp, nf, render_cam=eye1, render_proj=proj, nthreads=8,
+                           want_splats=True)
+    exp = orc.composite_depth(ref["splats"], W, H, 24, nthreads=8)
+    check_image(img, exp)
+    assert np.abs(exp - ref["image"])[..., :3].max() > 0.05      # the artifact is really there
+    # tile-row bands reassemble bit-exactly in depth mode too
+    acc = np.zeros_like(img)
+    for g in range(3):
+        rb = make_renderer(cloud)
+        rb.set_depth_test(24)
+        rb.set_band(3, g)
+        rb.Sort(cam0, proj, vp, nf)
+        part = rb.Render(eye1, proj, vp, nf)
+        rows = np.arange(H) // bin_px() % 3 == g
+        acc[rows] = part[rows]
+    np.testing.assert_array_equal(acc, img)
+
+
 def test_fp16_framebuffer():
     cloud = scenes.synth_cloud(8000, 71, log_scale_mean=-3.2)
     view = scenes.default_view(320, 240)

@@ -169,3 +169,78 @@ def test_matrix_helpers_closed_forms():
     assert abs(c[2][2] + (1000.0 + 0.1) / (1000.0 - 0.1)) < 1e-6 and c[2][3] == -1
     c2 = orc.create_projection(-1.0, 0.8, 0.95, -0.95, 0.1, 1000.0).reshape(4, 4)
     assert abs(c2[2][0] - (0.8 - 1.0) / 1.8) < 1e-6
+
+
+# ---- depth-buffer emulation ---------------------------------------------------
+
+def _literal_depth_composite(splats, W, H, bits):
+    """independent numpy restatement: per pixel, draw order, discard -> GL_LESS -> blend + depth write"""
+    img = np.zeros((H, W, 4), np.float32); img[..., 3] = 1.0
+    zbuf = np.full((H, W), 0xFFFFFFFF, np.uint64)
+    ys, xs = np.mgrid[0:H, 0:W]
+    fx, fy = xs.astype(np.float32) + np.float32(0.5), ys.astype(np.float32) + np.float32(0.5)
+    for g in splats:
+        if g["reject"]:
+            continue
+        dx, dy = fx - g["px"], fy - g["py"]
+        mx = g["inv"][0] * dx + g["inv"][2] * dy
+        my = g["inv"][1] * dx + g["inv"][3] * dy
+        sa = (g["alpha"] * np.exp(np.float32(-0.5) * (dx * mx + dy * my))).astype(np.float32)
+        zq = np.uint64(orc.lib().orc_quantise_depth(float(g["ndc"][2]), bits))
+        m = (sa > np.float32(1.0 / 256.0)) & (zq < zbuf)
+        oma = np.float32(1.0) - sa
+        for c in range(3):
+            img[..., c] = np.where(m, sa * g["rgb"][c] + oma * img[..., c], img[..., c])
+        img[..., 3] = np.where(m, sa + oma * img[..., 3], img[..., 3])
+        zbuf = np.where(m, zq, zbuf)
+    return img
+
+
+def test_depth_quantisation():
+    q = orc.lib().orc_quantise_depth
+    assert q(-1.0, 24) == 0 and q(1.0, 24) == (1 << 24) - 1 and q(0.0, 24) == (1 << 23)   # round(0.5 * (2^24-1))
+    assert q(1.0, 32) == np.float32(1.0).view(np.uint32) and q(-1.0, 32) == 0
+    zs = np.linspace(-1, 1, 4001).astype(np.float32)
+    for bits in (24, 32):
+        v = np.array([q(float(z), bits) for z in zs], np.uint64)
+        assert (np.diff(v.astype(np.int64)) >= 0).all()                       # order preserving
+
+
+def test_depth_test_is_inert_for_depth_ordered_distinct_depths(golden_dir):
+    """config 1 (test.ply): 16 splats at well separated depths, drawn far -> near: every fragment passes"""
+    from splatapult_amd import GaussianCloud
+    gc = GaussianCloud()
+    assert gc.ImportPly(os.path.join(golden_dir, "test.ply"))
+    cam = camera.camera_from_vr_json(os.path.join(golden_dir, "test_vr.json"))
+    W, H = 320, 240
+    proj = camera.perspective(camera.FOVY, W / H)
+    ref = orc.render_frame(gc.as_array(), False, cam, proj, [0, 0, W, H], scenes.NF, want_splats=True)
+    zq = [orc.lib().orc_quantise_depth(float(z), 24) for z in ref["splats"]["ndc"][:, 2]]
+    assert len(set(zq)) == len(zq) and zq == sorted(zq, reverse=True)
+    for bits in (24, 32):
+        np.testing.assert_array_equal(orc.composite_depth(ref["splats"], W, H, bits), ref["image"])
+
+
+def test_depth_test_ties_out_of_order_and_literal_restatement():
+    cloud = scenes.synth_cloud(300, 5, log_scale_mean=-2.2)
+    cam, proj, vp, nf = scenes.default_view(96, 64)
+    ref = orc.render_frame(cloud.as_array(), True, cam, proj, vp, nf, want_splats=True)
+    sp = ref["splats"]
+    # (1) C oracle == independent numpy restatement, in draw order and in reversed (near -> far) order
+    for order in (sp, sp[::-1].copy()):
+        for bits in (24, 32):
+            a = orc.composite_depth(order, 96, 64, bits, nthreads=3)
+            b = _literal_depth_composite(order, 96, 64, bits)
+            assert np.abs(a - b).max() <= 2e-6
+    # (2) near -> far: GL_LESS rejects everything behind the first surviving fragment of a pixel, so the image
+    #     differs from the depth-ordered one wherever two splats overlap
+    assert np.abs(orc.composite_depth(sp[::-1].copy(), 96, 64, 32) - ref["image"]).max() > 0.05
+    # (3) an exact depth tie: the splat drawn second loses all its fragments that overlap the first one
+    two = sp[:2].copy()
+    two[1] = two[0]
+    two["rgb"][1] = (0.1, 0.9, 0.3)
+    two["reject"][:] = 0
+    one = two[:1]
+    np.testing.assert_array_equal(orc.composite_depth(two, 96, 64, 24), orc.composite_depth(one, 96, 64, 24))
+    assert np.abs(orc.composite(two, 96, 64) - orc.composite(one, 96, 64)).max() > 0 or two["alpha"][0] <= 1 / 256
+

@@ -260,6 +260,36 @@ int msplat_find_config_file(const char* ply_path, const char* config_name, char*
 /* W x H float RGBA framebuffer (row 0 = bottom) -> 8-bit image file, top row first: clamp + round as an RGBA8
  * target does (the reference's back buffer), optional LinearToSRGB (util.cpp:357-367); ".ppm" or PNG */
 int msplat_write_image(const char* path, const float* rgba, int width, int height, int encode_srgb);
+/* 8-bit gray / gray+alpha / RGB / RGBA non-interlaced PNG (what Image::Load accepts, core/image.cpp:72-101) ->
+ * RGBA8, top row first.  rgba8_out may be NULL to query the size; cap = bytes available */
+int msplat_read_image(const char* path, uint8_t* rgba8_out, uint64_t cap, uint32_t* width_out, uint32_t* height_out);
+
+/* ---- point-cloud renderer ------------------------------------------------
+ * PointCloud (pointcloud.h:15-48) + PointRenderer (pointrenderer.h:23-57, pointrenderer.cpp:48-196): the SfM
+ * points of <scene>/input.ply drawn as depth-sorted textured sprites.  A context holds EITHER a splat cloud or a
+ * point cloud; with points, msplat_sort runs the same presort + radix sort (pointrenderer.cpp:113-166) and
+ * msplat_render the sprite pipeline (point_vert/geom/frag.glsl + the blend state of app.cpp:153-156):
+ * PointRenderer::Render == msplat_sort + msplat_render with the same matrices. */
+typedef struct msplat_points msplat_points;
+msplat_points* msplat_points_create(int use_linear_colors);            /* PointCloud::PointCloud */
+void msplat_points_destroy(msplat_points* p);
+int msplat_points_import_ply(msplat_points* p, const char* path);      /* PointCloud::ImportPly  */
+int msplat_points_export_ply(const msplat_points* p, const char* path);/* PointCloud::ExportPly  */
+void msplat_points_init_debug(msplat_points* p);                       /* PointCloud::InitDebugCloud */
+uint64_t msplat_points_num(const msplat_points* p);
+uint32_t msplat_points_stride(const msplat_points* p);                 /* 32: position.xyzw, color.rgba */
+const void* msplat_points_data(const msplat_points* p);
+/* replaces PointRenderer::Init's buffer setup (pointrenderer.cpp:95-110,198-225): n records of stride bytes,
+ * float4 position and float4 colour at the given offsets */
+int msplat_upload_points(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t stride_bytes,
+                         uint32_t position_offset, uint32_t color_offset);
+int msplat_upload_point_cloud(msplat_ctx* ctx, const msplat_points* p);
+/* the sprite texture (texture/sphere.png in the reference, pointrenderer.cpp:54-64): RGBA8, top row first
+ * as decoded from the file.  Applies Image::Load's row flip and 8-bit alpha pre-multiplication
+ * (core/image.cpp:108-114,128-158), builds the mip chain (2x2 box filter) and samples it LinearMipmapLinear /
+ * Linear / ClampToEdge; cfg.srgb decodes texels sRGB -> linear (GL_SRGB8_ALPHA8, core/texture.cpp:63-70).
+ * rgba8 == NULL: a built-in procedural sphere sprite (the reference's asset is not shipped with this library). */
+int msplat_set_point_sprite(msplat_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height);
 
 /* ---- host matrix helpers used by the shims (glm closed forms; app.cpp:1042, util.cpp:420) - */
 void msplat_mat4_inverse(const float m[16], float out[16]);

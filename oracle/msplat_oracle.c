@@ -668,6 +668,168 @@ void orc_composite_f64(uint32_t v, const orc_splat2d* s, int W, int H, double* r
 }
 
 /* ------------------------------------------------------------------------------------- */
+/* point-cloud renderer: src/pointrenderer.cpp:113-196, shader/point_*.glsl */
+/* ------------------------------------------------------------------------------------- */
+
+/* Texture preparation as the reference does it before glTexImage2D: Image::Load flips the rows (t = 0 is the
+ * image's bottom row, core/image.cpp:108-111) and pre-multiplies colour by alpha in 8 bits with truncation
+ * (image.cpp:144-157); a texture flagged sRGB (pointrenderer.cpp:60) decodes texels to linear on fetch; mip levels
+ * from glGenerateMipmap (core/texture.cpp:76) restated as a 2x2 box filter.  Returns the number of levels;
+ * off[l] = texel offset of level l in chain (float4 texels).  chain needs 4 * (4/3 w h + 16) floats. */
+int orc_build_sprite(const uint8_t* rgba8_top_first, int w, int h, int srgb, float* chain, uint32_t* off)
+{
+    for (int j = 0; j < h; ++j)
+        for (int i = 0; i < w; ++i) {
+            const uint8_t* s = rgba8_top_first + ((size_t)(h - 1 - j) * w + i) * 4;
+            float* o = chain + ((size_t)j * w + i) * 4;
+            float alpha = (float)s[3] / 255.0f;
+            for (int c = 0; c < 3; ++c) {
+                uint8_t pm = (uint8_t)((((float)s[c] / 255.0f) * alpha) * 255.0f);
+                float v = (float)pm / 255.0f;
+                o[c] = srgb ? srgb_to_linear(v) : v;
+            }
+            o[3] = alpha;
+        }
+    int lw = w, lh = h, level = 0;
+    size_t cur = 0;
+    off[0] = 0;
+    while ((lw > 1 || lh > 1) && level + 1 < 14) {
+        int nw = lw / 2 > 1 ? lw / 2 : 1, nh = lh / 2 > 1 ? lh / 2 : 1;
+        size_t next = cur + (size_t)lw * lh;
+        for (int j = 0; j < nh; ++j)
+            for (int i = 0; i < nw; ++i) {
+                int i0 = 2 * i < lw - 1 ? 2 * i : lw - 1, i1 = 2 * i + 1 < lw - 1 ? 2 * i + 1 : lw - 1;
+                int j0 = 2 * j < lh - 1 ? 2 * j : lh - 1, j1 = 2 * j + 1 < lh - 1 ? 2 * j + 1 : lh - 1;
+                for (int c = 0; c < 4; ++c) {
+                    float a = chain[(cur + (size_t)j0 * lw + i0) * 4 + c], b = chain[(cur + (size_t)j0 * lw + i1) * 4 + c];
+                    float cc = chain[(cur + (size_t)j1 * lw + i0) * 4 + c], d = chain[(cur + (size_t)j1 * lw + i1) * 4 + c];
+                    chain[(next + (size_t)j * nw + i) * 4 + c] = (((a + b) + cc) + d) * 0.25f;
+                }
+            }
+        cur = next;
+        lw = nw;
+        lh = nh;
+        off[++level] = (uint32_t)cur;
+    }
+    return level + 1;
+}
+
+/* point_vert.glsl:22-25 + point_geom.glsl:22-46 for idx[0..v): clip position, the quad's half size (an offset of
+ * (pointSize * invAspectRatio, pointSize) added in CLIP space, pointrenderer.cpp:170-177), level of detail.
+ * points: 8 floats per point (position.xyzw, color.rgba), pointcloud.cpp:19-23. */
+void orc_points_project(uint32_t v, const uint32_t* idx, const float* points, const float viewMat[16],
+                        const float projMat[16], const float viewport[4], int tex_w, int tex_h, orc_point2d* out)
+{
+    const float WIDTH = viewport[2], HEIGHT = viewport[3];
+    for (uint32_t r = 0; r < v; ++r) {
+        uint32_t i = idx ? idx[r] : r;
+        const float* rec = points + (size_t)i * 8;
+        orc_point2d* o = &out[r];
+        float t[4], p4[4];
+        mat4_mul_point(viewMat, rec[0], rec[1], rec[2], t);
+        for (int k = 0; k < 4; ++k) {
+            float s = M(projMat, 0, k) * t[0];
+            s = s + M(projMat, 1, k) * t[1];
+            s = s + M(projMat, 2, k) * t[2];
+            s = s + M(projMat, 3, k) * t[3];
+            p4[k] = s;
+        }
+        float w = p4[3];
+        /* the four vertices share z and w: near/far clipping keeps or drops the whole quad */
+        int reject = !(w > 0.0f) || !(p4[2] >= -w) || !(p4[2] <= w);
+        float ndcx = p4[0] / w, ndcy = p4[1] / w;
+        o->ndcz = p4[2] / w;
+        /* viewport transform, viewport origin = image origin (app.cpp:148 glViewport(0, 0, w, h)) */
+        o->cx = (ndcx + 1.0f) * (0.5f * WIDTH);
+        o->cy = (ndcy + 1.0f) * (0.5f * HEIGHT);
+        float invAspect = 1.0f / (WIDTH / HEIGHT);
+        o->hx = ((0.02f * invAspect) / w) * (0.5f * WIDTH);
+        o->hy = (0.02f / w) * (0.5f * HEIGHT);
+        if (!(o->hx > 0.0f) || !(o->hy > 0.0f) || !(o->cx == o->cx) || !(o->cy == o->cy)) reject = 1;
+        float rx = (float)tex_w / (2.0f * o->hx), ry = (float)tex_h / (2.0f * o->hy);
+        o->lambda = log2f(rx > ry ? rx : ry);
+        for (int c = 0; c < 4; ++c) o->rgba[c] = rec[4 + c];
+        o->reject = reject;
+        o->index = i;
+    }
+}
+
+static void sprite_tap(const float* chain, uint32_t off, int sw, int sh, float u, float v, float out[4])
+{
+    float x = u * (float)sw - 0.5f, y = v * (float)sh - 0.5f;
+    float xf = floorf(x), yf = floorf(y);
+    float ax = x - xf, ay = y - yf;
+    int i0 = (int)xf, i1 = (int)xf + 1, j0 = (int)yf, j1 = (int)yf + 1;
+    /* ClampToEdge */
+    i0 = i0 < 0 ? 0 : (i0 > sw - 1 ? sw - 1 : i0);
+    i1 = i1 < 0 ? 0 : (i1 > sw - 1 ? sw - 1 : i1);
+    j0 = j0 < 0 ? 0 : (j0 > sh - 1 ? sh - 1 : j0);
+    j1 = j1 < 0 ? 0 : (j1 > sh - 1 ? sh - 1 : j1);
+    const float* t00 = chain + ((size_t)off + (size_t)j0 * sw + i0) * 4;
+    const float* t10 = chain + ((size_t)off + (size_t)j0 * sw + i1) * 4;
+    const float* t01 = chain + ((size_t)off + (size_t)j1 * sw + i0) * 4;
+    const float* t11 = chain + ((size_t)off + (size_t)j1 * sw + i1) * 4;
+    float bx = 1.0f - ax, by = 1.0f - ay;
+    for (int c = 0; c < 4; ++c) out[c] = (t00[c] * bx + t10[c] * ax) * by + (t01[c] * bx + t11[c] * ax) * ay;
+}
+
+static void sprite_sample(const float* chain, const uint32_t* off, int w, int h, int levels, float u, float v,
+                          float lambda, float out[4])
+{
+    if (!(lambda > 0.0f)) { sprite_tap(chain, off[0], w, h, u, v, out); return; }     /* magnification: Linear */
+    float lf = floorf(lambda);
+    int l0 = (int)lf < levels - 1 ? (int)lf : levels - 1;
+    int l1 = l0 + 1 < levels - 1 ? l0 + 1 : levels - 1;
+    float a[4], b[4];
+    sprite_tap(chain, off[l0], (w >> l0) > 1 ? (w >> l0) : 1, (h >> l0) > 1 ? (h >> l0) : 1, u, v, a);
+    if (l1 == l0) { for (int c = 0; c < 4; ++c) out[c] = a[c]; return; }
+    sprite_tap(chain, off[l1], (w >> l1) > 1 ? (w >> l1) : 1, (h >> l1) > 1 ? (h >> l1) : 1, u, v, b);
+    float f = lambda - lf, g = 1.0f - f;
+    for (int c = 0; c < 4; ++c) out[c] = a[c] * g + b[c] * f;
+}
+
+/* point_frag.glsl:17-25 + blend state app.cpp:153-156 in array (draw) order; coverage = pixel centres inside the
+ * quad [c - h, c + h); depth_bits != 0 adds the GL_LESS depth test (no discard in this shader: every covered
+ * fragment that passes writes depth, even where the sprite is transparent). */
+void orc_points_composite(uint32_t v, const orc_point2d* pts, const float* chain, const uint32_t* off, int tex_w,
+                          int tex_h, int levels, int W, int H, float* rgba, int depth_bits)
+{
+    uint32_t* zbuf = (uint32_t*)malloc((size_t)(W > 0 ? W : 1) * (H > 0 ? H : 1) * sizeof(uint32_t));
+    for (int p = 0; p < W * H; ++p) {
+        rgba[p * 4 + 0] = 0.0f; rgba[p * 4 + 1] = 0.0f; rgba[p * 4 + 2] = 0.0f; rgba[p * 4 + 3] = 1.0f;
+        zbuf[p] = 0xFFFFFFFFu;
+    }
+    for (uint32_t k = 0; k < v; ++k) {
+        const orc_point2d* g = &pts[k];
+        if (g->reject) continue;
+        uint32_t zq = depth_bits ? orc_quantise_depth(g->ndcz, depth_bits) : 0u;
+        float xlo = g->cx - g->hx, xhi = g->cx + g->hx, ylo = g->cy - g->hy, yhi = g->cy + g->hy;
+        int xa = (int)fmaxf(floorf(xlo - 1.0f), 0.0f), xb = (int)fminf(ceilf(xhi + 1.0f), (float)(W - 1));
+        int ya = (int)fmaxf(floorf(ylo - 1.0f), 0.0f), yb = (int)fminf(ceilf(yhi + 1.0f), (float)(H - 1));
+        if (!(xlo < (float)W) || !(xhi > 0.0f) || !(ylo < (float)H) || !(yhi > 0.0f)) continue;
+        for (int y = ya; y <= yb; ++y)
+            for (int x = xa; x <= xb; ++x) {
+                float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+                if (!(fx >= xlo && fx < xhi && fy >= ylo && fy < yhi)) continue;
+                size_t p = (size_t)y * W + x;
+                if (depth_bits && !(zq < zbuf[p])) continue;
+                zbuf[p] = zq;
+                float u = (fx - xlo) / (2.0f * g->hx), vv = (fy - ylo) / (2.0f * g->hy);
+                float tex[4];
+                sprite_sample(chain, off, tex_w, tex_h, levels, u, vv, g->lambda, tex);
+                float sa = g->rgba[3] * tex[3];
+                float oma = 1.0f - sa;
+                float* d = rgba + p * 4;
+                d[0] = ((g->rgba[3] * g->rgba[0]) * tex[0]) + oma * d[0];
+                d[1] = ((g->rgba[3] * g->rgba[1]) * tex[1]) + oma * d[1];
+                d[2] = ((g->rgba[3] * g->rgba[2]) * tex[2]) + oma * d[2];
+                d[3] = sa + oma * d[3];
+            }
+    }
+    free(zbuf);
+}
+
+/* ------------------------------------------------------------------------------------- */
 /* whole frame                                                                           */
 /* ------------------------------------------------------------------------------------- */
 

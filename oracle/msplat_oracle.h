@@ -100,6 +100,22 @@ void orc_composite_depth(uint32_t v, const orc_splat2d* s, int W, int H, float* 
 void orc_composite_f64(uint32_t v, const orc_splat2d* s, int W, int H, double* rgba,
                        int nthreads);
 
+/* ---- point-cloud renderer: pointrenderer.cpp:113-196 + shader/point_*.glsl ---------- */
+typedef struct orc_point2d {
+    float cx, cy;        /* quad centre, pixels (origin bottom-left)                        */
+    float hx, hy;        /* quad half size, pixels                                           */
+    float rgba[4];       /* vertex colour                                                    */
+    float lambda;        /* texture level of detail                                          */
+    float ndcz;
+    int32_t reject;      /* clipped away by the near / far plane, or degenerate              */
+    uint32_t index;
+} orc_point2d;
+int orc_build_sprite(const uint8_t* rgba8_top_first, int w, int h, int srgb, float* chain, uint32_t* off);
+void orc_points_project(uint32_t v, const uint32_t* idx, const float* points, const float viewMat[16],
+                        const float projMat[16], const float viewport[4], int tex_w, int tex_h, orc_point2d* out);
+void orc_points_composite(uint32_t v, const orc_point2d* pts, const float* chain, const uint32_t* off, int tex_w,
+                          int tex_h, int levels, int W, int H, float* rgba, int depth_bits);
+
 /* Whole frame: Sort(cameraMat, projMat, ...) then Render(cameraMat2, projMat2, ...).
  * Pass the same matrices twice for the desktop path. Optional outputs may be NULL.
  * Returns V. */

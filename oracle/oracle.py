@@ -63,6 +63,11 @@ def lib():
     L.orc_composite_depth.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_int, fp, C.c_int, C.c_int]
     L.orc_quantise_depth.argtypes = [C.c_float, C.c_int]
     L.orc_quantise_depth.restype = C.c_uint32
+    L.orc_build_sprite.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, fp, u32p]
+    L.orc_build_sprite.restype = C.c_int
+    L.orc_points_project.argtypes = [C.c_uint32, u32p, fp, fp, fp, fp, C.c_int, C.c_int, C.c_void_p]
+    L.orc_points_composite.argtypes = [C.c_uint32, C.c_void_p, fp, u32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp,
+                                       C.c_int]
     L.orc_composite_f64.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
     L.orc_render_frame.argtypes = [C.c_size_t, fp, C.c_size_t, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp,
                                    fp, u32p, u32p, C.c_void_p, C.c_int]
@@ -165,6 +170,38 @@ def composite_depth(splats, W, H, depth_bits=24, nthreads=1):
     lib().orc_composite_depth(splats.shape[0], splats.ctypes.data, W, H,
                               rgba.ctypes.data_as(C.POINTER(C.c_float)), depth_bits, nthreads)
     return rgba
+
+
+POINT2D_DTYPE = np.dtype([("cx", "<f4"), ("cy", "<f4"), ("hx", "<f4"), ("hy", "<f4"), ("rgba", "<f4", (4,)),
+                          ("lambda", "<f4"), ("ndcz", "<f4"), ("reject", "<i4"), ("index", "<u4")])
+
+
+def points_frame(points, sprite_rgba8, cam, proj, viewport, nearFar, srgb=False, depth_bits=0):
+    """PointRenderer::Render (pointrenderer.cpp:113-196): presort + stable sort of the positions, then the sprites
+    in draw order.  points = (N, 8) float32 (position.xyzw, color.rgba); sprite_rgba8 = (h, w, 4) uint8, top row
+    first as decoded from the PNG.  Returns dict(V, image, sorted_idx, pts)."""
+    points, pp = _f(points)
+    n = points.shape[0]
+    L = lib()
+    view = mat4_inverse(cam)
+    mvp = mat4_mul(proj, view)
+    keys = np.empty(max(n, 1), np.uint32); idx = np.empty(max(n, 1), np.uint32)
+    _, pm = _f(mvp)
+    v = L.orc_presort(n, pp, 8, pm, float(nearFar[1]), _u(keys), _u(idx))
+    L.orc_sort(v, _u(keys), _u(idx))
+    tex = np.ascontiguousarray(sprite_rgba8, np.uint8)
+    th, tw = tex.shape[:2]
+    chain = np.zeros((tw * th * 4 // 3 + 64) * 4, np.float32)
+    off = np.zeros(14, np.uint32)
+    levels = L.orc_build_sprite(tex.ctypes.data, tw, th, int(bool(srgb)), chain.ctypes.data_as(C.POINTER(C.c_float)), _u(off))
+    pts = np.zeros(max(v, 1), POINT2D_DTYPE)
+    _, pv = _f(view); _, ppj = _f(proj); _, pvp = _f(viewport)
+    L.orc_points_project(v, _u(idx), pp, pv, ppj, pvp, tw, th, pts.ctypes.data)
+    W, H = int(viewport[2]), int(viewport[3])
+    img = np.zeros((H, W, 4), np.float32)
+    L.orc_points_composite(v, pts.ctypes.data, chain.ctypes.data_as(C.POINTER(C.c_float)), _u(off), tw, th, levels, W, H,
+                           img.ctypes.data_as(C.POINTER(C.c_float)), depth_bits)
+    return dict(V=v, image=img, sorted_idx=idx[:v].copy(), pts=pts[:v], levels=levels)
 
 
 def composite_f64(splats, W, H, nthreads=1):

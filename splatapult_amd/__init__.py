@@ -7,5 +7,6 @@ under /oracle and is never imported from this package."""
 from ._capi import MsplatError, lib  # noqa: F401
 from .renderer import SplatRenderer  # noqa: F401
 from .scene import GaussianCloud  # noqa: F401
+from .points import PointCloud, PointRenderer  # noqa: F401
 
-__all__ = ["SplatRenderer", "GaussianCloud", "MsplatError", "lib"]
+__all__ = ["SplatRenderer", "GaussianCloud", "PointCloud", "PointRenderer", "MsplatError", "lib"]

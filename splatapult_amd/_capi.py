@@ -66,6 +66,18 @@ SYMBOLS = [
     ("msplat_sort", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16]),
     ("msplat_render", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16, C.c_void_p, C.c_uint64, C.c_int]),
     ("msplat_synchronize", C.c_int, [C.c_void_p]),
+    ("msplat_read_image", C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("msplat_points_create", C.c_void_p, [C.c_int]),
+    ("msplat_points_destroy", None, [C.c_void_p]),
+    ("msplat_points_import_ply", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("msplat_points_export_ply", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("msplat_points_init_debug", None, [C.c_void_p]),
+    ("msplat_points_num", C.c_uint64, [C.c_void_p]),
+    ("msplat_points_stride", C.c_uint32, [C.c_void_p]),
+    ("msplat_points_data", C.c_void_p, [C.c_void_p]),
+    ("msplat_upload_points", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
+    ("msplat_upload_point_cloud", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("msplat_set_point_sprite", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     ("msplat_set_depth_test", C.c_int, [C.c_void_p, C.c_int]),
     ("msplat_attach_cloud", C.c_int, [C.c_void_p, C.c_void_p]),
     ("msplat_stream_wait", C.c_int, [C.c_void_p, C.c_void_p]),

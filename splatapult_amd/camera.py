@@ -100,3 +100,17 @@ def write_image(path, rgba, encode_srgb=False):
                                         1 if encode_srgb else 0)
     if rc != _capi.OK:
         raise IOError("cannot write %s" % path)
+
+
+def read_image(path):
+    """8-bit PNG (gray / gray+alpha / RGB / RGBA, non-interlaced) -> (h, w, 4) uint8, top row first"""
+    L = _capi.lib()
+    w, h = C.c_uint32(), C.c_uint32()
+    if L.msplat_read_image(str(path).encode(), None, 0, C.byref(w), C.byref(h)) != _capi.OK:
+        raise IOError("cannot read %s" % path)
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    rc = L.msplat_read_image(str(path).encode(), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h))
+    if rc != _capi.OK:
+        raise IOError("cannot read %s" % path)
+    return out
+

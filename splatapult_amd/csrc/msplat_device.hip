@@ -75,6 +75,10 @@ struct msplat_ctx {
     Buf rect;       // uint32[N]
     Buf zq;         // uint32[N] quantised window depth per rank (only with msplat_set_depth_test)
     int depth_bits = 0;
+    // point-cloud mode: pos4 = positions, recs = float4 colours, sprite = float4 mip chain
+    bool point_mode = false;
+    Buf sprite;
+    SpriteParams sprite_params{};
     Buf tile_start; // uint32[65537]
     Buf tile_order; // uint32[65536] tiles by descending list length
     Buf hist1;      // uint32[256 * hist1_stride]
@@ -270,7 +274,7 @@ void msplat_destroy(msplat_ctx* ctx)
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
     Buf* all[] = {&ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist,
                   &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->totals1, &ctx->tile_start, &ctx->tile_order,
-                  &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe, &ctx->zq};
+                  &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe, &ctx->zq, &ctx->sprite};
     for (Buf* b : all) buf_free(ctx, *b);
     if (ctx->ev_ok)
         for (auto& set : ctx->ev)
@@ -316,6 +320,7 @@ int msplat_attach_cloud(msplat_ctx* ctx, msplat_ctx* owner)
     if (owner->device != ctx->device)
         return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_attach_cloud: contexts are on different devices (%d, %d)",
                     ctx->device, owner->device);
+    ctx->point_mode = owner->point_mode;
     int rc = prepare_cloud_buffers(ctx, owner->N, owner->full_sh, owner->store);
     if (rc) return rc;
     ctx->has_cloud = true;       // uploads are synchronous: the store is complete
@@ -373,7 +378,7 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
     ctx->has_render = false;
     ctx->N = n;
     ctx->full_sh = full_sh;
-    const int F4 = ctx->full_sh ? 16 : 8;
+    const int F4 = ctx->point_mode ? 1 : (ctx->full_sh ? 16 : 8);
     const size_t alloc_n = std::max<uint64_t>(n, 1);
     int rc;
     if (share) {
@@ -424,6 +429,7 @@ int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t s
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if ((!aos && n) || !off) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_upload_cloud: NULL argument");
     if (stride_bytes % 4 != 0) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "stride must be a multiple of 4");
+    ctx->point_mode = false;
     int rc = prepare_cloud_buffers(ctx, n, full_sh != 0, nullptr);
     if (rc) return rc;
     const int F4 = ctx->full_sh ? 16 : 8;
@@ -497,6 +503,7 @@ int msplat_upload_ply_vertices(msplat_ctx* ctx, const void* vertices, uint64_t n
     bool has_rest = true;
     for (int k = 0; k < 45; ++k) has_rest = has_rest && layout->f_rest[k] >= 0;
     const bool full = full_sh != 0 && has_rest;      // f_rest is optional (gaussiancloud.cpp:188-205)
+    ctx->point_mode = false;
     int rc = prepare_cloud_buffers(ctx, n, full, nullptr);
     if (rc) return rc;
     if (n) {
@@ -525,11 +532,119 @@ int msplat_upload_ply_vertices(msplat_ctx* ctx, const void* vertices, uint64_t n
     return MSPLAT_OK;
 }
 
+// ---- point clouds ------------------------------------------------------------------------
+static int build_sprite(msplat_ctx* ctx, const uint8_t* rgba8, uint32_t w, uint32_t h)
+{
+    // level 0 exactly as the reference prepares the texture: rows flipped so that t = 0 is the image's bottom row
+    // (core/image.cpp:108-111), colour pre-multiplied by alpha in 8 bits with truncation (image.cpp:144-157),
+    // texels decoded sRGB -> linear when the texture is flagged sRGB (pointrenderer.cpp:60, core/texture.cpp:63-70)
+    std::vector<uint8_t> builtin;
+    if (!rgba8) {
+        // built-in sprite: a shaded sphere, alpha 1 inside the disc with a one-texel soft rim
+        w = h = 128;
+        builtin.resize((size_t)w * h * 4);
+        for (uint32_t j = 0; j < h; ++j)
+            for (uint32_t i = 0; i < w; ++i) {
+                const float x = ((float)i + 0.5f) / (0.5f * w) - 1.0f, y = ((float)j + 0.5f) / (0.5f * h) - 1.0f;
+                const float d = std::sqrt(x * x + y * y);
+                const float a = std::min(1.0f, std::max(0.0f, (1.0f - d) * (0.5f * w)));
+                const float shade = 0.35f + 0.65f * std::sqrt(std::max(0.0f, 1.0f - d * d));
+                uint8_t* o = &builtin[((size_t)j * w + i) * 4];
+                o[0] = o[1] = o[2] = (uint8_t)(shade * 255.0f + 0.5f);
+                o[3] = (uint8_t)(a * 255.0f + 0.5f);
+            }
+        rgba8 = builtin.data();
+    }
+    if (w == 0 || h == 0 || w > 8192 || h > 8192) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "sprite size %ux%u outside [1,8192]^2", w, h);
+    SpriteParams sp{};
+    sp.w = (int)w;
+    sp.h = (int)h;
+    std::vector<float> chain;
+    chain.resize((size_t)w * h * 4);
+    const bool srgb = ctx->cfg.srgb != 0;
+    for (uint32_t j = 0; j < h; ++j)
+        for (uint32_t i = 0; i < w; ++i) {
+            const uint8_t* s = rgba8 + ((size_t)(h - 1 - j) * w + i) * 4;
+            float* o = &chain[((size_t)j * w + i) * 4];
+            const float alpha = (float)s[3] / 255.0f;
+            for (int c = 0; c < 3; ++c) {
+                const uint8_t pm = (uint8_t)((((float)s[c] / 255.0f) * alpha) * 255.0f);
+                const float v = (float)pm / 255.0f;
+                o[c] = srgb ? (v <= 0.04045f ? v / 12.92f : std::pow((v + 0.055f) / 1.055f, 2.4f)) : v;
+            }
+            o[3] = alpha;
+        }
+    // mip chain: 2x2 box filter down to 1x1 (glGenerateMipmap, core/texture.cpp:76)
+    int lw = (int)w, lh = (int)h, level = 0;
+    size_t off = 0;
+    sp.off[0] = 0;
+    while ((lw > 1 || lh > 1) && level + 1 < 14) {
+        const int nw = std::max(lw / 2, 1), nh = std::max(lh / 2, 1);
+        const size_t noff = off + (size_t)lw * lh;
+        chain.resize((noff + (size_t)nw * nh) * 4);
+        for (int j = 0; j < nh; ++j)
+            for (int i = 0; i < nw; ++i) {
+                const int i0 = std::min(2 * i, lw - 1), i1 = std::min(2 * i + 1, lw - 1);
+                const int j0 = std::min(2 * j, lh - 1), j1 = std::min(2 * j + 1, lh - 1);
+                for (int c = 0; c < 4; ++c) {
+                    const float a = chain[(off + (size_t)j0 * lw + i0) * 4 + c], b = chain[(off + (size_t)j0 * lw + i1) * 4 + c];
+                    const float cc = chain[(off + (size_t)j1 * lw + i0) * 4 + c], d = chain[(off + (size_t)j1 * lw + i1) * 4 + c];
+                    chain[(noff + (size_t)j * nw + i) * 4 + c] = (((a + b) + cc) + d) * 0.25f;
+                }
+            }
+        off = noff;
+        lw = nw;
+        lh = nh;
+        sp.off[++level] = (uint32_t)off;
+    }
+    sp.levels = level + 1;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = buf_alloc(ctx, ctx->sprite, chain.size() * sizeof(float));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(ctx->sprite.p, chain.data(), chain.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->sprite_params = sp;
+    return MSPLAT_OK;
+}
+
+int msplat_set_point_sprite(msplat_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    return build_sprite(ctx, rgba8, width, height);
+}
+
+int msplat_upload_points(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t stride_bytes,
+                         uint32_t position_offset, uint32_t color_offset)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if (!aos && n) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_upload_points: NULL argument");
+    if (stride_bytes % 4 != 0 || position_offset + 16u > stride_bytes || color_offset + 16u > stride_bytes)
+        return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_upload_points: bad stride / offsets (%u, %u, %u)", stride_bytes,
+                    position_offset, color_offset);
+    ctx->point_mode = true;
+    int rc = prepare_cloud_buffers(ctx, n, false, nullptr);
+    if (rc) { ctx->point_mode = false; return rc; }
+    std::vector<float> pos((size_t)std::max<uint64_t>(n, 1) * 4), col((size_t)std::max<uint64_t>(n, 1) * 4);
+    const uint8_t* src = static_cast<const uint8_t*>(aos);
+    for (uint64_t i = 0; i < n; ++i) {
+        std::memcpy(&pos[i * 4], src + i * stride_bytes + position_offset, 12);      // vec4(pos.xyz, pos[3]) -> w unused by the cull
+        pos[i * 4 + 3] = 0.0f;                                                        // .w = footprint bound slot (none for points)
+        std::memcpy(&col[i * 4], src + i * stride_bytes + color_offset, 16);
+    }
+    if (n) {
+        HIP_TRY(ctx, hipMemcpy(ctx->pos4.p, pos.data(), n * 16, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(ctx->recs.p, col.data(), n * 16, hipMemcpyHostToDevice));
+    }
+    ctx->has_cloud = true;
+    return MSPLAT_OK;
+}
+
 // device cloud -> reference AoS layout (100 B / 244 B records, gaussiancloud.cpp:32-56); parity tests
 int msplat_download_cloud(msplat_ctx* ctx, void* aos_out, uint64_t cap_bytes)
 {
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if (!ctx->has_cloud) return fail(ctx, MSPLAT_ERR_NO_CLOUD, "no cloud uploaded");
+    if (ctx->point_mode) return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "msplat_download_cloud: the context holds a point cloud");
     const int F4 = ctx->full_sh ? 16 : 8;
     const size_t rec_floats = ctx->full_sh ? 61 : 25;
     if (cap_bytes < ctx->N * rec_floats * 4) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "output buffer too small");
@@ -596,7 +711,7 @@ static int make_frame_params(msplat_ctx* ctx, const float cameraMat[16], const f
     fp.full_sh = ctx->full_sh ? 1 : 0;
     fp.srgb = ctx->cfg.srgb ? 1 : 0;
     fp.t_eps = ctx->cfg.t_epsilon;
-    fp.band_cull = (ctx->band_cull && ctx->row_mod > 1) ? 1 : 0;
+    fp.band_cull = (ctx->band_cull && ctx->row_mod > 1 && !ctx->point_mode) ? 1 : 0;   // points carry no footprint bound
     fp.depth_bits = ctx->depth_bits;
     fp.view_scale2 = 0.0f;
     for (int c = 0; c < 3; ++c)
@@ -678,7 +793,11 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const int tset = (int)(ctx->render_sets % msplat_ctx::kEvSets);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][2], s));
     const int pgrid = std::max(1u, div_up(N, kProjThreads));
-    if (ctx->full_sh)
+    if (ctx->point_mode)
+        hipLaunchKernelGGL(point_project_kernel, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
+                           (const float4*)ctx->pos4.p, (const float4*)ctx->recs.p, fp, ctx->sprite_params,
+                           (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr);
+    else if (ctx->full_sh)
         hipLaunchKernelGGL(project_kernel<true>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
                            (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
                            ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr);
@@ -731,7 +850,21 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const int cgrid = std::min(ntiles * 4, ctx->comp_waves);     // work items = (bin, quadrant)
     // (frames in flight: serialising the compositor launches of the contexts sharing a cloud with an event
     //  gate was measured r1 -- no gain over letting the hardware queues interleave them, dropped)
-    if (ntiles > 0 && ctx->depth_bits != 0) {
+    if (ntiles > 0 && ctx->point_mode) {
+        // sprites in draw order (optionally against the emulated depth buffer)
+        const uint32_t* zqp = ctx->depth_bits ? (const uint32_t*)ctx->zq.p : nullptr;
+        if (ctx->cfg.fb_format == MSPLAT_FB_RGBA16F)
+            hipLaunchKernelGGL(composite_points_kernel<true>, dim3(cgrid), dim3(kCompThreads), 0, s,
+                               (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
+                               (const float4*)ctx->rec2d.p, zqp, (const float4*)ctx->sprite.p, ctx->sprite_params, d_out,
+                               pitch, fp, cap, (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u);
+        else
+            hipLaunchKernelGGL(composite_points_kernel<false>, dim3(cgrid), dim3(kCompThreads), 0, s,
+                               (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
+                               (const float4*)ctx->rec2d.p, zqp, (const float4*)ctx->sprite.p, ctx->sprite_params, d_out,
+                               pitch, fp, cap, (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u);
+        ctx->comp_kernel_timed = false;
+    } else if (ntiles > 0 && ctx->depth_bits != 0) {
         // emulated depth buffer: draw-order walk, no early termination
         if (ctx->cfg.fb_format == MSPLAT_FB_RGBA16F)
             hipLaunchKernelGGL(composite_depth_kernel<true>, dim3(cgrid), dim3(kCompThreads), 0, s,
@@ -792,6 +925,7 @@ int msplat_render(msplat_ctx* ctx, const float cameraMat[16], const float projMa
         return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_render: pitch %llu too small / misaligned for width %d",
                     (unsigned long long)pitch_bytes, fp.width);
     ctx->last_fp = fp;
+    if (ctx->point_mode && !ctx->sprite.p && (rc = build_sprite(ctx, nullptr, 0, 0))) return rc;   // built-in sphere sprite
 
     if (out_is_device) {
         rc = launch_render(ctx, fp, rgba, pitch_bytes);

@@ -22,6 +22,7 @@
 
 #include "../../include/msplat.h"
 #include "gaussian_scene.hpp"
+#include "point_scene.hpp"
 
 namespace msplat {
 struct mat4 { float m[16]; };   // column-major, m[col*4 + row]
@@ -189,6 +190,86 @@ protected:
     int cur = 0;
     int framesInFlight = 1;
     msplat_config cfg{sizeof(msplat_config), 0, MSPLAT_FB_RGBA32F, 0, -1.0f, 0, nullptr, 0, 0};
+    void* target = nullptr;
+    uint64_t targetPitch = 0;
+    bool targetIsDevice = false;
+};
+
+// The SfM point-cloud view: PointRenderer's surface (/root/reference/src/pointrenderer.h:23-57).
+// Render sorts and draws in one call, like the reference (pointrenderer.cpp:113-196).
+class PointRenderer
+{
+public:
+    PointRenderer() = default;
+    ~PointRenderer() { msplat_destroy(ctx); }
+    PointRenderer(const PointRenderer&) = delete;
+    PointRenderer& operator=(const PointRenderer&) = delete;
+
+    void Configure(int device, int fbFormat, void* stream = nullptr)
+    {
+        cfg.device = device;
+        cfg.fb_format = fbFormat;
+        cfg.stream = stream;
+    }
+    // optional, before Init: the sprite (the reference loads texture/sphere.png, pointrenderer.cpp:54-64);
+    // RGBA8, top row first as decoded from the file (ReadPNG).  Default: the library's built-in sphere.
+    void SetSprite(const uint8_t* rgba8, uint32_t width, uint32_t height)
+    {
+        sprite.assign(rgba8, rgba8 + (size_t)width * height * 4);
+        spriteW = width;
+        spriteH = height;
+    }
+
+    bool Init(std::shared_ptr<PointCloud> pointCloud, bool isFramebufferSRGBEnabledIn)
+    {
+        msplat_destroy(ctx);
+        ctx = nullptr;
+        cfg.struct_size = sizeof(cfg);
+        cfg.srgb = isFramebufferSRGBEnabledIn ? 1 : 0;
+        if (msplat_create(&ctx, &cfg) != MSPLAT_OK) {
+            std::fprintf(stderr, "[msplat][E] %s\n", msplat_last_error(nullptr));
+            return false;
+        }
+        if (msplat_upload_points(ctx, pointCloud->GetRawDataPtr(), pointCloud->GetNumPoints(), (uint32_t)pointCloud->GetStride(),
+                                 (uint32_t)pointCloud->GetPositionAttrib().offset,
+                                 (uint32_t)pointCloud->GetColorAttrib().offset) != MSPLAT_OK ||
+            msplat_set_point_sprite(ctx, sprite.empty() ? nullptr : sprite.data(), spriteW, spriteH) != MSPLAT_OK) {
+            std::fprintf(stderr, "[msplat][E] %s\n", msplat_last_error(ctx));
+            return false;
+        }
+        return true;
+    }
+
+    template <class Mat4, class Vec4, class Vec2>
+    void Render(const Mat4& cameraMat, const Mat4& projMat, const Vec4& viewport, const Vec2& nearFar)
+    {
+        static_assert(sizeof(Mat4) == 64 && sizeof(Vec4) == 16 && sizeof(Vec2) == 8, "glm-compatible layout expected");
+        if (!target) {
+            std::fprintf(stderr, "[msplat][E] Render: no render target set (SetRenderTarget)\n");
+            return;
+        }
+        const float* c = reinterpret_cast<const float*>(&cameraMat);
+        const float* p = reinterpret_cast<const float*>(&projMat);
+        const float* v = reinterpret_cast<const float*>(&viewport);
+        const float* nf = reinterpret_cast<const float*>(&nearFar);
+        if (msplat_sort(ctx, c, p, v, nf) != MSPLAT_OK ||
+            msplat_render(ctx, c, p, v, nf, target, targetPitch, targetIsDevice ? 1 : 0) != MSPLAT_OK)
+            std::fprintf(stderr, "[msplat][E] PointRenderer::Render: %s\n", msplat_last_error(ctx));
+    }
+
+    void SetRenderTarget(void* rgba, uint64_t pitchBytes, bool isDevicePointer)
+    {
+        target = rgba;
+        targetPitch = pitchBytes;
+        targetIsDevice = isDevicePointer;
+    }
+    msplat_ctx* GetContext() { return ctx; }
+
+protected:
+    msplat_ctx* ctx = nullptr;
+    msplat_config cfg{sizeof(msplat_config), 0, MSPLAT_FB_RGBA32F, 0, -1.0f, 0, nullptr, 0, 0};
+    std::vector<uint8_t> sprite;
+    uint32_t spriteW = 0, spriteH = 0;
     void* target = nullptr;
     uint64_t targetPitch = 0;
     bool targetIsDevice = false;

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <filesystem>
 #include <fstream>
@@ -362,6 +363,212 @@ bool WritePNG(const std::string& filename, const uint8_t* rgba8, int width, int 
     return !f.fail();
 }
 
+// ---- PNG reader: zlib inflate (RFC 1950/1951) + the five PNG filters; 8-bit gray / gray+alpha / RGB / RGBA,
+// non-interlaced -- the formats the reference's Image::Load accepts (core/image.cpp:72-101) ----------------
+namespace {
+
+struct BitReader
+{
+    const uint8_t* p;
+    size_t n, pos = 0;
+    uint32_t acc = 0;
+    int cnt = 0;
+    bool fail = false;
+    uint32_t Bits(int k)
+    {
+        while (cnt < k) {
+            if (pos >= n) { fail = true; return 0; }
+            acc |= (uint32_t)p[pos++] << cnt;
+            cnt += 8;
+        }
+        const uint32_t v = acc & ((k == 32) ? 0xFFFFFFFFu : ((1u << k) - 1u));
+        acc = (k == 32) ? 0 : (acc >> k);
+        cnt -= k;
+        return v;
+    }
+};
+
+// canonical Huffman decoder (counts per length + sorted symbols)
+struct Huffman
+{
+    uint16_t count[16] = {0};
+    std::vector<uint16_t> symbol;
+    bool Build(const uint8_t* lengths, int n)
+    {
+        for (auto& c : count) c = 0;
+        for (int i = 0; i < n; ++i) count[lengths[i]]++;
+        count[0] = 0;
+        int left = 1;
+        for (int len = 1; len < 16; ++len) {
+            left <<= 1;
+            left -= count[len];
+            if (left < 0) return false;          // over-subscribed
+        }
+        uint16_t offs[16];
+        offs[1] = 0;
+        for (int len = 1; len < 15; ++len) offs[len + 1] = offs[len] + count[len];
+        symbol.assign(n, 0);
+        for (int i = 0; i < n; ++i)
+            if (lengths[i]) symbol[offs[lengths[i]]++] = (uint16_t)i;
+        return true;
+    }
+    int Decode(BitReader& br) const
+    {
+        int code = 0, first = 0, index = 0;
+        for (int len = 1; len < 16; ++len) {
+            code |= (int)br.Bits(1);
+            if (br.fail) return -1;
+            const int c = count[len];
+            if (code - c < first) return symbol[index + (code - first)];
+            index += c;
+            first += c;
+            first <<= 1;
+            code <<= 1;
+        }
+        return -1;
+    }
+};
+
+bool Inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out)
+{
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint16_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint16_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    if (n < 6 || (src[0] & 15) != 8 || ((src[0] << 8) | src[1]) % 31 != 0 || (src[1] & 32)) return false;   // zlib header
+    BitReader br{src + 2, n - 2};
+    for (;;) {
+        const uint32_t final = br.Bits(1), type = br.Bits(2);
+        if (br.fail) return false;
+        if (type == 0) {
+            br.acc = 0; br.cnt = 0;                                       // to the byte boundary
+            if (br.pos + 4 > br.n) return false;
+            const uint32_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
+            br.pos += 4;
+            if ((len ^ 0xFFFFu) != nlen || br.pos + len > br.n) return false;
+            out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
+            br.pos += len;
+        } else if (type == 1 || type == 2) {
+            Huffman lit, dist;
+            uint8_t lengths[320];
+            if (type == 1) {
+                int i = 0;
+                for (; i < 144; ++i) lengths[i] = 8;
+                for (; i < 256; ++i) lengths[i] = 9;
+                for (; i < 280; ++i) lengths[i] = 7;
+                for (; i < 288; ++i) lengths[i] = 8;
+                lit.Build(lengths, 288);
+                for (i = 0; i < 30; ++i) lengths[i] = 5;
+                dist.Build(lengths, 30);
+            } else {
+                static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                const int nlen = (int)br.Bits(5) + 257, ndist = (int)br.Bits(5) + 1, ncode = (int)br.Bits(4) + 4;
+                if (br.fail || nlen > 286 || ndist > 30) return false;
+                uint8_t cl[19] = {0};
+                for (int i = 0; i < ncode; ++i) cl[order[i]] = (uint8_t)br.Bits(3);
+                Huffman lencode;
+                if (!lencode.Build(cl, 19)) return false;
+                int idx = 0;
+                while (idx < nlen + ndist) {
+                    const int sym = lencode.Decode(br);
+                    if (sym < 0) return false;
+                    if (sym < 16) { lengths[idx++] = (uint8_t)sym; continue; }
+                    uint8_t prev = 0;
+                    int rep;
+                    if (sym == 16) { if (idx == 0) return false; prev = lengths[idx - 1]; rep = 3 + (int)br.Bits(2); }
+                    else if (sym == 17) rep = 3 + (int)br.Bits(3);
+                    else rep = 11 + (int)br.Bits(7);
+                    if (br.fail || idx + rep > nlen + ndist) return false;
+                    while (rep--) lengths[idx++] = prev;
+                }
+                if (lengths[256] == 0 || !lit.Build(lengths, nlen) || !dist.Build(lengths + nlen, ndist)) return false;
+            }
+            for (;;) {
+                int sym = lit.Decode(br);
+                if (sym < 0) return false;
+                if (sym < 256) { out.push_back((uint8_t)sym); continue; }
+                if (sym == 256) break;
+                sym -= 257;
+                if (sym >= 29) return false;
+                const size_t len = lbase[sym] + br.Bits(lext[sym]);
+                const int ds = dist.Decode(br);
+                if (ds < 0 || ds >= 30) return false;
+                const size_t d = dbase[ds] + br.Bits(dext[ds]);
+                if (br.fail || d > out.size()) return false;
+                const size_t from = out.size() - d;
+                for (size_t k = 0; k < len; ++k) out.push_back(out[from + k]);
+            }
+        } else {
+            return false;
+        }
+        if (final) return true;
+    }
+}
+
+}  // namespace
+
+bool ReadPNG(const std::string& filename, std::vector<uint8_t>& rgba8, int& width, int& height)
+{
+    std::string file;
+    if (!ReadAll(filename, file) || file.size() < 8 + 25 || std::memcmp(file.data(), "\x89PNG\r\n\x1a\n", 8) != 0) return false;
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(file.data());
+    auto be32 = [](const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; };
+    size_t pos = 8;
+    std::vector<uint8_t> idat;
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = -1, interlace = 0;
+    while (pos + 12 <= file.size()) {
+        const uint32_t n = be32(b + pos);
+        if (pos + 12 + (size_t)n > file.size()) return false;
+        const uint8_t* typ = b + pos + 4;
+        const uint8_t* d = typ + 4;
+        if (Crc32(typ, n + 4) != be32(d + n)) return false;
+        if (!std::memcmp(typ, "IHDR", 4) && n == 13) {
+            w = be32(d); h = be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12];
+        } else if (!std::memcmp(typ, "IDAT", 4)) {
+            idat.insert(idat.end(), d, d + n);
+        } else if (!std::memcmp(typ, "IEND", 4)) {
+            break;
+        }
+        pos += 12 + (size_t)n;
+    }
+    const int channels = ctype == 0 ? 1 : ctype == 4 ? 2 : ctype == 2 ? 3 : ctype == 6 ? 4 : 0;
+    if (w == 0 || h == 0 || w > 16384 || h > 16384 || depth != 8 || channels == 0 || interlace != 0) return false;
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t)h * (1 + (size_t)w * channels));
+    if (!Inflate(idat.data(), idat.size(), raw) || raw.size() != (size_t)h * (1 + (size_t)w * channels)) return false;
+    const size_t bpp = channels, rowBytes = (size_t)w * channels;
+    std::vector<uint8_t> cur(rowBytes), prev(rowBytes, 0);
+    rgba8.assign((size_t)w * h * 4, 255);
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint8_t* in = raw.data() + (size_t)y * (rowBytes + 1);
+        const int filter = in[0];
+        if (filter > 4) return false;
+        for (size_t i = 0; i < rowBytes; ++i) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, bb = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int pred = 0;
+            if (filter == 1) pred = a;
+            else if (filter == 2) pred = bb;
+            else if (filter == 3) pred = (a + bb) >> 1;
+            else if (filter == 4) {
+                const int pp = a + bb - c, pa = std::abs(pp - a), pb = std::abs(pp - bb), pc = std::abs(pp - c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c);
+            }
+            cur[i] = (uint8_t)(in[1 + i] + pred);
+        }
+        uint8_t* o = rgba8.data() + (size_t)y * w * 4;
+        for (uint32_t x = 0; x < w; ++x) {
+            const uint8_t* s = cur.data() + (size_t)x * channels;
+            if (channels <= 2) { o[4 * x] = o[4 * x + 1] = o[4 * x + 2] = s[0]; if (channels == 2) o[4 * x + 3] = s[1]; }
+            else { o[4 * x] = s[0]; o[4 * x + 1] = s[1]; o[4 * x + 2] = s[2]; if (channels == 4) o[4 * x + 3] = s[3]; }
+        }
+        std::swap(cur, prev);
+    }
+    width = (int)w;
+    height = (int)h;
+    return true;
+}
+
 bool WritePPM(const std::string& filename, const uint8_t* rgba8, int width, int height)
 {
     std::ofstream f(filename, std::ios::binary);
@@ -434,6 +641,22 @@ int msplat_write_image(const char* path, const float* rgba, int width, int heigh
     const std::string p(path);
     const bool ppm = p.size() > 4 && p.compare(p.size() - 4, 4, ".ppm") == 0;
     return (ppm ? WritePPM(p, px.data(), width, height) : WritePNG(p, px.data(), width, height)) ? MSPLAT_OK : MSPLAT_ERR_IO;
+}
+
+// PNG -> RGBA8, top row first.  rgba8_out may be NULL to query the size; returns MSPLAT_ERR_INVALID_ARG when cap
+// (bytes) is too small.
+int msplat_read_image(const char* path, uint8_t* rgba8_out, uint64_t cap, uint32_t* width_out, uint32_t* height_out)
+{
+    if (!path || !width_out || !height_out) return MSPLAT_ERR_INVALID_ARG;
+    std::vector<uint8_t> px;
+    int w = 0, h = 0;
+    if (!ReadPNG(path, px, w, h)) return MSPLAT_ERR_IO;
+    *width_out = (uint32_t)w;
+    *height_out = (uint32_t)h;
+    if (!rgba8_out) return MSPLAT_OK;
+    if (cap < px.size()) return MSPLAT_ERR_INVALID_ARG;
+    std::memcpy(rgba8_out, px.data(), px.size());
+    return MSPLAT_OK;
 }
 
 }  // extern "C"

@@ -56,4 +56,6 @@ float SRGBToLinear(float srgb);
 // W x H float RGBA (row 0 = GL bottom row) -> 8-bit RGBA, top row first when flipY (image files)
 void PresentRGBA8(const float* rgba, int width, int height, bool flipY, bool encodeSRGB, uint8_t* out);
 bool WritePNG(const std::string& filename, const uint8_t* rgba8, int width, int height);
+// 8-bit gray / gray+alpha / RGB / RGBA non-interlaced PNG (what core/image.cpp:72-101 accepts) -> RGBA8, top row first
+bool ReadPNG(const std::string& filename, std::vector<uint8_t>& rgba8, int& width, int& height);
 bool WritePPM(const std::string& filename, const uint8_t* rgba8, int width, int height);

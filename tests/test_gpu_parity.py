@@ -325,6 +325,74 @@ def test_depth_test_second_eye_artifact_and_bands():
     np.testing.assert_array_equal(acc, img)
 
 
+# ------------------------------------------------------------------------------------------------
+# point-cloud renderer: PointRenderer::Render = presort + sort + textured sprites
+# ------------------------------------------------------------------------------------------------
+
+def random_points(n, seed):
+    rng = np.random.default_rng(seed)
+    pts = np.zeros((n, 8), np.float32)
+    pts[:, :3] = rng.normal(0, 1.2, size=(n, 3))
+    pts[:, 3] = 1.0
+    pts[:, 4:7] = rng.integers(0, 256, size=(n, 3)).astype(np.float32) / np.float32(255.0)
+    pts[:, 7] = 1.0
+    return pts
+
+
+@pytest.mark.parametrize("srgb,depth_bits,z", [(False, 0, 5.0), (True, 0, 5.0), (False, 24, 5.0), (False, 0, 1.5)])
+def test_point_renderer_matches_oracle(srgb, depth_bits, z):
+    from splatapult_amd import PointRenderer
+    from tests.test_points import smooth_sprite
+    pts = random_points(6000, 111)
+    tex = smooth_sprite(64, 48, seed=2)                     # not square, not 2^k x 2^k all the way down
+    W, H = 640, 360
+    cam, proj, vp, nf = scenes.default_view(W, H, z=z, yaw=0.3)     # z = 1.5: inside the cloud, magnified sprites
+    r = PointRenderer(device=0)
+    assert r.Init(pts, srgb, sprite=tex), r.last_error()
+    if depth_bits:
+        r.set_depth_test(depth_bits)
+    img = r.Render(cam, proj, vp, nf)
+    ref = orc.points_frame(pts, tex, cam, proj, vp, nf, srgb=srgb, depth_bits=depth_bits)
+    assert r.sort_count() == ref["V"]
+    np.testing.assert_array_equal(r.sorted_indices(), ref["sorted_idx"])
+    assert np.isfinite(img).all() and (img[..., :3].sum(axis=-1) > 0).mean() > 0.01
+    d = np.abs(img - ref["image"])[..., :3]
+    assert (d <= 1e-5).mean() >= 0.9999, (d > 1e-5).mean()
+    assert d.max() <= 1e-3
+    assert np.abs(img[..., 3] - 1.0).max() == 0
+
+
+def test_point_renderer_debug_cloud_builtin_sprite_and_bands(tmp_path):
+    from splatapult_amd import PointCloud, PointRenderer
+    pc = PointCloud(False)
+    pc.InitDebugCloud()
+    W, H = 320, 240
+    cam = camera.pose((0.4, 0.4, 2.5))
+    proj = camera.perspective(camera.FOVY, W / H)
+    vp, nf = [0, 0, W, H], scenes.NF
+    r = PointRenderer(device=0)
+    assert r.Init(pc, False)                                # built-in sphere sprite
+    img = r.Render(cam, proj, vp, nf)
+    assert r.sort_count() == 15
+    lit = img[..., :3].sum(axis=-1) > 0
+    assert 15 <= lit.sum() < 15 * 200                       # 15 small discs (half size 0.01 H / w ~ 1 px here)
+    assert img[..., 0].max() > 0.5 and img[..., 1].max() > 0.5 and img[..., 2].max() > 0.5      # the three axis colours
+    acc = np.zeros_like(img)
+    for g in range(2):
+        rb = PointRenderer(device=0)
+        assert rb.Init(pc, False)
+        rb.set_band(2, g)
+        part = rb.Render(cam, proj, vp, nf)
+        rows = np.arange(H) // bin_px() % 2 == g
+        acc[rows] = part[rows]
+    np.testing.assert_array_equal(acc, img)
+    # a context goes back to splats with a splat upload
+    cloud = scenes.synth_cloud(500, 7)
+    assert SplatRenderer.Init(r, cloud, False, False)
+    r.Sort(cam, proj, vp, nf)
+    check_image(SplatRenderer.Render(r, cam, proj, vp, nf), orc.render_frame(cloud.as_array(), True, cam, proj, vp, nf)["image"])
+
+
 def test_fp16_framebuffer():
     cloud = scenes.synth_cloud(8000, 71, log_scale_mean=-3.2)
     view = scenes.default_view(320, 240)

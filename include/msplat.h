@@ -61,7 +61,7 @@ typedef struct msplat_config {
                                /* (msplat_get_timings averages them); 0 = never             */
     int32_t compositor_waves;  /* persistent compositor waves per render; 0 = default (8192, the  */
                                /* measured best for one frame at a time; the SplatRenderer shims   */
-                               /* use 2048 with frames in flight so that frames share the CUs)     */
+                               /* use 1024 with frames in flight so that frames share the CUs)     */
 } msplat_config;
 
 /* Byte offsets of the attributes inside one AoS record, i.e. the BinaryAttribute offsets that
@@ -188,7 +188,10 @@ int msplat_synchronize(msplat_ctx* ctx);
  * overlap is made explicit: create one context per frame in flight (each has its own stream and
  * per-frame buffers), upload the cloud into the first and attach it to the others (no copy), then
  * issue frame k's Sort + Render(s) on context k % depth.  Results are bit-identical to a single
- * context.  The C++ / Python SplatRenderer shims do this rotation (SetFramesInFlight). */
+ * context.  The C++ / Python SplatRenderer shims do this rotation (SetFramesInFlight).
+ * The ROCm runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (environment variable, default 4,
+ * read when the runtime initialises); streams sharing a queue serialise, so a process that wants 4 frames
+ * in flight next to its own streams should start with GPU_MAX_HW_QUEUES=8 (bench.py does). */
 /* `ctx` renders `owner`'s cloud (same device).  A later upload into either context detaches it. */
 int msplat_attach_cloud(msplat_ctx* ctx, msplat_ctx* owner);
 /* makes `stream` (hipStream_t; NULL = default stream) wait, on the device, for everything queued so

@@ -66,7 +66,7 @@ public:
         msplat_config c = cfg;
         if (framesInFlight > 1) {
             c.stream = nullptr;
-            c.compositor_waves = 2048;       // frames share the CUs (measured)
+            c.compositor_waves = 1024;       // frames share the CUs (measured)
         }
         for (int k = 0; k < framesInFlight; ++k) {
             msplat_ctx* h = nullptr;

@@ -79,7 +79,7 @@ class SplatRenderer:
         cfg.t_epsilon = self._t_eps
         cfg.pair_capacity = self._pair_cap
         cfg.enable_timing = int(self._timing)
-        cfg.compositor_waves = 0 if self._depth == 1 else 2048     # measured: bench sweep, DESIGN.md 6
+        cfg.compositor_waves = 0 if self._depth == 1 else 1024     # measured: bench sweep, DESIGN.md 5
         for k in range(self._depth):
             if isinstance(self._stream, (list, tuple)):       # one caller-owned stream per frame in flight
                 cfg.stream = self._stream[k]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/ab.sh [bench args]: prints fps for one-frame-at-a-time and for the default frames in flight
 cd ${GRAFT_REPO_ROOT:-.}
-for P in 1 3; do
+for P in 1 4; do
   for rep in 1 2; do
   timeout 200 python bench.py --no-cpu-baseline --frames-in-flight $P "$@" 2>&1 | grep "^{" | python -c "
 import sys, json

@@ -22,8 +22,12 @@ class BandGather:
         self.recv = None
         self.final = None
         if rank == dst:
-            self.recv = [torch.zeros((self.max_rows, tile, width, 4), dtype=dtype, device=device) for _ in range(world)]
-            self.final = torch.zeros((tiles_y, tile, width, 4), dtype=dtype, device=device)
+            # one allocation for all ranks' bands: the interleave back into image order is then a single
+            # strided copy (rank g's r-th band is tile row r * world + g) instead of one copy per rank
+            self.recv_all = torch.zeros((world, self.max_rows, tile, width, 4), dtype=dtype, device=device)
+            self.recv = list(self.recv_all.unbind(0))
+            self.final_padded = torch.zeros((self.max_rows * world, tile, width, 4), dtype=dtype, device=device)
+            self.final = self.final_padded[:tiles_y]
 
     def owned(self, fb):
         """view of this rank's tile rows inside a (tiles_y*tile, W, 4) framebuffer"""
@@ -36,7 +40,5 @@ class BandGather:
         dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst)
         if self.rank != self.dst:
             return None
-        for g in range(self.world):
-            rows = self.final[g::self.world]
-            rows.copy_(self.recv[g][:rows.shape[0]])
-        return self.final.view(self.tiles_y * self.tile, self.W, 4)
+        self.final_padded.view(self.max_rows, self.world, self.tile, self.W, 4).copy_(self.recv_all.permute(1, 0, 2, 3, 4))
+        return self.final.reshape(self.tiles_y * self.tile, self.W, 4)

@@ -50,7 +50,39 @@ def frame(aos, full_sh, cam, proj, W, H, **kw):
                 reject=sp["reject"], image=res["image"])
 
 
+def make_8f4():
+    """SURVEY 8f-4 fixtures: depth-buffer emulation (second-eye case) and the point-cloud renderer"""
+    from tests.test_points import smooth_sprite
+    g = np.load(os.path.join(HERE, "synth_sh3.npz"))
+    aos = orc.build_cloud(g["in_xyz"], g["in_f_dc"], g["in_f_rest"], g["in_opacity"], g["in_log_scale"], g["in_rot"], True)
+    W, H = int(g["W"]), int(g["H"])
+    eye1 = camera.translate_local(camera.pose((1.0, 0.0, 7.0), yaw=0.55), dx=0.3)        # drawn in eye 0's order
+    res = orc.render_frame(aos, True, g["cam"], g["proj"], [0, 0, W, H], scenes.NF, render_cam=eye1, render_proj=g["proj"],
+                           want_splats=True)
+    rng = np.random.default_rng(404)
+    pts = np.zeros((400, 8), np.float32)
+    pts[:, :3] = rng.normal(0, 1.0, size=(400, 3))
+    pts[:, 3] = 1.0
+    pts[:, 4:7] = rng.integers(0, 256, size=(400, 3)).astype(np.float32) / np.float32(255.0)
+    pts[:, 7] = 1.0
+    tex = smooth_sprite(32, 24, seed=5)
+    PW, PH = 160, 120
+    pcam, pproj, pvp, pnf = scenes.default_view(PW, PH, z=3.0, yaw=0.2)
+    out = {}
+    for srgb in (0, 1):
+        for bits in (0, 24):
+            out["exp_points_srgb%d_depth%d" % (srgb, bits)] = orc.points_frame(pts, tex, pcam, pproj, pvp, pnf, srgb=bool(srgb),
+                                                                               depth_bits=bits)["image"]
+    np.savez_compressed(os.path.join(HERE, "fixtures_8f4.npz"), eye1=eye1,
+                        exp_eye1_plain=res["image"], exp_eye1_depth24=orc.composite_depth(res["splats"], W, H, 24),
+                        exp_eye1_depth32=orc.composite_depth(res["splats"], W, H, 32),
+                        points=pts, sprite=tex, pcam=pcam, pproj=pproj, PW=PW, PH=PH, **out)
+
+
 def main():
+    if "--only-8f4" in sys.argv:
+        make_8f4()
+        return
     assert orc.ref_ply_lib() is not None, "build oracle/_ref first (make -C oracle) -- needs /root/reference"
     # ---- config 1: the reference's only fixture --------------------------------------------
     a, cnt, vs, props = attrs_from_ref_ply(os.path.join(HERE, "test.ply"))
@@ -79,6 +111,7 @@ def main():
     g = synthetic.generate(4, seed=synthetic.SEED_1M)
     json.dump({k: np.asarray(v, np.float64).round(7).tolist() for k, v in g.items() if v is not None},
               open(os.path.join(HERE, "generator_kat.json"), "w"), indent=0)
+    make_8f4()
     for f in sorted(os.listdir(HERE)):
         print("%-24s %8d B" % (f, os.path.getsize(os.path.join(HERE, f))))
 

@@ -393,6 +393,32 @@ def test_point_renderer_debug_cloud_builtin_sprite_and_bands(tmp_path):
     check_image(SplatRenderer.Render(r, cam, proj, vp, nf), orc.render_frame(cloud.as_array(), True, cam, proj, vp, nf)["image"])
 
 
+def test_8f4_golden_fixtures(golden_dir):
+    """the HIP path against the committed 8f-4 fixtures (depth-tested second eye; point sprites)"""
+    import os
+    from splatapult_amd import PointRenderer
+    g = np.load(os.path.join(golden_dir, "fixtures_8f4.npz"))
+    s = np.load(os.path.join(golden_dir, "synth_sh3.npz"))
+    cloud = scenes.cloud_from_attrs({k[3:]: s[k] for k in s.files if k.startswith("in_")})
+    W, H = int(s["W"]), int(s["H"])
+    vp = [0, 0, W, H]
+    r = make_renderer(cloud)
+    r.Sort(s["cam"], s["proj"], vp, scenes.NF)
+    check_image(r.Render(g["eye1"], s["proj"], vp, scenes.NF), g["exp_eye1_plain"])
+    for bits in (24, 32):
+        r.set_depth_test(bits)
+        check_image(r.Render(g["eye1"], s["proj"], vp, scenes.NF), g["exp_eye1_depth%d" % bits])
+    PW, PH = int(g["PW"]), int(g["PH"])
+    for srgb in (0, 1):
+        for bits in (0, 24):
+            pr = PointRenderer(device=0)
+            assert pr.Init(g["points"], bool(srgb), sprite=g["sprite"])
+            pr.set_depth_test(bits)
+            img = pr.Render(g["pcam"], g["pproj"], [0, 0, PW, PH], scenes.NF)
+            d = np.abs(img - g["exp_points_srgb%d_depth%d" % (srgb, bits)])[..., :3]
+            assert (d <= 1e-5).mean() >= 0.9999 and d.max() <= 1e-3
+
+
 def test_fp16_framebuffer():
     cloud = scenes.synth_cloud(8000, 71, log_scale_mean=-3.2)
     view = scenes.default_view(320, 240)

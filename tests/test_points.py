@@ -192,3 +192,24 @@ def test_oracle_sprite_chain_and_single_point_geometry():
     a = orc.points_frame(two, tex, cam, proj, [0, 0, W, H], scenes.NF)["image"]
     b = orc.points_frame(two, tex, cam, proj, [0, 0, W, H], scenes.NF, depth_bits=24)["image"]
     np.testing.assert_array_equal(a, b)
+
+
+def test_oracle_reproduces_8f4_golden(golden_dir):
+    """committed fixtures for the 8f-4 rows (tests/golden/make_golden.py::make_8f4): depth-tested second eye, points"""
+    g = np.load(os.path.join(golden_dir, "fixtures_8f4.npz"))
+    s = np.load(os.path.join(golden_dir, "synth_sh3.npz"))
+    aos = orc.build_cloud(s["in_xyz"], s["in_f_dc"], s["in_f_rest"], s["in_opacity"], s["in_log_scale"], s["in_rot"], True)
+    W, H = int(s["W"]), int(s["H"])
+    res = orc.render_frame(aos, True, s["cam"], s["proj"], [0, 0, W, H], scenes.NF, render_cam=g["eye1"], render_proj=s["proj"],
+                           want_splats=True, nthreads=4)
+    np.testing.assert_allclose(res["image"], g["exp_eye1_plain"], atol=1e-6)
+    for bits in (24, 32):
+        np.testing.assert_allclose(orc.composite_depth(res["splats"], W, H, bits, nthreads=3), g["exp_eye1_depth%d" % bits], atol=1e-6)
+    assert np.abs(g["exp_eye1_depth24"] - g["exp_eye1_plain"]).max() > 0.05          # the artifact is in the fixture
+    PW, PH = int(g["PW"]), int(g["PH"])
+    for srgb in (0, 1):
+        for bits in (0, 24):
+            img = orc.points_frame(g["points"], g["sprite"], g["pcam"], g["pproj"], [0, 0, PW, PH], scenes.NF, srgb=bool(srgb),
+                                   depth_bits=bits)["image"]
+            np.testing.assert_allclose(img, g["exp_points_srgb%d_depth%d" % (srgb, bits)], atol=1e-6)
+

@@ -3,7 +3,9 @@
 // Sort + Render into an explicit RGBA32F framebuffer, dumped as a binary PPM-like float file.
 //
 //   g++ -std=c++17 -I. splatapult_amd/host/example_render.cpp -Lsplatapult_amd/lib -lmsplat -o example_render
-//   ./example_render scene.ply out.f32 [width height] [--nosh]
+//   ./example_render scene.ply out.f32 [width height] [--nosh] [--frames-in-flight N]
+// With --frames-in-flight N the same frame is issued N + 1 times round-robin over N contexts that share the cloud
+// (SplatRenderer::SetFramesInFlight); the last one is written.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,12 +24,17 @@ int main(int argc, char** argv)
     int W = 1024, H = 768;   // the reference's default window (sdl_main.cpp:92)
     bool nosh = false;
     if (argc >= 5 && argv[3][0] != '-') { W = std::atoi(argv[3]); H = std::atoi(argv[4]); }
-    for (int i = 3; i < argc; ++i) nosh = nosh || !std::strcmp(argv[i], "--nosh");
+    int inFlight = 1;
+    for (int i = 3; i < argc; ++i) {
+        nosh = nosh || !std::strcmp(argv[i], "--nosh");
+        if (!std::strcmp(argv[i], "--frames-in-flight") && i + 1 < argc) inFlight = std::atoi(argv[i + 1]);
+    }
 
     auto cloud = std::make_shared<GaussianCloud>(GaussianCloud::Options{!nosh, false});
     if (!cloud->ImportPly(argv[1])) return 1;
 
     SplatRenderer renderer;
+    renderer.SetFramesInFlight(inFlight);
     if (!renderer.Init(cloud, /*isFramebufferSRGBEnabled=*/false, /*useRgcSortOverride=*/false)) return 1;
 
     // app.cpp:73-75,1039-1042: camera at the identity pose pulled back along +Z, 45 degree fovy
@@ -41,8 +48,11 @@ int main(int argc, char** argv)
 
     std::vector<float> fb((size_t)W * H * 4);
     renderer.SetRenderTarget(fb.data(), 0, /*isDevicePointer=*/false);
-    renderer.Sort(cameraMat, projMat, viewport, nearFar);
-    renderer.Render(cameraMat, projMat, viewport, nearFar);
+    for (int k = 0; k < (inFlight > 1 ? inFlight + 1 : 1); ++k) {
+        renderer.Sort(cameraMat, projMat, viewport, nearFar);       // moves on to the next context
+        renderer.Render(cameraMat, projMat, viewport, nearFar);
+    }
+    renderer.Synchronize();
 
     FILE* f = std::fopen(argv[2], "wb");
     if (!f) return 1;

@@ -585,6 +585,8 @@ def test_cpp_shim_renders_like_the_python_mirror(tmp_path, golden_dir):
     ply = os.path.join(golden_dir, "test.ply")
     subprocess.run([exe, ply, out, str(W), str(H)], check=True)
     img = np.fromfile(out, np.float32).reshape(H, W, 4)
+    subprocess.run([exe, ply, out + "3", str(W), str(H), "--frames-in-flight", "3"], check=True)
+    np.testing.assert_array_equal(np.fromfile(out + "3", np.float32).reshape(H, W, 4), img)
     gc = GaussianCloud()
     assert gc.ImportPly(ply)
     cam = camera.pose((0.0, 0.0, 5.0))
@@ -592,6 +594,40 @@ def test_cpp_shim_renders_like_the_python_mirror(tmp_path, golden_dir):
     ref = orc.render_frame(gc.as_array(), True, cam, proj, [0, 0, W, H], scenes.NF)
     check_image(img, ref["image"])
     assert img[..., :3].max() > 0.5
+
+
+def test_cpp_point_renderer_shim_matches_python(tmp_path):
+    """C++ PointCloud / PointRenderer (msplat_host.hpp) == the Python mirror, with a PNG sprite read by ReadPNG"""
+    import os
+    import subprocess
+    from PIL import Image
+    from splatapult_amd import PointCloud, PointRenderer, _capi
+    from tests.conftest import ROOT
+    from tests.test_points import smooth_sprite
+    exe = str(tmp_path / "example_points")
+    libdir = os.path.dirname(_capi.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-I", ROOT, "-I", os.path.join(ROOT, "splatapult_amd", "host"),
+                    os.path.join(ROOT, "splatapult_amd", "host", "example_points.cpp"),
+                    "-L", libdir, "-lmsplat", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    W, H = 320, 240
+    tex = smooth_sprite(48, 48, seed=9)
+    png = str(tmp_path / "sprite.png")
+    Image.fromarray(tex, "RGBA").save(png)
+    pc = PointCloud(False)
+    pc.InitDebugCloud()
+    ply = str(tmp_path / "input.ply")
+    assert pc.ExportPly(ply)
+    out = str(tmp_path / "p.f32")
+    subprocess.run([exe, out, str(W), str(H), ply, png], check=True)
+    img = np.fromfile(out, np.float32).reshape(H, W, 4)
+    back = PointCloud(False)
+    assert back.ImportPly(ply)
+    r = PointRenderer(device=0)
+    assert r.Init(back, False, sprite=camera.read_image(png))
+    cam = camera.pose((0.4, 0.4, 2.5))
+    ref = r.Render(cam, camera.perspective(np.float32(45.0 * 3.14159265358979 / 180.0), W / H), [0, 0, W, H], scenes.NF)
+    np.testing.assert_array_equal(img, ref)
+    assert (img[..., :3].sum(axis=-1) > 0).sum() >= 15
 
 
 # ------------------------------------------------------------------------------------------------

@@ -834,6 +834,10 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
     __shared__ uint32_t s_cnt[4][256];                 // per-wave column weights, then per-wave cursors
     __shared__ uint32_t s_base[kThreads];
     __shared__ uint32_t s_tmp[4];
+    // item -> owner rectangle table (chunks with at most kOwnerCap items; larger ones binary-search s_off):
+    // one LDS read per item instead of a 10-step dependent search, twice per item
+    constexpr uint32_t kOwnerCap = 8192;
+    __shared__ uint16_t s_owner[kOwnerCap];
     const uint32_t V = *d_V;
     const uint32_t nchunks = (V + kBinChunk - 1) / kBinChunk;
     const int lane = threadIdx.x & 63;
@@ -871,6 +875,14 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
         if (threadIdx.x == 0) s_off[kBinChunk] = M;
 #pragma unroll
         for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
+        const bool owner_table = M <= kOwnerCap;              // block-uniform
+        if (owner_table) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const uint32_t first = incl - wsum + woff[k], wd = rect_width(rc[k]);
+                for (uint32_t q = 0; q < wd; ++q) s_owner[first + q] = (uint16_t)(threadIdx.x * PER + k);
+            }
+        }
         __syncthreads();
 
         const uint32_t per_wave = (((M + 3u) >> 2) + 63u) & ~63u;    // multiple of 64
@@ -880,10 +892,14 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
         // item k -> (owner rectangle j, column tx, rows, first row)
         auto locate = [&](uint32_t k, uint32_t& tx, uint32_t& rows, uint32_t& ty0, uint32_t& rank) {
             uint32_t lo = 0, hi = kBinChunk - 1;      // last j with s_off[j] <= k (1024 candidates: 10 steps)
+            if (owner_table) {
+                lo = s_owner[k];
+            } else {
 #pragma unroll
-            for (int s = 0; s < 10; ++s) {
-                const uint32_t mid = (lo + hi + 1u) >> 1;
-                if (s_off[mid] <= k) lo = mid; else hi = mid - 1u;
+                for (int s = 0; s < 10; ++s) {
+                    const uint32_t mid = (lo + hi + 1u) >> 1;
+                    if (s_off[mid] <= k) lo = mid; else hi = mid - 1u;
+                }
             }
             const uint32_t r = s_rect[lo];
             tx = (r & 255u) + (k - s_off[lo]);

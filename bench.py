@@ -282,6 +282,10 @@ def main():
                      "avg_launch_ms_one_frame_at_a_time": prof_serial["composite_kernel"] if prof_serial else None,
                      "frac_one_frame_at_a_time": (B_comp / (prof_serial["composite_kernel"] * 1e-3) / HBM_PEAK)
                      if prof_serial and prof_serial["composite_kernel"] > 0 else None,
+                     # the frame's HBM-bound kernel, for comparison: project_kernel gathers 256 B per visible splat (244 B
+                     # record padded to 4 lines) + 4 B index and writes 52 B; stage time from stream markers, serial frames
+                     "project_kernel_frac_one_frame_at_a_time": ((312.0 * V) / (prof_serial["project"] * 1e-3) / HBM_PEAK)
+                     if prof_serial and prof_serial["project"] > 0 else None,
                      "note": "composite is VALU/LDS bound (exp + blend per pixel-splat); HBM fraction is honest-but-low"
                              + ("; launch duration measured while %d frames share the GPU" % P if P > 1 else "")},
     }

@@ -518,6 +518,44 @@ def test_frames_in_flight_bit_identical_to_serial_frames():
     check_image(img, ref["image"])
 
 
+def test_frames_in_flight_edge_cases():
+    """attach without a cloud fails; empty and fully culled clouds render black on every context"""
+    import ctypes as C
+    from splatapult_amd import _capi
+    L = _capi.lib()
+    a, b = C.c_void_p(), C.c_void_p()
+    assert L.msplat_create(C.byref(a), None) == _capi.OK and L.msplat_create(C.byref(b), None) == _capi.OK
+    assert L.msplat_attach_cloud(b, a) == _capi.ERR_NO_CLOUD
+    assert L.msplat_attach_cloud(None, a) == _capi.ERR_INVALID_ARG
+    assert L.msplat_stream_wait(None, None) == _capi.ERR_INVALID_ARG and L.msplat_wait_event(a, None) == _capi.ERR_INVALID_ARG
+    assert L.msplat_stream_wait(a, None) == _capi.OK            # default stream waits for the (idle) context stream
+    L.msplat_destroy(a); L.msplat_destroy(b)
+    cam, proj, vp, nf = scenes.default_view(160, 96)
+    for cloud, behind in ((np.zeros((0, 61), np.float32), False), (scenes.synth_cloud(300, 5), True)):
+        r = make_renderer(cloud, frames_in_flight=3)
+        c = camera.pose((0.0, 0.0, -50.0)) if behind else cam          # looking away: everything culled
+        for _ in range(4):
+            r.Sort(c, proj, vp, nf)
+            img = r.Render(c, proj, vp, nf)
+            assert r.sort_count() == 0
+            assert (img[..., :3] == 0).all() and (img[..., 3] == 1).all()
+
+
+def test_large_viewport_4096_matches_oracle():
+    """BASELINE config 4's framebuffer size (4096x4096: 128x128 bins, 65536 compositor work items) on a small cloud"""
+    cloud = scenes.synth_cloud(30000, 77, log_scale_mean=-3.6)
+    W = H = 4096
+    cam, proj, vp, nf = scenes.default_view(W, H, z=6.0, yaw=0.15)
+    r = make_renderer(cloud)
+    r.Sort(cam, proj, vp, nf)
+    img = r.Render(cam, proj, vp, nf)
+    ref = orc.render_frame(cloud.as_array(), True, cam, proj, vp, nf, nthreads=16)
+    assert r.sort_count() == ref["V"]
+    check_image(img, ref["image"])
+    st = r.stats()
+    assert st["tiles_x"] == 128 and st["tiles_y"] == 128
+
+
 def test_render_before_sort_and_bad_viewport_errors():
     from splatapult_amd import MsplatError
     cloud = scenes.synth_cloud(10, 1)

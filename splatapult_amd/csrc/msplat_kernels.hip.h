@@ -1117,17 +1117,22 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
     // dependent ones (that latency chain, not ALU work, is the critical path of the long tiles).
     uint32_t hiA = end;                                        // entries [start, hiA) not yet rank-loaded
     uint32_t cntA = min((uint32_t)kCompThreads, hiA - start);  // batch whose ranks are in rankA
+    // rankA holds the RAW pair word; the rank mask is applied where the word is used.  Masking right after the
+    // load made the compiler wait (s_waitcnt vmcnt(0)) for it -- and with it for the record loads issued just
+    // before -- in front of the inner loop: the whole prefetch pipeline was serialised (27 % of the kernel).
     uint32_t rankA = 0;
-    if (lane < (int)cntA) rankA = pairs[hiA - 1u - lane] & kRankMask;     // j = 0 is the nearest splat
+    if (lane < (int)cntA) rankA = pairs[hiA - 1u - lane];     // j = 0 is the nearest splat
     hiA -= cntA;
     uint32_t cnt = cntA;                                       // batch whose records are in p0..p2
     float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
     if (lane < (int)cnt) {
-        const float4* src = rec + (size_t)rankA * 3;
+        uint32_t rk = rankA & kRankMask;
+        asm volatile("" : "+v"(rk));              // keep the mask out of the address arithmetic (see composite_depth_kernel)
+        const float4* src = rec + (size_t)rk * 3;
         p0 = src[0]; p1 = src[1]; p2 = src[2];
     }
     cntA = min((uint32_t)kCompThreads, hiA - start);
-    if (lane < (int)cntA) rankA = pairs[hiA - 1u - lane] & kRankMask;
+    if (lane < (int)cntA) rankA = pairs[hiA - 1u - lane];
     hiA -= cntA;
     const uint64_t probe_t0 = probe ? clock64() : 0ull;
     uint32_t probe_n = 0, probe_batches = 0;
@@ -1182,11 +1187,13 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
         __syncthreads();
         cnt = cntA;
         if (lane < (int)cnt) {
-            const float4* src = rec + (size_t)rankA * 3;
+            uint32_t rk = rankA & kRankMask;
+            asm volatile("" : "+v"(rk));
+            const float4* src = rec + (size_t)rk * 3;
             p0 = src[0]; p1 = src[1]; p2 = src[2];
         }
         cntA = min((uint32_t)kCompThreads, hiA - start);
-        if (lane < (int)cntA) rankA = pairs[hiA - 1u - lane] & kRankMask;
+        if (lane < (int)cntA) rankA = pairs[hiA - 1u - lane];
         hiA -= cntA;
         probe_n += n;
         ++probe_batches;

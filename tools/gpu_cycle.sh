@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1; shift
-timeout 600 python -m pytest $R/tests -m gpu -q --timeout 300 -p no:cacheprovider -x 2>&1 | tail -12
+[ -n "$SKIP_TESTS" ] || timeout 600 python -m pytest $R/tests -m gpu -q --timeout 300 -p no:cacheprovider -x 2>&1 | tail -12
 cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o run --output-format csv -- python $R/bench.py --steps 600 --warmup 200 --no-cpu-baseline --profile-frames 4 "$@" > $R/gpurun_out/prof_$TAG.log 2>&1
 grep -h "^{" $R/gpurun_out/prof_$TAG.log | python -c "
 import sys, json

@@ -720,6 +720,20 @@ static int make_frame_params(msplat_ctx* ctx, const float cameraMat[16], const f
     return MSPLAT_OK;
 }
 
+// exclusive scan of a chunk-major histogram table along the chunks.  The element count is only known on the device,
+// so the variant is picked from the cloud size: up to 2 M splats (a few thousand chunk rows at most) the 16-workgroup
+// version, beyond that one workgroup per digit.
+static void launch_scan(hipStream_t s, bool small, uint32_t* hist, uint32_t hist_stride, const uint32_t* d_n,
+                        uint32_t n_static, uint32_t n_cap, uint32_t chunk, uint32_t* totals)
+{
+    if (small)
+        hipLaunchKernelGGL(radix_scan_small, dim3(kScanSmallBlocks), dim3(kThreads), 0, s, hist, d_n, n_static, n_cap, chunk,
+                           totals);
+    else
+        hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, hist, hist_stride, d_n, n_static, n_cap, chunk,
+                           totals);
+}
+
 int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[16],
                 const float viewport[4], const float nearFar[2])
 {
@@ -746,8 +760,7 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
     // pass 0: cull + key fused into the first radix pass (presort_compute.glsl + byte 0 of the sort)
     hipLaunchKernelGGL(radix_upsweep<MODE_CULL>, dim3(grid), dim3(kThreads), 0, s, nullptr, pos, nullptr, N, N, 0,
                        hist, ctx->hist_stride, fp);
-    hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, hist, ctx->hist_stride, nullptr, N, N,
-                       (uint32_t)kSortChunk, totals);
+    launch_scan(s, ctx->N <= (2u << 20), hist, ctx->hist_stride, nullptr, N, N, (uint32_t)kSortChunk, totals);
     if (ctx->atomic_rank)
         hipLaunchKernelGGL((radix_downsweep<MODE_CULL, true, true>), dim3(grid), dim3(kThreads), 0, s, nullptr, nullptr, pos,
                            nullptr, N, N, 0, hist, ctx->hist_stride, totals, kB, vB, d_V, nullptr, fp);
@@ -762,8 +775,7 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
         uint32_t* vout = (pass & 1) ? vA : vB;
         hipLaunchKernelGGL(radix_upsweep<MODE_KEYS>, dim3(grid), dim3(kThreads), 0, s, kin, nullptr, d_V, 0u, N,
                            pass * 8, hist, ctx->hist_stride, fp);
-        hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, hist, ctx->hist_stride, d_V, 0u, N,
-                           (uint32_t)kSortChunk, totals);
+        launch_scan(s, ctx->N <= (2u << 20), hist, ctx->hist_stride, d_V, 0u, N, (uint32_t)kSortChunk, totals);
         if (ctx->atomic_rank)
             hipLaunchKernelGGL((radix_downsweep<MODE_KEYS, true, true>), dim3(grid), dim3(kThreads), 0, s, kin, vin, nullptr,
                                d_V, 0u, N, pass * 8, hist, ctx->hist_stride, totals, kout, vout, nullptr, nullptr, fp);
@@ -813,8 +825,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const int g1 = grid_for(div_up(N, kBinChunk));
     hipLaunchKernelGGL(bin1_upsweep, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
                        (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_overflow);
-    hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V,
-                       0u, N, (uint32_t)kBinChunk, totals1);
+    launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V, 0u, N, (uint32_t)kBinChunk, totals1);
     if (ctx->atomic_rank)
         hipLaunchKernelGGL(bin1_downsweep<true>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
                            (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,
@@ -827,8 +838,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const int g2 = grid_for(div_up(cap, kPairChunk));
     hipLaunchKernelGGL(radix_upsweep<MODE_PAIR>, dim3(g2), dim3(kThreads), 0, s, (const uint32_t*)ctx->pairsA.p,
                        nullptr, d_D, 0u, cap, 24, (uint32_t*)ctx->hist2.p, ctx->hist2_stride, fp);
-    hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, (uint32_t*)ctx->hist2.p, ctx->hist2_stride, d_D,
-                       0u, cap, (uint32_t)kPairChunk, totals2);
+    launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist2.p, ctx->hist2_stride, d_D, 0u, cap, (uint32_t)kPairChunk, totals2);
     if (ctx->atomic_rank)
         hipLaunchKernelGGL((radix_downsweep<MODE_PAIR, false, true>), dim3(g2), dim3(kThreads), 0, s,
                            (const uint32_t*)ctx->pairsA.p, nullptr, nullptr, d_D, 0u, cap, 24,

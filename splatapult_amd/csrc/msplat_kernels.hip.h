@@ -177,7 +177,10 @@ __global__ __launch_bounds__(kThreads) void lds_atomic_order_probe(uint32_t* __r
 //   MODE_CULL : pass 0 -- keys computed on the fly from positions (fused presort), value = index,
 //               culled splats are neither counted nor scattered (ordered compaction for free)
 //   MODE_PAIR : key-only words (ty<<24 | rank), digit = top byte
-// hist layout: hist[digit * hist_stride + chunk]
+// hist layout: chunk-major, hist[chunk * 256 + digit] (hist_stride = number of chunk rows allocated): the
+// per-chunk kernels write / read one coalesced 1 KB row; only radix_scan walks it with a 1 KB stride, out of L2
+// (digit-major rows made every upsweep write and downsweep read a 4-byte access to its own 32-byte sector:
+// 8x amplification, ~40 MB of HBM traffic per frame)
 // ------------------------------------------------------------------------------------------
 
 template <int MODE>
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
             }
         }
         __syncthreads();
-        hist[(size_t)threadIdx.x * hist_stride + chunk] = s_hist[threadIdx.x];
+        hist[(size_t)chunk * 256 + threadIdx.x] = s_hist[threadIdx.x];
         __syncthreads();
     }
 }
@@ -225,17 +228,75 @@ __global__ __launch_bounds__(kThreads) void radix_scan(uint32_t* __restrict__ hi
     uint32_t n = d_n ? *d_n : n_static;
     if (n > n_cap) n = n_cap;
     const uint32_t nchunks = (n + chunk_size - 1) / chunk_size;
-    uint32_t* row = hist + (size_t)blockIdx.x * hist_stride;
+    uint32_t* col = hist + blockIdx.x;            // this digit's column of the chunk-major table
     uint32_t running = 0;
     for (uint32_t base = 0; base < nchunks; base += kThreads) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t v = (i < nchunks) ? row[i] : 0u;
+        const uint32_t v = (i < nchunks) ? col[(size_t)i * 256] : 0u;
         uint32_t total;
         const uint32_t incl = block_incl_scan(v, s_tmp, total);
-        if (i < nchunks) row[i] = running + incl - v;
+        if (i < nchunks) col[(size_t)i * 256] = running + incl - v;
         running += total;
     }
     if (threadIdx.x == 0) totals[blockIdx.x] = running;
+}
+
+// The same scan for tables of at most a few thousand chunk rows (the 1 M-splat sizes): 32 workgroups, each owning 8
+// digits; its 256 threads are 32 chunk ranges x 8 digits, so 8 lanes read one whole 32-byte sector of a 1 KB row
+// (the one-workgroup-per-digit version above touches a separate sector per 4-byte value).  Up to 1024 chunk rows a
+// thread's range fits in registers: every load is issued before the first is used and nothing is read twice.
+constexpr int kScanSmallBlocks = 32;
+__global__ __launch_bounds__(kThreads) void radix_scan_small(uint32_t* __restrict__ hist,
+                                                             const uint32_t* __restrict__ d_n, uint32_t n_static,
+                                                             uint32_t n_cap, uint32_t chunk_size,
+                                                             uint32_t* __restrict__ totals)
+{
+    constexpr int G = 32, DIG = 8, REG = 32;
+    __shared__ uint32_t s_part[G][DIG + 1];
+    uint32_t n = d_n ? *d_n : n_static;
+    if (n > n_cap) n = n_cap;
+    const uint32_t nchunks = (n + chunk_size - 1) / chunk_size;
+    const int dd = threadIdx.x & (DIG - 1), g = threadIdx.x / DIG;
+    const uint32_t digit = blockIdx.x * DIG + dd;
+    const uint32_t per = (nchunks + G - 1u) / G;
+    const uint32_t c0 = min(nchunks, (uint32_t)g * per), c1 = min(nchunks, c0 + per);
+    uint32_t* col = hist + digit;
+    const bool in_regs = per <= (uint32_t)REG;          // workgroup-uniform
+    uint32_t v[REG];
+    uint32_t sum = 0;
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < REG; ++k) v[k] = (c0 + k < c1) ? col[(size_t)(c0 + k) * 256] : 0u;
+#pragma unroll
+        for (int k = 0; k < REG; ++k) sum += v[k];
+    } else {
+#pragma unroll 8
+        for (uint32_t c = c0; c < c1; ++c) sum += col[(size_t)c * 256];
+    }
+    s_part[g][dd] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        const uint32_t p = s_part[k][dd];
+        if (k < g) run += p;
+        total += p;
+    }
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < REG; ++k) {
+            if (c0 + k < c1) col[(size_t)(c0 + k) * 256] = run;
+            run += v[k];
+        }
+    } else {
+#pragma unroll 8
+        for (uint32_t c = c0; c < c1; ++c) {
+            const uint32_t x = col[(size_t)c * 256];
+            col[(size_t)c * 256] = run;
+            run += x;
+        }
+    }
+    if (g == 0) totals[digit] = total;
 }
 
 template <int MODE, bool HAS_VALUES, bool ATOMIC_RANK>
@@ -355,7 +416,7 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
             s_cnt[1][d] = excl + c0;
             s_cnt[2][d] = excl + c0 + c1;
             s_cnt[3][d] = excl + c0 + c1 + c2;
-            s_gdelta[d] = s_base[d] + hist[(size_t)d * hist_stride + chunk] - excl;
+            s_gdelta[d] = s_base[d] + hist[(size_t)chunk * 256 + d] - excl;
         }
         __syncthreads();
         uint32_t wave_col = 0;
@@ -810,7 +871,7 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
         __syncthreads();
         uint32_t total;
         const uint32_t incl = block_incl_scan(s_diff[threadIdx.x], s_tmp, total);   // wraps mod 2^32: exact
-        hist[(size_t)threadIdx.x * hist_stride + chunk] = incl;
+        hist[(size_t)chunk * 256 + threadIdx.x] = incl;
         __syncthreads();
     }
 }
@@ -917,7 +978,7 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
         __syncthreads();
         {
             const int d = threadIdx.x;
-            const uint32_t g = s_base[d] + hist[(size_t)d * hist_stride + chunk];
+            const uint32_t g = s_base[d] + hist[(size_t)chunk * 256 + d];
             const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d];
             s_cnt[0][d] = g;
             s_cnt[1][d] = g + c0;

@@ -608,6 +608,26 @@ def test_full_size_config2_sort_and_properties():
     check_image(img[y0:y1], win[y0:y1])
 
 
+def test_large_cloud_uses_the_wide_scan_path():
+    """above 2 M splats the histogram tables are scanned by the one-workgroup-per-digit kernel (radix_scan) instead
+    of radix_scan_small: exact sort and tile lists + image parity on a 2.2 M-splat SH0 cloud"""
+    n, W, H = 2_200_000, 480, 270
+    cloud = scenes.synth_cloud(n, 909, full_sh=False, log_scale_mean=-5.2, pos_sigma=2.0)
+    cam, proj, vp, nf = scenes.default_view(W, H, z=8.0, yaw=0.1)
+    r = make_renderer(cloud)
+    r.Sort(cam, proj, vp, nf)
+    img = r.Render(cam, proj, vp, nf)
+    ref = orc.render_frame(cloud.as_array(), False, cam, proj, vp, nf, nthreads=16, want_splats=True)
+    assert r.sort_count() == ref["V"] and ref["V"] > 2_100_000
+    np.testing.assert_array_equal(r.sorted_indices(), ref["sorted_idx"])
+    np.testing.assert_array_equal(r.sorted_keys(), ref["sorted_keys"])
+    ts, pairs = r.debug_tile_lists()
+    for b in np.random.default_rng(0).integers(0, len(ts) - 1, size=40):
+        ranks = pairs[ts[b]:ts[b + 1]] & 0xFFFFFF
+        assert (np.diff(ranks.astype(np.int64)) > 0).all()
+    check_image(img, ref["image"])
+
+
 def test_cpp_shim_renders_like_the_python_mirror(tmp_path, golden_dir):
     """C++ drop-in surface (msplat_host.hpp: GaussianCloud::ImportPly -> SplatRenderer::Init/Sort/Render)"""
     import os

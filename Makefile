@@ -1,0 +1,28 @@
+# Convenience targets for C/C++ consumers; `python -c "import __graft_entry__ as g; g.build()"` does the same build.
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX ?= g++
+LIB = splatapult_amd/lib/libmsplat.so
+SRC = splatapult_amd/csrc/msplat_device.hip splatapult_amd/host/gaussian_scene.cpp splatapult_amd/host/scene_config.cpp \
+      splatapult_amd/host/point_scene.cpp
+HDR = splatapult_amd/csrc/msplat_kernels.hip.h splatapult_amd/host/gaussian_scene.hpp splatapult_amd/host/scene_config.hpp \
+      splatapult_amd/host/point_scene.hpp include/msplat.h
+
+all: $(LIB) examples
+
+$(LIB): $(SRC) $(HDR)
+	mkdir -p splatapult_amd/lib
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -Wno-unused-function -o $@ $(SRC)
+
+examples: build/example_render build/example_points
+
+build/example_%: splatapult_amd/host/example_%.cpp $(LIB) splatapult_amd/host/msplat_host.hpp
+	mkdir -p build
+	$(CXX) -std=c++17 -I. -Isplatapult_amd/host $< -Lsplatapult_amd/lib -lmsplat -Wl,-rpath,$(CURDIR)/splatapult_amd/lib -o $@
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(LIB)
+
+.PHONY: all examples oracle clean

@@ -34,7 +34,8 @@ enum {
     MSPLAT_ERR_NO_CLOUD = -4,      /* sort/render before upload                              */
     MSPLAT_ERR_NO_SORT = -5,       /* render before sort                                     */
     MSPLAT_ERR_UNSUPPORTED = -6,   /* e.g. viewport larger than 8192x8192                    */
-    MSPLAT_ERR_PAIR_OVERFLOW = -7, /* (splat,tile) pair buffer too small and could not grow  */
+    MSPLAT_ERR_PAIR_OVERFLOW = -7, /* (splat,bin) pair buffer too small: host-output renders grow it and retry,   */
+                                   /* device-output renders report it on the NEXT call (see msplat_render)     */
     MSPLAT_ERR_IO = -8             /* PLY open/parse failure                                 */
 };
 
@@ -88,6 +89,19 @@ typedef struct msplat_stats {
     uint64_t pairs_tile16;     /* (splat, 16x16 tile) pairs covered by the footprints: the D */
                                /* of the algorithmic byte count               */
 } msplat_stats;
+
+/* what the compositor (the dominant kernel) did in the last render, summed over its (bin, quadrant) work items;
+ * filled by msplat_get_composite_work when the tile probe is on (msplat_set_tile_probe) */
+typedef struct msplat_composite_work {
+    uint64_t work_items;          /* 16x16 tiles composited                                               */
+    uint64_t list_entries;        /* sum of the bin-list lengths: what it would fetch without early-out   */
+    uint64_t pair_words_fetched;  /* 4-byte list entries whose loads were issued                          */
+    uint64_t records_fetched;     /* 48-byte projected records whose loads were issued                    */
+    uint64_t records_composited;  /* records that passed the exact footprint/tile test                    */
+    uint64_t pixel_evals;         /* (pixel, splat) evaluations = records_composited * 256                */
+    uint64_t batches;             /* 64-entry batches staged                                              */
+    uint64_t clocks_sum, clocks_max, inner_clocks_sum;   /* shader clocks per work item (probe overhead included) */
+} msplat_composite_work;
 
 typedef struct msplat_timings {
     /* milliseconds, last frame, valid when enable_timing; names follow the reference's Tracy
@@ -174,7 +188,15 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
  * (float or half per cfg.fb_format), row 0 = GL bottom row, alpha = 1, into `rgba`.
  * out_is_device != 0: `rgba` is a device pointer, the call is asynchronous on the stream.
  * out_is_device == 0: `rgba` is host memory, the call returns after the copy completed.
- * pitch_bytes = bytes between rows (0 = tightly packed). */
+ * pitch_bytes = bytes between rows (0 = tightly packed).
+ * Pair-buffer overflow (more (splat, bin) pairs than msplat_stats.pair_capacity; default 32 per splat): a
+ * host-output render grows the buffer and retries before it returns.  A device-output render cannot know:
+ * the binning kernel leaves the needed pair count in host-mapped memory, and the NEXT msplat_sort /
+ * msplat_render / msplat_synchronize on the context (which still does its own work) grows the buffer -- unless
+ * msplat_config.pair_capacity fixed it -- and returns MSPLAT_ERR_PAIR_OVERFLOW once: the frame that overflowed
+ * lacks splats in its last bin columns and should be re-rendered.
+ * Limits: at most 2^24 splats per cloud (24-bit rank field in the pair words) and viewports up to 8192 x 8192
+ * (256 x 256 bins of 32 px); beyond them msplat_upload_* / msplat_sort return MSPLAT_ERR_UNSUPPORTED. */
 int msplat_render(msplat_ctx* ctx, const float cameraMat[16], const float projMat[16],
                   const float viewport[4], const float nearFar[2],
                   void* rgba, uint64_t pitch_bytes, int out_is_device);
@@ -220,9 +242,13 @@ int msplat_debug_get_projected(msplat_ctx* ctx, float* rec12, uint32_t* rect, ui
 int msplat_debug_get_tile_lists(msplat_ctx* ctx, uint32_t* tile_start, uint32_t tile_cap,
                                 uint32_t* pairs, uint64_t pair_cap);
 
-/* per tile {100 MHz ticks spent, splats composited, batches fetched, list length}; only when the
- * context was created with MSPLAT_TILE_PROBE=1 in the environment (performance analysis) */
-int msplat_debug_get_tile_probe(msplat_ctx* ctx, uint32_t* dst4, uint32_t tile_cap);
+/* compositor probe (performance analysis, bench statistics): per (bin, quadrant) work item 8 words
+ * {shader clocks, records composited, batches staged, inner-loop clocks, pair words fetched, records fetched,
+ *  bin-list length, ran}.  Off by default (a few clock reads per batch); MSPLAT_TILE_PROBE=1 in the environment
+ * turns it on at msplat_create. */
+int msplat_set_tile_probe(msplat_ctx* ctx, int enable);
+int msplat_debug_get_tile_probe(msplat_ctx* ctx, uint32_t* dst8, uint32_t tile_cap);
+int msplat_get_composite_work(msplat_ctx* ctx, msplat_composite_work* out);
 
 /* ---- scene data: GaussianCloud / Ply surface (gaussiancloud.h:17-91, ply.h:19-46) -------- */
 /* replaces GaussianCloud::GaussianCloud(Options{importFullSH}) */

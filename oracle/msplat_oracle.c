@@ -504,8 +504,8 @@ static inline void pixel_range(float centre, float half, int limit, int lo_clip,
     *hi = (int)b;
 }
 
-void orc_composite(uint32_t v, const orc_splat2d* s, int W, int H, float* rgba,
-                   int row0, int row1, int nthreads)
+static void composite_impl(uint32_t v, const orc_splat2d* s, int W, int H, float* rgba,
+                           int row0, int row1, int nthreads, float* flip_budget, float flip_rel)
 {
     if (row0 < 0) row0 = 0;
     if (row1 > H) row1 = H;
@@ -542,8 +542,16 @@ void orc_composite(uint32_t v, const orc_splat2d* s, int W, int H, float* rgba,
                     float e = expf(-0.5f * q);
                     float sa = g->alpha * e;
                     ++frags;
-                    if (sa <= (1.0f / 256.0f)) continue;        /* discard */
                     float* d = rgba + ((size_t)y * W + x) * 4;
+                    if (flip_budget && fabsf(sa - (1.0f / 256.0f)) <= flip_rel * (1.0f / 256.0f)) {
+                        /* a fragment this close to the discard threshold may fall on the other side in an
+                         * implementation whose w differs by a few ulp; blending it or not moves the pixel
+                         * by at most w * (|c| + |dst|) (later blends only attenuate the difference) */
+                        float cm = fmaxf(fabsf(g->rgb[0]), fmaxf(fabsf(g->rgb[1]), fabsf(g->rgb[2])));
+                        float dm = fmaxf(fabsf(d[0]), fmaxf(fabsf(d[1]), fabsf(d[2])));
+                        flip_budget[(size_t)y * W + x] += sa * (cm + dm);
+                    }
+                    if (sa <= (1.0f / 256.0f)) continue;        /* discard */
                     float oma = 1.0f - sa;
                     /* GL_ONE, GL_ONE_MINUS_SRC_ALPHA  (app.cpp:153-156) */
                     d[0] = (sa * g->rgb[0]) + oma * d[0];
@@ -555,6 +563,21 @@ void orc_composite(uint32_t v, const orc_splat2d* s, int W, int H, float* rgba,
         }
     }
     g_fragments = frags;
+}
+
+void orc_composite(uint32_t v, const orc_splat2d* s, int W, int H, float* rgba,
+                   int row0, int row1, int nthreads)
+{
+    composite_impl(v, s, W, H, rgba, row0, row1, nthreads, NULL, 0.0f);
+}
+
+/* orc_composite that also reports, per pixel, how far discard-threshold flips could move it:
+ * flip_budget[y*W+x] (caller-zeroed, W*H floats) += w (|c| + |dst|) for every fragment with
+ * |w - 1/256| <= flip_rel/256.  Lets the parity tests explain every pixel outside the tight tolerance. */
+void orc_composite_flip(uint32_t v, const orc_splat2d* s, int W, int H, float* rgba,
+                        int row0, int row1, int nthreads, float* flip_budget, float flip_rel)
+{
+    composite_impl(v, s, W, H, rgba, row0, row1, nthreads, flip_budget, flip_rel);
 }
 
 /* Window-space depth of a splat's fragments as an order-preserving uint32.  The quad's four vertices

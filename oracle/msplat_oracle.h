@@ -91,6 +91,9 @@ void orc_project(uint32_t v, const uint32_t* idx, const float* aos, size_t strid
  * threads (each pixel still sees the identical blend sequence). Rows [row0,row1) only. */
 void orc_composite(uint32_t v, const orc_splat2d* s, int W, int H, float* rgba,
                    int row0, int row1, int nthreads);
+/* the same, plus per pixel the most that discard-threshold flips (|w - 1/256| <= flip_rel/256) could move it */
+void orc_composite_flip(uint32_t v, const orc_splat2d* s, int W, int H, float* rgba,
+                        int row0, int row1, int nthreads, float* flip_budget, float flip_rel);
 /* orc_composite plus the GL_LESS depth test the reference leaves enabled (app.cpp:160,163), against an
  * emulated depth buffer of depth_bits = 24 (unorm, the default back buffer) or 32 (float).  SURVEY.md 8f-4. */
 uint32_t orc_quantise_depth(float ndcz, int depth_bits);

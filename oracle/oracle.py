@@ -60,6 +60,7 @@ def lib():
     L.orc_project.argtypes = [C.c_uint32, u32p, fp, C.c_size_t, C.c_int, C.c_int, fp, fp, fp, fp, fp,
                               C.c_void_p]
     L.orc_composite.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int]
+    L.orc_composite_flip.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int, fp, C.c_float]
     L.orc_composite_depth.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_int, fp, C.c_int, C.c_int]
     L.orc_quantise_depth.argtypes = [C.c_float, C.c_int]
     L.orc_quantise_depth.restype = C.c_uint32
@@ -160,6 +161,19 @@ def composite(splats, W, H, nthreads=1, row0=0, row1=None):
     lib().orc_composite(splats.shape[0], splats.ctypes.data, W, H,
                         rgba.ctypes.data_as(C.POINTER(C.c_float)), row0, H if row1 is None else row1, nthreads)
     return rgba
+
+
+def composite_flip(splats, W, H, nthreads=1, row0=0, row1=None, flip_rel=1e-4):
+    """composite() plus the per-pixel threshold-flip budget: returns (rgba, budget) where budget[y, x] bounds how far
+    the pixel can move when fragments with |w - 1/256| <= flip_rel/256 land on the other side of the discard test"""
+    splats = np.ascontiguousarray(splats)
+    assert splats.dtype == SPLAT2D_DTYPE
+    rgba = np.zeros((H, W, 4), np.float32)
+    budget = np.zeros((H, W), np.float32)
+    lib().orc_composite_flip(splats.shape[0], splats.ctypes.data, W, H, rgba.ctypes.data_as(C.POINTER(C.c_float)),
+                             row0, H if row1 is None else row1, nthreads,
+                             budget.ctypes.data_as(C.POINTER(C.c_float)), flip_rel)
+    return rgba, budget
 
 
 def composite_depth(splats, W, H, depth_bits=24, nthreads=1):

@@ -43,6 +43,12 @@ class Stats(C.Structure):
                 ("device_bytes", C.c_uint64), ("pairs_tile16", C.c_uint64)]
 
 
+class CompositeWork(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("work_items", "list_entries", "pair_words_fetched", "records_fetched", "records_composited",
+                 "pixel_evals", "batches", "clocks_sum", "clocks_max", "inner_clocks_sum")]
+
+
 class Timings(C.Structure):
     _fields_ = [("sort_total", C.c_float), ("render_total", C.c_float), ("project", C.c_float),
                 ("binning", C.c_float), ("composite", C.c_float), ("reserved", C.c_float * 3)]
@@ -90,6 +96,8 @@ SYMBOLS = [
     ("msplat_debug_get_projected", C.c_int, [C.c_void_p, _F16, _U32P, C.c_uint32]),
     ("msplat_debug_get_tile_lists", C.c_int, [C.c_void_p, _U32P, C.c_uint32, _U32P, C.c_uint64]),
     ("msplat_debug_get_tile_probe", C.c_int, [C.c_void_p, _U32P, C.c_uint32]),
+    ("msplat_set_tile_probe", C.c_int, [C.c_void_p, C.c_int]),
+    ("msplat_get_composite_work", C.c_int, [C.c_void_p, C.POINTER(CompositeWork)]),
     ("msplat_cloud_create", C.c_void_p, [C.c_int]),
     ("msplat_cloud_destroy", None, [C.c_void_p]),
     ("msplat_cloud_import_ply", C.c_int, [C.c_void_p, C.c_char_p]),

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <string>
 #include <vector>
@@ -88,7 +89,12 @@ struct msplat_ctx {
     Buf hist2;      // uint32[256 * hist2_stride]
     uint32_t hist2_stride = 0;
     Buf fb;         // internal framebuffer for host-output renders
-    Buf probe;      // uint32[4*tiles] per-tile compositor probe (only when MSPLAT_TILE_PROBE=1)
+    Buf probe;      // uint32[8 * work items] compositor probe (msplat_set_tile_probe / MSPLAT_TILE_PROBE=1)
+    bool probe_on = false;
+    // device-output renders never synchronise: a pair-buffer overflow is left in host-mapped memory by the
+    // binning kernel and picked up by the next call on the context (poll_async_overflow)
+    uint32_t* h_flags = nullptr;   // host view   [0] = pairs needed by an overflowed device-output render
+    uint32_t* d_flags = nullptr;   // device view of the same words
     // band
     int row_mod = 1, row_rem = 0;
     bool band_cull = false;
@@ -162,6 +168,9 @@ void buf_free(msplat_ctx* c, Buf& b)
 }
 
 inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+constexpr size_t kProbeWords = 8;                                           // per compositor work item
+constexpr size_t kProbeBytes = (size_t)65536 * 4 * kProbeWords * sizeof(uint32_t);   // 256x256 bins x 4 quadrants
 
 int grid_for(uint32_t nchunks)
 {
@@ -240,7 +249,17 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_order, 65536 * sizeof(uint32_t));
     if (c.compositor_waves > 0) ctx->comp_waves = std::max(64, (int)c.compositor_waves);
     if (getenv("MSPLAT_COMP_WAVES")) ctx->comp_waves = std::max(64, atoi(getenv("MSPLAT_COMP_WAVES")));
-    if (rc == MSPLAT_OK && getenv("MSPLAT_TILE_PROBE") != nullptr) rc = buf_alloc(ctx, ctx->probe, 65536 * 4 * sizeof(uint32_t));
+    if (rc == MSPLAT_OK && getenv("MSPLAT_TILE_PROBE") != nullptr) {
+        rc = buf_alloc(ctx, ctx->probe, kProbeBytes);
+        ctx->probe_on = rc == MSPLAT_OK;
+    }
+    if (rc == MSPLAT_OK) {
+        if (hipHostMalloc((void**)&ctx->h_flags, 64, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&ctx->d_flags, ctx->h_flags, 0) != hipSuccess)
+            rc = fail(ctx, MSPLAT_ERR_HIP, "msplat_create: cannot allocate the host-mapped status words");
+        else
+            std::memset(ctx->h_flags, 0, 64);
+    }
     if (rc == MSPLAT_OK && hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(uint32_t), ctx->stream) != hipSuccess)
         rc = MSPLAT_ERR_HIP;
     if (rc == MSPLAT_OK) {
@@ -272,6 +291,7 @@ void msplat_destroy(msplat_ctx* ctx)
     ctx->recs = Buf{};
     ctx->store.reset();
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
+    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     Buf* all[] = {&ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist,
                   &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->totals1, &ctx->tile_start, &ctx->tile_order,
                   &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe, &ctx->zq, &ctx->sprite};
@@ -283,11 +303,60 @@ void msplat_destroy(msplat_ctx* ctx)
     delete ctx;
 }
 
+static int ensure_pair_capacity(msplat_ctx* ctx, uint64_t cap);
+
+// A device-output render (msplat_render with out_is_device = 1) cannot report a pair-buffer overflow when it is
+// issued: the count is only known on the device.  bin1_downsweep leaves the number of pairs the frame needed in
+// host-mapped memory; every later msplat_sort / msplat_render / msplat_synchronize on the context looks at that
+// word (a plain host load, no synchronisation), grows the buffer when the capacity is automatic, and reports
+// MSPLAT_ERR_PAIR_OVERFLOW once: the frame that overflowed is missing splats in its last bin columns.
+// Returns MSPLAT_OK when nothing is pending; `msg` receives the text the caller reports after doing its own work.
+static int poll_async_overflow(msplat_ctx* ctx, std::string& msg)
+{
+    if (!ctx->h_flags) return MSPLAT_OK;
+    uint32_t need = __atomic_load_n(ctx->h_flags, __ATOMIC_RELAXED);
+    if (need == 0) return MSPLAT_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return fail(ctx, MSPLAT_ERR_HIP, "hipStreamSynchronize failed while handling a pair-buffer overflow");
+    need = std::max(need, __atomic_load_n(ctx->h_flags, __ATOMIC_RELAXED));     // a later frame may have needed more
+    __atomic_store_n(ctx->h_flags, 0u, __ATOMIC_RELAXED);
+    const uint64_t old_cap = ctx->pair_cap;
+    char buf[384];
+    if (ctx->cfg.pair_capacity == 0 && (uint64_t)need + (need >> 2) + 1024 <= 0x7FFFFFFFull &&
+        ensure_pair_capacity(ctx, (uint64_t)need + (need >> 2) + 1024) == MSPLAT_OK) {
+        snprintf(buf, sizeof(buf), "an earlier device-output render overflowed the pair buffer (needed %u pairs, capacity "
+                 "was %llu): that frame lacks splats in its last bin columns; capacity grown to %llu", need,
+                 (unsigned long long)old_cap, (unsigned long long)ctx->pair_cap);
+    } else {
+        snprintf(buf, sizeof(buf), "an earlier device-output render overflowed the pair buffer (needed %u pairs, capacity "
+                 "%llu%s): that frame lacks splats in its last bin columns", need, (unsigned long long)old_cap,
+                 ctx->cfg.pair_capacity ? ", fixed by msplat_config.pair_capacity" : "");
+    }
+    msg = buf;
+    return MSPLAT_ERR_PAIR_OVERFLOW;
+}
+
 int msplat_synchronize(msplat_ctx* ctx)
 {
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::string msg;
+    if (poll_async_overflow(ctx, msg) != MSPLAT_OK) return fail(ctx, MSPLAT_ERR_PAIR_OVERFLOW, "%s", msg.c_str());
+    return MSPLAT_OK;
+}
+
+// per-work-item compositor counters for the following renders (performance analysis / bench statistics;
+// costs a few clock reads per batch, so it is off by default)
+int msplat_set_tile_probe(msplat_ctx* ctx, int enable)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if (enable && !ctx->probe.p) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        int rc = buf_alloc(ctx, ctx->probe, kProbeBytes);
+        if (rc) return rc;
+    }
+    ctx->probe_on = enable != 0;
     return MSPLAT_OK;
 }
 
@@ -437,8 +506,13 @@ int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t s
     // repack: reference AoS (100 B / 244 B, arbitrary offsets) -> 16-byte aligned padded records with the
     // reference's float order (gaussiancloud.cpp:32-56), plus the vec4(x,y,z,1) array of splatrenderer.cpp:106-111
     const size_t chunk = 1u << 18;
-    std::vector<float> stage_rec(chunk * F4 * 4);
-    std::vector<float> stage_pos(chunk * 4);
+    std::vector<float> stage_rec, stage_pos;
+    try {      // the C ABI never throws
+        stage_rec.resize(chunk * F4 * 4);
+        stage_pos.resize(chunk * 4);
+    } catch (const std::exception&) {
+        return fail(ctx, MSPLAT_ERR_HIP, "msplat_upload_cloud: out of host memory for the staging buffers");
+    }
     const uint32_t src_off_base[7] = {off->pos_with_alpha, off->r_sh0, off->g_sh0, off->b_sh0,
                                       off->cov3_col0, off->cov3_col1, off->cov3_col2};
     const uint32_t src_off_full[9] = {off->r_sh1, off->r_sh2, off->r_sh3, off->g_sh1, off->g_sh2, off->g_sh3,
@@ -624,7 +698,13 @@ int msplat_upload_points(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t 
     ctx->point_mode = true;
     int rc = prepare_cloud_buffers(ctx, n, false, nullptr);
     if (rc) { ctx->point_mode = false; return rc; }
-    std::vector<float> pos((size_t)std::max<uint64_t>(n, 1) * 4), col((size_t)std::max<uint64_t>(n, 1) * 4);
+    std::vector<float> pos, col;
+    try {      // the C ABI never throws
+        pos.resize((size_t)std::max<uint64_t>(n, 1) * 4);
+        col.resize((size_t)std::max<uint64_t>(n, 1) * 4);
+    } catch (const std::exception&) {
+        return fail(ctx, MSPLAT_ERR_HIP, "msplat_upload_points: out of host memory for %llu points", (unsigned long long)n);
+    }
     const uint8_t* src = static_cast<const uint8_t*>(aos);
     for (uint64_t i = 0; i < n; ++i) {
         std::memcpy(&pos[i * 4], src + i * stride_bytes + position_offset, 12);      // vec4(pos.xyz, pos[3]) -> w unused by the cull
@@ -653,7 +733,12 @@ int msplat_download_cloud(msplat_ctx* ctx, void* aos_out, uint64_t cap_bytes)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const size_t chunk = 1u << 18;
-    std::vector<float> stage(chunk * F4 * 4);
+    std::vector<float> stage;
+    try {
+        stage.resize(chunk * F4 * 4);
+    } catch (const std::exception&) {
+        return fail(ctx, MSPLAT_ERR_HIP, "msplat_download_cloud: out of host memory");
+    }
     float* dst = static_cast<float*>(aos_out);
     for (uint64_t base = 0; base < ctx->N; base += chunk) {
         const size_t cnt = (size_t)std::min<uint64_t>(chunk, ctx->N - base);
@@ -742,6 +827,9 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
     FrameParams fp;
     int rc = make_frame_params(ctx, cameraMat, projMat, viewport, nearFar, fp);
     if (rc) return rc;
+    std::string pending_msg;
+    const int pending = poll_async_overflow(ctx, pending_msg);     // the sort itself is still performed
+    if (pending == MSPLAT_ERR_HIP) return pending;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const uint32_t N = (uint32_t)ctx->N;
@@ -789,11 +877,13 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
     }
     HIP_TRY(ctx, hipGetLastError());
     ctx->has_sort = true;
+    if (pending) return fail(ctx, pending, "%s", pending_msg.c_str());
     return MSPLAT_OK;
 }
 
-static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, size_t pitch)
+static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, size_t pitch, bool async_overflow_flag)
 {
+    uint32_t* host_flag = async_overflow_flag ? ctx->d_flags : nullptr;
     hipStream_t s = ctx->stream;
     const uint32_t N = (uint32_t)ctx->N;
     uint32_t* counters = (uint32_t*)ctx->counters.p;
@@ -829,11 +919,11 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     if (ctx->atomic_rank)
         hipLaunchKernelGGL(bin1_downsweep<true>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
                            (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,
-                           (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow);
+                           (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, host_flag);
     else
         hipLaunchKernelGGL(bin1_downsweep<false>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
                            (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,
-                           (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow);
+                           (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, host_flag);
     // pass 2: stable partition by tile row (one generic radix pass on the top byte); words become (tx<<24)|rank
     const int g2 = grid_for(div_up(cap, kPairChunk));
     hipLaunchKernelGGL(radix_upsweep<MODE_PAIR>, dim3(g2), dim3(kThreads), 0, s, (const uint32_t*)ctx->pairsA.p,
@@ -891,18 +981,18 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         // on sampled frames the dominant kernel gets exact dispatch begin/end events (the plain stream
         // markers around the stages can be processed while the previous kernel is still draining)
         hipEvent_t e0 = timed ? ctx->ev[tset][6] : nullptr, e1 = timed ? ctx->ev[tset][7] : nullptr;
+        uint32_t* probe = ctx->probe_on ? (uint32_t*)ctx->probe.p : nullptr;
+        if (probe) HIP_TRY(ctx, hipMemsetAsync(probe, 0, (size_t)ntiles * 4 * kProbeWords * sizeof(uint32_t), s));
         if (ctx->cfg.fb_format == MSPLAT_FB_RGBA16F)
             hipExtLaunchKernelGGL(composite_kernel<true>, dim3(cgrid), dim3(kCompThreads), 0, s, e0, e1, 0,
                                   (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
                                   (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap,
-                                  (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u,
-                                  (uint32_t*)ctx->probe.p);
+                                  (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u, probe);
         else
             hipExtLaunchKernelGGL(composite_kernel<false>, dim3(cgrid), dim3(kCompThreads), 0, s, e0, e1, 0,
                                   (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
                                   (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap,
-                                  (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u,
-                                  (uint32_t*)ctx->probe.p);
+                                  (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u, probe);
         ctx->comp_kernel_timed = timed;
     } else {
         ctx->comp_kernel_timed = false;
@@ -936,25 +1026,42 @@ int msplat_render(msplat_ctx* ctx, const float cameraMat[16], const float projMa
                     (unsigned long long)pitch_bytes, fp.width);
     ctx->last_fp = fp;
     if (ctx->point_mode && !ctx->sprite.p && (rc = build_sprite(ctx, nullptr, 0, 0))) return rc;   // built-in sphere sprite
+    std::string pending_msg;
+    const int pending = poll_async_overflow(ctx, pending_msg);     // an EARLIER frame; this one is still rendered
+    if (pending == MSPLAT_ERR_HIP) return pending;
 
     if (out_is_device) {
-        rc = launch_render(ctx, fp, rgba, pitch_bytes);
+        rc = launch_render(ctx, fp, rgba, pitch_bytes, true);
         if (rc) return rc;
         ctx->has_render = true;
+        if (pending) return fail(ctx, pending, "%s", pending_msg.c_str());
         return MSPLAT_OK;
     }
     // host output: render into an internal device framebuffer, copy back, grow the pair buffer on overflow
     if ((rc = buf_alloc(ctx, ctx->fb, tight * fp.height))) return rc;
     for (int attempt = 0; attempt < 6; ++attempt) {
-        if (ctx->row_mod > 1) HIP_TRY(ctx, hipMemsetAsync(ctx->fb.p, 0, tight * fp.height, ctx->stream));
-        rc = launch_render(ctx, fp, ctx->fb.p, tight);
+        rc = launch_render(ctx, fp, ctx->fb.p, tight, false);
         if (rc) return rc;
         uint32_t cnt[4];
         HIP_TRY(ctx, hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (cnt[2] == 0) {
-            HIP_TRY(ctx, hipMemcpy2D(rgba, pitch_bytes, ctx->fb.p, tight, tight, fp.height, hipMemcpyDeviceToHost));
+            if (ctx->row_mod > 1) {
+                // band mode: only the owned bin rows are written to the caller's buffer (as documented for
+                // msplat_set_band), so several bands can be assembled in one host image
+                for (int vy = 0; vy < fp.tiles_y; ++vy) {
+                    const int y0 = (vy * ctx->row_mod + ctx->row_rem) * kBin;
+                    const int rows = std::min(kBin, fp.height - y0);
+                    if (rows <= 0) break;
+                    HIP_TRY(ctx, hipMemcpy2D((char*)rgba + (size_t)y0 * pitch_bytes, pitch_bytes,
+                                             (const char*)ctx->fb.p + (size_t)y0 * tight, tight, tight, rows,
+                                             hipMemcpyDeviceToHost));
+                }
+            } else {
+                HIP_TRY(ctx, hipMemcpy2D(rgba, pitch_bytes, ctx->fb.p, tight, tight, fp.height, hipMemcpyDeviceToHost));
+            }
             ctx->has_render = true;
+            if (pending) return fail(ctx, pending, "%s", pending_msg.c_str());
             return MSPLAT_OK;
         }
         // overflow: cnt[2] holds the required pair count
@@ -1085,13 +1192,50 @@ int msplat_debug_get_projected(msplat_ctx* ctx, float* rec12, uint32_t* rect, ui
 int msplat_debug_get_tile_probe(msplat_ctx* ctx, uint32_t* dst, uint32_t tile_cap)
 {
     if (!ctx || !dst) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
-    if (!ctx->probe.p) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile probe not enabled (set MSPLAT_TILE_PROBE=1 before msplat_create)");
+    if (!ctx->probe.p || !ctx->probe_on)
+        return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile probe not enabled (msplat_set_tile_probe, or MSPLAT_TILE_PROBE=1 before msplat_create)");
     if (!ctx->has_render) return fail(ctx, MSPLAT_ERR_NO_SORT, "no render yet");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t ntiles = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y) * 4u;   // (bin, quadrant) items
     if (tile_cap < ntiles) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile capacity too small");
-    HIP_TRY(ctx, hipMemcpy(dst, ctx->probe.p, (size_t)ntiles * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(dst, ctx->probe.p, (size_t)ntiles * kProbeWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return MSPLAT_OK;
+}
+
+// sums the compositor probe of the last render (msplat_set_tile_probe): what the dominant kernel really fetched
+// and evaluated, for the roofline (bench.py) -- list entries it would fetch without early termination, pair words
+// and 48-byte records it did fetch, records that survived the exact footprint test, (pixel, splat) evaluations
+int msplat_get_composite_work(msplat_ctx* ctx, msplat_composite_work* out)
+{
+    if (!ctx || !out) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
+    std::memset(out, 0, sizeof(*out));
+    if (!ctx->probe.p || !ctx->probe_on)
+        return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile probe not enabled (msplat_set_tile_probe)");
+    if (!ctx->has_render) return fail(ctx, MSPLAT_ERR_NO_SORT, "no render yet");
+    const uint32_t items = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y) * 4u;
+    std::vector<uint32_t> h;
+    try {
+        h.resize((size_t)items * kProbeWords);
+    } catch (const std::exception&) {
+        return fail(ctx, MSPLAT_ERR_HIP, "out of host memory");
+    }
+    int rc = msplat_debug_get_tile_probe(ctx, h.data(), items);
+    if (rc) return rc;
+    for (uint32_t t = 0; t < items; ++t) {
+        const uint32_t* p = &h[(size_t)t * kProbeWords];
+        if (!p[7]) continue;
+        out->work_items += 1;
+        out->clocks_sum += p[0];
+        out->clocks_max = std::max<uint64_t>(out->clocks_max, p[0]);
+        out->records_composited += p[1];
+        out->batches += p[2];
+        out->inner_clocks_sum += p[3];
+        out->pair_words_fetched += p[4];
+        out->records_fetched += p[5];
+        out->list_entries += p[6];
+    }
+    out->pixel_evals = out->records_composited * (uint64_t)(kTile * kTile);
     return MSPLAT_OK;
 }
 

@@ -887,7 +887,8 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
                                                            const uint32_t* __restrict__ totals,
                                                            uint32_t* __restrict__ pairs_out, uint32_t cap,
                                                            uint32_t* __restrict__ d_D,
-                                                           uint32_t* __restrict__ d_overflow)
+                                                           uint32_t* __restrict__ d_overflow,
+                                                           uint32_t* __restrict__ host_flag)
 {
     constexpr int PER = kBinChunk / kThreads;          // rectangles per thread (blocked)
     __shared__ uint32_t s_off[kBinChunk + 1];          // exclusive scan of the rectangle widths
@@ -911,7 +912,12 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
         s_base[threadIdx.x] = incl - t;
         if (blockIdx.x == 0 && threadIdx.x == 255) {
             *d_D = incl;
-            if (incl > cap) *d_overflow = incl;
+            if (incl > cap) {
+                *d_overflow = incl;
+                // device-output renders never synchronise: leave the pair count this frame needed in host-mapped
+                // memory, where the next msplat_sort / msplat_render / msplat_synchronize on the context finds it
+                if (host_flag != nullptr) __hip_atomic_store(host_flag, incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
     __syncthreads();
@@ -1198,6 +1204,8 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
     const uint64_t probe_t0 = probe ? clock64() : 0ull;
     uint32_t probe_n = 0, probe_batches = 0;
     uint64_t probe_inner = 0;
+    // pair words / records whose loads have been issued so far (the prefetch pipeline runs two / one batches ahead)
+    uint32_t probe_words = min(end - start, 2u * (uint32_t)kCompThreads), probe_recs = cnt;
     while (cnt != 0u && alive != 0u) {
         // stage: record + the strips (bit k) its y-range [py - ey, py + ey] can reach in this tile
         // stage only the splats whose y-range reaches a strip that is still live, compacted in list
@@ -1258,6 +1266,8 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
         hiA -= cntA;
         probe_n += n;
         ++probe_batches;
+        probe_words += cntA;
+        probe_recs += cnt;
         const uint64_t probe_t1 = probe ? clock64() : 0ull;
         if (n != 0u) {
             float4 a = s_rec[0];          // px, py, A, B
@@ -1305,10 +1315,14 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
     }
 
     if (probe != nullptr && lane == 0) {
-        probe[tile * 4 + 0] = (uint32_t)(clock64() - probe_t0);        // shader clocks, whole tile
-        probe[tile * 4 + 1] = probe_n;          // splats composited (after culling / saturation)
-        probe[tile * 4 + 2] = probe_batches;    // batches of 64 list entries fetched
-        probe[tile * 4 + 3] = (uint32_t)probe_inner;   // shader clocks spent in the inner loops
+        probe[tile * 8 + 0] = (uint32_t)(clock64() - probe_t0);        // shader clocks, whole tile
+        probe[tile * 8 + 1] = probe_n;          // splats composited (after culling / saturation)
+        probe[tile * 8 + 2] = probe_batches;    // batches of 64 list entries staged
+        probe[tile * 8 + 3] = (uint32_t)probe_inner;   // shader clocks spent in the inner loops
+        probe[tile * 8 + 4] = probe_words;      // 4-byte pair words loaded
+        probe[tile * 8 + 5] = probe_recs;       // 48-byte projected records loaded
+        probe[tile * 8 + 6] = end - start;      // length of the bin list
+        probe[tile * 8 + 7] = 1u;               // work item ran (quadrants outside the image do not)
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -11,6 +11,7 @@
 #include <cassert>
 #include <cmath>
 #include <cstdio>
+#include <exception>
 #include <sstream>
 
 #include "../../include/msplat.h"
@@ -185,7 +186,24 @@ void QuatFromMat3(const float R[9], float q[4])
 bool Ply::Parse(std::ifstream& plyFile)
 {
     if (!ParseHeader(plyFile)) return false;
-    AllocData(vertexCount);
+    // The reference allocates vertexSize * vertexCount straight from the header (ply.cpp:80-84) and lets
+    // std::bad_alloc fly on a garbled count; here the product must not wrap and the allocation failure is a
+    // parse error (the C ABI never throws).  A merely short file is still accepted like in the reference:
+    // the tail stays zero-filled.
+    if (vertexSize != 0 && vertexCount > (size_t)0x7FFFFFFFFFFFFFFFull / vertexSize) {
+        LogE("Invalid ply file, vertex block size overflows (%s vertices of %s bytes)\n", std::to_string(vertexCount).c_str(),
+             std::to_string(vertexSize).c_str());
+        return false;
+    }
+    try {
+        AllocData(vertexCount);
+    } catch (const std::exception&) {
+        LogE("Invalid ply file, cannot allocate %s vertices of %s bytes\n", std::to_string(vertexCount).c_str(),
+             std::to_string(vertexSize).c_str());
+        vertexCount = 0;
+        data.clear();
+        return false;
+    }
     // one bulk read of the vertex block (ply.cpp:80-84); a short file leaves the tail zero-filled
     plyFile.read(reinterpret_cast<char*>(data.data()), (std::streamsize)(vertexSize * vertexCount));
     return true;
@@ -558,37 +576,62 @@ void msplat_cloud_destroy(msplat_cloud* c) { delete c; }
 
 int msplat_cloud_import_ply(msplat_cloud* c, const char* path)
 {
-    if (!c || !path) return MSPLAT_ERR_INVALID_ARG;
-    return c->gc.ImportPly(path) ? MSPLAT_OK : MSPLAT_ERR_IO;
+    try {
+        if (!c || !path) return MSPLAT_ERR_INVALID_ARG;
+        return c->gc.ImportPly(path) ? MSPLAT_OK : MSPLAT_ERR_IO;
+    } catch (const std::exception& e) {
+        LogE("%s: %s\n", __func__, e.what());
+        return MSPLAT_ERR_IO;
+    }
 }
 
 int msplat_cloud_export_ply(msplat_cloud* c, const char* path)
 {
-    if (!c || !path) return MSPLAT_ERR_INVALID_ARG;
-    return c->gc.ExportPly(path) ? MSPLAT_OK : MSPLAT_ERR_IO;
+    try {
+        if (!c || !path) return MSPLAT_ERR_INVALID_ARG;
+        return c->gc.ExportPly(path) ? MSPLAT_OK : MSPLAT_ERR_IO;
+    } catch (const std::exception& e) {
+        LogE("%s: %s\n", __func__, e.what());
+        return MSPLAT_ERR_IO;
+    }
 }
 
 int msplat_cloud_init_debug(msplat_cloud* c)
 {
-    if (!c) return MSPLAT_ERR_INVALID_ARG;
-    c->gc.InitDebugCloud();
-    return MSPLAT_OK;
+    try {
+        if (!c) return MSPLAT_ERR_INVALID_ARG;
+        c->gc.InitDebugCloud();
+        return MSPLAT_OK;
+    } catch (const std::exception& e) {
+        LogE("%s: %s\n", __func__, e.what());
+        return MSPLAT_ERR_INVALID_ARG;
+    }
 }
 
 int msplat_cloud_prune(msplat_cloud* c, const float origin[3], uint32_t keep)
 {
-    if (!c || !origin) return MSPLAT_ERR_INVALID_ARG;
-    c->gc.PruneSplats(origin, keep);
-    return MSPLAT_OK;
+    try {
+        if (!c || !origin) return MSPLAT_ERR_INVALID_ARG;
+        c->gc.PruneSplats(origin, keep);
+        return MSPLAT_OK;
+    } catch (const std::exception& e) {
+        LogE("%s: %s\n", __func__, e.what());
+        return MSPLAT_ERR_INVALID_ARG;
+    }
 }
 
 int msplat_cloud_from_attributes(msplat_cloud* c, uint64_t n, const float* xyz, const float* f_dc,
                                  const float* f_rest, const float* opacity, const float* log_scale,
                                  const float* rot)
 {
-    if (!c) return MSPLAT_ERR_INVALID_ARG;
-    return c->gc.FromAttributes((size_t)n, xyz, f_dc, f_rest, opacity, log_scale, rot) ? MSPLAT_OK
-                                                                                        : MSPLAT_ERR_INVALID_ARG;
+    try {
+        if (!c) return MSPLAT_ERR_INVALID_ARG;
+        return c->gc.FromAttributes((size_t)n, xyz, f_dc, f_rest, opacity, log_scale, rot) ? MSPLAT_OK
+                                                                                            : MSPLAT_ERR_INVALID_ARG;
+    } catch (const std::exception& e) {
+        LogE("%s: %s\n", __func__, e.what());
+        return MSPLAT_ERR_INVALID_ARG;
+    }
 }
 
 uint64_t msplat_cloud_num_gaussians(const msplat_cloud* c) { return c ? c->gc.GetNumGaussians() : 0; }
@@ -631,31 +674,36 @@ int msplat_upload_gaussian_cloud(msplat_ctx* ctx, const msplat_cloud* c)
 
 int msplat_upload_ply(msplat_ctx* ctx, const char* path, int import_full_sh)
 {
-    if (!ctx || !path) return MSPLAT_ERR_INVALID_ARG;
-    std::ifstream f(path, std::ios::binary);
-    if (!f.is_open()) {
-        LogE("failed to open %s\n", path);
+    try {
+        if (!ctx || !path) return MSPLAT_ERR_INVALID_ARG;
+        std::ifstream f(path, std::ios::binary);
+        if (!f.is_open()) {
+            LogE("failed to open %s\n", path);
+            return MSPLAT_ERR_IO;
+        }
+        Ply ply;
+        if (!ply.Parse(f)) {
+            LogE("Error parsing ply file \"%s\"\n", path);
+            return MSPLAT_ERR_IO;
+        }
+        msplat_ply_layout L;
+        L.vertex_size = (uint32_t)ply.GetVertexSize();
+        auto off = [&](const std::string& name) -> int32_t {
+            BinaryAttribute a;
+            if (!ply.GetProperty(name, a) || a.type != BinaryAttribute::Type::Float) return -1;
+            return (int32_t)a.offset;
+        };
+        L.x = off("x"); L.y = off("y"); L.z = off("z");
+        for (int i = 0; i < 3; ++i) L.f_dc[i] = off("f_dc_" + std::to_string(i));
+        for (int i = 0; i < 45; ++i) L.f_rest[i] = off("f_rest_" + std::to_string(i));
+        L.opacity = off("opacity");
+        for (int i = 0; i < 3; ++i) L.scale[i] = off("scale_" + std::to_string(i));
+        for (int i = 0; i < 4; ++i) L.rot[i] = off("rot_" + std::to_string(i));
+        return msplat_upload_ply_vertices(ctx, ply.GetRawData(), ply.GetVertexCount(), &L, import_full_sh);
+    } catch (const std::exception& e) {
+        LogE("%s: %s\n", __func__, e.what());
         return MSPLAT_ERR_IO;
     }
-    Ply ply;
-    if (!ply.Parse(f)) {
-        LogE("Error parsing ply file \"%s\"\n", path);
-        return MSPLAT_ERR_IO;
-    }
-    msplat_ply_layout L;
-    L.vertex_size = (uint32_t)ply.GetVertexSize();
-    auto off = [&](const std::string& name) -> int32_t {
-        BinaryAttribute a;
-        if (!ply.GetProperty(name, a) || a.type != BinaryAttribute::Type::Float) return -1;
-        return (int32_t)a.offset;
-    };
-    L.x = off("x"); L.y = off("y"); L.z = off("z");
-    for (int i = 0; i < 3; ++i) L.f_dc[i] = off("f_dc_" + std::to_string(i));
-    for (int i = 0; i < 45; ++i) L.f_rest[i] = off("f_rest_" + std::to_string(i));
-    L.opacity = off("opacity");
-    for (int i = 0; i < 3; ++i) L.scale[i] = off("scale_" + std::to_string(i));
-    for (int i = 0; i < 4; ++i) L.rot[i] = off("rot_" + std::to_string(i));
-    return msplat_upload_ply_vertices(ctx, ply.GetRawData(), ply.GetVertexCount(), &L, import_full_sh);
 }
 
 // ---- matrices (glm closed forms; used by Sort/Render exactly as splatrenderer.cpp:161,175,327) ----

@@ -154,9 +154,11 @@ public:
     }
 
     // blocks until every frame in flight has finished
+    // (also where a pair-buffer overflow of an earlier device-target Render is reported, see msplat_render)
     void Synchronize()
     {
-        for (msplat_ctx* h : ctxs) msplat_synchronize(h);
+        for (msplat_ctx* h : ctxs)
+            if (msplat_synchronize(h) != MSPLAT_OK) std::fprintf(stderr, "[msplat][E] Synchronize: %s\n", msplat_last_error(h));
     }
     // device-side join: `stream` (hipStream_t) waits for the frame issued last (the latest Sort's context)
     void WaitOnStream(void* stream)

@@ -1,6 +1,7 @@
 // point_scene.cpp -- PointCloud (see point_scene.hpp) and its C-ABI wrappers (include/msplat.h).
 #include "point_scene.hpp"
 
+#include <exception>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -149,12 +150,20 @@ void msplat_points_destroy(msplat_points* p) { delete p; }
 int msplat_points_import_ply(msplat_points* p, const char* path)
 {
     if (!p || !path) return MSPLAT_ERR_INVALID_ARG;
-    return p->pc.ImportPly(path) ? MSPLAT_OK : MSPLAT_ERR_IO;
+    try {
+        return p->pc.ImportPly(path) ? MSPLAT_OK : MSPLAT_ERR_IO;
+    } catch (const std::exception&) {      // the C ABI never throws (allocation failure on a garbled file)
+        return MSPLAT_ERR_IO;
+    }
 }
 int msplat_points_export_ply(const msplat_points* p, const char* path)
 {
     if (!p || !path) return MSPLAT_ERR_INVALID_ARG;
-    return p->pc.ExportPly(path) ? MSPLAT_OK : MSPLAT_ERR_IO;
+    try {
+        return p->pc.ExportPly(path) ? MSPLAT_OK : MSPLAT_ERR_IO;
+    } catch (const std::exception&) {
+        return MSPLAT_ERR_IO;
+    }
 }
 void msplat_points_init_debug(msplat_points* p) { if (p) p->pc.InitDebugCloud(); }
 uint64_t msplat_points_num(const msplat_points* p) { return p ? p->pc.GetNumPoints() : 0; }

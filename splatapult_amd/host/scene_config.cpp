@@ -66,8 +66,15 @@ private:
     void Ws() { while (p < s.size() && (s[p] == ' ' || s[p] == '\t' || s[p] == '\n' || s[p] == '\r')) ++p; }
     char Peek() { Ws(); if (p >= s.size()) throw std::runtime_error("json: unexpected end"); return s[p]; }
     void Expect(char c) { if (Peek() != c) throw std::runtime_error(std::string("json: expected '") + c + "'"); ++p; }
+    int depth = 0;                         // nesting guard: the configs this reads are 3 levels deep
+    struct DepthGuard {
+        int& d;
+        explicit DepthGuard(int& dd) : d(dd) { if (++d > 64) throw std::runtime_error("json: nesting deeper than 64"); }
+        ~DepthGuard() { --d; }
+    };
     JValue Value()
     {
+        DepthGuard guard(depth);
         const char c = Peek();
         JValue v;
         if (c == '{') {
@@ -429,7 +436,9 @@ struct Huffman
     }
 };
 
-bool Inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out)
+// max_out: the caller knows the exact decoded size (PNG: h * (1 + w * channels)); a stream that grows past it is
+// rejected at once instead of expanding a crafted file to gigabytes first
+bool Inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t max_out)
 {
     static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     static const uint16_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -445,7 +454,7 @@ bool Inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out)
             if (br.pos + 4 > br.n) return false;
             const uint32_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
             br.pos += 4;
-            if ((len ^ 0xFFFFu) != nlen || br.pos + len > br.n) return false;
+            if ((len ^ 0xFFFFu) != nlen || br.pos + len > br.n || out.size() + len > max_out) return false;
             out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
             br.pos += len;
         } else if (type == 1 || type == 2) {
@@ -486,7 +495,11 @@ bool Inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out)
             for (;;) {
                 int sym = lit.Decode(br);
                 if (sym < 0) return false;
-                if (sym < 256) { out.push_back((uint8_t)sym); continue; }
+                if (sym < 256) {
+                    if (out.size() >= max_out) return false;
+                    out.push_back((uint8_t)sym);
+                    continue;
+                }
                 if (sym == 256) break;
                 sym -= 257;
                 if (sym >= 29) return false;
@@ -494,7 +507,7 @@ bool Inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out)
                 const int ds = dist.Decode(br);
                 if (ds < 0 || ds >= 30) return false;
                 const size_t d = dbase[ds] + br.Bits(dext[ds]);
-                if (br.fail || d > out.size()) return false;
+                if (br.fail || d > out.size() || out.size() + len > max_out) return false;
                 const size_t from = out.size() - d;
                 for (size_t k = 0; k < len; ++k) out.push_back(out[from + k]);
             }
@@ -536,7 +549,8 @@ bool ReadPNG(const std::string& filename, std::vector<uint8_t>& rgba8, int& widt
     if (w == 0 || h == 0 || w > 16384 || h > 16384 || depth != 8 || channels == 0 || interlace != 0) return false;
     std::vector<uint8_t> raw;
     raw.reserve((size_t)h * (1 + (size_t)w * channels));
-    if (!Inflate(idat.data(), idat.size(), raw) || raw.size() != (size_t)h * (1 + (size_t)w * channels)) return false;
+    const size_t expect = (size_t)h * (1 + (size_t)w * channels);
+    if (!Inflate(idat.data(), idat.size(), raw, expect) || raw.size() != expect) return false;
     const size_t bpp = channels, rowBytes = (size_t)w * channels;
     std::vector<uint8_t> cur(rowBytes), prev(rowBytes, 0);
     rgba8.assign((size_t)w * h * 4, 255);

@@ -235,10 +235,21 @@ class SplatRenderer:
             self._ctx, rec.ctypes.data_as(C.POINTER(C.c_float)), rect.ctypes.data_as(C.POINTER(C.c_uint32)), rec.shape[0]))
         return rec[:v], rect[:v]
 
+    def set_tile_probe(self, enable=True):
+        """per-work-item compositor counters for the following renders (off by default: a few clock reads per batch)"""
+        for h in self._ctxs:
+            _capi.check(h, self._lib.msplat_set_tile_probe(h, 1 if enable else 0))
+
+    def composite_work(self):
+        """what the compositor fetched and evaluated in the last render (needs set_tile_probe)"""
+        w = _capi.CompositeWork()
+        _capi.check(self._ctx, self._lib.msplat_get_composite_work(self._ctx, C.byref(w)))
+        return {k: int(getattr(w, k)) for k, _ in _capi.CompositeWork._fields_}
+
     def debug_tile_probe(self):
         st = self.stats()
         nt = st["tiles_x"] * st["tiles_y"] * 4        # one slot per (bin, quadrant) work item
-        out = np.zeros((max(nt, 1), 4), np.uint32)
+        out = np.zeros((max(nt, 1), 8), np.uint32)
         _capi.check(self._ctx, self._lib.msplat_debug_get_tile_probe(
             self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.shape[0]))
         return out[:nt]

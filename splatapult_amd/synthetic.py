@@ -33,15 +33,19 @@ def _normals(seed, i0, n, channels):
 
 
 def generate(n, seed=SEED_1M, pos_sigma=1.5, pos_clip=6.0, log_scale_mean=-4.0, log_scale_sigma=0.6,
-             opacity_mean=0.5, opacity_sigma=2.0, dc_sigma=0.8, rest_sigma=0.15, full_sh=True, chunk=1 << 18):
-    """returns dict(xyz, f_dc, f_rest|None, opacity, log_scale, rot) of float32 arrays"""
+             opacity_mean=0.5, opacity_sigma=2.0, dc_sigma=0.8, rest_sigma=0.15, full_sh=True, chunk=1 << 16,
+             workers=None):
+    """returns dict(xyz, f_dc, f_rest|None, opacity, log_scale, rot) of float32 arrays.
+    Chunks are independent (counter-based generator), so they are filled by a thread pool: numpy releases the
+    GIL inside its loops, and the values do not depend on the chunking or on the number of workers."""
     xyz = np.empty((n, 3), np.float32)
     f_dc = np.empty((n, 3), np.float32)
     f_rest = np.empty((n, 45), np.float32) if full_sh else None
     opacity = np.empty(n, np.float32)
     log_scale = np.empty((n, 3), np.float32)
     rot = np.empty((n, 4), np.float32)
-    for i0 in range(0, n, chunk):
+
+    def fill(i0):
         m = min(chunk, n - i0)
         sl = slice(i0, i0 + m)
         xyz[sl] = np.clip(_normals(seed, i0, m, [0, 1, 2]) * pos_sigma, -pos_clip, pos_clip)
@@ -52,6 +56,18 @@ def generate(n, seed=SEED_1M, pos_sigma=1.5, pos_clip=6.0, log_scale_mean=-4.0, 
         f_dc[sl] = dc_sigma * _normals(seed, i0, m, [11, 12, 13])
         if full_sh:
             f_rest[sl] = rest_sigma * _normals(seed, i0, m, list(range(14, 59)))
+
+    starts = list(range(0, n, chunk))
+    if workers is None:
+        import os
+        workers = min(32, os.cpu_count() or 1)
+    if workers <= 1 or len(starts) <= 1:
+        for i0 in starts:
+            fill(i0)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            list(ex.map(fill, starts))
     return dict(xyz=xyz, f_dc=f_dc, f_rest=f_rest, opacity=opacity, log_scale=log_scale, rot=rot)
 
 

@@ -5,9 +5,12 @@ Tolerances, stated once:
   projected centre ......................................... <= 1e-3 px
   conic / colour ........................................... rel 1e-4 (abs floor 1e-6)
   fp32 framebuffer ......................................... >= 99.9 % of values within 1e-4,
-                                                             mean |diff| <= 1e-4, max |diff| <= 2e-2
-     (one discard-threshold flip at w ~ 1/256 is worth <= |c|/256 ~ 4e-3 * |c|; colours are
-      unclamped SH so |c| can exceed 1; early termination adds <= t_eps * |c|)
+                                                             mean |diff| <= 1e-4, max |diff| <= 5e-3
+     A value above 5e-3 is accepted only when the oracle EXPLAINS it: orc_composite_flip reports per pixel
+     how far fragments within 1e-4 (relative) of the w = 1/256 discard threshold can move it (one flip is
+     worth <= w (|c| + |dst|), colours are unclamped SH so |c| can exceed 1); the test asserts
+     |diff| <= 5e-3 + that budget for every pixel and prints how many pixels needed it.
+     Early termination adds <= t_eps * |c| (t_eps = 2^-14).
   alpha channel ............................................ == 1 within 1e-5
   fp16 framebuffer ......................................... vs fp32 oracle: 2e-3 + 1 fp16 ulp
 """
@@ -34,7 +37,11 @@ def make_renderer(cloud, srgb=False, **kw):
     return r
 
 
-def check_image(img, ref, max_abs=2e-2, mean_abs=1e-4, frac=0.999, tol=1e-4):
+TIGHT = 5e-3          # max abs per channel
+
+
+def check_image(img, ref, max_abs=TIGHT, mean_abs=1e-4, frac=0.999, tol=1e-4, budget=None):
+    """budget: per-pixel threshold-flip allowance from orc.composite_flip (None = plain max_abs bound)"""
     assert img.shape == ref.shape
     d = np.abs(img.astype(np.float64) - ref.astype(np.float64))
     rgb = d[..., :3]
@@ -42,8 +49,37 @@ def check_image(img, ref, max_abs=2e-2, mean_abs=1e-4, frac=0.999, tol=1e-4):
     within = (rgb <= tol).mean()
     assert within >= frac, "only %.5f of values within %g (max %.3g)" % (within, tol, rgb.max())
     assert rgb.mean() <= mean_abs, "mean |diff| %.3g" % rgb.mean()
-    assert rgb.max() <= max_abs, "max |diff| %.3g" % rgb.max()
+    worst = rgb.max(axis=-1)
+    over = worst > max_abs
+    if over.any():
+        assert budget is not None, "max |diff| %.3g in %d pixel(s), no threshold-flip budget given" % (worst.max(), over.sum())
+        unexplained = over & (worst > max_abs + budget.astype(np.float64))
+        assert not unexplained.any(), "%d pixel(s) above %g not explained by a w ~ 1/256 flip (max %.3g, budget there %.3g)" % (
+            unexplained.sum(), max_abs, worst[unexplained].max(), budget[unexplained].max())
+        print("check_image: %d pixel(s) above %g, all within the oracle's threshold-flip budget (max %.3g)"
+              % (over.sum(), max_abs, worst.max()))
     assert np.abs(img[..., 3].astype(np.float64) - 1.0).max() <= 1e-5
+
+
+def check_fp16_image(img, ref, budget):
+    """RGBA16F target against the fp32 oracle: 2e-3 + 1 fp16 ulp (the target is rounded once; the reference's
+    ROP rounds after every blend), threshold flips explained like in check_image"""
+    assert img.dtype == np.float16
+    ulp = np.abs(ref[..., :3]) * 2.0 ** -10
+    d = np.abs(img[..., :3].astype(np.float32) - ref[..., :3])
+    assert (d <= 2e-3 + ulp + budget[..., None]).all(), "max excess %.3g" % (d - 2e-3 - ulp - budget[..., None]).max()
+    assert (d <= 2e-3 + ulp).mean() > 0.999
+    assert (img[..., 3] == 1).all()
+
+
+def oracle_frame(aos, full_sh, cam, proj, vp, nf, render_cam=None, render_proj=None, srgb=False, nthreads=16,
+                 row0=0, row1=None):
+    """oracle Sort + Render with the per-pixel threshold-flip budget: dict(V, image, budget, splats, sorted_*)"""
+    ref = orc.render_frame(aos, full_sh, cam, proj, vp, nf, render_cam=render_cam, render_proj=render_proj, srgb=srgb,
+                           nthreads=nthreads, want_image=False, want_splats=True)
+    W, H = int(vp[2]), int(vp[3])
+    ref["image"], ref["budget"] = orc.composite_flip(ref["splats"], W, H, nthreads=nthreads, row0=row0, row1=row1)
+    return ref
 
 
 def run_frame(cloud, view, full_sh=True, srgb=False, **kw):
@@ -51,7 +87,7 @@ def run_frame(cloud, view, full_sh=True, srgb=False, **kw):
     r = make_renderer(cloud, srgb=srgb, **kw)
     r.Sort(cam, proj, vp, nf)
     img = r.Render(cam, proj, vp, nf)
-    ref = orc.render_frame(cloud.as_array(), full_sh, cam, proj, vp, nf, srgb=srgb, nthreads=8, want_splats=True)
+    ref = oracle_frame(cloud.as_array(), full_sh, cam, proj, vp, nf, srgb=srgb)
     return r, img, ref
 
 
@@ -214,7 +250,7 @@ def test_image_test_ply_config1(golden_dir):
     r, img, ref = run_frame(gc, view, full_sh=False)
     assert ref["V"] == 16
     np.testing.assert_array_equal(r.sorted_indices(), ref["sorted_idx"])
-    check_image(img, ref["image"])
+    check_image(img, ref["image"], budget=ref["budget"])
     assert img[..., :3].max() > 0.9
 
 
@@ -224,7 +260,7 @@ def test_image_matches_oracle(n, W, H, seed, full_sh):
     cloud = scenes.synth_cloud(n, seed, full_sh=full_sh, log_scale_mean=-3.3)
     view = scenes.default_view(W, H, yaw=0.2)
     r, img, ref = run_frame(cloud, view, full_sh=full_sh)
-    check_image(img, ref["image"])
+    check_image(img, ref["image"], budget=ref["budget"])
 
 
 def test_image_exact_mode_no_early_termination():
@@ -232,7 +268,7 @@ def test_image_exact_mode_no_early_termination():
     cloud = scenes.synth_cloud(8000, 41, log_scale_mean=-3.0)
     view = scenes.default_view(400, 300)
     r, img, ref = run_frame(cloud, view, t_epsilon=0.0)
-    check_image(img, ref["image"], mean_abs=2e-5)
+    check_image(img, ref["image"], mean_abs=2e-5, budget=ref["budget"])
 
 
 def test_image_hard_cases():
@@ -240,7 +276,7 @@ def test_image_hard_cases():
     for yaw, z in ((0.0, 7.0), (0.9, 3.0)):
         view = scenes.default_view(640, 480, yaw=yaw, z=z)
         r, img, ref = run_frame(cloud, view)
-        check_image(img, ref["image"])
+        check_image(img, ref["image"], budget=ref["budget"])
 
 
 def test_image_srgb_flag():
@@ -250,7 +286,8 @@ def test_image_srgb_flag():
     ok = np.isfinite(ref["image"]).all(axis=-1)          # pow() of a negative colour is NaN in both
     assert ok.mean() > 0.5
     d = np.abs(img[ok] - ref["image"][ok])
-    assert (d[..., :3] <= 1e-4).mean() >= 0.999 and d[..., :3].max() <= 2e-2
+    assert (d[..., :3] <= 1e-4).mean() >= 0.999
+    assert (d[..., :3].max(axis=-1) <= TIGHT + ref["budget"][ok]).all()
 
 
 def test_two_views_share_one_sort():
@@ -265,9 +302,8 @@ def test_two_views_share_one_sort():
     r.Sort(eyes[0], projs[0], vp, nf)
     for e in range(2):
         img = r.Render(eyes[e], projs[e], vp, nf)
-        ref = orc.render_frame(cloud.as_array(), True, eyes[0], projs[0], vp, nf, render_cam=eyes[e],
-                               render_proj=projs[e], nthreads=8)
-        check_image(img, ref["image"])
+        ref = oracle_frame(cloud.as_array(), True, eyes[0], projs[0], vp, nf, render_cam=eyes[e], render_proj=projs[e])
+        check_image(img, ref["image"], budget=ref["budget"])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -427,12 +463,8 @@ def test_fp16_framebuffer():
     r.Sort(cam, proj, vp, nf)
     img = r.Render(cam, proj, vp, nf)
     assert img.dtype == np.float16
-    ref = orc.render_frame(cloud.as_array(), True, cam, proj, vp, nf, nthreads=8)["image"]
-    ulp = np.abs(ref) * 2.0 ** -10
-    d = np.abs(img.astype(np.float32) - ref)
-    assert ((d <= 2e-3 + ulp) | (d <= 2e-2)).all()
-    assert (d <= 2e-3 + ulp).mean() > 0.999
-    assert (img[..., 3] == 1).all()
+    o = oracle_frame(cloud.as_array(), True, cam, proj, vp, nf)
+    check_fp16_image(img, o["image"], o["budget"])
 
 
 def test_row_bands_reassemble_bit_exact():
@@ -514,8 +546,8 @@ def test_frames_in_flight_bit_identical_to_serial_frames():
     assert rp.Init(small, False, False)
     rp.Sort(cam, proj, vp, nf)
     img = rp.Render(cam, proj, vp, nf)
-    ref = orc.render_frame(small.as_array(), True, cam, proj, vp, nf)
-    check_image(img, ref["image"])
+    ref = oracle_frame(small.as_array(), True, cam, proj, vp, nf)
+    check_image(img, ref["image"], budget=ref["budget"])
 
 
 def test_frames_in_flight_edge_cases():
@@ -549,11 +581,69 @@ def test_large_viewport_4096_matches_oracle():
     r = make_renderer(cloud)
     r.Sort(cam, proj, vp, nf)
     img = r.Render(cam, proj, vp, nf)
-    ref = orc.render_frame(cloud.as_array(), True, cam, proj, vp, nf, nthreads=16)
+    ref = oracle_frame(cloud.as_array(), True, cam, proj, vp, nf)
     assert r.sort_count() == ref["V"]
-    check_image(img, ref["image"])
+    check_image(img, ref["image"], budget=ref["budget"])
     st = r.stats()
     assert st["tiles_x"] == 128 and st["tiles_y"] == 128
+
+
+def test_device_output_pair_overflow_is_reported_on_the_next_call():
+    """VERDICT r1 / ADVICE: a device-output render cannot know that the (splat, bin) pair buffer overflowed; the
+    binning kernel leaves the needed count in host-mapped memory and the next call on the context reports
+    MSPLAT_ERR_PAIR_OVERFLOW once, after growing the buffer (unless msplat_config.pair_capacity fixed it)"""
+    import torch
+    from splatapult_amd import MsplatError, _capi
+    # screen-filling splats: ~10 M pairs at 1024x1024 (32 x 32 bins), above the 4 M-pair minimum capacity
+    cloud = scenes.synth_cloud(12000, 123, log_scale_mean=-0.5, pos_sigma=1.0)
+    W = H = 1024
+    cam, proj, vp, nf = scenes.default_view(W, H, z=4.0)
+    dev = torch.device("cuda", 0)
+    fb = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    want = make_renderer(cloud)
+    want.Sort(cam, proj, vp, nf)
+    expect = want.Render(cam, proj, vp, nf)                 # host output: grows synchronously and retries
+    need = want.stats()["pairs"]
+    assert need > (1 << 22), need
+
+    # (a) automatic capacity, error surfaces at msplat_synchronize
+    r = make_renderer(cloud)
+    cap0 = 1 << 22
+    r.Sort(cam, proj, vp, nf)
+    r.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)      # OK: nothing is known yet
+    with pytest.raises(MsplatError) as e:
+        r.synchronize()
+    assert e.value.code == _capi.ERR_PAIR_OVERFLOW and "capacity grown" in str(e.value)
+    assert not np.array_equal(fb.cpu().numpy(), expect)     # that frame really was truncated
+    r.synchronize()                                         # reported once
+    r.Sort(cam, proj, vp, nf)
+    r.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)
+    r.synchronize()
+    assert r.stats()["pair_capacity"] >= need > cap0
+    np.testing.assert_array_equal(fb.cpu().numpy(), expect)
+
+    # (b) ... or at the next Sort, which is still performed
+    r = make_renderer(cloud)
+    r.Sort(cam, proj, vp, nf)
+    r.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)
+    torch.cuda.synchronize()
+    with pytest.raises(MsplatError) as e:
+        r.Sort(cam, proj, vp, nf)
+    assert e.value.code == _capi.ERR_PAIR_OVERFLOW
+    r.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)      # uses the sort that just ran
+    r.synchronize()
+    np.testing.assert_array_equal(fb.cpu().numpy(), expect)
+
+    # (c) capacity fixed by the caller: reported, cannot grow, reported again for the next overflowing frame
+    r = make_renderer(cloud, pair_capacity=100000)
+    for _ in range(2):
+        r.Sort(cam, proj, vp, nf)
+        r.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)
+        with pytest.raises(MsplatError) as e:
+            r.synchronize()
+        assert e.value.code == _capi.ERR_PAIR_OVERFLOW and "fixed by msplat_config.pair_capacity" in str(e.value)
+    with pytest.raises(MsplatError):                        # host output with a fixed capacity fails at once
+        r.Render(cam, proj, vp, nf)
 
 
 def test_render_before_sort_and_bad_viewport_errors():
@@ -571,41 +661,133 @@ def test_render_before_sort_and_bad_viewport_errors():
 # full size (BASELINE config 2): exact sort parity + size-independent properties
 # ------------------------------------------------------------------------------------------------
 
-def test_full_size_config2_sort_and_properties():
-    n, W, H = 1_000_000, 1920, 1080
-    cloud = scenes.synth_cloud(n, 0x5EED1234)
-    cam, proj, vp, nf = scenes.default_view(W, H, z=7.0)
-    r = make_renderer(cloud)
-    r.Sort(cam, proj, vp, nf)
-    aos = cloud.as_array()
+@pytest.fixture(scope="module")
+def cloud_1m():
+    """BASELINE configs[1] / configs[4] cloud (bench.py WORKLOADS cfg2 / cfg5)"""
+    return scenes.synth_cloud(1_000_000, 0x5EED1234)
+
+
+@pytest.fixture(scope="module")
+def cloud_6m():
+    """BASELINE configs[2] fallback / configs[3] cloud (bench.py WORKLOADS cfg3 / cfg4): 6 M splats, SH3"""
+    return scenes.synth_cloud(6_000_000, 0x5EED6000, pos_sigma=3.0)
+
+
+def _check_sort_exact(r, aos, cam, proj, nf):
     mvp = orc.mat4_mul(proj, orc.mat4_inverse(cam))
     keys, idx = orc.sort(*orc.presort(aos, mvp, nf[1]))
     gk, gi = r.sorted_keys(), r.sorted_indices()
     np.testing.assert_array_equal(gk, keys)
-    np.testing.assert_array_equal(gi, idx)
+    np.testing.assert_array_equal(gi, idx)                        # stable: ties in ascending splat index
     assert (np.diff(gk.astype(np.int64)) >= 0).all()              # sortedness
     assert np.unique(gi).shape[0] == gi.shape[0]                  # a permutation of the visible set
-    img = r.Render(cam, proj, vp, nf)
+    return keys.shape[0]
+
+
+def _check_tile_lists_ascending(r):
+    """every bin list is strictly increasing in rank (draw order preserved inside bins), lists tile the pair array"""
     st = r.stats()
-    assert st["sort_count"] == keys.shape[0] and st["pairs"] > st["drawn"] > 0
-    assert np.isfinite(img).all() and (img[..., 3] == 1).all()
-    # idempotence: rendering again from the same sort is bit-identical
-    np.testing.assert_array_equal(r.Render(cam, proj, vp, nf), img)
-    # linearity in colour is not available (SH offsets), but the image must be invariant to splat order
-    # in the cloud when no keys tie: render a shuffled copy
     ts, pairs = r.debug_tile_lists()
     assert (np.diff(ts.astype(np.int64)) >= 0).all() and ts[-1] == st["pairs"]
-    # every tile list is strictly increasing in rank (draw order preserved inside tiles)
     ranks = (pairs & 0xFFFFFF).astype(np.int64)
     d = np.diff(ranks)
     starts = ts[1:-1][(ts[1:-1] > 0) & (ts[1:-1] < ranks.shape[0])]
     d[starts - 1] = 1
     assert (d > 0).all()
-    # bounded oracle comparison: a 256x256 window of the full frame
-    ref = orc.render_frame(aos, True, cam, proj, vp, nf, nthreads=8, want_image=False, want_splats=True)
-    y0, y1 = 412, 668
-    win = orc.composite(ref["splats"], W, H, nthreads=8, row0=y0, row1=y1)
-    check_image(img[y0:y1], win[y0:y1])
+    return st
+
+
+def _check_window(img, aos, W, H, cam, proj, nf, y0, y1, render_cam=None, render_proj=None, fp16=False):
+    """bounded oracle comparison at full workload: rows [y0, y1) of the frame"""
+    ref = orc.render_frame(aos, True, cam, proj, [0, 0, W, H], nf, render_cam=render_cam, render_proj=render_proj,
+                           nthreads=32, want_image=False, want_splats=True)
+    win, bud = orc.composite_flip(ref["splats"], W, H, nthreads=32, row0=y0, row1=y1)
+    if fp16:
+        check_fp16_image(img[y0:y1], win[y0:y1], bud[y0:y1])
+    else:
+        check_image(img[y0:y1], win[y0:y1], budget=bud[y0:y1])
+    return ref
+
+
+def test_full_size_config2_sort_and_properties(cloud_1m):
+    n, W, H = 1_000_000, 1920, 1080
+    cloud = cloud_1m
+    cam, proj, vp, nf = scenes.default_view(W, H, z=7.0)
+    r = make_renderer(cloud)
+    r.Sort(cam, proj, vp, nf)
+    aos = cloud.as_array()
+    V = _check_sort_exact(r, aos, cam, proj, nf)
+    img = r.Render(cam, proj, vp, nf)
+    st = _check_tile_lists_ascending(r)
+    assert st["sort_count"] == V and st["pairs"] > st["drawn"] > 0
+    assert np.isfinite(img).all() and (img[..., 3] == 1).all()
+    # idempotence: rendering again from the same sort is bit-identical
+    np.testing.assert_array_equal(r.Render(cam, proj, vp, nf), img)
+    _check_window(img, aos, W, H, cam, proj, nf, 412, 668)
+
+
+def test_full_size_config3_6m_1080p(cloud_6m):
+    """BASELINE configs[2] (synthetic stand-in for the 6 M-splat Inria scene), 1920x1080 fp32: exact keys and
+    permutation, ordered bin lists, 256-row oracle window"""
+    W, H = 1920, 1080
+    cam, proj, vp, nf = scenes.default_view(W, H, z=12.0)
+    r = make_renderer(cloud_6m)
+    r.Sort(cam, proj, vp, nf)
+    aos = cloud_6m.as_array()
+    V = _check_sort_exact(r, aos, cam, proj, nf)
+    assert V > 5_000_000
+    img = r.Render(cam, proj, vp, nf)
+    st = _check_tile_lists_ascending(r)
+    assert st["sort_count"] == V and st["pairs"] > st["drawn"] > 4_000_000
+    assert np.isfinite(img).all() and (img[..., 3] == 1).all()
+    _check_window(img, aos, W, H, cam, proj, nf, 412, 668)
+
+
+def test_full_size_config4_6m_4096_and_8_bands(cloud_6m):
+    """BASELINE configs[3]: the 6 M cloud at 4096x4096 fp32 -- single-context frame vs a 128-row oracle window,
+    and the 8-GPU sharding (interleaved 32-px bin rows, band-restricted cull) reassembling bit-exactly"""
+    W = H = 4096
+    cam, proj, vp, nf = scenes.default_view(W, H, z=12.0)
+    r = make_renderer(cloud_6m)
+    r.Sort(cam, proj, vp, nf)
+    full = r.Render(cam, proj, vp, nf)
+    V = r.sort_count()
+    st = _check_tile_lists_ascending(r)
+    assert st["tiles_x"] == 128 and st["tiles_y"] == 128 and st["pairs"] > 20_000_000
+    assert np.isfinite(full).all() and (full[..., 3] == 1).all()
+    _check_window(full, cloud_6m.as_array(), W, H, cam, proj, nf, 1984, 2112)
+    G = 8
+    acc = np.zeros_like(full)
+    part = np.zeros_like(full)
+    vs = []
+    for g in range(G):
+        r.set_band(G, g, band_cull=True)
+        r.Sort(cam, proj, vp, nf)
+        vs.append(r.sort_count())
+        r.Render(cam, proj, vp, nf, out=part)
+        rows = np.arange(H) // bin_px() % G == g
+        acc[rows] = part[rows]
+    np.testing.assert_array_equal(acc, full)
+    assert max(vs) < 0.5 * V, (vs, V)          # the band cull really shrinks the per-rank sort
+
+
+def test_full_size_config5_stereo_fp16(cloud_1m):
+    """BASELINE configs[4]: 1 M splats, two asymmetric views of 2016x2240, RGBA16F target, ONE sort with view 0
+    (app.cpp:603-607); both eyes against a 256-row oracle window with the fp16 tolerance"""
+    W, H = 2016, 2240
+    cam0 = camera.pose((0.0, 0.0, 7.0))
+    eyes = [camera.translate_local(cam0, dx=-0.032), camera.translate_local(cam0, dx=+0.032)]
+    projs = [camera.create_projection(-1.0, 0.8, 0.95, -0.95), camera.create_projection(-0.8, 1.0, 0.95, -0.95)]
+    vp, nf = [0, 0, W, H], scenes.NF
+    r = make_renderer(cloud_1m, fb_format="fp16")
+    r.Sort(eyes[0], projs[0], vp, nf)
+    aos = cloud_1m.as_array()
+    _check_sort_exact(r, aos, eyes[0], projs[0], nf)
+    for e in range(2):
+        img = r.Render(eyes[e], projs[e], vp, nf)
+        assert img.dtype == np.float16 and img.shape == (H, W, 4)
+        _check_tile_lists_ascending(r)
+        _check_window(img, aos, W, H, eyes[0], projs[0], nf, 992, 1248, render_cam=eyes[e], render_proj=projs[e], fp16=True)
 
 
 def test_large_cloud_uses_the_wide_scan_path():
@@ -617,7 +799,7 @@ def test_large_cloud_uses_the_wide_scan_path():
     r = make_renderer(cloud)
     r.Sort(cam, proj, vp, nf)
     img = r.Render(cam, proj, vp, nf)
-    ref = orc.render_frame(cloud.as_array(), False, cam, proj, vp, nf, nthreads=16, want_splats=True)
+    ref = oracle_frame(cloud.as_array(), False, cam, proj, vp, nf)
     assert r.sort_count() == ref["V"] and ref["V"] > 2_100_000
     np.testing.assert_array_equal(r.sorted_indices(), ref["sorted_idx"])
     np.testing.assert_array_equal(r.sorted_keys(), ref["sorted_keys"])
@@ -625,7 +807,7 @@ def test_large_cloud_uses_the_wide_scan_path():
     for b in np.random.default_rng(0).integers(0, len(ts) - 1, size=40):
         ranks = pairs[ts[b]:ts[b + 1]] & 0xFFFFFF
         assert (np.diff(ranks.astype(np.int64)) > 0).all()
-    check_image(img, ref["image"])
+    check_image(img, ref["image"], budget=ref["budget"])
 
 
 def test_cpp_shim_renders_like_the_python_mirror(tmp_path, golden_dir):
@@ -649,8 +831,8 @@ def test_cpp_shim_renders_like_the_python_mirror(tmp_path, golden_dir):
     assert gc.ImportPly(ply)
     cam = camera.pose((0.0, 0.0, 5.0))
     proj = camera.perspective(np.float32(45.0 * 3.14159265358979 / 180.0), W / H)
-    ref = orc.render_frame(gc.as_array(), True, cam, proj, [0, 0, W, H], scenes.NF)
-    check_image(img, ref["image"])
+    ref = oracle_frame(gc.as_array(), True, cam, proj, [0, 0, W, H], scenes.NF)
+    check_image(img, ref["image"], budget=ref["budget"])
     assert img[..., :3].max() > 0.5
 
 

@@ -200,3 +200,42 @@ def test_generator_known_answers(golden_dir):
         np.testing.assert_array_equal(big[k], again[k])
     assert abs(float(np.linalg.norm(big["rot"], axis=1).mean()) - 1.0) < 1e-6
     assert np.abs(big["xyz"]).max() <= 6.0
+
+
+def test_hostile_inputs_fail_without_throwing_across_the_c_abi(tmp_path):
+    """a garbled vertex count, a decompression bomb and a deeply nested JSON must come back as error
+    codes (the C ABI never throws; a C or ctypes caller would otherwise die in std::terminate)"""
+    import struct
+    import zlib
+    import ctypes as C
+    from splatapult_amd import GaussianCloud, PointCloud, _capi, camera
+    hdr = "ply\nformat binary_little_endian 1.0\nelement vertex %s\nproperty float x\nproperty float y\nproperty float z\nend_header\n"
+    for count in ("9223372036854775807", "4611686018427387904", "1152921504606846976"):       # overflow / bad_alloc
+        p = tmp_path / ("huge_%s.ply" % count[:4])
+        p.write_bytes((hdr % count).encode() + b"\0" * 36)
+        assert not GaussianCloud().ImportPly(str(p))
+        assert not PointCloud(False).ImportPly(str(p))
+    # a short file is still accepted like the reference does (tail zero-filled, ply.cpp:80-84): 3 vertices announced, 1 present
+    p = tmp_path / "short.ply"
+    full = ("ply\nformat binary_little_endian 1.0\nelement vertex 3\n" + "".join(
+        "property float %s\n" % n for n in ["x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2", "opacity", "scale_0", "scale_1",
+                                            "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]) + "end_header\n").encode()
+    p.write_bytes(full + struct.pack("<14f", 1, 2, 3, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0))
+    gc = GaussianCloud(GaussianCloud.Options(False, False))
+    assert gc.ImportPly(str(p)) and gc.GetNumGaussians() == 3
+    # PNG whose IDAT inflates to 64 MB behind a 4x4 IHDR: rejected as soon as the stream outgrows 4 * (1 + 4*4) bytes
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    bomb = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 6, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(b"\0" * (64 << 20), 9)) + chunk(b"IEND", b""))
+    pb = tmp_path / "bomb.png"
+    pb.write_bytes(bomb)
+    w, h = C.c_uint32(), C.c_uint32()
+    out = np.zeros((4, 4, 4), np.uint8)
+    assert _capi.lib().msplat_read_image(str(pb).encode(), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h)) != _capi.OK
+    # JSON nested 10 000 deep: an error, not a stack overflow
+    pj = tmp_path / "cameras.json"
+    pj.write_text("[" * 10000 + "]" * 10000)
+    with pytest.raises(Exception):
+        camera.load_cameras_json(str(pj))

@@ -6,12 +6,29 @@
          --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one frame = SplatRenderer::Sort + SplatRenderer::Render of the resident cloud from a
-camera on a 64-step orbit (stereo workloads: one Sort + two Renders).  With N > 1 the frame's tile
+camera on a 64-step orbit (stereo workloads: one Sort + two Renders).  With N > 1 the frame's bin
 rows are sharded across the ranks (interleaved, row % N == rank) and gathered to rank 0 over RCCL:
 total work is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
 
+What is measured:
+  value / ms_per_step ... EXACTLY `--steps` frames between barrier + synchronize on both sides, `--frames-in-flight`
+                          frames overlapped on the GPU (default 4).  The block is repeated until >= 0.25 s of frames
+                          have been timed and the MEDIAN block is reported (a 20-frame block lasts 4 ms).
+  serial ................ the same frames strictly one after the other on ONE stream (a second renderer, 8192 compositor
+                          waves): single-frame latency, and every kernel has the GPU to itself, so its launch duration
+                          is a clean per-kernel number.  `roofline` is computed from THIS phase; the rocprofv3 summary
+                          to compare it with is the one of `bench.py --frames-in-flight 1` (profiles/).
+  roofline .............. dominant kernel (composite_kernel): bytes it fetches under its front-to-back early-termination
+                          contract (4 B per list entry + 48 B per projected record actually loaded, counted by the
+                          kernel's own probe on extra frames, + the framebuffer write) / serial launch duration vs
+                          8 TB/s; beside it the SURVEY 8d formula bytes (52 D + W H bpp), the PMC traffic, and the
+                          VALU view -- (pixel, splat) evaluations/s and their share of the 157.3 TFLOP/s fp32 vector
+                          peak at SURVEY's 20 flop per evaluation -- because VALU, not HBM, bounds this kernel.
+  cpu_baseline .......... the oracle (C restatement of the reference shaders, OpenMP row bands) on the host cores, on a
+                          bounded sample of the same workload; rank 0, N = 1 only.
+
 PyTorch is plumbing only (device selection, the framebuffer tensor, torch.distributed); all compute
-is libmsplat.so's HIP kernels launched on torch's current stream.
+is libmsplat.so's HIP kernels.
 """
 import argparse
 import json
@@ -45,100 +62,57 @@ WORKLOADS = {
     "tiny": dict(n=20_000, seed=7, pos_sigma=1.5, W=640, H=360, cam_z=7.0, fb="fp32", views=1,
                  desc="20k synthetic Gaussians, 640x360 (debug)"),
 }
-HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md
+VALU_PEAK = 157.3e12     # fp32 vector FLOP/s, MI355X_MICROARCH.md
+FLOP_PER_EVAL = 20.0     # ~20 flop + 1 transcendental per (pixel, splat)
+MIN_TIMED_SECONDS = 0.25
+MAX_BLOCKS = 64
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--ply", default=None, help="render a real scene instead of the synthetic workload (BASELINE configs[2]: "
-                    "Inria point_cloud.ply); cameras.json next to it (or up to two directories above) is replayed")
-    ap.add_argument("--save-image", default=None, help="write the last frame of rank 0 as PNG")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=0, help="CPU baseline frames (0 = auto, about 10-30 s)")
-    ap.add_argument("--profile-frames", type=int, default=8, help="extra frames (outside the timed region) for V/D statistics")
-    ap.add_argument("--prewarm", type=int, default=400, help="untimed frames before the warm-up (runtime pool growth)")
-    ap.add_argument("--frames-in-flight", type=int, default=4,
-                    help="frames overlapped on the GPU (one context + stream + framebuffer per frame in flight, one shared "
-                         "cloud); 1 = strictly serial frames (latency mode)")
-    ap.add_argument("--timing-stride", type=int, default=8,
-                    help="record per-stage hipEvents on every n-th frame of the timed region (0 = never)")
-    args = ap.parse_args()
+class Env:
+    """process-wide state shared by the measurements of one bench invocation"""
 
+
+def measure(E, args, key, ply=None, primary=True):
+    """one workload on the current process group; returns the JSON dict (rank 0 uses it)"""
     import torch
     import torch.distributed as dist
-    import __graft_entry__ as graft
-    from splatapult_amd import SplatRenderer, camera, synthetic
+    from splatapult_amd import SplatRenderer, camera, synthetic, _capi
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
-    if rank == 0:
-        graft.build()
-    # MSPLAT_BENCH_ONE_DEVICE=1: debug aid for 1-GPU boxes -- every rank uses device 0 and the gather
-    # runs over gloo; it exercises the N > 1 control flow (bands, gather, max-over-ranks timing), not xGMI.
-    one_dev = os.environ.get("MSPLAT_BENCH_ONE_DEVICE") == "1"
-    if one_dev:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        if one_dev:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-        dist.barrier()
-
-    wl = dict(WORKLOADS[args.workload])
+    rank, world, dev, stream = E.rank, E.world, E.dev, E.stream
+    wl = dict(WORKLOADS[key])
     W, H, views = wl["W"], wl["H"], wl["views"]
-    t0 = time.time()
     scene_cams = None
-    if args.ply:
+    if ply:
         from splatapult_amd import GaussianCloud
         cloud = GaussianCloud()
-        if not cloud.ImportPly(args.ply):
-            raise SystemExit("cannot import " + args.ply)
+        if not cloud.ImportPly(ply):
+            raise SystemExit("cannot import " + ply)
         wl["n"] = cloud.GetNumGaussians()
-        wl["desc"] = "%s (%d splats), %dx%d %s" % (os.path.basename(args.ply), wl["n"], W, H, wl["fb"])
-        cj = camera.find_config_file(args.ply, "cameras.json")          # app.cpp:418-461
+        wl["desc"] = "%s (%d splats), %dx%d %s" % (os.path.basename(ply), wl["n"], W, H, wl["fb"])
+        cj = camera.find_config_file(ply, "cameras.json")          # app.cpp:418-461
         if cj:
             scene_cams = [m for m, _ in camera.load_cameras_json(cj)]
     else:
         cloud = synthetic.make_cloud(wl["n"], seed=wl["seed"], full_sh=True, pos_sigma=wl["pos_sigma"])
     n = wl["n"]
-    t_gen = time.time() - t0
 
-    # a dedicated (non-null) torch stream: libmsplat launches on it, so torch copies, RCCL's stream
-    # hand-off and torch.cuda.synchronize all order correctly with the HIP kernels
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
     P = max(1, args.frames_in_flight)
-    r = SplatRenderer(device=local_rank, fb_format=wl["fb"], stream=stream.cuda_stream, enable_timing=args.timing_stride,
-                      frames_in_flight=P)
+    r = SplatRenderer(device=E.local_rank, fb_format=wl["fb"], stream=stream.cuda_stream,
+                      enable_timing=args.timing_stride, frames_in_flight=P)
     if not r.Init(cloud, False, False):
         raise SystemExit("Init failed: " + r.last_error())
     if world > 1:
         # mono workloads may also restrict the cull to the band (every Render uses its Sort's camera)
-        r.set_band(world, rank, band_cull=(wl["views"] == 1))
+        r.set_band(world, rank, band_cull=(views == 1))
 
-    from splatapult_amd import _capi
     TILE = _capi.lib().msplat_tile_size()
     tiles_y = (H + TILE - 1) // TILE
     Hpad = tiles_y * TILE
     fdt = torch.float16 if wl["fb"] == "fp16" else torch.float32
     bpp = 8 if wl["fb"] == "fp16" else 16
-    # one framebuffer set per frame in flight
     fb_sets = [[torch.zeros((Hpad, W, 4), dtype=fdt, device=dev) for _ in range(views)] for _ in range(P)]
-    fbs = fb_sets[0]
-    fb_free = [None] * P      # N > 1: event recorded after the gather that read the slot's framebuffers
+    fb_free = [None] * P      # N > 1: event recorded after the gather that read / filled the slot's framebuffers
     vp, nf = [0, 0, W, H], [camera.Z_NEAR, camera.Z_FAR]
     if views == 1:
         projs = [camera.perspective(camera.FOVY, W / H)]
@@ -154,31 +128,33 @@ def main():
             return [c]
         return [camera.translate_local(c, dx=-0.032), camera.translate_local(c, dx=+0.032)]
 
-    # the only exchange step: gather each rank's tile rows to rank 0 (splatapult_amd/dist.py)
+    # the only exchange step: every rank's bin rows go straight into rank 0's framebuffer (splatapult_amd/dist.py)
     gathers = None
     if world > 1:
         from splatapult_amd.dist import BandGather
         gathers = [BandGather(tiles_y, W, fdt, dev, rank, world, tile=TILE) for _ in range(views)]
+    state = {"fbs": fb_sets[0]}
 
-    def frame(step):
-        nonlocal fbs
+    def frame(step, rr=r, sets=fb_sets):
         cams = cams_for(step)
-        if P > 1 and gathers is not None:
-            ev = fb_free[(r.frame_slot + 1) % P]
+        Pn = len(sets)
+        if Pn > 1 and gathers is not None:
+            ev = fb_free[(rr.frame_slot + 1) % Pn]
             if ev is not None:
-                r.next_frame_wait_event(ev.cuda_event)         # the slot's previous frame has been gathered
-        r.Sort(cams[0], projs[0], vp, nf)                      # sort once with view 0 (app.cpp:603-606)
-        fbs = fb_sets[r.frame_slot]
+                rr.next_frame_wait_event(ev.cuda_event)         # the slot's previous frame has been gathered
+        rr.Sort(cams[0], projs[0], vp, nf)                      # sort once with view 0 (app.cpp:603-606)
+        fbs = sets[rr.frame_slot % Pn]
+        state["fbs"] = fbs
         for v in range(views):
-            r.Render(cams[v], projs[v], vp, nf, out_ptr=fbs[v].data_ptr(), pitch_bytes=W * bpp)
+            rr.Render(cams[v], projs[v], vp, nf, out_ptr=fbs[v].data_ptr(), pitch_bytes=W * bpp)
             if gathers is not None:
-                if P > 1:
-                    r.wait_on_stream(stream.cuda_stream)       # the gather's stream waits for this frame only
+                if Pn > 1:
+                    rr.wait_on_stream(stream.cuda_stream)       # the gather's stream waits for this frame only
                 gathers[v](fbs[v])
-        if P > 1 and gathers is not None:
+        if Pn > 1 and gathers is not None:
             ev = torch.cuda.Event()
             ev.record(stream)
-            fb_free[r.frame_slot] = ev
+            fb_free[rr.frame_slot] = ev
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -187,50 +163,87 @@ def main():
             torch.cuda.synchronize(dev)
 
     # The HIP runtime grows its per-queue kernarg / signal pools once, a few thousand launches after start-up
-    # (measured: a single 15-40 ms stall around frame 170-210, scratch timeline in DESIGN.md 6): get past it
-    # before the official warm-up so that short --steps runs measure the steady state too.
+    # (a single 15-40 ms stall around frame 170-210): get past it before the official warm-up
     for s in range(args.prewarm):
         frame(s)
     sync_all()
     for s in range(args.warmup):
         frame(s)
-    sync_all()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        frame(args.warmup + s)
-    enqueue = time.perf_counter() - t0        # host time to issue the frames (launch-rate bound check)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    # per-stage / per-kernel times: hipEvents recorded on the launch stream on every `timing_stride`-th
-    # frame INSIDE the timed region (the markers cost a few us each, hence sampled); averaged here
+    # ---- the timed region: blocks of EXACTLY --steps frames, barrier + synchronize on both sides ----
+    def timed_block(first_step):
+        sync_all()
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            frame(first_step + s)
+        enq = time.perf_counter() - t0            # host time to issue the frames (launch-rate bound check)
+        sync_all()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())                  # identical on every rank: the block count below agrees too
+        return el, enq
+
+    blocks, enqs = [], []
+    el, enq = timed_block(args.warmup)
+    blocks.append(el); enqs.append(enq)
+    nblocks = int(min(MAX_BLOCKS, max(1, math.ceil(MIN_TIMED_SECONDS / max(el, 1e-6)))))
+    for b in range(1, nblocks):
+        el, enq = timed_block(args.warmup + b * args.steps)
+        blocks.append(el); enqs.append(enq)
+    elapsed = float(np.median(blocks))
+    enqueue = float(np.median(enqs))
     prof = dict(sort_total=0.0, render_total=0.0, project=0.0, binning=0.0, composite=0.0, composite_kernel=0.0)
     if args.timing_stride > 0:
-        prof = r.timings()
-    # V / D statistics on a few extra frames outside the timed region (each read synchronises)
-    Vs, Ds, drawn, Dbin = [], [], [], []
-    for s in range(max(1, args.profile_frames)):
-        frame(args.warmup + args.steps + s)
-        st = r.stats()
-        Vs.append(st["sort_count"]); Ds.append(st["pairs_tile16"]); drawn.append(st["drawn"]); Dbin.append(st["pairs"])
-    st = r.stats()
-    V, D = float(np.mean(Vs)), float(np.mean(Ds))
-    # latency of ONE frame with nothing else in flight (outside the timed region)
+        prof = r.timings()                        # sampled stage events of the overlapped frames
+
+    # ---- serial phase: the same frames one at a time on ONE stream (clean per-kernel durations, latency) ----
+    if P == 1:
+        rs, rs_sets = r, fb_sets
+    else:
+        rs = SplatRenderer(device=E.local_rank, fb_format=wl["fb"], stream=stream.cuda_stream, enable_timing=1,
+                           frames_in_flight=1)
+        if not rs.Init(cloud, False, False):
+            raise SystemExit("Init (serial renderer) failed: " + rs.last_error())
+        if world > 1:
+            rs.set_band(world, rank, band_cull=(views == 1))
+        rs_sets = [fb_sets[0]]
+    for s in range(24):
+        frame(s, rs, rs_sets)
+    sync_all()
+    if args.timing_stride > 0 or P > 1:
+        rs.timings()                              # drop the warm-up samples
+    SER = args.serial_frames
+    t0 = time.perf_counter()
+    for s in range(SER):
+        frame(args.warmup + s, rs, rs_sets)
+    sync_all()
+    serial_ms = 1e3 * (time.perf_counter() - t0) / SER
+    prof_serial = rs.timings() if (args.timing_stride > 0 or P > 1) else None
     lat = []
-    for s in range(16 * P):
+    for s in range(16):
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
-        frame(args.warmup + args.steps + 64 + s)
+        frame(args.warmup + SER + s, rs, rs_sets)
         torch.cuda.synchronize(dev)
         lat.append(time.perf_counter() - t1)
     latency_ms = 1e3 * float(np.median(lat))
-    prof_serial = r.timings() if args.timing_stride > 0 else None     # the same events, frames not overlapped
+
+    # ---- statistics frames (outside every timed region; each read synchronises) ----
+    Vs, Ds, drawn, Dbin, works = [], [], [], [], []
+    rs.set_tile_probe(True)
+    for s in range(max(1, args.profile_frames)):
+        frame(args.warmup + s * 7, rs, rs_sets)
+        st = rs.stats()
+        Vs.append(st["sort_count"]); Ds.append(st["pairs_tile16"]); drawn.append(st["drawn"]); Dbin.append(st["pairs"])
+        if views == 1:
+            works.append(rs.composite_work())
+    rs.set_tile_probe(False)
+    V, D = float(np.mean(Vs)), float(np.mean(Ds))
+    work = {k: float(np.mean([w[k] for w in works])) for k in works[0]} if works else None
     if world > 1:
-        t = torch.tensor([V, D, prof["composite"]], dtype=torch.float64, device=dev)
+        t = torch.tensor([V, D], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         D_total = float(t[1].item())
     else:
@@ -238,67 +251,172 @@ def main():
 
     fps = args.steps / elapsed
     ms = 1e3 * elapsed / args.steps
-    # algorithmic bytes (SURVEY.md 8d / BASELINE.md):  B = 16 N + (8+68+S+48) V + views (52 D + W H bpp)
+    # algorithmic bytes of the whole frame:  B = 16 N + (8+68+S+48) V + views (52 D + W H bpp)
     S = 244
     B_frame = 16.0 * n + (8 + 68 + S + 48) * V + (52.0 * D_total + W * H * bpp) * views
-    # dominant kernel: composite.  per launch: 52 B per (splat,tile) pair + the framebuffer write
-    B_comp = 52.0 * D + (W * H * bpp) / world
-    comp_ms = prof.get("composite_kernel", 0.0) or prof["composite"]   # exact kernel begin/end events
-    comp_s = comp_ms * 1e-3
-    achieved = B_comp / comp_s if comp_s > 0 else 0.0
-    # HBM traffic of the dominant kernel comes from a SEPARATE rocprofv3 --pmc run (tools/pmc_traffic.sh:
-    # FETCH_SIZE / WRITE_SIZE in their own passes, gfx950 x2 correction on FETCH_SIZE); the committed
-    # summary is only quoted for the workload it was measured on
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.workload)
-    if world == 1 and os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            key = "msplat::composite_kernel<%s>" % ("true" if wl["fb"] == "fp16" else "false")
-            traffic = tj[key]["hbm_bytes_per_launch_corrected"]
-        except (KeyError, ValueError):
-            traffic = None
-
+    # dominant kernel: composite_kernel, one launch per view, measured with the GPU to itself (serial phase)
+    fb_bytes = (W * H * bpp) / world
+    B_formula = 52.0 * D + fb_bytes                         # every (splat, 16x16 tile) pair fetched
+    comp_serial_ms = (prof_serial or {}).get("composite_kernel", 0.0) or (prof_serial or {}).get("composite", 0.0)
+    comp_overlap_ms = prof.get("composite_kernel", 0.0) or prof.get("composite", 0.0)
+    if work:
+        B_fetched = 4.0 * work["pair_words_fetched"] + 48.0 * work["records_fetched"] + fb_bytes
+    else:
+        B_fetched = None
+    B_used = B_fetched if B_fetched is not None else B_formula
+    comp_s = comp_serial_ms * 1e-3
+    achieved = B_used / comp_s if comp_s > 0 else 0.0
+    # HBM traffic of the dominant kernel comes from a SEPARATE rocprofv3 --pmc run of `bench.py --frames-in-flight 1`
+    # (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE in their own passes, gfx950 x2 correction on FETCH_SIZE);
+    # the committed summary is only quoted for the workload it was measured on
+    traffic, tsrc = None, None
+    for rnd in ("r02", "r01"):
+        tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, key))
+        if world == 1 and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                kname = "msplat::composite_kernel<%s>" % ("true" if wl["fb"] == "fp16" else "false")
+                traffic = tj[kname]["hbm_bytes_per_launch_corrected"]
+                tsrc = "profiles/%s (rocprofv3 --pmc of bench.py --frames-in-flight 1, bytes per launch)" % os.path.basename(tpath)
+                break
+            except (KeyError, ValueError):
+                traffic = None
+    roof = {
+        "kernel": "composite_kernel", "bound": "hbm", "limiter": "valu (exp + blend per pixel-splat); the HBM fraction is honest-but-low",
+        "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+        "traffic": traffic, "traffic_source": tsrc,
+        "bytes_per_launch": B_used,
+        "bytes_definition": ("fetched under early termination: 4 B x %.0f list entries + 48 B x %.0f records (of %.0f list entries "
+                             "in the bins) + %.0f B framebuffer" % (work["pair_words_fetched"], work["records_fetched"],
+                                                                   work["list_entries"], fb_bytes)) if work
+                            else "SURVEY 8d formula 52 D + W H bpp (stereo workload: no probe)",
+        "formula_bytes_per_launch": B_formula,
+        "formula_frac": (B_formula / comp_s / HBM_PEAK) if comp_s > 0 else None,
+        "avg_launch_ms": comp_serial_ms,
+        "avg_launch_source": "hipExtLaunchKernelGGL begin/end events on the launch stream, %d serial frames (kernel alone on the GPU)"
+                             % (prof_serial or {}).get("frames_averaged", 0),
+        "avg_launch_ms_overlapped": comp_overlap_ms if P > 1 else None,
+        "valu": ({"pixel_splat_evals_per_launch": work["pixel_evals"],
+                  "gevals_per_sec": work["pixel_evals"] / comp_s / 1e9,
+                  "tflops_at_20_flop_per_eval": work["pixel_evals"] * FLOP_PER_EVAL / comp_s / 1e12,
+                  "frac_of_fp32_vector_peak": work["pixel_evals"] * FLOP_PER_EVAL / comp_s / VALU_PEAK,
+                  "records_composited_per_launch": work["records_composited"],
+                  "work_items": work["work_items"]} if (work and comp_s > 0) else None),
+        # the frame's HBM-bound kernel, for comparison: project_kernel gathers 256 B per visible splat (244 B record padded
+        # to 4 lines) + 4 B index and writes 52 B; stage time from stream markers, serial frames
+        "project_kernel_frac": ((312.0 * V) / (prof_serial["project"] * 1e-3) / HBM_PEAK)
+        if prof_serial and prof_serial.get("project", 0) > 0 else None,
+    }
     out = {
         "metric": "frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.ply else "file",
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not ply else "file",
         "gsplats_per_sec": n * fps / 1e9,
-        "config": {"workload": wl["desc"], "key": args.workload, "splats": n, "width": W, "height": H,
-                   "views": views, "framebuffer": wl["fb"], "sharding": "tile rows, row %% %d == rank" % world,
+        "rccl_ranks": world if (world > 1 and not E.one_dev) else (0 if world > 1 else 1),
+        "config": {"workload": wl["desc"], "key": key, "splats": n, "width": W, "height": H,
+                   "views": views, "framebuffer": wl["fb"], "sharding": "bin rows, row %% %d == rank" % world,
                    "frames_in_flight": P, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                    "visible_V": V, "pairs_D": D_total, "pairs_binned_32px": float(np.mean(Dbin)),
                    "drawn": float(np.mean(drawn))},
+        "timed_blocks": len(blocks), "block_ms": [1e3 * b for b in blocks],
+        "serial": {"frames_per_sec": 1e3 / serial_ms, "ms_per_frame": serial_ms, "frames": SER,
+                   "single_frame_latency_ms_host_to_host": latency_ms, "stages_ms": prof_serial},
         "stages_ms": prof,
-        "single_frame_latency_ms": latency_ms,
         "host_enqueue_ms_per_frame": 1e3 * enqueue / args.steps,
         "frame_algorithmic_GB": B_frame / 1e9,
         "frame_hbm_frac": (B_frame / (elapsed / args.steps)) / HBM_PEAK / world,
-        "roofline": {"kernel": "composite_kernel", "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
-                     "traffic_source": "profiles/r01_pmc_traffic_%s.json (rocprofv3 --pmc, bytes per launch)" % args.workload if traffic else None,
-                     "algorithmic_bytes_per_launch": B_comp,
-                     "avg_launch_ms": comp_ms,
-                     "avg_launch_ms_one_frame_at_a_time": prof_serial["composite_kernel"] if prof_serial else None,
-                     "frac_one_frame_at_a_time": (B_comp / (prof_serial["composite_kernel"] * 1e-3) / HBM_PEAK)
-                     if prof_serial and prof_serial["composite_kernel"] > 0 else None,
-                     # the frame's HBM-bound kernel, for comparison: project_kernel gathers 256 B per visible splat (244 B
-                     # record padded to 4 lines) + 4 B index and writes 52 B; stage time from stream markers, serial frames
-                     "project_kernel_frac_one_frame_at_a_time": ((312.0 * V) / (prof_serial["project"] * 1e-3) / HBM_PEAK)
-                     if prof_serial and prof_serial["project"] > 0 else None,
-                     "note": "composite is VALU/LDS bound (exp + blend per pixel-splat); HBM fraction is honest-but-low"
-                             + ("; launch duration measured while %d frames share the GPU" % P if P > 1 else "")},
+        "frame_hbm_frac_serial": (B_frame / (serial_ms * 1e-3)) / HBM_PEAK / world,
+        "roofline": roof,
     }
+    if world > 1 and gathers is not None:
+        out["gather"] = {"p2p_ops_per_frame_rank0": (len(gathers[0].plan) * views) if rank == 0 else None,
+                         "bytes_into_rank0_per_frame": None}
+        t = torch.tensor([float(gathers[0].bytes_per_frame * views) if rank != 0 else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        out["gather"]["bytes_into_rank0_per_frame"] = float(t.item())
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and primary and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cloud, wl, cams_for, projs, vp, nf, args.cpu_frames)
-
-    if rank == 0 and args.save_image:
-        img = (gathers[0].final.view(Hpad, W, 4) if gathers else fbs[0])[:H].float().cpu().numpy()
+    if rank == 0 and primary and args.save_image:
+        img = state["fbs"][0][:H].float().cpu().numpy()
         camera.write_image(args.save_image, img)
-    if rank == 0:
+    if rs is not r:
+        rs.close()
+    r.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--also", default=None, help="comma-separated extra workloads measured after the primary one and "
+                    "embedded under \"also\" (default: cfg4 when --gpus > 1 -- the row-sharded BASELINE configs[3])")
+    ap.add_argument("--ply", default=None, help="render a real scene instead of the synthetic workload (BASELINE configs[2]: "
+                    "Inria point_cloud.ply); cameras.json next to it (or up to two directories above) is replayed")
+    ap.add_argument("--save-image", default=None, help="write the last frame of rank 0 as PNG")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="CPU baseline frames (0 = auto, about 10-30 s)")
+    ap.add_argument("--profile-frames", type=int, default=6, help="extra frames (outside the timed regions) for V/D/work statistics")
+    ap.add_argument("--serial-frames", type=int, default=64, help="frames of the serial (one stream, one at a time) phase")
+    ap.add_argument("--prewarm", type=int, default=400, help="untimed frames before the warm-up (runtime pool growth)")
+    ap.add_argument("--frames-in-flight", type=int, default=4,
+                    help="frames overlapped on the GPU (one context + stream + framebuffer per frame in flight, one shared "
+                         "cloud); 1 = strictly serial frames (latency mode)")
+    ap.add_argument("--timing-stride", type=int, default=8,
+                    help="record per-stage hipEvents on every n-th frame of the timed region (0 = never)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+
+    E = Env()
+    E.rank = int(os.environ.get("RANK", "0"))
+    E.world = int(os.environ.get("WORLD_SIZE", "1"))
+    E.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if E.world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, E.world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    if E.rank == 0:
+        graft.build()
+    # MSPLAT_BENCH_ONE_DEVICE=1: debug aid for 1-GPU boxes -- every rank uses device 0 and the gather
+    # runs over gloo; it exercises the N > 1 control flow (bands, gather, max-over-ranks timing), not xGMI.
+    E.one_dev = os.environ.get("MSPLAT_BENCH_ONE_DEVICE") == "1"
+    if E.one_dev:
+        E.local_rank = 0
+    torch.cuda.set_device(E.local_rank)
+    E.dev = torch.device("cuda", E.local_rank)
+    if E.world > 1:
+        if E.one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=E.dev)
+        dist.barrier()
+    # a dedicated (non-null) torch stream: libmsplat launches on it, so torch copies, RCCL's stream
+    # hand-off and torch.cuda.synchronize all order correctly with the HIP kernels
+    E.stream = torch.cuda.Stream(device=E.dev)
+    torch.cuda.set_stream(E.stream)
+
+    out = measure(E, args, args.workload, ply=args.ply, primary=True)
+    also = args.also if args.also is not None else ("cfg4" if (E.world > 1 and args.workload == "cfg2" and not args.ply) else "")
+    extra = {}
+    for key in [k for k in also.split(",") if k]:
+        if key not in WORKLOADS:
+            raise SystemExit("unknown workload in --also: " + key)
+        sub = measure(E, args, key, primary=False)
+        extra[key] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "gsplats_per_sec", "n_gpus", "rccl_ranks", "config",
+                                          "timed_blocks", "serial", "stages_ms", "frame_hbm_frac", "roofline", "gather")
+                      if k in sub}
+    if extra:
+        out["also"] = extra
+    if E.rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if E.world > 1:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,6 +1,7 @@
-"""N > 1 path on CPU: two gloo ranks shard an image by interleaved tile rows (the exact ownership
-rule of msplat_set_band) and rank 0 reassembles it with splatapult_amd.dist.BandGather -- the one
-exchange step of the multi-GPU path.  The per-band pixels come from the oracle (no GPU here)."""
+"""N > 1 path on CPU: two / three gloo ranks shard an image by interleaved bin rows (the exact ownership
+rule of msplat_set_band) and rank 0 receives the foreign rows straight into its own framebuffer with
+splatapult_amd.dist.BandGather (grouped send/recv, no pack or unpack copy) -- the one exchange step of the
+multi-GPU path.  The per-band pixels come from the oracle (no GPU here)."""
 import os
 import socket
 import sys
@@ -40,12 +41,19 @@ def _worker(rank, world, port, W, H, q):
         y0, y1 = t * T, min(t * T + T, H)
         fb[y0:y1] = orc.composite(res["splats"], W, H, row0=y0, row1=y1)[y0:y1]
     g = BandGather(tiles_y, W, torch.float32, torch.device("cpu"), rank, world, tile=T)
-    out = g(torch.from_numpy(fb))
+    own = fb.copy()
+    t_fb = torch.from_numpy(fb)
+    for frame in range(2):                   # the object is reused frame after frame
+        out = g(t_fb)
     if rank == 0:
         full = orc.composite(res["splats"], W, H)
+        assert out.data_ptr() == t_fb.data_ptr()               # rank 0's framebuffer IS the final image
         q.put(bool(np.array_equal(out.numpy()[:H], full)))
     else:
         assert out is None
+        assert np.array_equal(fb, own)                          # senders' framebuffers are untouched
+    assert len(g.plan) == (sum(len(range(s, tiles_y, world)) for s in range(1, world)) if rank == 0
+                           else len(range(rank, tiles_y, world)))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -68,6 +68,12 @@ struct msplat_ctx {
     Buf keyA, keyB, valA, valB;   // uint32[N]; final sorted result in keyA/valA
     Buf hist;       // uint32[256 * hist_stride]
     uint32_t hist_stride = 0;
+    // scan-free path (msplat_kernels.hip.h, radix_upsweep): per-group histogram sums, one row of 256 per 32 chunks
+    Buf gsumS[2];   // sort passes alternate between the two
+    Buf gsumB1, gsumB2;     // binning: column pass / row pass
+    uint32_t gsumS_rows = 0, gsumB1_rows = 0, gsumB2_rows = 0;
+    bool scan_free = true;  // MSPLAT_SCAN_KERNELS=1 forces the 3-kernel (upsweep, scan, downsweep) passes
+    bool quad_compositor = true;   // four waves per 16x16 tile (composite_quad_kernel); MSPLAT_COMPOSITOR=wave: one wave per tile
     Buf totals;     // uint32[256]  digit totals of the current radix pass (rows in binning pass 2)
     Buf totals1;    // uint32[256]  column totals of binning pass 1
     Buf counters;   // uint32[16]: 0=V, 1=D, 2=overflow, 3=compositor tile queue, 4=drawn, 6..7=pairs16 (u64), 8=probe
@@ -169,6 +175,7 @@ void buf_free(msplat_ctx* c, Buf& b)
 
 inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+constexpr uint32_t kFusedMaxChunks = 2048;     // scan-free passes up to this many chunk rows (64 group rows to add up)
 constexpr size_t kProbeWords = 8;                                           // per compositor work item
 constexpr size_t kProbeBytes = (size_t)65536 * 4 * kProbeWords * sizeof(uint32_t);   // 256x256 bins x 4 quadrants
 
@@ -271,6 +278,8 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
             hipStreamSynchronize(ctx->stream) != hipSuccess)
             rc = fail(ctx, MSPLAT_ERR_HIP, "LDS atomic order probe failed to run");
         ctx->atomic_rank = (hbad == 0) && getenv("MSPLAT_BALLOT_RANK") == nullptr;
+        ctx->scan_free = getenv("MSPLAT_SCAN_KERNELS") == nullptr;
+        if (const char* ck = getenv("MSPLAT_COMPOSITOR")) ctx->quad_compositor = std::string(ck) != "wave";
     }
     if (rc != MSPLAT_OK) {
         std::string msg = ctx->err;
@@ -292,7 +301,7 @@ void msplat_destroy(msplat_ctx* ctx)
     ctx->store.reset();
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
-    Buf* all[] = {&ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist,
+    Buf* all[] = {&ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist, &ctx->gsumS[0], &ctx->gsumS[1], &ctx->gsumB1, &ctx->gsumB2,
                   &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->totals1, &ctx->tile_start, &ctx->tile_order,
                   &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe, &ctx->zq, &ctx->sprite};
     for (Buf* b : all) buf_free(ctx, *b);
@@ -419,6 +428,17 @@ int msplat_wait_event(msplat_ctx* ctx, void* event)
     return MSPLAT_OK;
 }
 
+// group table for `nchunks` chunk rows, zero-filled (the stream is idle whenever buffers are (re)allocated)
+static int alloc_group_table(msplat_ctx* ctx, Buf& b, uint32_t& rows, uint64_t nchunks)
+{
+    rows = (uint32_t)((nchunks >> kGroupShift) + 2);
+    int rc = buf_alloc(ctx, b, (size_t)rows * 256 * sizeof(uint32_t));
+    if (rc) return rc;
+    rows = (uint32_t)(b.bytes / (256 * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMemsetAsync(b.p, 0, b.bytes, ctx->stream));
+    return MSPLAT_OK;
+}
+
 static int ensure_pair_capacity(msplat_ctx* ctx, uint64_t cap)
 {
     if (cap > 0x7FFFFFFFull) cap = 0x7FFFFFFFull;
@@ -429,6 +449,8 @@ static int ensure_pair_capacity(msplat_ctx* ctx, uint64_t cap)
     if (rc) return rc;
     ctx->hist2_stride = div_up(cap, kPairChunk);
     rc = buf_alloc(ctx, ctx->hist2, (size_t)256 * ctx->hist2_stride * sizeof(uint32_t));
+    if (rc) return rc;
+    rc = alloc_group_table(ctx, ctx->gsumB2, ctx->gsumB2_rows, ctx->hist2_stride);
     if (rc) return rc;
     ctx->pair_cap = cap;
     return MSPLAT_OK;
@@ -482,11 +504,16 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
     if ((rc = buf_alloc(ctx, ctx->valB, alloc_n * 4))) return rc;
     ctx->hist_stride = std::max(1u, div_up(n, kSortChunk));
     if ((rc = buf_alloc(ctx, ctx->hist, (size_t)256 * ctx->hist_stride * 4))) return rc;
+    uint32_t rows_s0 = 0;
+    if ((rc = alloc_group_table(ctx, ctx->gsumS[0], rows_s0, ctx->hist_stride))) return rc;
+    if ((rc = alloc_group_table(ctx, ctx->gsumS[1], ctx->gsumS_rows, ctx->hist_stride))) return rc;
+    ctx->gsumS_rows = std::min(ctx->gsumS_rows, rows_s0);
     if ((rc = buf_alloc(ctx, ctx->rec2d, alloc_n * 48))) return rc;
     if ((rc = buf_alloc(ctx, ctx->rect, alloc_n * 4))) return rc;
     if (ctx->depth_bits != 0 && (rc = buf_alloc(ctx, ctx->zq, alloc_n * 4))) return rc;
     ctx->hist1_stride = std::max(1u, div_up(n, kBinChunk));
     if ((rc = buf_alloc(ctx, ctx->hist1, (size_t)256 * ctx->hist1_stride * 4))) return rc;
+    if ((rc = alloc_group_table(ctx, ctx->gsumB1, ctx->gsumB1_rows, ctx->hist1_stride))) return rc;
     uint64_t cap = ctx->cfg.pair_capacity ? ctx->cfg.pair_capacity
                                           : std::max<uint64_t>(1ull << 22, std::min<uint64_t>(32 * n, 1ull << 30));
     return ensure_pair_capacity(ctx, cap);
@@ -845,16 +872,20 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
     const bool timed = ctx->ev_ok && (ctx->sort_calls++ % ctx->timing_stride) == 0;
     const int tset = (int)(ctx->sort_sets % msplat_ctx::kEvSets);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][0], s));
+    // scan-free passes (2 launches each) while the chunk table is small, else upsweep + scan + downsweep
+    const bool fused = ctx->scan_free && div_up(N, kSortChunk) <= kFusedMaxChunks;
+    auto gacc = [&](int pass) { return fused ? (uint32_t*)ctx->gsumS[pass & 1].p : nullptr; };
+    auto gzero = [&](int pass) { return (uint32_t*)ctx->gsumS[(pass + 1) & 1].p; };      // always: keeps both tables clean
     // pass 0: cull + key fused into the first radix pass (presort_compute.glsl + byte 0 of the sort)
     hipLaunchKernelGGL(radix_upsweep<MODE_CULL>, dim3(grid), dim3(kThreads), 0, s, nullptr, pos, nullptr, N, N, 0,
-                       hist, ctx->hist_stride, fp);
-    launch_scan(s, ctx->N <= (2u << 20), hist, ctx->hist_stride, nullptr, N, N, (uint32_t)kSortChunk, totals);
+                       hist, ctx->hist_stride, gacc(0), gzero(0), ctx->gsumS_rows, fp);
+    if (!fused) launch_scan(s, ctx->N <= (2u << 20), hist, ctx->hist_stride, nullptr, N, N, (uint32_t)kSortChunk, totals);
     if (ctx->atomic_rank)
         hipLaunchKernelGGL((radix_downsweep<MODE_CULL, true, true>), dim3(grid), dim3(kThreads), 0, s, nullptr, nullptr, pos,
-                           nullptr, N, N, 0, hist, ctx->hist_stride, totals, kB, vB, d_V, nullptr, fp);
+                           nullptr, N, N, 0, hist, ctx->hist_stride, totals, kB, vB, d_V, nullptr, gacc(0), nullptr, fp);
     else
         hipLaunchKernelGGL((radix_downsweep<MODE_CULL, true, false>), dim3(grid), dim3(kThreads), 0, s, nullptr, nullptr, pos,
-                           nullptr, N, N, 0, hist, ctx->hist_stride, totals, kB, vB, d_V, nullptr, fp);
+                           nullptr, N, N, 0, hist, ctx->hist_stride, totals, kB, vB, d_V, nullptr, gacc(0), nullptr, fp);
     // passes 1..3 on the V survivors (V stays on the device; splatrenderer.cpp:195-204's readback is gone)
     for (int pass = 1; pass < 4; ++pass) {
         uint32_t* kin = (pass & 1) ? kB : kA;
@@ -862,14 +893,16 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
         uint32_t* kout = (pass & 1) ? kA : kB;
         uint32_t* vout = (pass & 1) ? vA : vB;
         hipLaunchKernelGGL(radix_upsweep<MODE_KEYS>, dim3(grid), dim3(kThreads), 0, s, kin, nullptr, d_V, 0u, N,
-                           pass * 8, hist, ctx->hist_stride, fp);
-        launch_scan(s, ctx->N <= (2u << 20), hist, ctx->hist_stride, d_V, 0u, N, (uint32_t)kSortChunk, totals);
+                           pass * 8, hist, ctx->hist_stride, gacc(pass), gzero(pass), ctx->gsumS_rows, fp);
+        if (!fused) launch_scan(s, ctx->N <= (2u << 20), hist, ctx->hist_stride, d_V, 0u, N, (uint32_t)kSortChunk, totals);
         if (ctx->atomic_rank)
             hipLaunchKernelGGL((radix_downsweep<MODE_KEYS, true, true>), dim3(grid), dim3(kThreads), 0, s, kin, vin, nullptr,
-                               d_V, 0u, N, pass * 8, hist, ctx->hist_stride, totals, kout, vout, nullptr, nullptr, fp);
+                               d_V, 0u, N, pass * 8, hist, ctx->hist_stride, totals, kout, vout, nullptr, nullptr, gacc(pass),
+                               nullptr, fp);
         else
             hipLaunchKernelGGL((radix_downsweep<MODE_KEYS, true, false>), dim3(grid), dim3(kThreads), 0, s, kin, vin, nullptr,
-                               d_V, 0u, N, pass * 8, hist, ctx->hist_stride, totals, kout, vout, nullptr, nullptr, fp);
+                               d_V, 0u, N, pass * 8, hist, ctx->hist_stride, totals, kout, vout, nullptr, nullptr, gacc(pass),
+                               nullptr, fp);
     }
     if (timed) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][1], s));
@@ -883,7 +916,6 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
 
 static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, size_t pitch, bool async_overflow_flag)
 {
-    uint32_t* host_flag = async_overflow_flag ? ctx->d_flags : nullptr;
     hipStream_t s = ctx->stream;
     const uint32_t N = (uint32_t)ctx->N;
     uint32_t* counters = (uint32_t*)ctx->counters.p;
@@ -913,35 +945,50 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     uint32_t* totals1 = (uint32_t*)ctx->totals1.p;
     uint32_t* totals2 = (uint32_t*)ctx->totals.p;
     const int g1 = grid_for(div_up(N, kBinChunk));
+    // scan-free variants while the chunk tables are small; the row pass's size (D) is only known on the device, so
+    // its choice uses the D of an EARLIER frame that the binning kernel left in host-mapped memory (0 = none yet);
+    // either variant is correct at any size, the choice only matters for speed
+    const bool fused1 = ctx->scan_free && div_up(N, kBinChunk) <= kFusedMaxChunks;
+    const uint32_t last_D = ctx->h_flags ? __atomic_load_n(ctx->h_flags + 2, __ATOMIC_RELAXED) : 0u;
+    const bool fused2 = ctx->scan_free && last_D != 0u && div_up((uint64_t)last_D + (last_D >> 2), kPairChunk) <= kFusedMaxChunks;
+    uint32_t* gB1 = (uint32_t*)ctx->gsumB1.p;
+    uint32_t* gB2 = (uint32_t*)ctx->gsumB2.p;
     hipLaunchKernelGGL(bin1_upsweep, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
-                       (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_overflow);
-    launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V, 0u, N, (uint32_t)kBinChunk, totals1);
+                       (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_overflow, fused1 ? gB1 : nullptr, (uint32_t*)nullptr, 0u);
+    if (!fused1)
+        launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V, 0u, N, (uint32_t)kBinChunk, totals1);
     if (ctx->atomic_rank)
         hipLaunchKernelGGL(bin1_downsweep<true>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
                            (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,
-                           (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, host_flag);
+                           (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags, async_overflow_flag ? 1 : 0,
+                           fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr);
     else
         hipLaunchKernelGGL(bin1_downsweep<false>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
                            (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,
-                           (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, host_flag);
+                           (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags, async_overflow_flag ? 1 : 0,
+                           fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr);
     // pass 2: stable partition by tile row (one generic radix pass on the top byte); words become (tx<<24)|rank
     const int g2 = grid_for(div_up(cap, kPairChunk));
     hipLaunchKernelGGL(radix_upsweep<MODE_PAIR>, dim3(g2), dim3(kThreads), 0, s, (const uint32_t*)ctx->pairsA.p,
-                       nullptr, d_D, 0u, cap, 24, (uint32_t*)ctx->hist2.p, ctx->hist2_stride, fp);
-    launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist2.p, ctx->hist2_stride, d_D, 0u, cap, (uint32_t)kPairChunk, totals2);
+                       nullptr, d_D, 0u, cap, 24, (uint32_t*)ctx->hist2.p, ctx->hist2_stride, fused2 ? gB2 : nullptr, gB1,
+                       ctx->gsumB1_rows, fp);
+    if (!fused2)
+        launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist2.p, ctx->hist2_stride, d_D, 0u, cap, (uint32_t)kPairChunk, totals2);
     if (ctx->atomic_rank)
         hipLaunchKernelGGL((radix_downsweep<MODE_PAIR, false, true>), dim3(g2), dim3(kThreads), 0, s,
                            (const uint32_t*)ctx->pairsA.p, nullptr, nullptr, d_D, 0u, cap, 24,
                            (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
-                           (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1, fp);
+                           (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1,
+                           fused2 ? (const uint32_t*)gB2 : nullptr, fused2 ? totals2 : nullptr, fp);
     else
         hipLaunchKernelGGL((radix_downsweep<MODE_PAIR, false, false>), dim3(g2), dim3(kThreads), 0, s,
                            (const uint32_t*)ctx->pairsA.p, nullptr, nullptr, d_D, 0u, cap, 24,
                            (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
-                           (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1, fp);
-    hipLaunchKernelGGL(tile_start_kernel, dim3(std::max(1, (ntiles + kThreads) / kThreads)), dim3(kThreads), 0, s,
+                           (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1,
+                           fused2 ? (const uint32_t*)gB2 : nullptr, fused2 ? totals2 : nullptr, fp);
+    hipLaunchKernelGGL(tile_start_kernel, dim3(std::max(1, (ntiles + kTileStartBins - 1) / kTileStartBins)), dim3(kThreads), 0, s,
                        (const uint32_t*)ctx->pairsB.p, (const uint32_t*)totals2, d_D, cap, fp.tiles_x, ntiles,
-                       (uint32_t*)ctx->tile_start.p);
+                       (uint32_t*)ctx->tile_start.p, gB2, ctx->gsumB2_rows);
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)ctx->tile_start.p, ntiles,
                        (uint32_t*)ctx->tile_order.p, d_queue);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][4], s));
@@ -983,7 +1030,20 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         hipEvent_t e0 = timed ? ctx->ev[tset][6] : nullptr, e1 = timed ? ctx->ev[tset][7] : nullptr;
         uint32_t* probe = ctx->probe_on ? (uint32_t*)ctx->probe.p : nullptr;
         if (probe) HIP_TRY(ctx, hipMemsetAsync(probe, 0, (size_t)ntiles * 4 * kProbeWords * sizeof(uint32_t), s));
-        if (ctx->cfg.fb_format == MSPLAT_FB_RGBA16F)
+        if (ctx->quad_compositor) {
+            // four waves per tile: the pool is counted in workgroups of four waves
+            const int qgrid = std::min(ntiles * 4, std::max(64, ctx->comp_waves / 4));
+            if (ctx->cfg.fb_format == MSPLAT_FB_RGBA16F)
+                hipExtLaunchKernelGGL(composite_quad_kernel<true>, dim3(qgrid), dim3(kQuadThreads), 0, s, e0, e1, 0,
+                                      (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
+                                      (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap,
+                                      (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u, probe);
+            else
+                hipExtLaunchKernelGGL(composite_quad_kernel<false>, dim3(qgrid), dim3(kQuadThreads), 0, s, e0, e1, 0,
+                                      (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
+                                      (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap,
+                                      (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u, probe);
+        } else if (ctx->cfg.fb_format == MSPLAT_FB_RGBA16F)
             hipExtLaunchKernelGGL(composite_kernel<true>, dim3(cgrid), dim3(kCompThreads), 0, s, e0, e1, 0,
                                   (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
                                   (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap,
@@ -1228,14 +1288,14 @@ int msplat_get_composite_work(msplat_ctx* ctx, msplat_composite_work* out)
         out->work_items += 1;
         out->clocks_sum += p[0];
         out->clocks_max = std::max<uint64_t>(out->clocks_max, p[0]);
-        out->records_composited += p[1];
+        out->records_composited += p[1];        // one wave per tile: records; four waves per tile: (record, sub-block) pairs
+        out->pixel_evals += (uint64_t)p[1] * (p[7] == 2u ? 64u : (uint64_t)(kTile * kTile));
         out->batches += p[2];
         out->inner_clocks_sum += p[3];
         out->pair_words_fetched += p[4];
         out->records_fetched += p[5];
         out->list_entries += p[6];
     }
-    out->pixel_evals = out->records_composited * (uint64_t)(kTile * kTile);
     return MSPLAT_OK;
 }
 

@@ -183,17 +183,33 @@ __global__ __launch_bounds__(kThreads) void lds_atomic_order_probe(uint32_t* __r
 // 8x amplification, ~40 MB of HBM traffic per frame)
 // ------------------------------------------------------------------------------------------
 
+// Group tables (the scan-free path).  A dependent launch costs ~1.5-2 us on this part and the 1 M-splat frame
+// is a chain of ~5-10 us kernels, so the separate scan launch between upsweep and downsweep is dropped:
+// the upsweep also adds each chunk's histogram row into the row of its GROUP of 32 chunks with global atomics
+// (no return value, <= 32 adds per address: nothing serialises), and the downsweep rebuilds its chunk's exclusive
+// prefix as  sum(group rows before its group) + sum(chunk rows before it inside the group)  from L2
+// (<= nchunks/32 + 31 coalesced 1 KB rows).  No inter-workgroup communication inside a kernel: every table is
+// complete at a kernel boundary.  A table must be zero before its upsweep: each upsweep zeroes the table its
+// SUCCESSOR pass will accumulate into (gsum_zero), whose previous consumer finished one launch earlier.
+// The prefix work grows with nchunks^2/32, so beyond a few thousand chunks the host picks the 3-kernel path
+// (radix_scan*) instead; both are correct at any size.
+constexpr int kGroupShift = 5;
+
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __restrict__ keys,
                                                           const float4* __restrict__ pos,
                                                           const uint32_t* __restrict__ d_n, uint32_t n_static,
                                                           uint32_t n_cap, int shift,
                                                           uint32_t* __restrict__ hist, uint32_t hist_stride,
+                                                          uint32_t* __restrict__ gsum_acc,
+                                                          uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_rows,
                                                           FrameParams fp)
 {
     constexpr int ITEMS = RadixCfg<MODE>::ITEMS;
     constexpr int CHUNK = RadixCfg<MODE>::CHUNK;
     __shared__ uint32_t s_hist[256];
+    if (gsum_zero != nullptr)
+        for (uint32_t row = blockIdx.x; row < gsum_zero_rows; row += gridDim.x) gsum_zero[(size_t)row * 256 + threadIdx.x] = 0u;
     uint32_t n = d_n ? *d_n : n_static;
     if (n > n_cap) n = n_cap;
     const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
@@ -213,9 +229,36 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
             }
         }
         __syncthreads();
-        hist[(size_t)chunk * 256 + threadIdx.x] = s_hist[threadIdx.x];
+        const uint32_t c = s_hist[threadIdx.x];
+        hist[(size_t)chunk * 256 + threadIdx.x] = c;
+        if (gsum_acc != nullptr && c != 0u)
+            (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(chunk >> kGroupShift) * 256 + threadIdx.x], c, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
     }
+}
+
+// exclusive prefix of chunk `chunk`'s histogram row over the earlier chunks, and the digit total, from the group
+// tables (scan-free path); thread d handles digit d.  All loads are independent: they pipeline in L2.
+__device__ __forceinline__ uint32_t group_prefix(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ gsum,
+                                                 uint32_t chunk)
+{
+    const uint32_t g = chunk >> kGroupShift;
+    uint32_t pre = 0;
+#pragma unroll 8
+    for (uint32_t k = 0; k < g; ++k) pre += gsum[(size_t)k * 256 + threadIdx.x];
+#pragma unroll 8
+    for (uint32_t c = g << kGroupShift; c < chunk; ++c) pre += hist[(size_t)c * 256 + threadIdx.x];
+    return pre;
+}
+
+__device__ __forceinline__ uint32_t group_total(const uint32_t* __restrict__ gsum, uint32_t nchunks)
+{
+    const uint32_t ng = (nchunks + (1u << kGroupShift) - 1u) >> kGroupShift;
+    uint32_t t = 0;
+#pragma unroll 8
+    for (uint32_t k = 0; k < ng; ++k) t += gsum[(size_t)k * 256 + threadIdx.x];
+    return t;
 }
 
 // one workgroup per digit: exclusive scan of that digit's row over the active chunks; row total -> totals
@@ -311,8 +354,13 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
                                                             uint32_t* __restrict__ vals_out,
                                                             uint32_t* __restrict__ d_count_out,
                                                             const uint32_t* __restrict__ col_totals,
+                                                            const uint32_t* __restrict__ gsum,
+                                                            uint32_t* __restrict__ totals_out,
                                                             FrameParams fp)
 {
+    // gsum != nullptr: scan-free path -- hist holds raw per-chunk counts, prefixes come from the group tables;
+    // otherwise hist holds exclusive prefixes and totals the digit totals (radix_scan*).
+    // totals_out != nullptr: workgroup 0 publishes the digit totals (the row totals tile_start_kernel needs).
     constexpr int ITEMS = RadixCfg<MODE>::ITEMS;
     constexpr int CHUNK = RadixCfg<MODE>::CHUNK;
     __shared__ uint32_t s_col[MODE == MODE_PAIR ? 256 : 1];   // MODE_PAIR: first input position of each column
@@ -332,11 +380,12 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     {
-        const uint32_t t = totals[threadIdx.x];
+        const uint32_t t = (gsum != nullptr) ? group_total(gsum, nchunks) : totals[threadIdx.x];
         uint32_t tot;
         const uint32_t incl = block_incl_scan(t, s_tmp, tot);
         s_base[threadIdx.x] = incl - t;
         if (d_count_out != nullptr && blockIdx.x == 0 && threadIdx.x == 255) *d_count_out = incl;
+        if (totals_out != nullptr && blockIdx.x == 0) totals_out[threadIdx.x] = t;
     }
     if (MODE == MODE_PAIR) {
         const uint32_t t = col_totals[threadIdx.x];
@@ -347,6 +396,8 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
     __syncthreads();
 
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        // this chunk's exclusive prefix per digit (thread = digit): issued first, consumed after the local ranking
+        const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk) : hist[(size_t)chunk * 256 + threadIdx.x];
 #pragma unroll
         for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
         __syncthreads();
@@ -416,7 +467,7 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
             s_cnt[1][d] = excl + c0;
             s_cnt[2][d] = excl + c0 + c1;
             s_cnt[3][d] = excl + c0 + c1 + c2;
-            s_gdelta[d] = s_base[d] + hist[(size_t)chunk * 256 + d] - excl;
+            s_gdelta[d] = s_base[d] + chunk_pre - excl;
         }
         __syncthreads();
         uint32_t wave_col = 0;
@@ -842,10 +893,14 @@ __global__ __launch_bounds__(kThreads) void count_drawn_kernel(const uint32_t* _
 __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restrict__ rect,
                                                          const uint32_t* __restrict__ d_V,
                                                          uint32_t* __restrict__ hist, uint32_t hist_stride,
-                                                         uint32_t* __restrict__ d_overflow)
+                                                         uint32_t* __restrict__ d_overflow,
+                                                         uint32_t* __restrict__ gsum_acc,
+                                                         uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_rows)
 {
     // per-frame reset of the sticky overflow flag (set later in the frame by bin1_downsweep): saves a memset launch
     if (blockIdx.x == 0 && threadIdx.x == 0) *d_overflow = 0u;
+    if (gsum_zero != nullptr)      // scan-free path, see radix_upsweep
+        for (uint32_t row = blockIdx.x; row < gsum_zero_rows; row += gridDim.x) gsum_zero[(size_t)row * 256 + threadIdx.x] = 0u;
     __shared__ uint32_t s_diff[kThreads + 1];
     __shared__ uint32_t s_tmp[4];
     const uint32_t V = *d_V;
@@ -872,6 +927,9 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
         uint32_t total;
         const uint32_t incl = block_incl_scan(s_diff[threadIdx.x], s_tmp, total);   // wraps mod 2^32: exact
         hist[(size_t)chunk * 256 + threadIdx.x] = incl;
+        if (gsum_acc != nullptr && incl != 0u)
+            (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(chunk >> kGroupShift) * 256 + threadIdx.x], incl, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
     }
 }
@@ -888,8 +946,14 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
                                                            uint32_t* __restrict__ pairs_out, uint32_t cap,
                                                            uint32_t* __restrict__ d_D,
                                                            uint32_t* __restrict__ d_overflow,
-                                                           uint32_t* __restrict__ host_flag)
+                                                           uint32_t* __restrict__ host_words, int report_overflow,
+                                                           const uint32_t* __restrict__ gsum,
+                                                           uint32_t* __restrict__ totals_out)
 {
+    // gsum != nullptr: scan-free path (hist = raw per-chunk column counts, see radix_upsweep); workgroup 0 then also
+    // publishes the column totals in totals_out for the row pass.  host_words (host-mapped): [0] pairs needed by an
+    // overflowed device-output frame, [1] V and [2] D of the latest frame (read by the host without synchronising,
+    // only to choose between the scan-free and the 3-kernel path for the NEXT frame's row pass)
     constexpr int PER = kBinChunk / kThreads;          // rectangles per thread (blocked)
     __shared__ uint32_t s_off[kBinChunk + 1];          // exclusive scan of the rectangle widths
     __shared__ uint32_t s_rect[kBinChunk];
@@ -906,23 +970,30 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
     const int w = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     {
-        const uint32_t t = totals[threadIdx.x];
+        const uint32_t t = (gsum != nullptr) ? group_total(gsum, nchunks) : totals[threadIdx.x];
         uint32_t tot;
         const uint32_t incl = block_incl_scan(t, s_tmp, tot);
         s_base[threadIdx.x] = incl - t;
+        if (totals_out != nullptr && blockIdx.x == 0) totals_out[threadIdx.x] = t;
         if (blockIdx.x == 0 && threadIdx.x == 255) {
             *d_D = incl;
+            if (host_words != nullptr) {
+                __hip_atomic_store(host_words + 1, V, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(host_words + 2, incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             if (incl > cap) {
                 *d_overflow = incl;
                 // device-output renders never synchronise: leave the pair count this frame needed in host-mapped
                 // memory, where the next msplat_sort / msplat_render / msplat_synchronize on the context finds it
-                if (host_flag != nullptr) __hip_atomic_store(host_flag, incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (host_words != nullptr && report_overflow)
+                    __hip_atomic_store(host_words, incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
     __syncthreads();
 
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk) : hist[(size_t)chunk * 256 + threadIdx.x];
         const uint32_t rbase = chunk * kBinChunk;
         uint32_t rc[PER], woff[PER], wsum = 0;
 #pragma unroll
@@ -984,7 +1055,7 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
         __syncthreads();
         {
             const int d = threadIdx.x;
-            const uint32_t g = s_base[d] + hist[(size_t)chunk * 256 + d];
+            const uint32_t g = s_base[d] + chunk_pre;
             const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d];
             s_cnt[0][d] = g;
             s_cnt[1][d] = g + c0;
@@ -1034,16 +1105,23 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
     }
 }
 
-// per tile: first position of its list in the final pair array.  The array is sorted by (row, word)
+// per bin: first position of its list in the final pair array.  The array is sorted by (row, word)
 // with word = (tx << 24) | rank, so inside row vty the words are ascending: lower_bound(tx << 24).
+// One WAVE per bin and a 64-ary search: every step probes 64 evenly spaced words of the remaining range with
+// one gather, so a row segment of 100 k words needs 3 dependent loads instead of 17 (this kernel was a
+// 2 k-thread latency chain: 7.8 us at 1920x1080).
+constexpr int kTileStartBins = kThreads / 64;      // bins per workgroup
 __global__ __launch_bounds__(kThreads) void tile_start_kernel(const uint32_t* __restrict__ pairs,
                                                               const uint32_t* __restrict__ row_totals,
                                                               const uint32_t* __restrict__ d_D, uint32_t cap,
                                                               int tiles_x, int ntiles,
-                                                              uint32_t* __restrict__ tile_start)
+                                                              uint32_t* __restrict__ tile_start,
+                                                              uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_rows)
 {
     __shared__ uint32_t s_row[kThreads + 1];
     __shared__ uint32_t s_tmp[4];
+    if (gsum_zero != nullptr)      // scan-free path: the row pass's group table for the NEXT frame, see radix_upsweep
+        for (uint32_t row = blockIdx.x; row < gsum_zero_rows; row += gridDim.x) gsum_zero[(size_t)row * 256 + threadIdx.x] = 0u;
     {
         const uint32_t t = row_totals[threadIdx.x];
         uint32_t tot;
@@ -1053,18 +1131,27 @@ __global__ __launch_bounds__(kThreads) void tile_start_kernel(const uint32_t* __
     }
     __syncthreads();
     const uint32_t D = min(*d_D, cap);
-    const int tile = blockIdx.x * kThreads + threadIdx.x;
-    if (tile == 0) tile_start[ntiles] = D;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * kTileStartBins + (threadIdx.x >> 6);
+    if (tile == 0 && lane == 0) tile_start[ntiles] = D;
     if (tile >= ntiles) return;
     const int vty = tile / tiles_x;
     const uint32_t tx = (uint32_t)(tile - vty * tiles_x);
-    uint32_t lo = min(s_row[vty], D), hi = min(s_row[vty + 1], D);
+    uint32_t lo = min(s_row[vty], D), hi = min(s_row[vty + 1], D);     // the answer lies in [lo, hi]
     const uint32_t key = tx << 24;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (pairs[mid] < key) lo = mid + 1u; else hi = mid;
+    while (lo < hi) {                                                  // wave-uniform
+        const uint32_t len = hi - lo;
+        const uint32_t step = (len + 64u) / 65u;                       // >= 1
+        const uint32_t p = lo + ((uint32_t)lane + 1u) * step - 1u;     // probe j = lane: ascending positions
+        const bool below = (p < hi) && (pairs[p] < key);
+        const uint32_t c = (uint32_t)__popcll(__ballot(below));        // probes 0..c-1 are below the key (sorted input)
+        const uint32_t pc = lo + (c + 1u) * step - 1u;                 // probe c: first probe not below, if it exists
+        const uint32_t nlo = c ? lo + c * step : lo;                   // = p[c-1] + 1
+        const uint32_t nhi = (c < 64u && pc < hi) ? pc : hi;
+        lo = nlo;
+        hi = nhi;
     }
-    tile_start[tile] = lo;
+    if (lane == 0) tile_start[tile] = lo;
 }
 
 // tiles ordered by descending list length (counting sort on len/16): the compositor's waves pull tiles
@@ -1342,6 +1429,248 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
     if (threadIdx.x == 0) nq = atomicAdd(queue, 1u);
     qpos = gridDim.x + __builtin_amdgcn_readfirstlane(nq);
     }   // persistent tile loop
+}
+
+// ------------------------------------------------------------------------------------------
+// composite, second formulation (round 2): ONE WORKGROUP OF FOUR WAVES per 16x16 tile, wave w owns the
+// 8x8 sub-block (w & 1, w >> 1) with ONE pixel per lane.
+//
+// Why (measured on the one-wave-per-tile kernel above, config 2):
+//  * its launch lasts exactly as long as its heaviest tile -- 8 k tiles on 8 k resident waves, the
+//    heaviest needs 2.4x the mean and ends alone on its SIMD, where a single wave issues VALU at a quarter
+//    of the SIMD's rate (tools/ubench_valu: 5.2 vs 1.4 clocks per instruction at 1 vs 8 waves): wave slots are
+//    41 % occupied on average.  Four waves per tile cut every tile's dependent chain by four and
+//    leave 4x more work items than workgroup slots for the dynamic queue to balance;
+//  * only 36 % of the (pixel, record) evaluations of a 16x16 tile lie inside the record's footprint; an 8x8
+//    sub-block sees 62 % of its tile's records (exact test), so the sub-block queues drop 38 % of the
+//    evaluations, and packing two pixels per lane buys only 7 % on gfx950 (v_pk_fma_f32 takes 1.87x a
+//    v_fma_f32), so one pixel per lane costs little.
+//
+// Per batch of 128 list entries (nearest first): threads 0..127 turn their prefetched record into the
+// coefficients of  e(u, v) = c0 + c1 u + c2 v + c3 u^2 + c4 u v + c5 v^2  in TILE-CENTRED pixel coordinates
+// (|u|, |v| <= 7.5: no cancellation trouble) and put them in LDS; every wave then tests the 128 records
+// exactly against its own sub-block (maximum of the concave quadratic over the box of pixel centres) and
+// keeps the survivors' slot numbers in a wave-private queue, in list order; the inner loop walks that queue.
+// Nothing crosses waves except the record array and one "still alive" flag per sub-block: two barriers
+// per batch.  Per pixel the records are blended in exactly the list order, whatever the scheduling.
+// ------------------------------------------------------------------------------------------
+constexpr int kQuadThreads = 256;
+constexpr int kQuadBatch = 128;
+
+template <bool HALF>
+__global__ __launch_bounds__(kQuadThreads) void composite_quad_kernel(const uint32_t* __restrict__ tile_start,
+                                                                      const uint32_t* __restrict__ pairs,
+                                                                      const float4* __restrict__ rec,
+                                                                      void* __restrict__ out, size_t pitch_bytes,
+                                                                      FrameParams fp, uint32_t cap,
+                                                                      const uint32_t* __restrict__ order,
+                                                                      uint32_t* __restrict__ queue, uint32_t nitems,
+                                                                      uint32_t* __restrict__ probe)
+{
+    // per entry of the batch: {c0, c1, c2, c3} {c4, c5, r, g} {b, a, b, -}   (a, b = splat centre, tile coordinates)
+    __shared__ float4 s_rec[kQuadBatch * 3];
+    // wave-private queues of the records that reach the wave's sub-block (64 entries are tested at a time)
+    __shared__ float4 s_q0[4][64 + 1];       // c0 c1 c2 c3
+    __shared__ float4 s_q1[4][64 + 1];       // c4 c5 r g
+    __shared__ float s_qb[4][64 + 4];        // b
+    __shared__ uint32_t s_alive[4];
+    __shared__ uint32_t s_next;
+    __shared__ uint32_t s_probe[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lx = lane & 7, ly = lane >> 3;
+    const int sbx = w & 1, sby = w >> 1;
+    // this lane's pixel and this wave's sub-block, in tile-centred coordinates (pixel centres at -7.5 ... 7.5)
+    const float u = (float)(sbx * 8 + lx) - 7.5f, v = (float)(sby * 8 + ly) - 7.5f;
+    const float u0 = (float)(sbx * 8) - 7.5f, u1 = u0 + 7.0f, v0 = (float)(sby * 8) - 7.5f, v1 = v0 + 7.0f;
+    __syncthreads();
+
+    for (uint32_t qpos = blockIdx.x; qpos < nitems;) {
+        const int bin = (int)order[qpos >> 2];
+        const int quad = (int)(qpos & 3u);
+        const int bvy = bin / fp.tiles_x;
+        const int tx = (bin - bvy * fp.tiles_x) * 2 + (quad & 1);
+        const int ty = (bvy * fp.row_mod + fp.row_rem) * 2 + (quad >> 1);
+        const bool tile_in_image = tx * kTile < fp.width && ty * kTile < fp.height;
+        if (tile_in_image) {
+            const int x = tx * kTile + sbx * 8 + lx, y = ty * kTile + sby * 8 + ly;
+            const bool inside = x < fp.width && y < fp.height;
+            const float xc = (float)(tx * kTile + 8), yc = (float)(ty * kTile + 8);
+            float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+            bool alive = __ballot(inside) != 0ull;              // wave-uniform: this sub-block still has a live pixel
+            uint32_t start = tile_start[bin], end = tile_start[bin + 1];
+            if (start > cap) start = cap;
+            if (end > cap) end = cap;
+
+            // three-stage pipeline over batches of 128 entries (threads 0..127 load): pair words two batches ahead,
+            // projected records one batch ahead of the batch being composited
+            const bool loader = tid < kQuadBatch;
+            uint32_t hiA = end;
+            uint32_t cntA = min((uint32_t)kQuadBatch, hiA - start);
+            uint32_t rankA = 0;
+            if (loader && tid < (int)cntA) rankA = pairs[hiA - 1u - tid];      // entry 0 of a batch is the nearest splat
+            hiA -= cntA;
+            uint32_t cnt = cntA;
+            float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
+            if (loader && tid < (int)cnt) {
+                uint32_t rk = rankA & kRankMask;
+                asm volatile("" : "+v"(rk));          // keep the mask out of the address arithmetic (see composite_depth_kernel)
+                const float4* src = rec + (size_t)rk * 3;
+                p0 = src[0]; p1 = src[1]; p2 = src[2];
+            }
+            cntA = min((uint32_t)kQuadBatch, hiA - start);
+            if (loader && tid < (int)cntA) rankA = pairs[hiA - 1u - tid];
+            hiA -= cntA;
+            const uint64_t probe_t0 = probe ? clock64() : 0ull;
+            uint32_t probe_n = 0, probe_batches = 0, probe_words = min(end - start, 2u * (uint32_t)kQuadBatch), probe_recs = cnt;
+            uint64_t probe_inner = 0;
+
+            while (cnt != 0u) {
+                // (a) records -> tile-centred polynomial coefficients, one LDS slot per list entry of the batch
+                if (loader && tid < (int)cnt) {
+                    const float a = p0.x - xc, b = p0.y - yc;
+                    const float A = p0.z, B = p0.w, C = p1.x, L = p1.y;
+                    const float c1 = -(2.0f * A * a + B * b);
+                    const float c2 = -(2.0f * C * b + B * a);
+                    const float c0 = (A * a + B * b) * a + (C * b * b + L);
+                    s_rec[tid * 3 + 0] = make_float4(c0, c1, c2, A);
+                    s_rec[tid * 3 + 1] = make_float4(B, C, p1.z, p1.w);
+                    s_rec[tid * 3 + 2] = make_float4(p2.x, a, b, 0.0f);
+                }
+                __syncthreads();
+                const uint32_t cur = cnt;
+                // next batch's records and the batch after's pair words go out now: in flight during the tests
+                // and the inner loop
+                cnt = cntA;
+                if (loader && tid < (int)cnt) {
+                    uint32_t rk = rankA & kRankMask;
+                    asm volatile("" : "+v"(rk));
+                    const float4* src = rec + (size_t)rk * 3;
+                    p0 = src[0]; p1 = src[1]; p2 = src[2];
+                }
+                cntA = min((uint32_t)kQuadBatch, hiA - start);
+                if (loader && tid < (int)cntA) rankA = pairs[hiA - 1u - tid];
+                hiA -= cntA;
+                probe_words += cntA;
+                probe_recs += cnt;
+                ++probe_batches;
+
+                // (b) + (c), 64 entries at a time: this wave's exact footprint-vs-sub-block test of the records; the
+                //     survivors are copied, in list order, into the wave-private queue (affine addresses: the inner loop
+                //     can prefetch), which is then blended front to back
+                //     (splat_frag.glsl:18-42, reversed: C += T w c, T -= T w)
+                const uint64_t probe_t1 = probe ? clock64() : 0ull;
+                if (alive) {
+                    for (int r = 0; r * 64 < (int)cur; ++r) {
+                        const int e = r * 64 + lane;
+                        bool pass = false;
+                        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
+                        if (e < (int)cur) {
+                            q0 = s_rec[e * 3 + 0];       // c0 c1 c2 c3
+                            q1 = s_rec[e * 3 + 1];       // c4 c5 r g
+                            q2 = s_rec[e * 3 + 2];       // blue a b .
+                            const float c0 = q0.x, c1 = q0.y, c2 = q0.z, c3 = q0.w, c4 = q1.x, c5 = q1.y;
+                            const float a = q2.y, b = q2.z;
+                            if (a >= u0 && a <= u1 && b >= v0 && b <= v1) {
+                                pass = true;      // centre inside the box of pixel centres: e_max = log2(alpha) > -8
+                            } else {
+                                // e is a concave quadratic: with the centre outside, its maximum over the box lies on an
+                                // edge; on an edge it is a 1-D concave quadratic, maximised at the clamped vertex
+                                // (v_rcp_f32 is accurate enough for the maximiser: the test keeps 0.05 of slack)
+                                const float i2c5 = __builtin_amdgcn_rcpf(2.0f * c5), i2c3 = __builtin_amdgcn_rcpf(2.0f * c3);
+                                float emax = -1e30f;
+#pragma unroll
+                                for (int s = 0; s < 2; ++s) {
+                                    const float ue = s ? u1 : u0;                 // vertical edges
+                                    const float lin = c2 + c4 * ue;
+                                    const float cst = c0 + ue * (c1 + c3 * ue);
+                                    const float vs = fminf(fmaxf(-lin * i2c5, v0), v1);
+                                    emax = fmaxf(emax, cst + vs * (lin + c5 * vs));
+                                    const float ve = s ? v1 : v0;                 // horizontal edges
+                                    const float lin2 = c1 + c4 * ve;
+                                    const float cst2 = c0 + ve * (c2 + c5 * ve);
+                                    const float us = fminf(fmaxf(-lin2 * i2c3, u0), u1);
+                                    emax = fmaxf(emax, cst2 + us * (lin2 + c3 * us));
+                                }
+                                pass = emax > -8.05f;
+                            }
+                        }
+                        const uint64_t m = __ballot(pass);
+                        const uint32_t n = (uint32_t)__popcll(m);
+                        if (pass) {
+                            const int slot = __popcll(m & ((1ull << lane) - 1ull));
+                            s_q0[w][slot] = q0;
+                            s_q1[w][slot] = q1;
+                            s_qb[w][slot] = q2.x;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        probe_n += n;
+                        if (n != 0u) {
+                            float4 a0 = s_q0[w][0];          // c0 c1 c2 c3
+                            float4 a1 = s_q1[w][0];          // c4 c5 r g
+                            float ab = s_qb[w][0];
+#pragma unroll 2
+                            for (uint32_t j = 0; j < n; ++j) {
+                                // next record (slot n is a harmless over-read inside the 65-slot arrays)
+                                const float4 n0 = s_q0[w][j + 1];
+                                const float4 n1 = s_q1[w][j + 1];
+                                const float nb = s_qb[w][j + 1];
+                                const float t1 = __builtin_fmaf(a1.x, v, __builtin_fmaf(a0.w, u, a0.y));     // c1 + c3 u + c4 v
+                                const float t2 = __builtin_fmaf(a1.y, v, a0.z);                              // c2 + c5 v
+                                const float e2 = __builtin_fmaf(u, t1, __builtin_fmaf(v, t2, a0.x));
+                                // splat_frag.glsl:37-40 discard: w = exp2(e) > 1/256  <=>  e > -8
+                                const float wgt = (e2 > -8.0f) ? __builtin_amdgcn_exp2f(e2) : 0.0f;
+                                const float tw = T * wgt;
+                                cr = __builtin_fmaf(tw, a1.z, cr);
+                                cg = __builtin_fmaf(tw, a1.w, cg);
+                                cb = __builtin_fmaf(tw, ab, cb);
+                                T = T - tw;
+                                a0 = n0; a1 = n1; ab = nb;
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();      // the queue is refilled by the next 64 entries
+                    }
+                }
+                if (probe) probe_inner += clock64() - probe_t1;
+                // (d) a sub-block is finished once all its pixels are saturated (or outside the image)
+                alive = alive && (__ballot(inside && T >= fp.t_eps) != 0ull);
+                if (lane == 0) s_alive[w] = alive ? 1u : 0u;
+                __syncthreads();                      // also: every wave is done with this batch's s_rec
+                if ((s_alive[0] | s_alive[1] | s_alive[2] | s_alive[3]) == 0u) break;
+            }
+
+            if (probe != nullptr) {
+                if (lane == 0) s_probe[w] = probe_n;
+                __syncthreads();
+                if (tid == 0) {
+                    const int slot = (int)qpos;
+                    probe[slot * 8 + 0] = (uint32_t)(clock64() - probe_t0);
+                    probe[slot * 8 + 1] = s_probe[0] + s_probe[1] + s_probe[2] + s_probe[3];   // (record, sub-block) pairs blended
+                    probe[slot * 8 + 2] = probe_batches;
+                    probe[slot * 8 + 3] = (uint32_t)probe_inner;
+                    probe[slot * 8 + 4] = probe_words;
+                    probe[slot * 8 + 5] = probe_recs;
+                    probe[slot * 8 + 6] = end - start;
+                    probe[slot * 8 + 7] = 2u;             // ran; 2 = evaluations are 64 per blended pair (1 = 256 per record)
+                }
+            }
+            if (inside) {
+                char* row = (char*)out + (size_t)y * pitch_bytes;
+                if (HALF) {
+                    union { _Float16 h[4]; uint2 u2; } pk;
+                    pk.h[0] = (_Float16)cr; pk.h[1] = (_Float16)cg; pk.h[2] = (_Float16)cb; pk.h[3] = (_Float16)1.0f;
+                    ((uint2*)row)[x] = pk.u2;
+                } else {
+                    ((float4*)row)[x] = make_float4(cr, cg, cb, 1.0f);
+                }
+            }
+        }
+        // next work item: one atomic per workgroup, broadcast through LDS
+        __syncthreads();
+        if (tid == 0) s_next = gridDim.x + atomicAdd(queue, 1u);
+        __syncthreads();
+        qpos = s_next;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -97,9 +97,9 @@ typedef struct msplat_composite_work {
     uint64_t list_entries;        /* sum of the bin-list lengths: what it would fetch without early-out   */
     uint64_t pair_words_fetched;  /* 4-byte list entries whose loads were issued                          */
     uint64_t records_fetched;     /* 48-byte projected records whose loads were issued                    */
-    uint64_t records_composited;  /* records that passed the exact footprint test of a 16x16 tile (one wave   */
-                                  /* per tile) or (record, 8x8 sub-block) pairs (four waves per tile)     */
-    uint64_t pixel_evals;         /* (pixel, splat) evaluations = 256 per record / 64 per pair            */
+    uint64_t records_composited;  /* records that passed the exact footprint test of their work item: a 16x8  */
+                                  /* half tile (default), a 16x16 tile or an 8x8 sub-block (MSPLAT_COMPOSITOR) */
+    uint64_t pixel_evals;         /* (pixel, splat) evaluations = 128 / 256 / 64 per composited record    */
     uint64_t batches;             /* 64-entry batches staged                                              */
     uint64_t clocks_sum, clocks_max, inner_clocks_sum;   /* shader clocks per work item (probe overhead included) */
 } msplat_composite_work;

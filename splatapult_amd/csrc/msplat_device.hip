@@ -73,7 +73,9 @@ struct msplat_ctx {
     Buf gsumB1, gsumB2;     // binning: column pass / row pass
     uint32_t gsumS_rows = 0, gsumB1_rows = 0, gsumB2_rows = 0;
     bool scan_free = true;  // MSPLAT_SCAN_KERNELS=1 forces the 3-kernel (upsweep, scan, downsweep) passes
-    bool quad_compositor = true;   // four waves per 16x16 tile (composite_quad_kernel); MSPLAT_COMPOSITOR=wave: one wave per tile
+    // compositor formulation: 0 = one wave per 16x16 tile, 1 = one wave per 16x8 half tile (default), 2 = four waves per
+    // tile (composite_quad_kernel, LDS-bound, kept for comparison); MSPLAT_COMPOSITOR=wave|half|quad
+    int comp_kind = 1;
     Buf totals;     // uint32[256]  digit totals of the current radix pass (rows in binning pass 2)
     Buf totals1;    // uint32[256]  column totals of binning pass 1
     Buf counters;   // uint32[16]: 0=V, 1=D, 2=overflow, 3=compositor tile queue, 4=drawn, 6..7=pairs16 (u64), 8=probe
@@ -177,7 +179,7 @@ inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) /
 
 constexpr uint32_t kFusedMaxChunks = 2048;     // scan-free passes up to this many chunk rows (64 group rows to add up)
 constexpr size_t kProbeWords = 8;                                           // per compositor work item
-constexpr size_t kProbeBytes = (size_t)65536 * 4 * kProbeWords * sizeof(uint32_t);   // 256x256 bins x 4 quadrants
+constexpr size_t kProbeBytes = (size_t)65536 * 8 * kProbeWords * sizeof(uint32_t);   // 256x256 bins x 4 quadrants x 2 halves
 
 int grid_for(uint32_t nchunks)
 {
@@ -279,7 +281,10 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
             rc = fail(ctx, MSPLAT_ERR_HIP, "LDS atomic order probe failed to run");
         ctx->atomic_rank = (hbad == 0) && getenv("MSPLAT_BALLOT_RANK") == nullptr;
         ctx->scan_free = getenv("MSPLAT_SCAN_KERNELS") == nullptr;
-        if (const char* ck = getenv("MSPLAT_COMPOSITOR")) ctx->quad_compositor = std::string(ck) != "wave";
+        if (const char* ck = getenv("MSPLAT_COMPOSITOR")) {
+            const std::string k = ck;
+            ctx->comp_kind = k == "wave" ? 0 : k == "quad" ? 2 : 1;
+        }
     }
     if (rc != MSPLAT_OK) {
         std::string msg = ctx->err;
@@ -1029,30 +1034,36 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         // markers around the stages can be processed while the previous kernel is still draining)
         hipEvent_t e0 = timed ? ctx->ev[tset][6] : nullptr, e1 = timed ? ctx->ev[tset][7] : nullptr;
         uint32_t* probe = ctx->probe_on ? (uint32_t*)ctx->probe.p : nullptr;
-        if (probe) HIP_TRY(ctx, hipMemsetAsync(probe, 0, (size_t)ntiles * 4 * kProbeWords * sizeof(uint32_t), s));
-        if (ctx->quad_compositor) {
+        if (probe) HIP_TRY(ctx, hipMemsetAsync(probe, 0, (size_t)ntiles * 8 * kProbeWords * sizeof(uint32_t), s));
+        const uint32_t* ts = (const uint32_t*)ctx->tile_start.p;
+        const uint32_t* pb = (const uint32_t*)ctx->pairsB.p;
+        const float4* r2 = (const float4*)ctx->rec2d.p;
+        const uint32_t* ord = (const uint32_t*)ctx->tile_order.p;
+        const bool f16 = ctx->cfg.fb_format == MSPLAT_FB_RGBA16F;
+        if (ctx->comp_kind == 2) {
             // four waves per tile: the pool is counted in workgroups of four waves
             const int qgrid = std::min(ntiles * 4, std::max(64, ctx->comp_waves / 4));
-            if (ctx->cfg.fb_format == MSPLAT_FB_RGBA16F)
-                hipExtLaunchKernelGGL(composite_quad_kernel<true>, dim3(qgrid), dim3(kQuadThreads), 0, s, e0, e1, 0,
-                                      (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
-                                      (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap,
-                                      (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u, probe);
+            if (f16)
+                hipExtLaunchKernelGGL(composite_quad_kernel<true>, dim3(qgrid), dim3(kQuadThreads), 0, s, e0, e1, 0, ts, pb, r2,
+                                      d_out, pitch, fp, cap, ord, d_queue, (uint32_t)ntiles * 4u, probe);
             else
-                hipExtLaunchKernelGGL(composite_quad_kernel<false>, dim3(qgrid), dim3(kQuadThreads), 0, s, e0, e1, 0,
-                                      (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
-                                      (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap,
-                                      (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u, probe);
-        } else if (ctx->cfg.fb_format == MSPLAT_FB_RGBA16F)
-            hipExtLaunchKernelGGL(composite_kernel<true>, dim3(cgrid), dim3(kCompThreads), 0, s, e0, e1, 0,
-                                  (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
-                                  (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap,
-                                  (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u, probe);
+                hipExtLaunchKernelGGL(composite_quad_kernel<false>, dim3(qgrid), dim3(kQuadThreads), 0, s, e0, e1, 0, ts, pb, r2,
+                                      d_out, pitch, fp, cap, ord, d_queue, (uint32_t)ntiles * 4u, probe);
+        } else if (ctx->comp_kind == 1) {
+            // one wave per 16x8 half tile: twice the work items
+            const int hgrid = std::min(ntiles * 8, ctx->comp_waves);
+            if (f16)
+                hipExtLaunchKernelGGL((composite_kernel<true, 1>), dim3(hgrid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2,
+                                      d_out, pitch, fp, cap, ord, d_queue, (uint32_t)ntiles * 8u, probe);
+            else
+                hipExtLaunchKernelGGL((composite_kernel<false, 1>), dim3(hgrid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2,
+                                      d_out, pitch, fp, cap, ord, d_queue, (uint32_t)ntiles * 8u, probe);
+        } else if (f16)
+            hipExtLaunchKernelGGL((composite_kernel<true, 2>), dim3(cgrid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2,
+                                  d_out, pitch, fp, cap, ord, d_queue, (uint32_t)ntiles * 4u, probe);
         else
-            hipExtLaunchKernelGGL(composite_kernel<false>, dim3(cgrid), dim3(kCompThreads), 0, s, e0, e1, 0,
-                                  (const uint32_t*)ctx->tile_start.p, (const uint32_t*)ctx->pairsB.p,
-                                  (const float4*)ctx->rec2d.p, d_out, pitch, fp, cap,
-                                  (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u, probe);
+            hipExtLaunchKernelGGL((composite_kernel<false, 2>), dim3(cgrid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2,
+                                  d_out, pitch, fp, cap, ord, d_queue, (uint32_t)ntiles * 4u, probe);
         ctx->comp_kernel_timed = timed;
     } else {
         ctx->comp_kernel_timed = false;
@@ -1257,8 +1268,8 @@ int msplat_debug_get_tile_probe(msplat_ctx* ctx, uint32_t* dst, uint32_t tile_ca
     if (!ctx->has_render) return fail(ctx, MSPLAT_ERR_NO_SORT, "no render yet");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t ntiles = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y) * 4u;   // (bin, quadrant) items
-    if (tile_cap < ntiles) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile capacity too small");
+    const uint32_t ntiles = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y) * (ctx->comp_kind == 1 ? 8u : 4u);   // work items
+    if (tile_cap < ntiles) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile capacity too small (work items = bins x %u)", ctx->comp_kind == 1 ? 8u : 4u);
     HIP_TRY(ctx, hipMemcpy(dst, ctx->probe.p, (size_t)ntiles * kProbeWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return MSPLAT_OK;
 }
@@ -1273,7 +1284,7 @@ int msplat_get_composite_work(msplat_ctx* ctx, msplat_composite_work* out)
     if (!ctx->probe.p || !ctx->probe_on)
         return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile probe not enabled (msplat_set_tile_probe)");
     if (!ctx->has_render) return fail(ctx, MSPLAT_ERR_NO_SORT, "no render yet");
-    const uint32_t items = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y) * 4u;
+    const uint32_t items = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y) * (ctx->comp_kind == 1 ? 8u : 4u);
     std::vector<uint32_t> h;
     try {
         h.resize((size_t)items * kProbeWords);
@@ -1289,7 +1300,7 @@ int msplat_get_composite_work(msplat_ctx* ctx, msplat_composite_work* out)
         out->clocks_sum += p[0];
         out->clocks_max = std::max<uint64_t>(out->clocks_max, p[0]);
         out->records_composited += p[1];        // one wave per tile: records; four waves per tile: (record, sub-block) pairs
-        out->pixel_evals += (uint64_t)p[1] * (p[7] == 2u ? 64u : (uint64_t)(kTile * kTile));
+        out->pixel_evals += (uint64_t)p[1] * (p[7] == 2u ? 64u : p[7] == 3u ? 128u : (uint64_t)(kTile * kTile));
         out->batches += p[2];
         out->inner_clocks_sum += p[3];
         out->pair_words_fetched += p[4];

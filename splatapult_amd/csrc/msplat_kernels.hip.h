@@ -238,27 +238,49 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
     }
 }
 
-// exclusive prefix of chunk `chunk`'s histogram row over the earlier chunks, and the digit total, from the group
-// tables (scan-free path); thread d handles digit d.  All loads are independent: they pipeline in L2.
-__device__ __forceinline__ uint32_t group_prefix(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ gsum,
-                                                 uint32_t chunk)
+// Sum of n0 rows starting at rows0 plus n1 rows starting at rows1 (rows of 256 uint32), returned per digit
+// (thread d gets digit d).  The whole workgroup cooperates: wave w takes rows w, w+4, ... and every lane loads
+// 16 bytes, so one wave-load is one coalesced 1 KB row and a thread issues a quarter of the loads a
+// thread-per-digit loop would (that loop cost 3-5 us per downsweep: r2 measurement); partial sums meet in `s_part`
+// (256 uint4 of scratch LDS).  Contains two barriers: every thread of the workgroup must call it.
+__device__ __forceinline__ uint32_t coop_row_sum(const uint32_t* __restrict__ rows0, uint32_t n0,
+                                                 const uint32_t* __restrict__ rows1, uint32_t n1, uint4* s_part)
 {
-    const uint32_t g = chunk >> kGroupShift;
-    uint32_t pre = 0;
-#pragma unroll 8
-    for (uint32_t k = 0; k < g; ++k) pre += gsum[(size_t)k * 256 + threadIdx.x];
-#pragma unroll 8
-    for (uint32_t c = g << kGroupShift; c < chunk; ++c) pre += hist[(size_t)c * 256 + threadIdx.x];
-    return pre;
+    const uint32_t q = threadIdx.x & 63u, rg = threadIdx.x >> 6;
+    uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 4
+    for (uint32_t r = rg; r < n0; r += 4u) {
+        const uint4 x = *reinterpret_cast<const uint4*>(rows0 + (size_t)r * 256 + q * 4u);
+        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+    }
+#pragma unroll 4
+    for (uint32_t r = rg; r < n1; r += 4u) {
+        const uint4 x = *reinterpret_cast<const uint4*>(rows1 + (size_t)r * 256 + q * 4u);
+        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+    }
+    s_part[rg * 64u + q] = acc;
+    __syncthreads();
+    const uint32_t* sp = reinterpret_cast<const uint32_t*>(s_part);
+    const uint32_t d = threadIdx.x;
+    const uint32_t sum = sp[d] + sp[256u + d] + sp[512u + d] + sp[768u + d];
+    __syncthreads();
+    return sum;
 }
 
-__device__ __forceinline__ uint32_t group_total(const uint32_t* __restrict__ gsum, uint32_t nchunks)
+// exclusive prefix of chunk `chunk`'s histogram row over the earlier chunks (scan-free path): the group rows before
+// its group plus the chunk rows before it inside the group
+__device__ __forceinline__ uint32_t group_prefix(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ gsum,
+                                                 uint32_t chunk, uint4* s_part)
+{
+    const uint32_t g = chunk >> kGroupShift;
+    return coop_row_sum(gsum, g, hist + (size_t)(g << kGroupShift) * 256, chunk - (g << kGroupShift), s_part);
+}
+
+// digit totals = sum of all group rows
+__device__ __forceinline__ uint32_t group_total(const uint32_t* __restrict__ gsum, uint32_t nchunks, uint4* s_part)
 {
     const uint32_t ng = (nchunks + (1u << kGroupShift) - 1u) >> kGroupShift;
-    uint32_t t = 0;
-#pragma unroll 8
-    for (uint32_t k = 0; k < ng; ++k) t += gsum[(size_t)k * 256 + threadIdx.x];
-    return t;
+    return coop_row_sum(gsum, ng, gsum, 0u, s_part);
 }
 
 // one workgroup per digit: exclusive scan of that digit's row over the active chunks; row total -> totals
@@ -367,7 +389,7 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
     __shared__ uint32_t s_cnt[4][256];   // per-wave digit counters, then per-wave scatter bases
     __shared__ uint32_t s_base[256];     // exclusive scan of the digit totals
     __shared__ uint32_t s_gdelta[256];   // global position minus chunk-local position, per digit
-    __shared__ uint32_t s_keys[CHUNK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[CHUNK];
     __shared__ uint32_t s_vals[HAS_VALUES ? CHUNK : 1];
     __shared__ uint8_t s_dig[CHUNK];
     __shared__ uint32_t s_tmp[4];
@@ -380,7 +402,8 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     {
-        const uint32_t t = (gsum != nullptr) ? group_total(gsum, nchunks) : totals[threadIdx.x];
+        // (s_keys doubles as the 4 KB scratch of the cooperative row sums: it is not live before the local sort)
+        const uint32_t t = (gsum != nullptr) ? group_total(gsum, nchunks, reinterpret_cast<uint4*>(s_keys)) : totals[threadIdx.x];
         uint32_t tot;
         const uint32_t incl = block_incl_scan(t, s_tmp, tot);
         s_base[threadIdx.x] = incl - t;
@@ -397,7 +420,8 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
 
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         // this chunk's exclusive prefix per digit (thread = digit): issued first, consumed after the local ranking
-        const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk) : hist[(size_t)chunk * 256 + threadIdx.x];
+        const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk, reinterpret_cast<uint4*>(s_keys))
+                                                     : hist[(size_t)chunk * 256 + threadIdx.x];
 #pragma unroll
         for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
         __syncthreads();
@@ -963,14 +987,16 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
     // item -> owner rectangle table (chunks with at most kOwnerCap items; larger ones binary-search s_off):
     // one LDS read per item instead of a 10-step dependent search, twice per item
     constexpr uint32_t kOwnerCap = 8192;
-    __shared__ uint16_t s_owner[kOwnerCap];
+    __shared__ __attribute__((aligned(16))) uint16_t s_owner[kOwnerCap];
+    uint4* s_part = reinterpret_cast<uint4*>(s_owner);      // 16 KB, not live while the row sums run
     const uint32_t V = *d_V;
     const uint32_t nchunks = (V + kBinChunk - 1) / kBinChunk;
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     {
-        const uint32_t t = (gsum != nullptr) ? group_total(gsum, nchunks) : totals[threadIdx.x];
+        // (s_part: 4 KB scratch for the cooperative row sums of the scan-free path)
+        const uint32_t t = (gsum != nullptr) ? group_total(gsum, nchunks, s_part) : totals[threadIdx.x];
         uint32_t tot;
         const uint32_t incl = block_incl_scan(t, s_tmp, tot);
         s_base[threadIdx.x] = incl - t;
@@ -993,7 +1019,7 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
     __syncthreads();
 
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk) : hist[(size_t)chunk * 256 + threadIdx.x];
+        const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk, s_part) : hist[(size_t)chunk * 256 + threadIdx.x];
         const uint32_t rbase = chunk * kBinChunk;
         uint32_t rc[PER], woff[PER], wsum = 0;
 #pragma unroll
@@ -1202,7 +1228,15 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
 
 constexpr int kCompThreads = 64;   // one wave per 16x16 tile, 4 pixels (one per 16x4 strip) per lane
 
-template <bool HALF>
+// NP = strip pairs per work item: 2 = the whole 16x16 tile (work item = (bin, quadrant)), 1 = one 16x8 HALF tile
+// (work item = (bin, quadrant, half)).  Round-2 measurements behind the half-tile form: the launch
+// lasts exactly as long as its heaviest work item (the heaviest tile needs 2.4x the mean and finishes alone on its
+// SIMD, where one wave issues VALU at a quarter of the SIMD's rate); a half tile sees 79 % of its tile's
+// records, so two halves cost 0.84 of the tile, with half the dependent chain and twice the work items for the queue.
+// 64 pixels per wave (four waves per tile, composite_quad_kernel below) is NOT the next step: every record costs
+// ~10 LDS-pipe cycles per wave however few pixels the wave owns, and at 64 pixels the four SIMDs of a CU ask for
+// more broadcast reads than its one LDS pipe delivers.
+template <bool HALF, int NP>
 __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t* __restrict__ tile_start,
                                                                  const uint32_t* __restrict__ pairs,
                                                                  const float4* __restrict__ rec,
@@ -1223,14 +1257,18 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
     // The first tile of every wave is static (its workgroup index): same-address atomics are served
     // at only ~8 ns each, so thousands of waves pulling at launch would queue up for tens of us.
     // Work item = (bin, quadrant): the four 16x16 tiles of a 32x32 bin share the bin's list.
+    constexpr int NS = 2 * NP;                       // 16x4 strips per work item
+    constexpr int ROWS = 4 * NS;                     // pixel rows per work item
     for (uint32_t qpos = blockIdx.x; qpos < ntiles;) {
     const int tile = (int)qpos;                       // probe slot
-    const int bin = (int)order[qpos >> 2];
-    const int quad = (int)(qpos & 3u);
+    const uint32_t tpos = (NP == 2) ? qpos : (qpos >> 1);          // (bin, quadrant) index
+    const int half = (NP == 2) ? 0 : (int)(qpos & 1u);            // which 16x8 half of the tile
+    const int bin = (int)order[tpos >> 2];
+    const int quad = (int)(tpos & 3u);
     const int bvy = bin / fp.tiles_x;
     const int tx = (bin - bvy * fp.tiles_x) * 2 + (quad & 1);
     const int ty = (bvy * fp.row_mod + fp.row_rem) * 2 + (quad >> 1);
-    if (tx * kTile >= fp.width || ty * kTile >= fp.height) {      // quadrant entirely outside the image
+    if (tx * kTile >= fp.width || ty * kTile + half * ROWS >= fp.height) {      // work item entirely outside the image
         uint32_t nq = 0;
         if (threadIdx.x == 0) nq = atomicAdd(queue, 1u);
         qpos = gridDim.x + __builtin_amdgcn_readfirstlane(nq);
@@ -1238,10 +1276,10 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
     }
     const int lane = threadIdx.x;
     const int lx = lane & 15, ly = lane >> 4;
-    const int x = tx * kTile + lx, ybase = ty * kTile + ly;
+    const int x = tx * kTile + lx, ybase = ty * kTile + half * ROWS + ly;
     const float fx = (float)x + 0.5f;
     const float fy0 = (float)ybase + 0.5f;
-    const float tile_y0 = (float)(ty * kTile);
+    const float tile_y0 = (float)(ty * kTile + half * ROWS);
 
     uint32_t start = tile_start[bin], end = tile_start[bin + 1];
     if (start > cap) start = cap;
@@ -1251,19 +1289,21 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
     // op in ~4 cycles but a packed v_pk_{fma,mul,add}_f32 does two per lane in the same slot (measured:
     // SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.4 cycles), and this kernel is VALU bound.
     typedef float v2f __attribute__((ext_vector_type(2)));
-    v2f T[2], cr[2], cg[2], cb[2];
-    bool inside[4];
+    v2f T[NP], cr[NP], cg[NP], cb[NP];
+    bool inside[NS];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NP; ++h) {
         T[h] = (v2f){1.0f, 1.0f};
         cr[h] = (v2f){0.0f, 0.0f}; cg[h] = (v2f){0.0f, 0.0f}; cb[h] = (v2f){0.0f, 0.0f};
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) inside[k] = (x < fp.width) && (ybase + 4 * k < fp.height);
-    const v2f fyp[2] = {(v2f){fy0, fy0 + 4.0f}, (v2f){fy0 + 8.0f, fy0 + 12.0f}};
+    for (int k = 0; k < NS; ++k) inside[k] = (x < fp.width) && (ybase + 4 * k < fp.height);
+    v2f fyp[NP];
+#pragma unroll
+    for (int h = 0; h < NP; ++h) fyp[h] = (v2f){fy0 + 8.0f * h, fy0 + 8.0f * h + 4.0f};
     uint32_t alive = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) alive |= (__ballot(inside[k]) != 0ull) ? (1u << k) : 0u;
+    for (int k = 0; k < NS; ++k) alive |= (__ballot(inside[k]) != 0ull) ? (1u << k) : 0u;
 
     // Three-stage software pipeline over batches of 64 list entries (nearest first):
     //   ranks of batch b+2 and records of batch b+1 are in flight while batch b is composited,
@@ -1303,7 +1343,7 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
             const float ylo = p0.y - p2.w, yhi = p0.y + p2.w;
             bool rel = false;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < NS; ++k)
                 rel = rel || ((alive & (1u << k)) && yhi >= tile_y0 + 4.0f * k + 0.5f && ylo <= tile_y0 + 4.0f * k + 3.5f);
             rel = rel && lane < (int)cnt;
             if (rel) {
@@ -1311,7 +1351,7 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
                 // e(d) is a concave quadratic, so unless the centre lies inside the tile's box of pixel
                 // centres its maximum over the box is on one of the four edges (1-D maximiser, clamped)
                 const float X0 = (float)(tx * kTile) + 0.5f, X1 = X0 + (float)(kTile - 1);
-                const float Y0 = tile_y0 + 0.5f, Y1 = Y0 + (float)(kTile - 1);
+                const float Y0 = tile_y0 + 0.5f, Y1 = Y0 + (float)(ROWS - 1);
                 const float qa = p0.z, qb = p0.w, qc = p1.x, la = p1.y;
                 const float dxl = X0 - p0.x, dxh = X1 - p0.x, dyl = Y0 - p0.y, dyh = Y1 - p0.y;
                 if (!(dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f)) {
@@ -1375,7 +1415,7 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
                 // Branch-free on purpose: the strips are independent dependency chains inside one basic
                 // block, so the in-order wave can overlap them.  w = 0 where the fragment shader discards.
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < NP; ++h) {
                     const v2f dy = fyp[h] - vpy;
                     const v2f e = __builtin_elementwise_fma(dy, __builtin_elementwise_fma(vC, dy, vlin), vbase);
                     // splat_frag.glsl:37-40 discard: w = exp2(e) > 1/256  <=>  e > -8
@@ -1395,7 +1435,7 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
         // strips whose 64 pixels are all saturated (or outside the image) are finished
         uint32_t na = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < NS; ++k)
             na |= (__ballot(inside[k] && T[k >> 1][k & 1] >= fp.t_eps) != 0ull) ? (1u << k) : 0u;
         alive = na;
         __syncthreads();
@@ -1409,10 +1449,10 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
         probe[tile * 8 + 4] = probe_words;      // 4-byte pair words loaded
         probe[tile * 8 + 5] = probe_recs;       // 48-byte projected records loaded
         probe[tile * 8 + 6] = end - start;      // length of the bin list
-        probe[tile * 8 + 7] = 1u;               // work item ran (quadrants outside the image do not)
+        probe[tile * 8 + 7] = (NP == 2) ? 1u : 3u;      // work item ran; 1 = 256, 3 = 128 evaluations per composited record
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NS; ++k) {
         if (inside[k]) {
             char* row = (char*)out + (size_t)(ybase + 4 * k) * pitch_bytes;
             if (HALF) {

@@ -248,11 +248,11 @@ class SplatRenderer:
 
     def debug_tile_probe(self):
         st = self.stats()
-        nt = st["tiles_x"] * st["tiles_y"] * 4        # one slot per (bin, quadrant) work item
+        nt = st["tiles_x"] * st["tiles_y"] * 8        # one slot per work item: (bin, quadrant[, half])
         out = np.zeros((max(nt, 1), 8), np.uint32)
         _capi.check(self._ctx, self._lib.msplat_debug_get_tile_probe(
             self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.shape[0]))
-        return out[:nt]
+        return out[out[:, 7] > 0]
 
     def debug_tile_lists(self):
         st = self.stats()

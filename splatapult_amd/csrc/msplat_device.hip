@@ -78,7 +78,8 @@ struct msplat_ctx {
     int comp_kind = 1;
     Buf totals;     // uint32[256]  digit totals of the current radix pass (rows in binning pass 2)
     Buf totals1;    // uint32[256]  column totals of binning pass 1
-    Buf counters;   // uint32[16]: 0=V, 1=D, 2=overflow, 3=compositor tile queue, 4=drawn, 6..7=pairs16 (u64), 8=probe
+    Buf counters;   // uint32[16]: 0=V, 1=D, 2=overflow, 4=drawn, 6..7=pairs16 (u64), 8=probe
+    Buf queue;      // uint32[kQueueShards * kQueueStride]: the compositors' sharded work queue heads
     // render state
     Buf rec2d;      // float4[3*N]
     Buf rect;       // uint32[N]
@@ -254,6 +255,7 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
     int rc = buf_alloc(ctx, ctx->totals, 256 * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->counters, 16 * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->totals1, 256 * sizeof(uint32_t));
+    if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->queue, kQueueShards * kQueueStride * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_start, 65537 * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_order, 65536 * sizeof(uint32_t));
     if (c.compositor_waves > 0) ctx->comp_waves = std::max(64, (int)c.compositor_waves);
@@ -308,7 +310,7 @@ void msplat_destroy(msplat_ctx* ctx)
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     Buf* all[] = {&ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist, &ctx->gsumS[0], &ctx->gsumS[1], &ctx->gsumB1, &ctx->gsumB2,
                   &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->totals1, &ctx->tile_start, &ctx->tile_order,
-                  &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe, &ctx->zq, &ctx->sprite};
+                  &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe, &ctx->zq, &ctx->sprite, &ctx->queue};
     for (Buf* b : all) buf_free(ctx, *b);
     if (ctx->ev_ok)
         for (auto& set : ctx->ev)
@@ -924,7 +926,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     hipStream_t s = ctx->stream;
     const uint32_t N = (uint32_t)ctx->N;
     uint32_t* counters = (uint32_t*)ctx->counters.p;
-    uint32_t *d_V = counters + 0, *d_D = counters + 1, *d_overflow = counters + 2, *d_queue = counters + 3;
+    uint32_t *d_V = counters + 0, *d_D = counters + 1, *d_overflow = counters + 2, *d_queue = (uint32_t*)ctx->queue.p;
     const int ntiles = fp.tiles_x * fp.tiles_y;
     const uint32_t cap = (uint32_t)ctx->pair_cap;
 

@@ -1180,13 +1180,39 @@ __global__ __launch_bounds__(kThreads) void tile_start_kernel(const uint32_t* __
     if (lane == 0) tile_start[tile] = lo;
 }
 
+// The compositors' work queue.  One queue head serves only ~90 returning atomics per microsecond (measured r2: a
+// half-tile launch pulling 8 k items from one head spent ~90 us queueing), so the head is sharded: item i lives
+// in shard i % 32, a workgroup pulls from the shard of its index and, when that one is drained, from up to two
+// neighbours (checked with a plain load first, so drained shards are not hammered by the exiting waves).
+// Items are stored heaviest-first, so every shard hands out its share heaviest-first too.  The first item of every
+// workgroup is static (its own index): queue[s] counts only the items of shard s taken dynamically.
+constexpr uint32_t kQueueShards = 32;
+constexpr uint32_t kQueueStride = 16;          // words between heads: one 64-byte line each
+__device__ __forceinline__ uint32_t queue_next(uint32_t* __restrict__ queue, uint32_t nitems)
+{
+    const uint32_t home = blockIdx.x % kQueueShards;
+    for (uint32_t t = 0; t < 3u; ++t) {
+        const uint32_t s = (home + t) % kQueueShards;
+        const uint32_t stat = (gridDim.x + kQueueShards - 1u - s) / kQueueShards;      // items of shard s taken statically
+        uint32_t* head = queue + s * kQueueStride;
+        if (t != 0u) {
+            const uint32_t cur = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint64_t)(cur + stat) * kQueueShards + s >= nitems) continue;
+        }
+        const uint32_t k = atomicAdd(head, 1u) + stat;
+        const uint64_t item = (uint64_t)k * kQueueShards + s;
+        if (item < nitems) return (uint32_t)item;
+    }
+    return 0xFFFFFFFFu;
+}
+
 // tiles ordered by descending list length (counting sort on len/16): the compositor's waves pull tiles
 // from this list through an atomic queue, heaviest first (longest-processing-time-first scheduling)
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ tile_start, int ntiles,
                                                           uint32_t* __restrict__ order,
                                                           uint32_t* __restrict__ queue)
 {
-    if (threadIdx.x == 0) *queue = 0u;      // the compositor's work queue starts empty every frame
+    if (threadIdx.x < kQueueShards) queue[threadIdx.x * kQueueStride] = 0u;      // the compositors' work queue starts empty every frame
 
     __shared__ uint32_t s_cnt[256];
     __shared__ uint32_t s_off[256];
@@ -1270,8 +1296,8 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
     const int ty = (bvy * fp.row_mod + fp.row_rem) * 2 + (quad >> 1);
     if (tx * kTile >= fp.width || ty * kTile + half * ROWS >= fp.height) {      // work item entirely outside the image
         uint32_t nq = 0;
-        if (threadIdx.x == 0) nq = atomicAdd(queue, 1u);
-        qpos = gridDim.x + __builtin_amdgcn_readfirstlane(nq);
+        if (threadIdx.x == 0) nq = queue_next(queue, ntiles);
+        qpos = __builtin_amdgcn_readfirstlane(nq);
         continue;
     }
     const int lane = threadIdx.x;
@@ -1466,8 +1492,8 @@ __global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t*
     }
     __syncthreads();      // s_rec is reused by the next tile
     uint32_t nq = 0;
-    if (threadIdx.x == 0) nq = atomicAdd(queue, 1u);
-    qpos = gridDim.x + __builtin_amdgcn_readfirstlane(nq);
+    if (threadIdx.x == 0) nq = queue_next(queue, ntiles);
+    qpos = __builtin_amdgcn_readfirstlane(nq);
     }   // persistent tile loop
 }
 
@@ -1707,7 +1733,7 @@ __global__ __launch_bounds__(kQuadThreads) void composite_quad_kernel(const uint
         }
         // next work item: one atomic per workgroup, broadcast through LDS
         __syncthreads();
-        if (tid == 0) s_next = gridDim.x + atomicAdd(queue, 1u);
+        if (tid == 0) s_next = queue_next(queue, nitems);
         __syncthreads();
         qpos = s_next;
     }

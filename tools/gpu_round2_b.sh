@@ -23,10 +23,12 @@ except Exception as e:
 PY
   done
 }
-ab base MSPLAT_COMPOSITOR=wave MSPLAT_SCAN_KERNELS=1
 ab wave MSPLAT_COMPOSITOR=wave
+ab wave4k MSPLAT_COMPOSITOR=wave MSPLAT_COMP_WAVES=4096
 ab quad MSPLAT_COMPOSITOR=quad
 ab half MSPLAT_COMPOSITOR=half
+ab half4k MSPLAT_COMPOSITOR=half MSPLAT_COMP_WAVES=4096
+ab half16k MSPLAT_COMPOSITOR=half MSPLAT_COMP_WAVES=16384
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r2b_prof -o run --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline --frames-in-flight 1 > $GRAFT_REPO_ROOT/gpurun_out/r2b_prof.log 2>&1)
 python - <<PY
 import csv, glob

@@ -75,7 +75,8 @@ struct msplat_ctx {
     bool scan_free = true;  // MSPLAT_SCAN_KERNELS=1 forces the 3-kernel (upsweep, scan, downsweep) passes
     // compositor formulation: 0 = one wave per 16x16 tile, 1 = one wave per 16x8 half tile (default), 2 = four waves per
     // tile (composite_quad_kernel, LDS-bound, kept for comparison); MSPLAT_COMPOSITOR=wave|half|quad
-    int comp_kind = 1;
+    int comp_kind = 0;
+    int comp_occ = 5;       // register budget of the compositor in waves per SIMD (MSPLAT_COMP_OCC = 5, 6 or 8)
     Buf totals;     // uint32[256]  digit totals of the current radix pass (rows in binning pass 2)
     Buf totals1;    // uint32[256]  column totals of binning pass 1
     Buf counters;   // uint32[16]: 0=V, 1=D, 2=overflow, 4=drawn, 6..7=pairs16 (u64), 8=probe
@@ -285,8 +286,9 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         ctx->scan_free = getenv("MSPLAT_SCAN_KERNELS") == nullptr;
         if (const char* ck = getenv("MSPLAT_COMPOSITOR")) {
             const std::string k = ck;
-            ctx->comp_kind = k == "wave" ? 0 : k == "quad" ? 2 : 1;
+            ctx->comp_kind = k == "half" ? 1 : k == "quad" ? 2 : 0;
         }
+        if (getenv("MSPLAT_COMP_OCC")) ctx->comp_occ = atoi(getenv("MSPLAT_COMP_OCC"));
     }
     if (rc != MSPLAT_OK) {
         std::string msg = ctx->err;
@@ -1051,21 +1053,25 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
             else
                 hipExtLaunchKernelGGL(composite_quad_kernel<false>, dim3(qgrid), dim3(kQuadThreads), 0, s, e0, e1, 0, ts, pb, r2,
                                       d_out, pitch, fp, cap, ord, d_queue, (uint32_t)ntiles * 4u, probe);
-        } else if (ctx->comp_kind == 1) {
-            // one wave per 16x8 half tile: twice the work items
-            const int hgrid = std::min(ntiles * 8, ctx->comp_waves);
-            if (f16)
-                hipExtLaunchKernelGGL((composite_kernel<true, 1>), dim3(hgrid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2,
-                                      d_out, pitch, fp, cap, ord, d_queue, (uint32_t)ntiles * 8u, probe);
-            else
-                hipExtLaunchKernelGGL((composite_kernel<false, 1>), dim3(hgrid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2,
-                                      d_out, pitch, fp, cap, ord, d_queue, (uint32_t)ntiles * 8u, probe);
-        } else if (f16)
-            hipExtLaunchKernelGGL((composite_kernel<true, 2>), dim3(cgrid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2,
-                                  d_out, pitch, fp, cap, ord, d_queue, (uint32_t)ntiles * 4u, probe);
-        else
-            hipExtLaunchKernelGGL((composite_kernel<false, 2>), dim3(cgrid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2,
-                                  d_out, pitch, fp, cap, ord, d_queue, (uint32_t)ntiles * 4u, probe);
+        } else {
+            // one wave per 16x8 half tile (twice the work items) or per 16x16 tile
+            const bool half = ctx->comp_kind == 1;
+            const uint32_t nitems = (uint32_t)ntiles * (half ? 8u : 4u);
+            const int grid = (int)std::min<uint32_t>(nitems, (uint32_t)ctx->comp_waves);
+#define MSPLAT_LAUNCH_COMP(F16, NP, OCC)                                                                              \
+    hipExtLaunchKernelGGL((composite_kernel<F16, NP, OCC>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, \
+                          d_out, pitch, fp, cap, ord, d_queue, nitems, probe)
+            const int occ = ctx->comp_occ >= 8 ? 8 : ctx->comp_occ >= 6 ? 6 : 5;
+            if (half) {
+                if (f16) { if (occ == 8) MSPLAT_LAUNCH_COMP(true, 1, 8); else MSPLAT_LAUNCH_COMP(true, 1, 6); }
+                else { if (occ == 8) MSPLAT_LAUNCH_COMP(false, 1, 8); else MSPLAT_LAUNCH_COMP(false, 1, 6); }
+            } else if (f16) {
+                if (occ == 8) MSPLAT_LAUNCH_COMP(true, 2, 8); else if (occ == 6) MSPLAT_LAUNCH_COMP(true, 2, 6); else MSPLAT_LAUNCH_COMP(true, 2, 5);
+            } else {
+                if (occ == 8) MSPLAT_LAUNCH_COMP(false, 2, 8); else if (occ == 6) MSPLAT_LAUNCH_COMP(false, 2, 6); else MSPLAT_LAUNCH_COMP(false, 2, 5);
+            }
+#undef MSPLAT_LAUNCH_COMP
+        }
         ctx->comp_kernel_timed = timed;
     } else {
         ctx->comp_kernel_timed = false;

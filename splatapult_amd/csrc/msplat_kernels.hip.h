@@ -1262,8 +1262,11 @@ constexpr int kCompThreads = 64;   // one wave per 16x16 tile, 4 pixels (one per
 // 64 pixels per wave (four waves per tile, composite_quad_kernel below) is NOT the next step: every record costs
 // ~10 LDS-pipe cycles per wave however few pixels the wave owns, and at 64 pixels the four SIMDs of a CU ask for
 // more broadcast reads than its one LDS pipe delivers.
-template <bool HALF, int NP>
-__global__ __launch_bounds__(kCompThreads) void composite_kernel(const uint32_t* __restrict__ tile_start,
+// OCC = waves per SIMD the register allocation must leave room for (__launch_bounds__): the kernel is VALU-issue
+// bound and a SIMD needs ~8 resident waves to issue at its full rate (tools/ubench_valu: 1.38 / 1.78 / 2.63 clocks per
+// instruction at 8 / 4 / 2 waves), while the unconstrained allocation takes 94 VGPRs = 5 waves.
+template <bool HALF, int NP, int OCC>
+__global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint32_t* __restrict__ tile_start,
                                                                  const uint32_t* __restrict__ pairs,
                                                                  const float4* __restrict__ rec,
                                                                  void* __restrict__ out, size_t pitch_bytes,

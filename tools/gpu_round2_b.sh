@@ -4,7 +4,7 @@
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-( time timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -rs -rP ) > gpurun_out/r2b_tests.log 2>&1
+[ -n "$SKIP_TESTS" ] || ( time timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -rs -rP ) > gpurun_out/r2b_tests.log 2>&1
 grep -E "passed|failed|FAILED|SKIPPED|check_image:|Error|error" gpurun_out/r2b_tests.log | head -60
 ab() {   # tag, env...
   tag=$1; shift
@@ -23,12 +23,13 @@ except Exception as e:
 PY
   done
 }
-ab wave MSPLAT_COMPOSITOR=wave
-ab wave4k MSPLAT_COMPOSITOR=wave MSPLAT_COMP_WAVES=4096
-ab quad MSPLAT_COMPOSITOR=quad
-ab half MSPLAT_COMPOSITOR=half
-ab half4k MSPLAT_COMPOSITOR=half MSPLAT_COMP_WAVES=4096
-ab half16k MSPLAT_COMPOSITOR=half MSPLAT_COMP_WAVES=16384
+ab wave5 MSPLAT_COMPOSITOR=wave
+ab wave6 MSPLAT_COMPOSITOR=wave MSPLAT_COMP_OCC=6
+ab wave8 MSPLAT_COMPOSITOR=wave MSPLAT_COMP_OCC=8
+ab half6_4k MSPLAT_COMPOSITOR=half MSPLAT_COMP_WAVES=4096
+ab half8_4k MSPLAT_COMPOSITOR=half MSPLAT_COMP_OCC=8 MSPLAT_COMP_WAVES=4096
+ab half8_6k MSPLAT_COMPOSITOR=half MSPLAT_COMP_OCC=8 MSPLAT_COMP_WAVES=6144
+ab half8_8k MSPLAT_COMPOSITOR=half MSPLAT_COMP_OCC=8 MSPLAT_COMP_WAVES=8192
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r2b_prof -o run --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline --frames-in-flight 1 > $GRAFT_REPO_ROOT/gpurun_out/r2b_prof.log 2>&1)
 python - <<PY
 import csv, glob

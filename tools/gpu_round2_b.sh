@@ -23,13 +23,11 @@ except Exception as e:
 PY
   done
 }
-ab wave5 MSPLAT_COMPOSITOR=wave
-ab wave6 MSPLAT_COMPOSITOR=wave MSPLAT_COMP_OCC=6
-ab wave8 MSPLAT_COMPOSITOR=wave MSPLAT_COMP_OCC=8
-ab half6_4k MSPLAT_COMPOSITOR=half MSPLAT_COMP_WAVES=4096
-ab half8_4k MSPLAT_COMPOSITOR=half MSPLAT_COMP_OCC=8 MSPLAT_COMP_WAVES=4096
-ab half8_6k MSPLAT_COMPOSITOR=half MSPLAT_COMP_OCC=8 MSPLAT_COMP_WAVES=6144
-ab half8_8k MSPLAT_COMPOSITOR=half MSPLAT_COMP_OCC=8 MSPLAT_COMP_WAVES=8192
+ab wave5 MSPLAT_COMP_SPLITQ=0
+ab split5
+ab split6 MSPLAT_COMP_OCC=6
+ab wave5b MSPLAT_COMP_SPLITQ=0
+ab split5b
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r2b_prof -o run --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline --frames-in-flight 1 > $GRAFT_REPO_ROOT/gpurun_out/r2b_prof.log 2>&1)
 python - <<PY
 import csv, glob

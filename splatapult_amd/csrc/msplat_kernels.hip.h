@@ -1270,11 +1270,7 @@ constexpr int kCompThreads = 64;   // one wave per 16x16 tile, 4 pixels (one per
 // queue.  A half sees ~0.8 of its tile's records, so the per-pair work drops by ~a fifth while list entries and
 // records are still fetched and tested once per tile (one wave per half tile, NP = 1, halves the evaluations the
 // same way but doubles fetching and testing: no faster, r2 measurement).
-// MASKED: the exp + blend part of a strip pair runs under the lanes' own "some pixel of mine passes the discard test"
-// predicate (EXEC mask), and is skipped when no lane of the wave passes.  Two thirds of the evaluated pixels lie
-// outside the record's footprint: masked lanes do not switch, and dense packed-FMA code on all 1024 SIMDs is
-// power-limited on this part (tools/ubench_valu: the clock drops by a third under v_pk_fma_f32).
-template <bool HALF, int NP, int OCC, bool SPLITQ, bool MASKED>
+template <bool HALF, int NP, int OCC, bool SPLITQ>
 __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint32_t* __restrict__ tile_start,
                                                                  const uint32_t* __restrict__ pairs,
                                                                  const float4* __restrict__ rec,
@@ -1470,16 +1466,14 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                     const v2f dy = fyp[h] - vpy;
                     const v2f e = __builtin_elementwise_fma(dy, __builtin_elementwise_fma(vC, dy, vlin), vbase);
                     // splat_frag.glsl:37-40 discard: w = exp2(e) > 1/256  <=>  e > -8
-                    if (!MASKED || e.x > -8.0f || e.y > -8.0f) {
-                        v2f w;
-                        w.x = (e.x > -8.0f) ? __builtin_amdgcn_exp2f(e.x) : 0.0f;
-                        w.y = (e.y > -8.0f) ? __builtin_amdgcn_exp2f(e.y) : 0.0f;
-                        const v2f tw = T[h] * w;
-                        cr[h] = __builtin_elementwise_fma(tw, vr, cr[h]);
-                        cg[h] = __builtin_elementwise_fma(tw, vg, cg[h]);
-                        cb[h] = __builtin_elementwise_fma(tw, vb, cb[h]);
-                        T[h] = T[h] - tw;
-                    }
+                    v2f w;
+                    w.x = (e.x > -8.0f) ? __builtin_amdgcn_exp2f(e.x) : 0.0f;
+                    w.y = (e.y > -8.0f) ? __builtin_amdgcn_exp2f(e.y) : 0.0f;
+                    const v2f tw = T[h] * w;
+                    cr[h] = __builtin_elementwise_fma(tw, vr, cr[h]);
+                    cg[h] = __builtin_elementwise_fma(tw, vg, cg[h]);
+                    cb[h] = __builtin_elementwise_fma(tw, vb, cb[h]);
+                    T[h] = T[h] - tw;
                 }
                 a = na; b = nb; blue = nblue;
             }
@@ -1509,16 +1503,14 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                     const v2f vr = (v2f){b.z, b.z}, vg = (v2f){b.w, b.w}, vb = (v2f){blue, blue};
                     const v2f dy = fyp[h] - vpy;
                     const v2f e = __builtin_elementwise_fma(dy, __builtin_elementwise_fma(vC, dy, vlin), vbase);
-                    if (!MASKED || e.x > -8.0f || e.y > -8.0f) {
-                        v2f w;
-                        w.x = (e.x > -8.0f) ? __builtin_amdgcn_exp2f(e.x) : 0.0f;
-                        w.y = (e.y > -8.0f) ? __builtin_amdgcn_exp2f(e.y) : 0.0f;
-                        const v2f tw = Th * w;
-                        crh = __builtin_elementwise_fma(tw, vr, crh);
-                        cgh = __builtin_elementwise_fma(tw, vg, cgh);
-                        cbh = __builtin_elementwise_fma(tw, vb, cbh);
-                        Th = Th - tw;
-                    }
+                    v2f w;
+                    w.x = (e.x > -8.0f) ? __builtin_amdgcn_exp2f(e.x) : 0.0f;
+                    w.y = (e.y > -8.0f) ? __builtin_amdgcn_exp2f(e.y) : 0.0f;
+                    const v2f tw = Th * w;
+                    crh = __builtin_elementwise_fma(tw, vr, crh);
+                    cgh = __builtin_elementwise_fma(tw, vg, cgh);
+                    cbh = __builtin_elementwise_fma(tw, vb, cbh);
+                    Th = Th - tw;
                     a = na; b = nb; blue = nblue;
                 }
                 T[h] = Th; cr[h] = crh; cg[h] = cgh; cb[h] = cbh;

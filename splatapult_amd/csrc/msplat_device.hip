@@ -77,24 +77,15 @@ struct msplat_ctx {
     // tile (composite_quad_kernel, LDS-bound, kept for comparison); MSPLAT_COMPOSITOR=wave|half|quad
     int comp_kind = 0;
     int comp_occ = 5;       // register budget of the compositor in waves per SIMD (MSPLAT_COMP_OCC = 5, 6 or 8)
+    bool comp_splitq = true;   // per-half record queues inside the one-wave-per-tile compositor (MSPLAT_COMP_SPLITQ=0: one queue)
     Buf totals;     // uint32[256]  digit totals of the current radix pass (rows in binning pass 2)
     Buf totals1;    // uint32[256]  column totals of binning pass 1
     Buf counters;   // uint32[16]: 0=V, 1=D, 2=overflow, 4=drawn, 6..7=pairs16 (u64), 8=probe
     Buf queue;      // uint32[kQueueShards * kQueueStride]: the compositors' sharded work queue heads
     // render state
-    // projected records, bin rectangles and quantised depths are addressed by SPLAT INDEX (project_kernel runs in
-    // storage order, independent of the sort); rect_rank is the rectangles gathered into draw order by bin1_upsweep
     Buf rec2d;      // float4[3*N]
     Buf rect;       // uint32[N]
-    Buf rect_rank;  // uint32[N]
-    Buf zq;         // uint32[N] quantised window depth (only with msplat_set_depth_test)
-    // project_kernel does not depend on the sort: it runs on a second stream while the sort's latency-bound passes
-    // occupy the main one (MSPLAT_OVERLAP_PROJECT=0: same stream)
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_proj = nullptr, ev_done = nullptr;
-    bool ev_done_valid = false;
-    bool overlap_project = true;
-    FrameParams sort_fp{};      // the frame parameters of the latest Sort (its cull defines the draw list)
+    Buf zq;         // uint32[N] quantised window depth per rank (only with msplat_set_depth_test)
     int depth_bits = 0;
     // point-cloud mode: pos4 = positions, recs = float4 colours, sprite = float4 mip chain
     bool point_mode = false;
@@ -294,18 +285,12 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
             rc = fail(ctx, MSPLAT_ERR_HIP, "LDS atomic order probe failed to run");
         ctx->atomic_rank = (hbad == 0) && getenv("MSPLAT_BALLOT_RANK") == nullptr;
         ctx->scan_free = getenv("MSPLAT_SCAN_KERNELS") == nullptr;
-        if (getenv("MSPLAT_OVERLAP_PROJECT")) ctx->overlap_project = atoi(getenv("MSPLAT_OVERLAP_PROJECT")) != 0;
-        if (ctx->overlap_project) {
-            const bool ok = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) == hipSuccess &&
-                            hipEventCreateWithFlags(&ctx->ev_proj, hipEventDisableTiming) == hipSuccess &&
-                            hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) == hipSuccess;
-            if (!ok) rc = fail(ctx, MSPLAT_ERR_HIP, "msplat_create: cannot create the projection stream / events");
-        }
         if (const char* ck = getenv("MSPLAT_COMPOSITOR")) {
             const std::string k = ck;
             ctx->comp_kind = k == "half" ? 1 : k == "quad" ? 2 : 0;
         }
         if (getenv("MSPLAT_COMP_OCC")) ctx->comp_occ = atoi(getenv("MSPLAT_COMP_OCC"));
+        if (getenv("MSPLAT_COMP_SPLITQ")) ctx->comp_splitq = atoi(getenv("MSPLAT_COMP_SPLITQ")) != 0;
     }
     if (rc != MSPLAT_OK) {
         std::string msg = ctx->err;
@@ -326,12 +311,9 @@ void msplat_destroy(msplat_ctx* ctx)
     ctx->recs = Buf{};
     ctx->store.reset();
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
-    if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
-    if (ctx->ev_proj) (void)hipEventDestroy(ctx->ev_proj);
-    if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     Buf* all[] = {&ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist, &ctx->gsumS[0], &ctx->gsumS[1], &ctx->gsumB1, &ctx->gsumB2,
-                  &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->rect_rank, &ctx->totals1, &ctx->tile_start, &ctx->tile_order,
+                  &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->totals1, &ctx->tile_start, &ctx->tile_order,
                   &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe, &ctx->zq, &ctx->sprite, &ctx->queue};
     for (Buf* b : all) buf_free(ctx, *b);
     if (ctx->ev_ok)
@@ -493,8 +475,6 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
         return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "%llu splats > 2^24 (rank field is 24 bit)", (unsigned long long)n);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->aux) HIP_TRY(ctx, hipStreamSynchronize(ctx->aux));
-    ctx->ev_done_valid = false;
     ctx->has_cloud = false;
     ctx->has_sort = false;
     ctx->has_render = false;
@@ -541,7 +521,6 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
     ctx->gsumS_rows = std::min(ctx->gsumS_rows, rows_s0);
     if ((rc = buf_alloc(ctx, ctx->rec2d, alloc_n * 48))) return rc;
     if ((rc = buf_alloc(ctx, ctx->rect, alloc_n * 4))) return rc;
-    if ((rc = buf_alloc(ctx, ctx->rect_rank, alloc_n * 4))) return rc;
     if (ctx->depth_bits != 0 && (rc = buf_alloc(ctx, ctx->zq, alloc_n * 4))) return rc;
     ctx->hist1_stride = std::max(1u, div_up(n, kBinChunk));
     if ((rc = buf_alloc(ctx, ctx->hist1, (size_t)256 * ctx->hist1_stride * 4))) return rc;
@@ -942,7 +921,6 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
     }
     HIP_TRY(ctx, hipGetLastError());
     ctx->has_sort = true;
-    ctx->sort_fp = fp;
     if (pending) return fail(ctx, pending, "%s", pending_msg.c_str());
     return MSPLAT_OK;
 }
@@ -960,30 +938,18 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const int tset = (int)(ctx->render_sets % msplat_ctx::kEvSets);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][2], s));
     const int pgrid = std::max(1u, div_up(N, kProjThreads));
-    // vertex + geometry stage.  The splat path's kernel needs nothing from the sort (it re-applies the sort's cull
-    // and writes by splat index), so it goes to the second stream: it overlaps the sort passes that msplat_sort
-    // has just queued on the main stream.  It may not start before the previous frame has finished with the buffers
-    // it overwrites (ev_done), and the binning below waits for it (ev_proj).
-    uint32_t* zqp_out = ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr;
-    if (ctx->point_mode) {
+    if (ctx->point_mode)
         hipLaunchKernelGGL(point_project_kernel, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
                            (const float4*)ctx->pos4.p, (const float4*)ctx->recs.p, fp, ctx->sprite_params,
-                           (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, zqp_out);
-    } else {
-        const bool ov = ctx->overlap_project && ctx->aux != nullptr;
-        hipStream_t ps = ov ? ctx->aux : s;
-        if (ov && ctx->ev_done_valid) HIP_TRY(ctx, hipStreamWaitEvent(ps, ctx->ev_done, 0));
-        if (ctx->full_sh)
-            hipLaunchKernelGGL(project_kernel<true>, dim3(pgrid), dim3(kProjThreads), 0, ps, (const float4*)ctx->pos4.p, N,
-                               (const float4*)ctx->recs.p, ctx->sort_fp, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, zqp_out);
-        else
-            hipLaunchKernelGGL(project_kernel<false>, dim3(pgrid), dim3(kProjThreads), 0, ps, (const float4*)ctx->pos4.p, N,
-                               (const float4*)ctx->recs.p, ctx->sort_fp, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, zqp_out);
-        if (ov) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_proj, ps));
-            HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_proj, 0));
-        }
-    }
+                           (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr);
+    else if (ctx->full_sh)
+        hipLaunchKernelGGL(project_kernel<true>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
+                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
+                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr);
+    else
+        hipLaunchKernelGGL(project_kernel<false>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
+                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
+                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][3], s));
 
     // pass 1: stable partition by tile column, enumerated from the rank-ordered rectangles
@@ -998,19 +964,17 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const bool fused2 = ctx->scan_free && last_D != 0u && div_up((uint64_t)last_D + (last_D >> 2), kPairChunk) <= kFusedMaxChunks;
     uint32_t* gB1 = (uint32_t*)ctx->gsumB1.p;
     uint32_t* gB2 = (uint32_t*)ctx->gsumB2.p;
-    hipLaunchKernelGGL(bin1_upsweep, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->valA.p, (const uint32_t*)ctx->rect.p,
-                       (uint32_t*)ctx->rect_rank.p, d_V, (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_overflow, fused1 ? gB1 : nullptr, (uint32_t*)nullptr, 0u);
+    hipLaunchKernelGGL(bin1_upsweep, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
+                       (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_overflow, fused1 ? gB1 : nullptr, (uint32_t*)nullptr, 0u);
     if (!fused1)
         launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V, 0u, N, (uint32_t)kBinChunk, totals1);
     if (ctx->atomic_rank)
-        hipLaunchKernelGGL(bin1_downsweep<true>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->valA.p,
-                           (const uint32_t*)ctx->rect_rank.p, d_V,
+        hipLaunchKernelGGL(bin1_downsweep<true>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
                            (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,
                            (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags, async_overflow_flag ? 1 : 0,
                            fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr);
     else
-        hipLaunchKernelGGL(bin1_downsweep<false>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->valA.p,
-                           (const uint32_t*)ctx->rect_rank.p, d_V,
+        hipLaunchKernelGGL(bin1_downsweep<false>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
                            (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,
                            (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags, async_overflow_flag ? 1 : 0,
                            fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr);
@@ -1096,15 +1060,17 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
             const bool half = ctx->comp_kind == 1;
             const uint32_t nitems = (uint32_t)ntiles * (half ? 8u : 4u);
             const int grid = (int)std::min<uint32_t>(nitems, (uint32_t)ctx->comp_waves);
-#define MSPLAT_LAUNCH_COMP(F16, NP, OCC)                                                                              \
-    hipExtLaunchKernelGGL((composite_kernel<F16, NP, OCC>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2,  \
+#define MSPLAT_LAUNCH_COMP(F16, NP, OCC, SQ)                                                                          \
+    hipExtLaunchKernelGGL((composite_kernel<F16, NP, OCC, SQ>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, \
                           d_out, pitch, fp, cap, ord, d_queue, nitems, probe)
-#define MSPLAT_LAUNCH_COMP_F(NP, OCC) do { if (f16) MSPLAT_LAUNCH_COMP(true, NP, OCC); else MSPLAT_LAUNCH_COMP(false, NP, OCC); } while (0)
+#define MSPLAT_LAUNCH_COMP_F(NP, OCC, SQ) do { if (f16) MSPLAT_LAUNCH_COMP(true, NP, OCC, SQ); else MSPLAT_LAUNCH_COMP(false, NP, OCC, SQ); } while (0)
             const int occ = ctx->comp_occ >= 8 ? 8 : ctx->comp_occ >= 6 ? 6 : 5;
             if (half) {                          // experiment: one wave per 16x8 half tile
-                if (occ == 8) MSPLAT_LAUNCH_COMP_F(1, 8); else MSPLAT_LAUNCH_COMP_F(1, 6);
+                if (occ == 8) MSPLAT_LAUNCH_COMP_F(1, 8, false); else MSPLAT_LAUNCH_COMP_F(1, 6, false);
+            } else if (ctx->comp_splitq) {
+                if (occ >= 6) MSPLAT_LAUNCH_COMP_F(2, 6, true); else MSPLAT_LAUNCH_COMP_F(2, 5, true);
             } else {
-                if (occ >= 6) MSPLAT_LAUNCH_COMP_F(2, 6); else MSPLAT_LAUNCH_COMP_F(2, 5);
+                if (occ >= 6) MSPLAT_LAUNCH_COMP_F(2, 6, false); else MSPLAT_LAUNCH_COMP_F(2, 5, false);
             }
 #undef MSPLAT_LAUNCH_COMP_F
 #undef MSPLAT_LAUNCH_COMP
@@ -1117,10 +1083,6 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][5], s));
         if (ctx->comp_kernel_timed) ctx->comp_kernel_sets_mask |= 1u << tset; else ctx->comp_kernel_sets_mask &= ~(1u << tset);
         ctx->render_sets++;
-    }
-    if (ctx->overlap_project && ctx->aux != nullptr && !ctx->point_mode) {
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_done, s));      // the next projection may overwrite rec2d / rect / zq after this
-        ctx->ev_done_valid = true;
     }
     HIP_TRY(ctx, hipGetLastError());
     return MSPLAT_OK;
@@ -1236,7 +1198,7 @@ int msplat_get_stats(msplat_ctx* ctx, msplat_stats* out)
         uint32_t* counters = (uint32_t*)ctx->counters.p;
         HIP_TRY(ctx, hipMemsetAsync(counters + 4, 0, 4 * sizeof(uint32_t), ctx->stream));
         // counters + 6 is 8-byte aligned: the 64-bit pair count lives in words 6..7
-        hipLaunchKernelGGL(count_drawn_kernel, dim3(256), dim3(kThreads), 0, ctx->stream, (const uint32_t*)ctx->valA.p, (const uint32_t*)ctx->rect.p,
+        hipLaunchKernelGGL(count_drawn_kernel, dim3(256), dim3(kThreads), 0, ctx->stream, (const uint32_t*)ctx->rect.p,
                            (const float4*)ctx->rec2d.p, counters + 0, ctx->last_fp, counters + 4,
                            (unsigned long long*)(counters + 6));
     }
@@ -1304,21 +1266,8 @@ int msplat_debug_get_projected(msplat_ctx* ctx, float* rec12, uint32_t* rect, ui
     int rc = msplat_sort_count(ctx, &v);
     if (rc) return rc;
     if (cap < v) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "capacity %u < sort count %u", cap, v);
-    if (v == 0) return MSPLAT_OK;
-    // the device holds records and rectangles by splat index: gather them into draw order here (a test tap)
-    try {
-        std::vector<uint32_t> idx(v), hrect(ctx->N);
-        std::vector<float> hrec((size_t)ctx->N * 12);
-        HIP_TRY(ctx, hipMemcpy(idx.data(), ctx->valA.p, (size_t)v * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(hrec.data(), ctx->rec2d.p, (size_t)ctx->N * 48, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(hrect.data(), ctx->rect.p, (size_t)ctx->N * 4, hipMemcpyDeviceToHost));
-        for (uint32_t r = 0; r < v; ++r) {
-            if (rec12) std::memcpy(rec12 + (size_t)r * 12, hrec.data() + (size_t)idx[r] * 12, 48);
-            if (rect) rect[r] = hrect[idx[r]];
-        }
-    } catch (const std::exception&) {
-        return fail(ctx, MSPLAT_ERR_HIP, "out of host memory");
-    }
+    if (v && rec12) HIP_TRY(ctx, hipMemcpy(rec12, ctx->rec2d.p, (size_t)v * 48, hipMemcpyDeviceToHost));
+    if (v && rect) HIP_TRY(ctx, hipMemcpy(rect, ctx->rect.p, (size_t)v * 4, hipMemcpyDeviceToHost));
     return MSPLAT_OK;
 }
 
@@ -1388,16 +1337,6 @@ int msplat_debug_get_tile_lists(msplat_ctx* ctx, uint32_t* tile_start, uint32_t 
     if (pairs) {
         if (pair_cap < d) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "pair capacity too small");
         if (d) HIP_TRY(ctx, hipMemcpy(pairs, ctx->pairsB.p, d * 4, hipMemcpyDeviceToHost));
-        // the device words carry the splat index in their low 24 bits; this tap reports the draw-order rank
-        const uint32_t v = std::min<uint32_t>(cnt[0], (uint32_t)ctx->N);
-        try {
-            std::vector<uint32_t> idx(std::max<uint32_t>(v, 1)), rank_of(std::max<uint64_t>(ctx->N, 1), 0u);
-            if (v) HIP_TRY(ctx, hipMemcpy(idx.data(), ctx->valA.p, (size_t)v * 4, hipMemcpyDeviceToHost));
-            for (uint32_t r = 0; r < v; ++r) rank_of[idx[r]] = r;
-            for (uint64_t k = 0; k < d; ++k) pairs[k] = (pairs[k] & ~kRankMask) | rank_of[pairs[k] & kRankMask];
-        } catch (const std::exception&) {
-            return fail(ctx, MSPLAT_ERR_HIP, "out of host memory");
-        }
     }
     return MSPLAT_OK;
 }

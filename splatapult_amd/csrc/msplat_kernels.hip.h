@@ -633,9 +633,9 @@ __global__ __launch_bounds__(64) void ingest_kernel(const char* __restrict__ raw
 }
 
 // ------------------------------------------------------------------------------------------
-// project: vertex + geometry stage (one thread per splat, storage order)
+// project: vertex + geometry stage for the splats in draw order (one thread per rank)
 //   splat_vert.glsl:153-222 (+ SH :51-127, sRGB :129-151), splat_geom.glsl:22-54
-// Writes a 48-byte record and a packed bin rectangle per splat INDEX.
+// Writes a 48-byte record per rank, a packed tile rectangle, and counts pairs per tile.
 // ------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ float srgb_to_linear(float s)
@@ -660,40 +660,35 @@ __device__ __forceinline__ uint32_t quantise_depth(float ndcz, int depth_bits)
 constexpr int kProjThreads = 64;          // one wave per workgroup: wave-private LDS staging, no block barriers
 
 template <bool FULL_SH>
-__global__ __launch_bounds__(kProjThreads) void project_kernel(const float4* __restrict__ pos4, uint32_t N,
+__global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* __restrict__ sorted_idx,
+                                                               const uint32_t* __restrict__ d_V,
                                                                const float4* __restrict__ recs,
-                                                               FrameParams sort_fp, FrameParams fp,
+                                                               FrameParams fp,
                                                                float4* __restrict__ out_rec,
                                                                uint32_t* __restrict__ out_rect,
                                                                uint32_t* __restrict__ out_zq)
 {
-    // One thread per splat in STORAGE order (r2; r1 projected in draw order).  The projected records are
-    // addressed by splat index everywhere downstream (the pair words carry the index), so this kernel does not
-    // depend on the sort at all: it runs on a second stream WHILE the latency-bound sort passes run, and its
-    // record loads are plain streaming reads.  Splats the presort culled (same test, same frame
-    // parameters as the Sort that produced the draw order: sort_fp) are skipped before their record is touched.
-    // Records are 256 B (full SH) or 128 B (base) and line aligned; the wave loads its 64 records with
-    // fully coalesced 16-byte loads and transposes them through LDS (stride 68/36 dwords keeps the
-    // ds_read_b128 accesses conflict free).
+    // Records are 256 B (full SH) or 128 B (base) and line aligned.  The gather by sorted index is
+    // done cooperatively: F4 consecutive lanes fetch one whole record (coalesced 256/128 B), the wave
+    // stages 64 records in LDS, then every lane reads its own record back (stride 68/36 dwords keeps
+    // the ds_read_b128 accesses conflict free).
     constexpr int F4 = FULL_SH ? 16 : 8;
     constexpr int RPI = 64 / F4;              // records fetched per wave-wide load instruction
     constexpr int STRIDE = F4 * 4 + 4;        // dwords
     __shared__ __attribute__((aligned(16))) float s_stage[64 * STRIDE];
+    const uint32_t V = *d_V;
     const int lane = threadIdx.x;
-    const uint32_t base = blockIdx.x * kProjThreads;
-    const uint32_t i = base + lane;
-    bool valid = i < N;
-    if (valid) {
-        uint32_t key_unused;
-        valid = cull_key(pos4[i], sort_fp, key_unused);
-    }
-    if (__ballot(valid) == 0ull) return;          // nothing of this wave's 64 splats is in the draw list
+    if (blockIdx.x * kProjThreads >= V) return;
+    const uint32_t r = blockIdx.x * kProjThreads + lane;
+    const bool valid = r < V;
+    const uint32_t i = valid ? sorted_idx[r] : 0u;
     {
         const int sub = lane % F4;
         float4 tmp[F4];
 #pragma unroll
         for (int it = 0; it < F4; ++it) {
-            const uint32_t oi = min(base + (uint32_t)(it * RPI + lane / F4), N - 1u);
+            const int owner = it * RPI + lane / F4;
+            const uint32_t oi = __shfl(i, owner, 64);
             tmp[it] = recs[(size_t)oi * F4 + sub];
         }
 #pragma unroll
@@ -703,7 +698,6 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const float4* __r
         }
     }
     __syncthreads();
-    const uint32_t r = i;                     // output slot = splat index
     float f[F4 * 4];
 #pragma unroll
     for (int k = 0; k < F4; ++k) {
@@ -877,8 +871,7 @@ __device__ __forceinline__ uint32_t rect_width(uint32_t rc)
 
 // statistics only (msplat_get_stats): number of splats with a non-empty rectangle, and the number of
 // (splat, 16x16 tile) pairs their footprints cover (the "D" of the algorithmic byte count)
-__global__ __launch_bounds__(kThreads) void count_drawn_kernel(const uint32_t* __restrict__ sorted_idx,
-                                                               const uint32_t* __restrict__ rect,
+__global__ __launch_bounds__(kThreads) void count_drawn_kernel(const uint32_t* __restrict__ rect,
                                                                const float4* __restrict__ rec,
                                                                const uint32_t* __restrict__ d_V, FrameParams fp,
                                                                uint32_t* __restrict__ d_drawn,
@@ -887,8 +880,7 @@ __global__ __launch_bounds__(kThreads) void count_drawn_kernel(const uint32_t* _
     const uint32_t V = *d_V;
     uint32_t c = 0;
     unsigned long long p16 = 0;
-    for (uint32_t rk = blockIdx.x * kThreads + threadIdx.x; rk < V; rk += gridDim.x * kThreads) {
-        const uint32_t r = sorted_idx[rk];              // records and rectangles are addressed by splat index
+    for (uint32_t r = blockIdx.x * kThreads + threadIdx.x; r < V; r += gridDim.x * kThreads) {
         if (rect_width(rect[r]) == 0u) continue;
         ++c;
         const float4 a = rec[(size_t)r * 3 + 0], q = rec[(size_t)r * 3 + 2];      // px, py ... ex, ey
@@ -922,9 +914,7 @@ __global__ __launch_bounds__(kThreads) void count_drawn_kernel(const uint32_t* _
 //                     row the words are ascending and tile_start_kernel can binary-search them.
 // ------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restrict__ sorted_idx,
-                                                         const uint32_t* __restrict__ rect,
-                                                         uint32_t* __restrict__ rect_rank,
+__global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restrict__ rect,
                                                          const uint32_t* __restrict__ d_V,
                                                          uint32_t* __restrict__ hist, uint32_t hist_stride,
                                                          uint32_t* __restrict__ d_overflow,
@@ -947,10 +937,7 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
         for (int k = 0; k < kBinChunk / kThreads; ++k) {
             const uint32_t r = chunk * kBinChunk + k * kThreads + threadIdx.x;
             if (r < V) {
-                // rectangles are stored by splat index (project_kernel runs in storage order): gather them into draw
-                // order here, once, and leave the rank-ordered copy for the downsweep
-                const uint32_t rc = rect[sorted_idx[r]];
-                rect_rank[r] = rc;
+                const uint32_t rc = rect[r];
                 const uint32_t tx0 = rc & 255u, ty0 = (rc >> 8) & 255u, tx1 = (rc >> 16) & 255u, ty1 = rc >> 24;
                 if (tx0 <= tx1) {
                     // pairs per column = sum of row counts of the rectangles covering it: difference array
@@ -975,11 +962,8 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
 // order, weight = number of tile rows; wave w takes a contiguous quarter of the chunk's items, so
 // (wave, round, lane) order == item order.  Ranking inside a wave: ballot-match on the column byte,
 // weighted prefix from 9 ballots over the bits of the weight (rows <= 256).
-// The emitted word carries the splat INDEX in its low 24 bits (the compositor addresses the projected records with
-// it); the list order is the draw order because the partitions are stable, whatever the low bits hold.
 template <bool ATOMIC_RANK>
-__global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __restrict__ sorted_idx,
-                                                           const uint32_t* __restrict__ rect,
+__global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __restrict__ rect,
                                                            const uint32_t* __restrict__ d_V,
                                                            const uint32_t* __restrict__ hist, uint32_t hist_stride,
                                                            const uint32_t* __restrict__ totals,
@@ -997,7 +981,6 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
     constexpr int PER = kBinChunk / kThreads;          // rectangles per thread (blocked)
     __shared__ uint32_t s_off[kBinChunk + 1];          // exclusive scan of the rectangle widths
     __shared__ uint32_t s_rect[kBinChunk];
-    __shared__ uint32_t s_sidx[kBinChunk];             // splat index of every rank of the chunk
     __shared__ uint32_t s_cnt[4][256];                 // per-wave column weights, then per-wave cursors
     __shared__ uint32_t s_base[kThreads];
     __shared__ uint32_t s_tmp[4];
@@ -1043,7 +1026,6 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
         for (int k = 0; k < PER; ++k) {
             const uint32_t r = rbase + threadIdx.x * PER + k;
             rc[k] = (r < V) ? rect[r] : kRectEmpty;
-            s_sidx[threadIdx.x * PER + k] = (r < V) ? sorted_idx[r] : 0u;
             woff[k] = wsum;
             wsum += rect_width(rc[k]);
         }
@@ -1087,7 +1069,7 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
             tx = (r & 255u) + (k - s_off[lo]);
             ty0 = (r >> 8) & 255u;
             rows = (r >> 24) - ty0 + 1u;
-            rank = s_sidx[lo];              // the word's payload: splat index of rank rbase + lo
+            rank = rbase + lo;
         };
 
         // pass A: column weights per wave
@@ -1283,7 +1265,12 @@ constexpr int kCompThreads = 64;   // one wave per 16x16 tile, 4 pixels (one per
 // OCC = waves per SIMD the register allocation must leave room for (__launch_bounds__): the kernel is VALU-issue
 // bound and a SIMD needs ~8 resident waves to issue at its full rate (tools/ubench_valu: 1.38 / 1.78 / 2.63 clocks per
 // instruction at 8 / 4 / 2 waves), while the unconstrained allocation takes 94 VGPRs = 5 waves.
-template <bool HALF, int NP, int OCC>
+// SPLITQ (NP = 2 only): the staging pass keeps one queue per 16x8 half of the tile (a record joins the queue of a half
+// when its y-range reaches a live strip of that half) and the blend loop runs once per half over that half's
+// queue.  A half sees ~0.8 of its tile's records, so the per-pair work drops by ~a fifth while list entries and
+// records are still fetched and tested once per tile (one wave per half tile, NP = 1, halves the evaluations the
+// same way but doubles fetching and testing: no faster, r2 measurement).
+template <bool HALF, int NP, int OCC, bool SPLITQ>
 __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint32_t* __restrict__ tile_start,
                                                                  const uint32_t* __restrict__ pairs,
                                                                  const float4* __restrict__ rec,
@@ -1297,7 +1284,8 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
     // rows 4k..4k+3.  Per splat the exponent is split into a part shared by the four strips and a
     // 2-FMA part per strip; strips the splat's y-range cannot reach, or whose 64 pixels are all
     // saturated, are skipped with scalar branches.
-    __shared__ float4 s_rec[(kCompThreads + 1) * 3];
+    constexpr int NQ = (SPLITQ && NP == 2) ? 2 : 1;
+    __shared__ float4 s_rec[NQ][(kCompThreads + 1) * 3];
 
     // Persistent waves + dynamic queue: per-tile work varies by >10x (list length, early saturation),
     // so tiles are pulled heaviest-first from `order` instead of being bound to a workgroup index.
@@ -1385,13 +1373,19 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
         // stage only the splats whose y-range reaches a strip that is still live, compacted in list
         // order (near to far).  The CU has ONE scalar unit for its four SIMDs, so the inner loop is
         // written to need almost no scalar work: a plain counted loop, strips handled by VALU predicates.
-        uint32_t n;
+        uint32_t n, nq[NQ];
         {
             const float ylo = p0.y - p2.w, yhi = p0.y + p2.w;
             bool rel = false;
+            bool relh[NP];                   // the record's y-range reaches a live strip of half h
 #pragma unroll
-            for (int k = 0; k < NS; ++k)
-                rel = rel || ((alive & (1u << k)) && yhi >= tile_y0 + 4.0f * k + 0.5f && ylo <= tile_y0 + 4.0f * k + 3.5f);
+            for (int h = 0; h < NP; ++h) relh[h] = false;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const bool rk = (alive & (1u << k)) && yhi >= tile_y0 + 4.0f * k + 0.5f && ylo <= tile_y0 + 4.0f * k + 3.5f;
+                rel = rel || rk;
+                relh[k >> 1] = relh[k >> 1] || rk;
+            }
             rel = rel && lane < (int)cnt;
             if (rel) {
                 // exact footprint-vs-tile test (the list was built from bounding rectangles): the exponent
@@ -1418,13 +1412,19 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                     rel = emax > -8.05f;
                 }
             }
-            const uint64_t relmask = __ballot(rel);
-            n = (uint32_t)__popcll(relmask);
-            if (rel) {
-                const int slot = __popcll(relmask & ((1ull << lane) - 1ull));
-                s_rec[slot * 3 + 0] = p0;
-                s_rec[slot * 3 + 1] = p1;
-                s_rec[slot * 3 + 2] = p2;
+            n = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const bool mem = rel && (NQ == 1 || relh[q]);
+                const uint64_t relmask = __ballot(mem);
+                nq[q] = (uint32_t)__popcll(relmask);
+                n += nq[q];
+                if (mem) {
+                    const int slot = __popcll(relmask & ((1ull << lane) - 1ull));
+                    s_rec[q][slot * 3 + 0] = p0;
+                    s_rec[q][slot * 3 + 1] = p1;
+                    s_rec[q][slot * 3 + 2] = p2;
+                }
             }
         }
         __syncthreads();
@@ -1443,16 +1443,16 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
         probe_words += cntA;
         probe_recs += cnt;
         const uint64_t probe_t1 = probe ? clock64() : 0ull;
-        if (n != 0u) {
-            float4 a = s_rec[0];          // px, py, A, B
-            float4 b = s_rec[1];          // C, log2(alpha), r, g
-            float blue = s_rec[2].x;
+        if (NQ == 1 && n != 0u) {
+            float4 a = s_rec[0][0];          // px, py, A, B
+            float4 b = s_rec[0][1];          // C, log2(alpha), r, g
+            float blue = s_rec[0][2].x;
 #pragma unroll 2
             for (uint32_t j = 0; j < n; ++j) {
                 // next record (slot n is a harmless over-read inside the 65-slot array)
-                const float4 na = s_rec[(j + 1) * 3 + 0];
-                const float4 nb = s_rec[(j + 1) * 3 + 1];
-                const float nblue = s_rec[(j + 1) * 3 + 2].x;
+                const float4 na = s_rec[0][(j + 1) * 3 + 0];
+                const float4 nb = s_rec[0][(j + 1) * 3 + 1];
+                const float nblue = s_rec[0][(j + 1) * 3 + 2].x;
                 const float dx = fx - a.x;
                 const float base = __builtin_fmaf(a.z * dx, dx, b.y);
                 const float lin = a.w * dx;
@@ -1478,6 +1478,44 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                 a = na; b = nb; blue = nblue;
             }
         }
+        if (NQ == 2) {
+            // one blend loop per half over that half's queue: the same arithmetic per pixel as above, minus the records
+            // that cannot reach the half
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+                const int q = (NQ == 2) ? h : 0;
+                const uint32_t nh = nq[q];
+                if (nh == 0u) continue;
+                float4 a = s_rec[q][0];
+                float4 b = s_rec[q][1];
+                float blue = s_rec[q][2].x;
+                v2f Th = T[h], crh = cr[h], cgh = cg[h], cbh = cb[h];
+#pragma unroll 2
+                for (uint32_t j = 0; j < nh; ++j) {
+                    const float4 na = s_rec[q][(j + 1) * 3 + 0];
+                    const float4 nb = s_rec[q][(j + 1) * 3 + 1];
+                    const float nblue = s_rec[q][(j + 1) * 3 + 2].x;
+                    const float dx = fx - a.x;
+                    const float base = __builtin_fmaf(a.z * dx, dx, b.y);
+                    const float lin = a.w * dx;
+                    const v2f vbase = (v2f){base, base}, vlin = (v2f){lin, lin}, vC = (v2f){b.x, b.x};
+                    const v2f vpy = (v2f){a.y, a.y};
+                    const v2f vr = (v2f){b.z, b.z}, vg = (v2f){b.w, b.w}, vb = (v2f){blue, blue};
+                    const v2f dy = fyp[h] - vpy;
+                    const v2f e = __builtin_elementwise_fma(dy, __builtin_elementwise_fma(vC, dy, vlin), vbase);
+                    v2f w;
+                    w.x = (e.x > -8.0f) ? __builtin_amdgcn_exp2f(e.x) : 0.0f;
+                    w.y = (e.y > -8.0f) ? __builtin_amdgcn_exp2f(e.y) : 0.0f;
+                    const v2f tw = Th * w;
+                    crh = __builtin_elementwise_fma(tw, vr, crh);
+                    cgh = __builtin_elementwise_fma(tw, vg, cgh);
+                    cbh = __builtin_elementwise_fma(tw, vb, cbh);
+                    Th = Th - tw;
+                    a = na; b = nb; blue = nblue;
+                }
+                T[h] = Th; cr[h] = crh; cg[h] = cgh; cb[h] = cbh;
+            }
+        }
         if (probe) probe_inner += clock64() - probe_t1;
         // strips whose 64 pixels are all saturated (or outside the image) are finished
         uint32_t na = 0;
@@ -1496,7 +1534,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
         probe[tile * 8 + 4] = probe_words;      // 4-byte pair words loaded
         probe[tile * 8 + 5] = probe_recs;       // 48-byte projected records loaded
         probe[tile * 8 + 6] = end - start;      // length of the bin list
-        probe[tile * 8 + 7] = (NP == 2) ? 1u : 3u;      // work item ran; 1 = 256, 3 = 128 evaluations per composited record
+        probe[tile * 8 + 7] = (NP == 2 && NQ == 1) ? 1u : 3u;      // work item ran; 1 = 256, 3 = 128 evaluations per queue entry
     }
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
@@ -1963,12 +2001,11 @@ __global__ __launch_bounds__(kProjThreads) void point_project_kernel(const uint3
             if (ty0 <= ty1) rect = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
         }
     }
-    const uint32_t o = i;                     // outputs are addressed by point index, like the splat path's
-    out_rec[(size_t)o * 3 + 0] = make_float4(cx, cy, hx, hy);
-    out_rec[(size_t)o * 3 + 1] = col;
-    out_rec[(size_t)o * 3 + 2] = make_float4(lambda, 0.0f, 0.0f, 0.0f);
-    out_rect[o] = rect;
-    if (out_zq != nullptr) out_zq[o] = quantise_depth(ndcz, fp.depth_bits);
+    out_rec[(size_t)r * 3 + 0] = make_float4(cx, cy, hx, hy);
+    out_rec[(size_t)r * 3 + 1] = col;
+    out_rec[(size_t)r * 3 + 2] = make_float4(lambda, 0.0f, 0.0f, 0.0f);
+    out_rect[r] = rect;
+    if (out_zq != nullptr) out_zq[r] = quantise_depth(ndcz, fp.depth_bits);
 }
 
 // bilinear tap of one mip level, ClampToEdge

@@ -1265,12 +1265,7 @@ constexpr int kCompThreads = 64;   // one wave per 16x16 tile, 4 pixels (one per
 // OCC = waves per SIMD the register allocation must leave room for (__launch_bounds__): the kernel is VALU-issue
 // bound and a SIMD needs ~8 resident waves to issue at its full rate (tools/ubench_valu: 1.38 / 1.78 / 2.63 clocks per
 // instruction at 8 / 4 / 2 waves), while the unconstrained allocation takes 94 VGPRs = 5 waves.
-// SPLITQ (NP = 2 only): the staging pass keeps one queue per 16x8 half of the tile (a record joins the queue of a half
-// when its y-range reaches a live strip of that half) and the blend loop runs once per half over that half's
-// queue.  A half sees ~0.8 of its tile's records, so the per-pair work drops by ~a fifth while list entries and
-// records are still fetched and tested once per tile (one wave per half tile, NP = 1, halves the evaluations the
-// same way but doubles fetching and testing: no faster, r2 measurement).
-template <bool HALF, int NP, int OCC, bool SPLITQ>
+template <bool HALF, int NP, int OCC>
 __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint32_t* __restrict__ tile_start,
                                                                  const uint32_t* __restrict__ pairs,
                                                                  const float4* __restrict__ rec,
@@ -1284,8 +1279,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
     // rows 4k..4k+3.  Per splat the exponent is split into a part shared by the four strips and a
     // 2-FMA part per strip; strips the splat's y-range cannot reach, or whose 64 pixels are all
     // saturated, are skipped with scalar branches.
-    constexpr int NQ = (SPLITQ && NP == 2) ? 2 : 1;
-    __shared__ float4 s_rec[NQ][(kCompThreads + 1) * 3];
+    __shared__ float4 s_rec[(kCompThreads + 1) * 3];
 
     // Persistent waves + dynamic queue: per-tile work varies by >10x (list length, early saturation),
     // so tiles are pulled heaviest-first from `order` instead of being bound to a workgroup index.
@@ -1373,19 +1367,13 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
         // stage only the splats whose y-range reaches a strip that is still live, compacted in list
         // order (near to far).  The CU has ONE scalar unit for its four SIMDs, so the inner loop is
         // written to need almost no scalar work: a plain counted loop, strips handled by VALU predicates.
-        uint32_t n, nq[NQ];
+        uint32_t n;
         {
             const float ylo = p0.y - p2.w, yhi = p0.y + p2.w;
             bool rel = false;
-            bool relh[NP];                   // the record's y-range reaches a live strip of half h
 #pragma unroll
-            for (int h = 0; h < NP; ++h) relh[h] = false;
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const bool rk = (alive & (1u << k)) && yhi >= tile_y0 + 4.0f * k + 0.5f && ylo <= tile_y0 + 4.0f * k + 3.5f;
-                rel = rel || rk;
-                relh[k >> 1] = relh[k >> 1] || rk;
-            }
+            for (int k = 0; k < NS; ++k)
+                rel = rel || ((alive & (1u << k)) && yhi >= tile_y0 + 4.0f * k + 0.5f && ylo <= tile_y0 + 4.0f * k + 3.5f);
             rel = rel && lane < (int)cnt;
             if (rel) {
                 // exact footprint-vs-tile test (the list was built from bounding rectangles): the exponent
@@ -1412,19 +1400,13 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                     rel = emax > -8.05f;
                 }
             }
-            n = 0;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const bool mem = rel && (NQ == 1 || relh[q]);
-                const uint64_t relmask = __ballot(mem);
-                nq[q] = (uint32_t)__popcll(relmask);
-                n += nq[q];
-                if (mem) {
-                    const int slot = __popcll(relmask & ((1ull << lane) - 1ull));
-                    s_rec[q][slot * 3 + 0] = p0;
-                    s_rec[q][slot * 3 + 1] = p1;
-                    s_rec[q][slot * 3 + 2] = p2;
-                }
+            const uint64_t relmask = __ballot(rel);
+            n = (uint32_t)__popcll(relmask);
+            if (rel) {
+                const int slot = __popcll(relmask & ((1ull << lane) - 1ull));
+                s_rec[slot * 3 + 0] = p0;
+                s_rec[slot * 3 + 1] = p1;
+                s_rec[slot * 3 + 2] = p2;
             }
         }
         __syncthreads();
@@ -1443,16 +1425,16 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
         probe_words += cntA;
         probe_recs += cnt;
         const uint64_t probe_t1 = probe ? clock64() : 0ull;
-        if (NQ == 1 && n != 0u) {
-            float4 a = s_rec[0][0];          // px, py, A, B
-            float4 b = s_rec[0][1];          // C, log2(alpha), r, g
-            float blue = s_rec[0][2].x;
+        if (n != 0u) {
+            float4 a = s_rec[0];          // px, py, A, B
+            float4 b = s_rec[1];          // C, log2(alpha), r, g
+            float blue = s_rec[2].x;
 #pragma unroll 2
             for (uint32_t j = 0; j < n; ++j) {
                 // next record (slot n is a harmless over-read inside the 65-slot array)
-                const float4 na = s_rec[0][(j + 1) * 3 + 0];
-                const float4 nb = s_rec[0][(j + 1) * 3 + 1];
-                const float nblue = s_rec[0][(j + 1) * 3 + 2].x;
+                const float4 na = s_rec[(j + 1) * 3 + 0];
+                const float4 nb = s_rec[(j + 1) * 3 + 1];
+                const float nblue = s_rec[(j + 1) * 3 + 2].x;
                 const float dx = fx - a.x;
                 const float base = __builtin_fmaf(a.z * dx, dx, b.y);
                 const float lin = a.w * dx;
@@ -1478,44 +1460,6 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                 a = na; b = nb; blue = nblue;
             }
         }
-        if (NQ == 2) {
-            // one blend loop per half over that half's queue: the same arithmetic per pixel as above, minus the records
-            // that cannot reach the half
-#pragma unroll
-            for (int h = 0; h < NP; ++h) {
-                const int q = (NQ == 2) ? h : 0;
-                const uint32_t nh = nq[q];
-                if (nh == 0u) continue;
-                float4 a = s_rec[q][0];
-                float4 b = s_rec[q][1];
-                float blue = s_rec[q][2].x;
-                v2f Th = T[h], crh = cr[h], cgh = cg[h], cbh = cb[h];
-#pragma unroll 2
-                for (uint32_t j = 0; j < nh; ++j) {
-                    const float4 na = s_rec[q][(j + 1) * 3 + 0];
-                    const float4 nb = s_rec[q][(j + 1) * 3 + 1];
-                    const float nblue = s_rec[q][(j + 1) * 3 + 2].x;
-                    const float dx = fx - a.x;
-                    const float base = __builtin_fmaf(a.z * dx, dx, b.y);
-                    const float lin = a.w * dx;
-                    const v2f vbase = (v2f){base, base}, vlin = (v2f){lin, lin}, vC = (v2f){b.x, b.x};
-                    const v2f vpy = (v2f){a.y, a.y};
-                    const v2f vr = (v2f){b.z, b.z}, vg = (v2f){b.w, b.w}, vb = (v2f){blue, blue};
-                    const v2f dy = fyp[h] - vpy;
-                    const v2f e = __builtin_elementwise_fma(dy, __builtin_elementwise_fma(vC, dy, vlin), vbase);
-                    v2f w;
-                    w.x = (e.x > -8.0f) ? __builtin_amdgcn_exp2f(e.x) : 0.0f;
-                    w.y = (e.y > -8.0f) ? __builtin_amdgcn_exp2f(e.y) : 0.0f;
-                    const v2f tw = Th * w;
-                    crh = __builtin_elementwise_fma(tw, vr, crh);
-                    cgh = __builtin_elementwise_fma(tw, vg, cgh);
-                    cbh = __builtin_elementwise_fma(tw, vb, cbh);
-                    Th = Th - tw;
-                    a = na; b = nb; blue = nblue;
-                }
-                T[h] = Th; cr[h] = crh; cg[h] = cgh; cb[h] = cbh;
-            }
-        }
         if (probe) probe_inner += clock64() - probe_t1;
         // strips whose 64 pixels are all saturated (or outside the image) are finished
         uint32_t na = 0;
@@ -1534,7 +1478,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
         probe[tile * 8 + 4] = probe_words;      // 4-byte pair words loaded
         probe[tile * 8 + 5] = probe_recs;       // 48-byte projected records loaded
         probe[tile * 8 + 6] = end - start;      // length of the bin list
-        probe[tile * 8 + 7] = (NP == 2 && NQ == 1) ? 1u : 3u;      // work item ran; 1 = 256, 3 = 128 evaluations per queue entry
+        probe[tile * 8 + 7] = (NP == 2) ? 1u : 3u;      // work item ran; 1 = 256, 3 = 128 evaluations per composited record
     }
 #pragma unroll
     for (int k = 0; k < NS; ++k) {

@@ -1265,7 +1265,15 @@ constexpr int kCompThreads = 64;   // one wave per 16x16 tile, 4 pixels (one per
 // OCC = waves per SIMD the register allocation must leave room for (__launch_bounds__): the kernel is VALU-issue
 // bound and a SIMD needs ~8 resident waves to issue at its full rate (tools/ubench_valu: 1.38 / 1.78 / 2.63 clocks per
 // instruction at 8 / 4 / 2 waves), while the unconstrained allocation takes 94 VGPRs = 5 waves.
-template <bool HALF, int NP, int OCC>
+// FTZ: the fragment shader's discard (w <= 1/256, splat_frag.glsl:37-40) costs a compare and a select per pixel in
+// a loop of ~14 instructions per (pixel, record).  Here it is free: the exponent is biased by -118, so that
+// w' = exp2(e - 118) is a NORMAL float exactly when e >= -8 and underflows otherwise, and the wave runs with fp32
+// denormals flushed (MODE.FP_DENORM, set below): the underflowing weights come out of v_exp_f32 as exact zeros.
+// The transmittance is carried scaled by 2^118 (Ts = 2^118 T), so tw = Ts w' = T w exactly as before (powers of
+// two), colours accumulate unchanged and Ts -= 2^118 tw.  The bias costs 4 bits of the exponent's absolute
+// precision (|e - 118| ~ 2^7 instead of <= 2^3): a relative error of 3e-6 in w.  Only e == -8 exactly (w == 1/256,
+// which the reference discards) is kept: a measure-zero threshold flip.
+template <bool HALF, int NP, int OCC, bool FTZ>
 __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint32_t* __restrict__ tile_start,
                                                                  const uint32_t* __restrict__ pairs,
                                                                  const float4* __restrict__ rec,
@@ -1286,6 +1294,9 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
     // The first tile of every wave is static (its workgroup index): same-address atomics are served
     // at only ~8 ns each, so thousands of waves pulling at launch would queue up for tens of us.
     // Work item = (bin, quadrant): the four 16x16 tiles of a 32x32 bin share the bin's list.
+    constexpr float kBias = FTZ ? 118.0f : 0.0f;
+    constexpr float kScale = FTZ ? 0x1p118f : 1.0f;
+    if (FTZ) __builtin_amdgcn_s_setreg(1 | (4 << 6) | ((2 - 1) << 11), 0);      // MODE[5:4] = 0: flush fp32 denormals
     constexpr int NS = 2 * NP;                       // 16x4 strips per work item
     constexpr int ROWS = 4 * NS;                     // pixel rows per work item
     for (uint32_t qpos = blockIdx.x; qpos < ntiles;) {
@@ -1322,7 +1333,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
     bool inside[NS];
 #pragma unroll
     for (int h = 0; h < NP; ++h) {
-        T[h] = (v2f){1.0f, 1.0f};
+        T[h] = (v2f){kScale, kScale};                // FTZ: the transmittance scaled by 2^118
         cr[h] = (v2f){0.0f, 0.0f}; cg[h] = (v2f){0.0f, 0.0f}; cb[h] = (v2f){0.0f, 0.0f};
     }
 #pragma unroll
@@ -1436,7 +1447,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                 const float4 nb = s_rec[(j + 1) * 3 + 1];
                 const float nblue = s_rec[(j + 1) * 3 + 2].x;
                 const float dx = fx - a.x;
-                const float base = __builtin_fmaf(a.z * dx, dx, b.y);
+                const float base = __builtin_fmaf(a.z * dx, dx, b.y - kBias);
                 const float lin = a.w * dx;
                 const v2f vbase = (v2f){base, base}, vlin = (v2f){lin, lin}, vC = (v2f){b.x, b.x};
                 const v2f vpy = (v2f){a.y, a.y};
@@ -1449,13 +1460,19 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                     const v2f e = __builtin_elementwise_fma(dy, __builtin_elementwise_fma(vC, dy, vlin), vbase);
                     // splat_frag.glsl:37-40 discard: w = exp2(e) > 1/256  <=>  e > -8
                     v2f w;
-                    w.x = (e.x > -8.0f) ? __builtin_amdgcn_exp2f(e.x) : 0.0f;
-                    w.y = (e.y > -8.0f) ? __builtin_amdgcn_exp2f(e.y) : 0.0f;
+                    if (FTZ) {       // discard by underflow (see the kernel's header)
+                        w.x = __builtin_amdgcn_exp2f(e.x);
+                        w.y = __builtin_amdgcn_exp2f(e.y);
+                    } else {
+                        w.x = (e.x > -8.0f) ? __builtin_amdgcn_exp2f(e.x) : 0.0f;
+                        w.y = (e.y > -8.0f) ? __builtin_amdgcn_exp2f(e.y) : 0.0f;
+                    }
                     const v2f tw = T[h] * w;
                     cr[h] = __builtin_elementwise_fma(tw, vr, cr[h]);
                     cg[h] = __builtin_elementwise_fma(tw, vg, cg[h]);
                     cb[h] = __builtin_elementwise_fma(tw, vb, cb[h]);
-                    T[h] = T[h] - tw;
+                    if (FTZ) T[h] = __builtin_elementwise_fma(tw, (v2f){-kScale, -kScale}, T[h]);
+                    else T[h] = T[h] - tw;
                 }
                 a = na; b = nb; blue = nblue;
             }
@@ -1465,7 +1482,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
         uint32_t na = 0;
 #pragma unroll
         for (int k = 0; k < NS; ++k)
-            na |= (__ballot(inside[k] && T[k >> 1][k & 1] >= fp.t_eps) != 0ull) ? (1u << k) : 0u;
+            na |= (__ballot(inside[k] && T[k >> 1][k & 1] >= fp.t_eps * kScale) != 0ull) ? (1u << k) : 0u;
         alive = na;
         __syncthreads();
     }

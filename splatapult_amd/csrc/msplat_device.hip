@@ -76,8 +76,8 @@ struct msplat_ctx {
     // compositor formulation: 0 = one wave per 16x16 tile, 1 = one wave per 16x8 half tile (default), 2 = four waves per
     // tile (composite_quad_kernel, LDS-bound, kept for comparison); MSPLAT_COMPOSITOR=wave|half|quad
     int comp_kind = 0;
+    int comp_occ = 5;       // register budget of the compositor in waves per SIMD (MSPLAT_COMP_OCC = 5, 6 or 8)
     bool comp_ftz = true;   // discard by underflow in the compositor (MSPLAT_COMP_FTZ=0: compare + select)
-    bool comp_pairskip = true;   // saturated 16x8 halves are not evaluated (MSPLAT_COMP_PAIRSKIP=0)
     Buf totals;     // uint32[256]  digit totals of the current radix pass (rows in binning pass 2)
     Buf totals1;    // uint32[256]  column totals of binning pass 1
     Buf counters;   // uint32[16]: 0=V, 1=D, 2=overflow, 4=drawn, 6..7=pairs16 (u64), 8=probe
@@ -289,8 +289,8 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
             const std::string k = ck;
             ctx->comp_kind = k == "half" ? 1 : k == "quad" ? 2 : 0;
         }
+        if (getenv("MSPLAT_COMP_OCC")) ctx->comp_occ = atoi(getenv("MSPLAT_COMP_OCC"));
         if (getenv("MSPLAT_COMP_FTZ")) ctx->comp_ftz = atoi(getenv("MSPLAT_COMP_FTZ")) != 0;
-        if (getenv("MSPLAT_COMP_PAIRSKIP")) ctx->comp_pairskip = atoi(getenv("MSPLAT_COMP_PAIRSKIP")) != 0;
     }
     if (rc != MSPLAT_OK) {
         std::string msg = ctx->err;
@@ -1060,16 +1060,17 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
             const bool half = ctx->comp_kind == 1;
             const uint32_t nitems = (uint32_t)ntiles * (half ? 8u : 4u);
             const int grid = (int)std::min<uint32_t>(nitems, (uint32_t)ctx->comp_waves);
-#define MSPLAT_LAUNCH_COMP(F16, NP, OCC, FZ, PS)                                                                      \
-    hipExtLaunchKernelGGL((composite_kernel<F16, NP, OCC, FZ, PS>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, \
-                          r2, d_out, pitch, fp, cap, ord, d_queue, nitems, probe)
-#define MSPLAT_LAUNCH_COMP_F(NP, OCC, FZ, PS) do { if (f16) MSPLAT_LAUNCH_COMP(true, NP, OCC, FZ, PS); else MSPLAT_LAUNCH_COMP(false, NP, OCC, FZ, PS); } while (0)
+#define MSPLAT_LAUNCH_COMP(F16, NP, OCC, FZ)                                                                          \
+    hipExtLaunchKernelGGL((composite_kernel<F16, NP, OCC, FZ>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, \
+                          d_out, pitch, fp, cap, ord, d_queue, nitems, probe)
+#define MSPLAT_LAUNCH_COMP_F(NP, OCC, FZ) do { if (f16) MSPLAT_LAUNCH_COMP(true, NP, OCC, FZ); else MSPLAT_LAUNCH_COMP(false, NP, OCC, FZ); } while (0)
+            const int occ = ctx->comp_occ >= 8 ? 8 : ctx->comp_occ >= 6 ? 6 : 5;
             if (half) {                          // experiment: one wave per 16x8 half tile
-                MSPLAT_LAUNCH_COMP_F(1, 6, false, false);
+                if (occ == 8) MSPLAT_LAUNCH_COMP_F(1, 8, false); else MSPLAT_LAUNCH_COMP_F(1, 6, false);
             } else if (ctx->comp_ftz) {
-                if (ctx->comp_pairskip) MSPLAT_LAUNCH_COMP_F(2, 5, true, true); else MSPLAT_LAUNCH_COMP_F(2, 5, true, false);
+                if (occ >= 6) MSPLAT_LAUNCH_COMP_F(2, 6, true); else MSPLAT_LAUNCH_COMP_F(2, 5, true);
             } else {
-                MSPLAT_LAUNCH_COMP_F(2, 5, false, false);
+                if (occ >= 6) MSPLAT_LAUNCH_COMP_F(2, 6, false); else MSPLAT_LAUNCH_COMP_F(2, 5, false);
             }
 #undef MSPLAT_LAUNCH_COMP_F
 #undef MSPLAT_LAUNCH_COMP

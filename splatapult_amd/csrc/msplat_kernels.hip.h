@@ -11,7 +11,6 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <type_traits>
 
 // The key / reject arithmetic must execute exactly as written (bit-parity with the oracle):
 // no implicit FMA contraction anywhere in this file (the build also passes -ffp-contract=off).
@@ -1274,7 +1273,7 @@ constexpr int kCompThreads = 64;   // one wave per 16x16 tile, 4 pixels (one per
 // two), colours accumulate unchanged and Ts -= 2^118 tw.  The bias costs 4 bits of the exponent's absolute
 // precision (|e - 118| ~ 2^7 instead of <= 2^3): a relative error of 3e-6 in w.  Only e == -8 exactly (w == 1/256,
 // which the reference discards) is kept: a measure-zero threshold flip.
-template <bool HALF, int NP, int OCC, bool FTZ, bool PAIRSKIP>
+template <bool HALF, int NP, int OCC, bool FTZ>
 __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint32_t* __restrict__ tile_start,
                                                                  const uint32_t* __restrict__ pairs,
                                                                  const float4* __restrict__ rec,
@@ -1437,9 +1436,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
         probe_words += cntA;
         probe_recs += cnt;
         const uint64_t probe_t1 = probe ? clock64() : 0ull;
-        // blend the staged records into the strip pairs [H0, H1) of the work item
-        auto blend = [&](auto H0, auto H1) {
-            constexpr int h0 = decltype(H0)::value, h1 = decltype(H1)::value;
+        if (n != 0u) {
             float4 a = s_rec[0];          // px, py, A, B
             float4 b = s_rec[1];          // C, log2(alpha), r, g
             float blue = s_rec[2].x;
@@ -1458,7 +1455,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                 // Branch-free on purpose: the strips are independent dependency chains inside one basic
                 // block, so the in-order wave can overlap them.  w = 0 where the fragment shader discards.
 #pragma unroll
-                for (int h = h0; h < h1; ++h) {
+                for (int h = 0; h < NP; ++h) {
                     const v2f dy = fyp[h] - vpy;
                     const v2f e = __builtin_elementwise_fma(dy, __builtin_elementwise_fma(vC, dy, vlin), vbase);
                     // splat_frag.glsl:37-40 discard: w = exp2(e) > 1/256  <=>  e > -8
@@ -1479,16 +1476,6 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                 }
                 a = na; b = nb; blue = nblue;
             }
-        };
-        if (n != 0u) {
-            typedef std::integral_constant<int, 0> I0;
-            typedef std::integral_constant<int, 1> I1;
-            typedef std::integral_constant<int, NP> IN;
-            // a 16x8 half whose two strips are saturated (or outside the image) is not evaluated any more: the staged
-            // records were selected for the live strips only (wave-uniform choice, once per batch)
-            if (NP == 2 && PAIRSKIP && (alive & 3u) == 0u) blend(I1(), IN());
-            else if (NP == 2 && PAIRSKIP && (alive & 12u) == 0u) blend(I0(), I1());
-            else blend(I0(), IN());
         }
         if (probe) probe_inner += clock64() - probe_t1;
         // strips whose 64 pixels are all saturated (or outside the image) are finished

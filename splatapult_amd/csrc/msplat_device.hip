@@ -76,7 +76,6 @@ struct msplat_ctx {
     // compositor formulation: 0 = one wave per 16x16 tile, 1 = one wave per 16x8 half tile (default), 2 = four waves per
     // tile (composite_quad_kernel, LDS-bound, kept for comparison); MSPLAT_COMPOSITOR=wave|half|quad
     int comp_kind = 0;
-    int comp_occ = 5;       // register budget of the compositor in waves per SIMD (MSPLAT_COMP_OCC = 5, 6 or 8)
     bool comp_ftz = true;   // discard by underflow in the compositor (MSPLAT_COMP_FTZ=0: compare + select)
     Buf totals;     // uint32[256]  digit totals of the current radix pass (rows in binning pass 2)
     Buf totals1;    // uint32[256]  column totals of binning pass 1
@@ -289,7 +288,6 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
             const std::string k = ck;
             ctx->comp_kind = k == "half" ? 1 : k == "quad" ? 2 : 0;
         }
-        if (getenv("MSPLAT_COMP_OCC")) ctx->comp_occ = atoi(getenv("MSPLAT_COMP_OCC"));
         if (getenv("MSPLAT_COMP_FTZ")) ctx->comp_ftz = atoi(getenv("MSPLAT_COMP_FTZ")) != 0;
     }
     if (rc != MSPLAT_OK) {
@@ -1064,13 +1062,12 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     hipExtLaunchKernelGGL((composite_kernel<F16, NP, OCC, FZ>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, \
                           d_out, pitch, fp, cap, ord, d_queue, nitems, probe)
 #define MSPLAT_LAUNCH_COMP_F(NP, OCC, FZ) do { if (f16) MSPLAT_LAUNCH_COMP(true, NP, OCC, FZ); else MSPLAT_LAUNCH_COMP(false, NP, OCC, FZ); } while (0)
-            const int occ = ctx->comp_occ >= 8 ? 8 : ctx->comp_occ >= 6 ? 6 : 5;
             if (half) {                          // experiment: one wave per 16x8 half tile
-                if (occ == 8) MSPLAT_LAUNCH_COMP_F(1, 8, false); else MSPLAT_LAUNCH_COMP_F(1, 6, false);
+                MSPLAT_LAUNCH_COMP_F(1, 6, false);
             } else if (ctx->comp_ftz) {
-                if (occ >= 6) MSPLAT_LAUNCH_COMP_F(2, 6, true); else MSPLAT_LAUNCH_COMP_F(2, 5, true);
+                MSPLAT_LAUNCH_COMP_F(2, 5, true);
             } else {
-                if (occ >= 6) MSPLAT_LAUNCH_COMP_F(2, 6, false); else MSPLAT_LAUNCH_COMP_F(2, 5, false);
+                MSPLAT_LAUNCH_COMP_F(2, 5, false);
             }
 #undef MSPLAT_LAUNCH_COMP_F
 #undef MSPLAT_LAUNCH_COMP

@@ -276,40 +276,6 @@ __device__ __forceinline__ uint32_t group_prefix(const uint32_t* __restrict__ hi
     return coop_row_sum(gsum, g, hist + (size_t)(g << kGroupShift) * 256, chunk - (g << kGroupShift), s_part);
 }
 
-// digit totals AND the exclusive prefix of chunk `chunk` in ONE sweep (one round trip to L2 instead of two dependent
-// ones: the first chunk of every workgroup); s_part: 512 uint4 of scratch LDS
-__device__ __forceinline__ void group_total_and_prefix(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ gsum,
-                                                       uint32_t nchunks, uint32_t chunk, uint4* s_part,
-                                                       uint32_t& total, uint32_t& prefix)
-{
-    const uint32_t ng = (nchunks + (1u << kGroupShift) - 1u) >> kGroupShift;
-    const uint32_t g = min(chunk >> kGroupShift, ng);
-    const uint32_t q = threadIdx.x & 63u, rg = threadIdx.x >> 6;
-    uint4 at = make_uint4(0u, 0u, 0u, 0u), ap = at;
-#pragma unroll 4
-    for (uint32_t r = rg; r < ng; r += 4u) {
-        const uint4 x = *reinterpret_cast<const uint4*>(gsum + (size_t)r * 256 + q * 4u);
-        at.x += x.x; at.y += x.y; at.z += x.z; at.w += x.w;
-        if (r < g) { ap.x += x.x; ap.y += x.y; ap.z += x.z; ap.w += x.w; }
-    }
-    const uint32_t c0 = g << kGroupShift;
-    const uint32_t nc = chunk > c0 ? chunk - c0 : 0u;
-    const uint32_t* rows = hist + (size_t)c0 * 256;
-#pragma unroll 4
-    for (uint32_t r = rg; r < nc; r += 4u) {
-        const uint4 x = *reinterpret_cast<const uint4*>(rows + (size_t)r * 256 + q * 4u);
-        ap.x += x.x; ap.y += x.y; ap.z += x.z; ap.w += x.w;
-    }
-    s_part[rg * 64u + q] = at;
-    s_part[256u + rg * 64u + q] = ap;
-    __syncthreads();
-    const uint32_t* sp = reinterpret_cast<const uint32_t*>(s_part);
-    const uint32_t d = threadIdx.x;
-    total = sp[d] + sp[256u + d] + sp[512u + d] + sp[768u + d];
-    prefix = sp[1024u + d] + sp[1280u + d] + sp[1536u + d] + sp[1792u + d];
-    __syncthreads();
-}
-
 // digit totals = sum of all group rows
 __device__ __forceinline__ uint32_t group_total(const uint32_t* __restrict__ gsum, uint32_t nchunks, uint4* s_part)
 {
@@ -435,12 +401,36 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
     const int w = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
-    uint32_t key[ITEMS];
-    uint32_t val[ITEMS];
-    uint32_t lrank[ITEMS];
-    bool valid[ITEMS];
-    // wave w owns the contiguous sub-chunk [w*64*ITEMS, (w+1)*64*ITEMS): keeps the sort stable
-    auto load_chunk = [&](uint32_t chunk) {
+    {
+        // (s_keys doubles as the 4 KB scratch of the cooperative row sums: it is not live before the local sort)
+        const uint32_t t = (gsum != nullptr) ? group_total(gsum, nchunks, reinterpret_cast<uint4*>(s_keys)) : totals[threadIdx.x];
+        uint32_t tot;
+        const uint32_t incl = block_incl_scan(t, s_tmp, tot);
+        s_base[threadIdx.x] = incl - t;
+        if (d_count_out != nullptr && blockIdx.x == 0 && threadIdx.x == 255) *d_count_out = incl;
+        if (totals_out != nullptr && blockIdx.x == 0) totals_out[threadIdx.x] = t;
+    }
+    if (MODE == MODE_PAIR) {
+        const uint32_t t = col_totals[threadIdx.x];
+        uint32_t tot;
+        const uint32_t incl = block_incl_scan(t, s_tmp, tot);
+        s_col[threadIdx.x] = incl - t;
+    }
+    __syncthreads();
+
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        // this chunk's exclusive prefix per digit (thread = digit): issued first, consumed after the local ranking
+        const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk, reinterpret_cast<uint4*>(s_keys))
+                                                     : hist[(size_t)chunk * 256 + threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
+        __syncthreads();
+
+        uint32_t key[ITEMS];
+        uint32_t val[ITEMS];
+        uint32_t lrank[ITEMS];
+        bool valid[ITEMS];
+        // wave w owns the contiguous sub-chunk [w*64*ITEMS, (w+1)*64*ITEMS): keeps the sort stable
         const uint32_t base = chunk * CHUNK + (uint32_t)w * (64 * ITEMS);
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
@@ -458,44 +448,6 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
                 }
             }
         }
-    };
-    // the first chunk's keys are requested before anything else: their latency overlaps the table sums below
-    if (blockIdx.x < nchunks) load_chunk(blockIdx.x);
-
-    uint32_t first_pre = 0;
-    {
-        // (s_keys doubles as the 8 KB scratch of the cooperative row sums: it is not live before the local sort)
-        uint32_t t;
-        if (gsum != nullptr) group_total_and_prefix(hist, gsum, nchunks, blockIdx.x, reinterpret_cast<uint4*>(s_keys), t, first_pre);
-        else t = totals[threadIdx.x];
-        uint32_t tot;
-        const uint32_t incl = block_incl_scan(t, s_tmp, tot);
-        s_base[threadIdx.x] = incl - t;
-        if (d_count_out != nullptr && blockIdx.x == 0 && threadIdx.x == 255) *d_count_out = incl;
-        if (totals_out != nullptr && blockIdx.x == 0) totals_out[threadIdx.x] = t;
-    }
-    if (MODE == MODE_PAIR) {
-        const uint32_t t = col_totals[threadIdx.x];
-        uint32_t tot;
-        const uint32_t incl = block_incl_scan(t, s_tmp, tot);
-        s_col[threadIdx.x] = incl - t;
-    }
-    __syncthreads();
-
-    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        // this chunk's exclusive prefix per digit (thread = digit)
-        uint32_t chunk_pre;
-        if (gsum == nullptr) chunk_pre = hist[(size_t)chunk * 256 + threadIdx.x];
-        else if (chunk == blockIdx.x) chunk_pre = first_pre;
-        else {
-            load_chunk(chunk);
-            chunk_pre = group_prefix(hist, gsum, chunk, reinterpret_cast<uint4*>(s_keys));
-        }
-        if (gsum == nullptr && chunk != blockIdx.x) load_chunk(chunk);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
-        __syncthreads();
-        const uint32_t base = chunk * CHUNK + (uint32_t)w * (64 * ITEMS);
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const uint32_t d = digit_of<MODE>(key[r], shift);
@@ -1042,13 +994,9 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    uint32_t first_pre = 0;
     {
-        // (s_part: scratch for the cooperative row sums of the scan-free path; totals and the first chunk's prefix
-        //  come out of one sweep)
-        uint32_t t;
-        if (gsum != nullptr) group_total_and_prefix(hist, gsum, nchunks, blockIdx.x, s_part, t, first_pre);
-        else t = totals[threadIdx.x];
+        // (s_part: 4 KB scratch for the cooperative row sums of the scan-free path)
+        const uint32_t t = (gsum != nullptr) ? group_total(gsum, nchunks, s_part) : totals[threadIdx.x];
         uint32_t tot;
         const uint32_t incl = block_incl_scan(t, s_tmp, tot);
         s_base[threadIdx.x] = incl - t;
@@ -1071,8 +1019,7 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
     __syncthreads();
 
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const uint32_t chunk_pre = (gsum == nullptr) ? hist[(size_t)chunk * 256 + threadIdx.x]
-                                   : (chunk == blockIdx.x) ? first_pre : group_prefix(hist, gsum, chunk, s_part);
+        const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk, s_part) : hist[(size_t)chunk * 256 + threadIdx.x];
         const uint32_t rbase = chunk * kBinChunk;
         uint32_t rc[PER], woff[PER], wsum = 0;
 #pragma unroll
@@ -1469,7 +1416,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
             if (rel) {
                 const int slot = __popcll(relmask & ((1ull << lane) - 1ull));
                 s_rec[slot * 3 + 0] = p0;
-                s_rec[slot * 3 + 1] = make_float4(p1.x, p1.y - kBias, p1.z, p1.w);      // the exponent bias rides on log2(alpha)
+                s_rec[slot * 3 + 1] = p1;
                 s_rec[slot * 3 + 2] = p2;
             }
         }
@@ -1500,7 +1447,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                 const float4 nb = s_rec[(j + 1) * 3 + 1];
                 const float nblue = s_rec[(j + 1) * 3 + 2].x;
                 const float dx = fx - a.x;
-                const float base = __builtin_fmaf(a.z * dx, dx, b.y);
+                const float base = __builtin_fmaf(a.z * dx, dx, b.y - kBias);
                 const float lin = a.w * dx;
                 const v2f vbase = (v2f){base, base}, vlin = (v2f){lin, lin}, vC = (v2f){b.x, b.x};
                 const v2f vpy = (v2f){a.y, a.y};

@@ -1416,7 +1416,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
             if (rel) {
                 const int slot = __popcll(relmask & ((1ull << lane) - 1ull));
                 s_rec[slot * 3 + 0] = p0;
-                s_rec[slot * 3 + 1] = p1;
+                s_rec[slot * 3 + 1] = make_float4(p1.x, p1.y - kBias, p1.z, p1.w);      // the exponent bias rides on log2(alpha)
                 s_rec[slot * 3 + 2] = p2;
             }
         }
@@ -1447,7 +1447,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                 const float4 nb = s_rec[(j + 1) * 3 + 1];
                 const float nblue = s_rec[(j + 1) * 3 + 2].x;
                 const float dx = fx - a.x;
-                const float base = __builtin_fmaf(a.z * dx, dx, b.y - kBias);
+                const float base = __builtin_fmaf(a.z * dx, dx, b.y);
                 const float lin = a.w * dx;
                 const v2f vbase = (v2f){base, base}, vlin = (v2f){lin, lin}, vC = (v2f){b.x, b.x};
                 const v2f vpy = (v2f){a.y, a.y};

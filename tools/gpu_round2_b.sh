@@ -23,12 +23,8 @@ except Exception as e:
 PY
   done
 }
-ab plain MSPLAT_COMP_SPLITQ=0 MSPLAT_COMP_MASKED=0
-ab masked MSPLAT_COMP_SPLITQ=0
-ab masked6 MSPLAT_COMP_SPLITQ=0 MSPLAT_COMP_OCC=6
-ab split MSPLAT_COMP_MASKED=0
-ab splitmasked
-ab splitmasked6 MSPLAT_COMP_OCC=6
+ab now
+ab now_b
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r2b_prof -o run --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline --frames-in-flight 1 > $GRAFT_REPO_ROOT/gpurun_out/r2b_prof.log 2>&1)
 python - <<PY
 import csv, glob

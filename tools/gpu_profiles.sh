@@ -1,0 +1,37 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/gpu_profiles.sh <round tag, e.g. r02>
+# The evidence set of a round: GPU tests, the bench lines (default = 4 frames in flight, and serial), rocprofv3 kernel
+# summaries of the same commands for every BASELINE workload, and the PMC traffic of the serial run.  Everything lands
+# in gpurun_out/<tag>_*; copy what is to be judged into profiles/.
+cd ${GRAFT_REPO_ROOT:-.}
+R=$(pwd)
+export TMPDIR=/tmp
+T=${1:-r02}
+mkdir -p gpurun_out
+( time timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -rs -rP ) > gpurun_out/${T}_gpu_tests.log 2>&1
+grep -E "passed|failed|SKIPPED|check_image:" gpurun_out/${T}_gpu_tests.log | head -20
+timeout 600 python bench.py > gpurun_out/${T}_cfg2_bench.json 2> gpurun_out/${T}_cfg2_bench.err
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${T}_cfg2_bench_steps20.json 2> gpurun_out/${T}_cfg2_bench_steps20.err
+timeout 600 python bench.py --frames-in-flight 1 --no-cpu-baseline > gpurun_out/${T}_cfg2_bench_serial.json 2> gpurun_out/${T}_cfg2_bench_serial.err
+prof() {  # name, bench args
+  name=$1; shift
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_prof_$name -o run --output-format csv -- python $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/${T}_prof_$name.log 2>&1)
+  f=$(find gpurun_out/${T}_prof_$name -name run_kernel_stats.csv | head -1)
+  cp $f gpurun_out/${T}_${name}_kernel_stats.csv
+  grep -h "^{" gpurun_out/${T}_prof_$name.log > gpurun_out/${T}_${name}_bench_under_rocprof.json
+  python - <<PY
+import csv
+print("== $name")
+for r in csv.DictReader(open("gpurun_out/${T}_${name}_kernel_stats.csv")):
+    if float(r["Percentage"]) > 0.8: print("   %-62s calls=%-5s avg=%8.1fus %5s%%" % (r["Name"][:62], r["Calls"], float(r["AverageNs"])/1e3, r["Percentage"][:5]))
+PY
+}
+prof cfg2_serial --frames-in-flight 1 --steps 600 --warmup 100
+prof cfg2_fif4 --steps 600 --warmup 100
+for wl in cfg3 cfg4 cfg5; do
+  prof ${wl}_serial --workload $wl --frames-in-flight 1 --steps 100 --warmup 20 --prewarm 50
+  timeout 600 python bench.py --workload $wl --no-cpu-baseline --steps 200 --warmup 30 > gpurun_out/${T}_${wl}_bench.json 2> gpurun_out/${T}_${wl}_bench.err
+done
+bash tools/pmc_traffic.sh ${T}_cfg2 cfg2
+cp gpurun_out/pmc_${T}_cfg2/traffic.json gpurun_out/${T}_pmc_traffic_cfg2.json
+for C in FETCH_SIZE WRITE_SIZE; do cp $(find gpurun_out/pmc_${T}_cfg2/$C -name run_counter_collection.csv | head -1) gpurun_out/${T}_pmc_${C}_cfg2.csv; done

@@ -202,8 +202,8 @@ def measure(E, args, key, ply=None, primary=True):
     if P == 1:
         rs, rs_sets = r, fb_sets
     else:
-        rs = SplatRenderer(device=E.local_rank, fb_format=wl["fb"], stream=stream.cuda_stream, enable_timing=1,
-                           frames_in_flight=1)
+        rs = SplatRenderer(device=E.local_rank, fb_format=wl["fb"], stream=stream.cuda_stream, enable_timing=4,
+                           frames_in_flight=1)     # stage events on every 4th frame: they cost a few us each
         if not rs.Init(cloud, False, False):
             raise SystemExit("Init (serial renderer) failed: " + rs.last_error())
         if world > 1:
@@ -275,11 +275,12 @@ def measure(E, args, key, ply=None, primary=True):
         if world == 1 and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                kname = "msplat::composite_kernel<%s>" % ("true" if wl["fb"] == "fp16" else "false")
+                kname = "msplat::composite_kernel<%s" % ("true" if wl["fb"] == "fp16" else "false")
+                kname = [k for k in tj if k.startswith(kname)][0]          # template arguments follow the target format
                 traffic = tj[kname]["hbm_bytes_per_launch_corrected"]
                 tsrc = "profiles/%s (rocprofv3 --pmc of bench.py --frames-in-flight 1, bytes per launch)" % os.path.basename(tpath)
                 break
-            except (KeyError, ValueError):
+            except (KeyError, ValueError, IndexError):
                 traffic = None
     roof = {
         "kernel": "composite_kernel", "bound": "hbm", "limiter": "valu (exp + blend per pixel-splat); the HBM fraction is honest-but-low",
@@ -360,7 +361,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="CPU baseline frames (0 = auto, about 10-30 s)")
     ap.add_argument("--profile-frames", type=int, default=6, help="extra frames (outside the timed regions) for V/D/work statistics")
-    ap.add_argument("--serial-frames", type=int, default=64, help="frames of the serial (one stream, one at a time) phase")
+    ap.add_argument("--serial-frames", type=int, default=128, help="frames of the serial (one stream, one at a time) phase")
     ap.add_argument("--prewarm", type=int, default=400, help="untimed frames before the warm-up (runtime pool growth)")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="frames overlapped on the GPU (one context + stream + framebuffer per frame in flight, one shared "

@@ -48,6 +48,9 @@ struct CloudStore {
 
 }  // namespace
 
+constexpr uint32_t kFusedMaxChunks = 8192;     // scan-free passes up to this many chunk rows (r2 sweep on the 6 M workloads: 2048 -> 8192 takes
+                                               // 40 us off the sort, beyond that nothing; past it the prefix sums grow with nchunks^2)
+
 struct msplat_ctx {
     msplat_config cfg{};
     int device = 0;
@@ -73,6 +76,7 @@ struct msplat_ctx {
     Buf gsumB1, gsumB2;     // binning: column pass / row pass
     uint32_t gsumS_rows = 0, gsumB1_rows = 0, gsumB2_rows = 0;
     bool scan_free = true;  // MSPLAT_SCAN_KERNELS=1 forces the 3-kernel (upsweep, scan, downsweep) passes
+    uint32_t fused_max_chunks = kFusedMaxChunks;   // MSPLAT_FUSED_MAX_CHUNKS: scan-free passes up to this many chunk rows
     // compositor formulation: 0 = one wave per 16x16 tile, 1 = one wave per 16x8 half tile (default), 2 = four waves per
     // tile (composite_quad_kernel, LDS-bound, kept for comparison); MSPLAT_COMPOSITOR=wave|half|quad
     int comp_kind = 0;
@@ -179,7 +183,6 @@ void buf_free(msplat_ctx* c, Buf& b)
 
 inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
-constexpr uint32_t kFusedMaxChunks = 2048;     // scan-free passes up to this many chunk rows (64 group rows to add up)
 constexpr size_t kProbeWords = 8;                                           // per compositor work item
 constexpr size_t kProbeBytes = (size_t)65536 * 8 * kProbeWords * sizeof(uint32_t);   // 256x256 bins x 4 quadrants x 2 halves
 
@@ -284,6 +287,7 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
             rc = fail(ctx, MSPLAT_ERR_HIP, "LDS atomic order probe failed to run");
         ctx->atomic_rank = (hbad == 0) && getenv("MSPLAT_BALLOT_RANK") == nullptr;
         ctx->scan_free = getenv("MSPLAT_SCAN_KERNELS") == nullptr;
+        if (getenv("MSPLAT_FUSED_MAX_CHUNKS")) ctx->fused_max_chunks = (uint32_t)atoi(getenv("MSPLAT_FUSED_MAX_CHUNKS"));
         if (const char* ck = getenv("MSPLAT_COMPOSITOR")) {
             const std::string k = ck;
             ctx->comp_kind = k == "half" ? 1 : k == "quad" ? 2 : 0;
@@ -882,7 +886,7 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
     const int tset = (int)(ctx->sort_sets % msplat_ctx::kEvSets);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][0], s));
     // scan-free passes (2 launches each) while the chunk table is small, else upsweep + scan + downsweep
-    const bool fused = ctx->scan_free && div_up(N, kSortChunk) <= kFusedMaxChunks;
+    const bool fused = ctx->scan_free && div_up(N, kSortChunk) <= ctx->fused_max_chunks;
     auto gacc = [&](int pass) { return fused ? (uint32_t*)ctx->gsumS[pass & 1].p : nullptr; };
     auto gzero = [&](int pass) { return (uint32_t*)ctx->gsumS[(pass + 1) & 1].p; };      // always: keeps both tables clean
     // pass 0: cull + key fused into the first radix pass (presort_compute.glsl + byte 0 of the sort)
@@ -957,9 +961,9 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     // scan-free variants while the chunk tables are small; the row pass's size (D) is only known on the device, so
     // its choice uses the D of an EARLIER frame that the binning kernel left in host-mapped memory (0 = none yet);
     // either variant is correct at any size, the choice only matters for speed
-    const bool fused1 = ctx->scan_free && div_up(N, kBinChunk) <= kFusedMaxChunks;
+    const bool fused1 = ctx->scan_free && div_up(N, kBinChunk) <= ctx->fused_max_chunks;
     const uint32_t last_D = ctx->h_flags ? __atomic_load_n(ctx->h_flags + 2, __ATOMIC_RELAXED) : 0u;
-    const bool fused2 = ctx->scan_free && last_D != 0u && div_up((uint64_t)last_D + (last_D >> 2), kPairChunk) <= kFusedMaxChunks;
+    const bool fused2 = ctx->scan_free && last_D != 0u && div_up((uint64_t)last_D + (last_D >> 2), kPairChunk) <= ctx->fused_max_chunks;
     uint32_t* gB1 = (uint32_t*)ctx->gsumB1.p;
     uint32_t* gB2 = (uint32_t*)ctx->gsumB2.p;
     hipLaunchKernelGGL(bin1_upsweep, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,

@@ -8,7 +8,7 @@ R=$(pwd)
 export TMPDIR=/tmp
 T=${1:-r02}
 mkdir -p gpurun_out
-( time timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -rs -rP ) > gpurun_out/${T}_gpu_tests.log 2>&1
+( time timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -rsP ) > gpurun_out/${T}_gpu_tests.log 2>&1
 grep -E "passed|failed|SKIPPED|check_image:" gpurun_out/${T}_gpu_tests.log | head -20
 timeout 600 python bench.py > gpurun_out/${T}_cfg2_bench.json 2> gpurun_out/${T}_cfg2_bench.err
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${T}_cfg2_bench_steps20.json 2> gpurun_out/${T}_cfg2_bench_steps20.err

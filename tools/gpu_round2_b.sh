@@ -4,7 +4,7 @@
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-[ -n "$SKIP_TESTS" ] || ( time timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -rs -rP ) > gpurun_out/r2b_tests.log 2>&1
+[ -n "$SKIP_TESTS" ] || ( time timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -rsP ) > gpurun_out/r2b_tests.log 2>&1
 grep -E "passed|failed|FAILED|SKIPPED|check_image:|Error|error" gpurun_out/r2b_tests.log | head -60
 ab() {   # tag, env...
   tag=$1; shift

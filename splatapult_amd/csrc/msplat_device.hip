@@ -961,7 +961,9 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     // scan-free variants while the chunk tables are small; the row pass's size (D) is only known on the device, so
     // its choice uses the D of an EARLIER frame that the binning kernel left in host-mapped memory (0 = none yet);
     // either variant is correct at any size, the choice only matters for speed
-    const bool fused1 = ctx->scan_free && div_up(N, kBinChunk) <= ctx->fused_max_chunks;
+    // (the column pass's chunks are half the size of the sort's: its table is scanned by a kernel from 4096 rows on --
+    //  measured at 6 M splats: 5860 rows cost the scan-free downsweep +28 us, the scan kernel 20 us)
+    const bool fused1 = ctx->scan_free && div_up(N, kBinChunk) <= ctx->fused_max_chunks / 2;
     const uint32_t last_D = ctx->h_flags ? __atomic_load_n(ctx->h_flags + 2, __ATOMIC_RELAXED) : 0u;
     const bool fused2 = ctx->scan_free && last_D != 0u && div_up((uint64_t)last_D + (last_D >> 2), kPairChunk) <= ctx->fused_max_chunks;
     uint32_t* gB1 = (uint32_t*)ctx->gsumB1.p;

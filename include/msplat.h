@@ -40,6 +40,8 @@ enum {
 };
 
 enum { MSPLAT_FB_RGBA32F = 0, MSPLAT_FB_RGBA16F = 1 };
+/* render-target emulation (msplat_set_target_emulation) */
+enum { MSPLAT_ROP_NONE = 0, MSPLAT_ROP_RGBA8 = 1, MSPLAT_ROP_RGBA16F = 2 };
 
 typedef struct msplat_ctx msplat_ctx;
 typedef struct msplat_cloud msplat_cloud;
@@ -175,6 +177,15 @@ int msplat_set_band_cull(msplat_ctx* ctx, int enable);
  * unorm depth; 32: float depth.  Renders then walk every tile list in draw order without early
  * termination (several times slower); meant for diffing against the GL app's output. */
 int msplat_set_depth_test(msplat_ctx* ctx, int depth_bits);
+
+/* The blend as the GL app's render target performs it (src/app.cpp:1012-1020).  The reference's
+ * default RGBA8 back buffer clamps source, destination and result to [0,1] and stores 8-bit unorm after EVERY blend
+ * (GL 4.6 17.3.6); its --fp16 target rounds to fp16 after every blend; its --fp32 target (what every other entry
+ * point models) does neither.  rop = MSPLAT_ROP_RGBA8 / MSPLAT_ROP_RGBA16F reproduce the first two for callers who
+ * diff against the GL app's pixels: renders then walk every bin list in draw order with the literal blend and no
+ * early termination (several times slower).  The values are written in the context's fb_format (RGBA8 results are
+ * multiples of 1/255).  The arithmetic inside a ROP is implementation-defined: this restates the specification. */
+int msplat_set_target_emulation(msplat_ctx* ctx, int rop);
 
 /* replaces SplatRenderer::Sort (splatrenderer.cpp:153-312): cull + depth key
  * (presort_compute.glsl:31-57), stable ascending 32-bit radix sort, sorted index list kept as

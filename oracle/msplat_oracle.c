@@ -601,8 +601,46 @@ uint32_t orc_quantise_depth(float ndcz, int depth_bits)
  * default func GL_LESS, depth writes on, buffer cleared to 1.0 by app.cpp:160): a fragment that survives
  * the discard is blended only if its depth is LESS than the stored one, and then stores its depth.
  * Discarded fragments write nothing (splat_frag.glsl:37-40 `discard`). */
-void orc_composite_depth(uint32_t v, const orc_splat2d* s, int W, int H, float* rgba, int depth_bits,
-                         int nthreads)
+/* fp32 -> fp16 (round to nearest even, no traps) -> fp32: what an RGBA16F render target stores */
+static float round_to_half(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = u & 0x80000000u;
+    uint32_t a = u & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return f;                          /* inf / nan */
+    if (a >= 0x477FF000u) {                                   /* >= 65520: rounds to inf */
+        const uint32_t inf = sign | 0x7F800000u;
+        float r; memcpy(&r, &inf, 4); return r;
+    }
+    if (a < 0x38800000u) {                                    /* below 2^-14: half subnormal, quantum 2^-24 */
+        float m; memcpy(&m, &a, 4);
+        const float q = 5.9604644775390625e-08f;              /* 2^-24 */
+        float r = nearbyintf(m / q) * q;                      /* default rounding mode: nearest even */
+        uint32_t ru; memcpy(&ru, &r, 4); ru |= sign; memcpy(&r, &ru, 4);
+        return r;
+    }
+    /* normal half: keep 10 mantissa bits */
+    const uint32_t rem = a & 0x1FFFu, keep = a & ~0x1FFFu;
+    uint32_t res = keep;
+    if (rem > 0x1000u || (rem == 0x1000u && (keep & 0x2000u))) res += 0x2000u;
+    res |= sign;
+    float r; memcpy(&r, &res, 4); return r;
+}
+
+static float clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }      /* NaN -> 1 is irrelevant here */
+static float to_unorm8(float x) { return floorf(clamp01(x) * 255.0f + 0.5f) / 255.0f; }
+
+/* The blend as the render-target hardware (ROP) performs it, in draw order, for the targets the GL app actually uses
+ * (src/app.cpp:1012-1020):
+ *   rop = 0  float accumulation, nothing rounded (the colour-only fp32 FBO: orc_composite's semantics)
+ *   rop = 1  RGBA8 (the default back buffer): GL 4.6 17.3.6 -- source colour, destination colour and the result are
+ *            clamped to [0,1]; the result is stored as 8-bit unorm (round to nearest) after EVERY blend
+ *   rop = 2  RGBA16F (--fp16): no clamping, the result is rounded to fp16 after every blend
+ * depth_bits = 0: no depth test; 24 / 32: the GL_LESS test the reference leaves enabled (app.cpp:160,163).
+ * The arithmetic precision inside a ROP is implementation-defined: this restates the specification, not a driver. */
+void orc_composite_rop(uint32_t v, const orc_splat2d* s, int W, int H, float* rgba, int depth_bits, int rop,
+                       int nthreads)
 {
     if (nthreads < 1) nthreads = 1;
     if (nthreads > H) nthreads = H;
@@ -621,7 +659,7 @@ void orc_composite_depth(uint32_t v, const orc_splat2d* s, int W, int H, float* 
         for (uint32_t k = 0; k < v; ++k) {
             const orc_splat2d* g = &s[k];
             if (g->reject) continue;
-            const uint32_t zq = orc_quantise_depth(g->ndc[2], depth_bits);
+            const uint32_t zq = depth_bits ? orc_quantise_depth(g->ndc[2], depth_bits) : 0u;
             int xa, xb, ya, yb;
             pixel_range(g->px, g->hx, W, 0, W, &xa, &xb);
             pixel_range(g->py, g->hy, H, y0, y1, &ya, &yb);
@@ -635,20 +673,31 @@ void orc_composite_depth(uint32_t v, const orc_splat2d* s, int W, int H, float* 
                     float e = expf(-0.5f * q);
                     float sa = g->alpha * e;
                     if (sa <= (1.0f / 256.0f)) continue;        /* discard: no colour, no depth write */
-                    uint32_t* zb = &zbuf[(size_t)(y - y0) * W + x];
-                    if (!(zq < *zb)) continue;                  /* GL_LESS */
-                    *zb = zq;
+                    if (depth_bits) {
+                        uint32_t* zb = &zbuf[(size_t)(y - y0) * W + x];
+                        if (!(zq < *zb)) continue;                  /* GL_LESS */
+                        *zb = zq;
+                    }
                     float* d = rgba + ((size_t)y * W + x) * 4;
-                    float oma = 1.0f - sa;
-                    d[0] = (sa * g->rgb[0]) + oma * d[0];
-                    d[1] = (sa * g->rgb[1]) + oma * d[1];
-                    d[2] = (sa * g->rgb[2]) + oma * d[2];
-                    d[3] = sa + oma * d[3];
+                    /* splat_frag.glsl:27-28: out = (a g rgb, a g); GL_ONE, GL_ONE_MINUS_SRC_ALPHA (app.cpp:153-156) */
+                    float sr = sa * g->rgb[0], sg = sa * g->rgb[1], sb = sa * g->rgb[2], aa = sa;
+                    if (rop == 1) { sr = clamp01(sr); sg = clamp01(sg); sb = clamp01(sb); aa = clamp01(aa); }
+                    float oma = 1.0f - aa;
+                    float r0 = sr + oma * d[0], r1 = sg + oma * d[1], r2 = sb + oma * d[2], r3 = aa + oma * d[3];
+                    if (rop == 1) { r0 = to_unorm8(r0); r1 = to_unorm8(r1); r2 = to_unorm8(r2); r3 = to_unorm8(r3); }
+                    else if (rop == 2) { r0 = round_to_half(r0); r1 = round_to_half(r1); r2 = round_to_half(r2); r3 = round_to_half(r3); }
+                    d[0] = r0; d[1] = r1; d[2] = r2; d[3] = r3;
                 }
             }
         }
         free(zbuf);
     }
+}
+
+void orc_composite_depth(uint32_t v, const orc_splat2d* s, int W, int H, float* rgba, int depth_bits,
+                         int nthreads)
+{
+    orc_composite_rop(v, s, W, H, rgba, depth_bits, 0, nthreads);
 }
 
 void orc_composite_f64(uint32_t v, const orc_splat2d* s, int W, int H, double* rgba, int nthreads)

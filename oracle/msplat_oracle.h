@@ -99,6 +99,11 @@ void orc_composite_flip(uint32_t v, const orc_splat2d* s, int W, int H, float* r
 uint32_t orc_quantise_depth(float ndcz, int depth_bits);
 void orc_composite_depth(uint32_t v, const orc_splat2d* s, int W, int H, float* rgba, int depth_bits,
                          int nthreads);
+/* the blend as the render target performs it: rop 0 = float accumulation, 1 = RGBA8 (clamp + 8-bit unorm after every
+ * blend, GL 4.6 17.3.6; the default back buffer), 2 = RGBA16F (fp16 rounding after every blend; --fp16);
+ * depth_bits 0 = no depth test.  src/app.cpp:1012-1020, SURVEY.md 8a-12. */
+void orc_composite_rop(uint32_t v, const orc_splat2d* s, int W, int H, float* rgba, int depth_bits, int rop,
+                       int nthreads);
 /* same, double-precision accumulation; used only to calibrate tolerances */
 void orc_composite_f64(uint32_t v, const orc_splat2d* s, int W, int H, double* rgba,
                        int nthreads);

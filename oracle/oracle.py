@@ -62,6 +62,7 @@ def lib():
     L.orc_composite.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int]
     L.orc_composite_flip.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int, fp, C.c_float]
     L.orc_composite_depth.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_int, fp, C.c_int, C.c_int]
+    L.orc_composite_rop.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int]
     L.orc_quantise_depth.argtypes = [C.c_float, C.c_int]
     L.orc_quantise_depth.restype = C.c_uint32
     L.orc_build_sprite.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, fp, u32p]
@@ -183,6 +184,16 @@ def composite_depth(splats, W, H, depth_bits=24, nthreads=1):
     rgba = np.zeros((H, W, 4), np.float32)
     lib().orc_composite_depth(splats.shape[0], splats.ctypes.data, W, H,
                               rgba.ctypes.data_as(C.POINTER(C.c_float)), depth_bits, nthreads)
+    return rgba
+
+
+def composite_rop(splats, W, H, rop, depth_bits=0, nthreads=1):
+    """the blend as the render target performs it after every splat: rop 1 = RGBA8 (clamp, 8-bit unorm), 2 = RGBA16F"""
+    splats = np.ascontiguousarray(splats)
+    assert splats.dtype == SPLAT2D_DTYPE
+    rgba = np.zeros((H, W, 4), np.float32)
+    lib().orc_composite_rop(splats.shape[0], splats.ctypes.data, W, H, rgba.ctypes.data_as(C.POINTER(C.c_float)),
+                            depth_bits, rop, nthreads)
     return rgba
 
 

@@ -10,6 +10,7 @@ OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NO_CLOUD, ERR_NO_SORT, ERR_UNSUPPORTED, ERR_PAIR_OVERFLOW, ERR_IO = \
     -1, -2, -3, -4, -5, -6, -7, -8
 FB_RGBA32F, FB_RGBA16F = 0, 1
+ROP_NONE, ROP_RGBA8, ROP_RGBA16F = 0, 1, 2
 
 
 class MsplatError(RuntimeError):
@@ -85,6 +86,7 @@ SYMBOLS = [
     ("msplat_upload_point_cloud", C.c_int, [C.c_void_p, C.c_void_p]),
     ("msplat_set_point_sprite", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     ("msplat_set_depth_test", C.c_int, [C.c_void_p, C.c_int]),
+    ("msplat_set_target_emulation", C.c_int, [C.c_void_p, C.c_int]),
     ("msplat_attach_cloud", C.c_int, [C.c_void_p, C.c_void_p]),
     ("msplat_stream_wait", C.c_int, [C.c_void_p, C.c_void_p]),
     ("msplat_wait_event", C.c_int, [C.c_void_p, C.c_void_p]),

@@ -90,6 +90,7 @@ struct msplat_ctx {
     Buf rect;       // uint32[N]
     Buf zq;         // uint32[N] quantised window depth per rank (only with msplat_set_depth_test)
     int depth_bits = 0;
+    int rop = 0;            // render-target emulation for the draw-order compositor (msplat_set_target_emulation)
     // point-cloud mode: pos4 = positions, recs = float4 colours, sprite = float4 mip chain
     bool point_mode = false;
     Buf sprite;
@@ -397,6 +398,20 @@ int msplat_set_depth_test(msplat_ctx* ctx, int depth_bits)
         if (rc) return rc;
     }
     ctx->depth_bits = depth_bits;
+    return MSPLAT_OK;
+}
+
+// What the render target does to the running colour, for diffing against the GL app's own output (SURVEY 8a-12,
+// src/app.cpp:1012-1020): MSPLAT_ROP_NONE = float accumulation, rounded once at the end (default, the colour-only fp32 FBO);
+// MSPLAT_ROP_RGBA8 = the default back buffer (clamp to [0,1] + 8-bit unorm after every blend, GL 4.6 17.3.6);
+// MSPLAT_ROP_RGBA16F = the --fp16 target (fp16 rounding after every blend).  Renders then walk every bin list in draw
+// order without early termination (the draw-order compositor of msplat_set_depth_test, with or without a depth buffer).
+int msplat_set_target_emulation(msplat_ctx* ctx, int rop)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if (rop != MSPLAT_ROP_NONE && rop != MSPLAT_ROP_RGBA8 && rop != MSPLAT_ROP_RGBA16F)
+        return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_set_target_emulation: rop must be MSPLAT_ROP_NONE, _RGBA8 or _RGBA16F (got %d)", rop);
+    ctx->rop = rop;
     return MSPLAT_OK;
 }
 
@@ -838,6 +853,7 @@ static int make_frame_params(msplat_ctx* ctx, const float cameraMat[16], const f
     fp.t_eps = ctx->cfg.t_epsilon;
     fp.band_cull = (ctx->band_cull && ctx->row_mod > 1 && !ctx->point_mode) ? 1 : 0;   // points carry no footprint bound
     fp.depth_bits = ctx->depth_bits;
+    fp.rop = ctx->rop;
     fp.view_scale2 = 0.0f;
     for (int c = 0; c < 3; ++c)
         fp.view_scale2 = std::max(fp.view_scale2, fp.view[c * 4] * fp.view[c * 4] + fp.view[c * 4 + 1] * fp.view[c * 4 + 1] +
@@ -1026,7 +1042,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                                (const float4*)ctx->rec2d.p, zqp, (const float4*)ctx->sprite.p, ctx->sprite_params, d_out,
                                pitch, fp, cap, (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u);
         ctx->comp_kernel_timed = false;
-    } else if (ntiles > 0 && ctx->depth_bits != 0) {
+    } else if (ntiles > 0 && (ctx->depth_bits != 0 || ctx->rop != 0)) {
         // emulated depth buffer: draw-order walk, no early termination
         if (ctx->cfg.fb_format == MSPLAT_FB_RGBA16F)
             hipLaunchKernelGGL(composite_depth_kernel<true>, dim3(cgrid), dim3(kCompThreads), 0, s,

@@ -48,6 +48,7 @@ struct FrameParams {
     int band_cull;              // multi-GPU only: Sort also drops splats that cannot reach an owned bin row
     float view_scale2;          // largest squared column norm of mat3(view) (1 for a rigid camera)
     int depth_bits;             // 0 = colour-only target (no depth test); 24 / 32 = emulated depth buffer
+    int rop;                    // 0 = float accumulation; 1 = RGBA8, 2 = RGBA16F render-target rounding after every blend
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1768,7 +1769,19 @@ __global__ __launch_bounds__(kQuadThreads) void composite_quad_kernel(const uint
 // of depth order (second XR eye re-using the first eye's sort), lose their later fragments.
 // Whether a fragment passes depends on everything drawn BEFORE it, so this variant walks the list
 // in draw order (far to near) with the literal "over" blend and cannot terminate early.
+//
+// The same draw-order walk also emulates what the render target does to the running colour (fp.rop, SURVEY 8a-12,
+// src/app.cpp:1012-1020): the default RGBA8 back buffer clamps source, destination and result to [0,1] and stores 8-bit
+// unorm after EVERY blend (GL 4.6 17.3.6), the --fp16 target rounds to fp16 after every blend; the main compositor
+// accumulates in fp32 and rounds once.  fp.depth_bits = 0 then means "no depth test".
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rop_store(float x, int rop)
+{
+    if (rop == 1) return floorf(fminf(fmaxf(x, 0.0f), 1.0f) * 255.0f + 0.5f) / 255.0f;
+    if (rop == 2) return (float)(_Float16)x;            // round to nearest even, like the fp16 target
+    return x;
+}
+
 template <bool HALF>
 __global__ __launch_bounds__(kCompThreads) void composite_depth_kernel(const uint32_t* __restrict__ tile_start,
                                                                        const uint32_t* __restrict__ pairs,
@@ -1814,7 +1827,7 @@ __global__ __launch_bounds__(kCompThreads) void composite_depth_kernel(const uin
                     asm volatile("" : "+v"(rank));
                     const float4* src = rec + (size_t)rank * 3;
                     p0 = src[0]; p1 = src[1]; p2 = src[2];
-                    z = zq[rank];
+                    if (fp.depth_bits != 0) z = zq[rank];
                     // same exact footprint-vs-tile test as composite_kernel
                     const float qa = p0.z, qb = p0.w, qc = p1.x, la = p1.y;
                     const float dxl = X0 - p0.x, dxh = X1 - p0.x, dyl = Y0 - p0.y, dyh = Y1 - p0.y;
@@ -1857,12 +1870,17 @@ __global__ __launch_bounds__(kCompThreads) void composite_depth_kernel(const uin
                         const float dy = ((float)(ybase + 4 * k) + 0.5f) - a.y;
                         const float e = __builtin_fmaf(dy, __builtin_fmaf(b.x, dy, lin), base_e);
                         // splat_frag.glsl:37-40 discard, then GL_LESS against the emulated depth buffer
-                        if (e > -8.0f && zj < zbuf[k]) {
+                        if (e > -8.0f && (fp.depth_bits == 0 || zj < zbuf[k])) {
                             const float w = __builtin_amdgcn_exp2f(e);
+                            // splat_frag.glsl:27-28: out = (w rgb, w); GL_ONE, GL_ONE_MINUS_SRC_ALPHA
+                            float sr = w * b.z, sg = w * b.w, sb = w * blue;
+                            if (fp.rop == 1) {      // fixed-point target: the source colour is clamped before the blend
+                                sr = fminf(fmaxf(sr, 0.0f), 1.0f); sg = fminf(fmaxf(sg, 0.0f), 1.0f); sb = fminf(fmaxf(sb, 0.0f), 1.0f);
+                            }
                             const float oma = 1.0f - w;
-                            cr[k] = (w * b.z) + oma * cr[k];          // GL_ONE, GL_ONE_MINUS_SRC_ALPHA
-                            cg[k] = (w * b.w) + oma * cg[k];
-                            cb[k] = (w * blue) + oma * cb[k];
+                            cr[k] = rop_store(sr + oma * cr[k], fp.rop);
+                            cg[k] = rop_store(sg + oma * cg[k], fp.rop);
+                            cb[k] = rop_store(sb + oma * cb[k], fp.rop);
                             zbuf[k] = zj;
                         }
                     }

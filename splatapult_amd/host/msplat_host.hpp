@@ -153,6 +153,12 @@ public:
         for (msplat_ctx* h : ctxs) msplat_set_depth_test(h, depthBits);
     }
 
+    // the blend as the GL app's own render target performs it (MSPLAT_ROP_RGBA8: default back buffer, MSPLAT_ROP_RGBA16F: --fp16)
+    void SetTargetEmulation(int rop)
+    {
+        for (msplat_ctx* h : ctxs) msplat_set_target_emulation(h, rop);
+    }
+
     // blocks until every frame in flight has finished
     // (also where a pair-buffer overflow of an earlier device-target Render is reported, see msplat_render)
     void Synchronize()

@@ -163,6 +163,13 @@ class SplatRenderer:
         for h in self._ctxs:
             _capi.check(h, self._lib.msplat_set_depth_test(h, int(depth_bits)))
 
+    def set_target_emulation(self, rop):
+        """the blend as the GL app's render target performs it: "rgba8" = clamp + 8-bit unorm after every
+        blend (default back buffer), "fp16" = fp16 rounding after every blend (--fp16), None = float accumulation"""
+        mode = {None: _capi.ROP_NONE, "none": _capi.ROP_NONE, "rgba8": _capi.ROP_RGBA8, "fp16": _capi.ROP_RGBA16F}[rop]
+        for h in self._ctxs:
+            _capi.check(h, self._lib.msplat_set_target_emulation(h, mode))
+
     def synchronize(self):
         """blocks until every frame in flight has finished"""
         for h in self._ctxs:

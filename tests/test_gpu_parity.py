@@ -361,6 +361,40 @@ def test_depth_test_second_eye_artifact_and_bands():
     np.testing.assert_array_equal(acc, img)
 
 
+@pytest.mark.parametrize("rop,depth_bits,fb", [("rgba8", 0, "fp32"), ("rgba8", 24, "fp32"), ("fp16", 0, "fp16"), ("fp16", 0, "fp32")])
+def test_render_target_emulation_matches_oracle(rop, depth_bits, fb):
+    """SURVEY.md 8a-12 / VERDICT r1 missing #4: the GL app's default RGBA8 target clamps to [0,1] and stores 8-bit unorm after
+    EVERY blend, its --fp16 target rounds to fp16 after every blend (src/app.cpp:1012-1020); msplat_set_target_emulation
+    reproduces both on the draw-order compositor, against orc_composite_rop.  One rounding-boundary flip (w differs by an
+    ulp between exp2 on the GPU and expf in the oracle) moves a value by one 8-bit / fp16 step."""
+    cloud = scenes.synth_cloud(20000, 131, log_scale_mean=-3.0)
+    W, H = 640, 360
+    cam, proj, vp, nf = scenes.default_view(W, H, yaw=0.2)
+    r = make_renderer(cloud, fb_format=fb)
+    r.Sort(cam, proj, vp, nf)
+    plain = r.Render(cam, proj, vp, nf)
+    r.set_target_emulation(rop)
+    if depth_bits:
+        r.set_depth_test(depth_bits)
+    img = r.Render(cam, proj, vp, nf).astype(np.float32)
+    ref = orc.render_frame(cloud.as_array(), True, cam, proj, vp, nf, nthreads=8, want_splats=True)
+    want = orc.composite_rop(ref["splats"], W, H, 1 if rop == "rgba8" else 2, depth_bits=depth_bits, nthreads=8)
+    d = np.abs(img - want)[..., :3]
+    step = 1.0 / 255.0 if rop == "rgba8" else np.maximum(np.abs(want[..., :3]) * 2.0 ** -10, 2.0 ** -14)
+    assert (d <= 1e-6).mean() > 0.99, (d > 1e-6).mean()
+    assert (d <= 2.0 * step + 1e-6).all(), d.max()
+    assert (img[..., 3] == 1).all()
+    if rop == "rgba8":
+        assert np.allclose(img * 255.0, np.round(img * 255.0), atol=1e-4) and img.min() >= 0 and img.max() <= 1
+        assert np.abs(img[..., :3] - np.clip(plain[..., :3].astype(np.float32), 0, 1)).max() > 0.02     # not the same picture
+    r.set_target_emulation(None)
+    r.set_depth_test(0)
+    np.testing.assert_array_equal(r.Render(cam, proj, vp, nf), plain)
+    from splatapult_amd import MsplatError, _capi
+    with pytest.raises(MsplatError):
+        _capi.check(r._ctx, _capi.lib().msplat_set_target_emulation(r._ctx, 7))
+
+
 # ------------------------------------------------------------------------------------------------
 # point-cloud renderer (SURVEY.md 8f-4): PointRenderer::Render = presort + sort + textured sprites
 # ------------------------------------------------------------------------------------------------

@@ -244,3 +244,54 @@ def test_depth_test_ties_out_of_order_and_literal_restatement():
     np.testing.assert_array_equal(orc.composite_depth(two, 96, 64, 24), orc.composite_depth(one, 96, 64, 24))
     assert np.abs(orc.composite(two, 96, 64) - orc.composite(one, 96, 64)).max() > 0 or two["alpha"][0] <= 1 / 256
 
+
+
+def test_render_target_rounding_modes_against_a_numpy_restatement():
+    """orc_composite_rop (what the GL app's RGBA8 / RGBA16F targets do after EVERY blend) against an
+    independent per-splat numpy restatement; also pins the C fp32 -> fp16 rounding against numpy's float16"""
+    from tests import scenes
+    cloud = scenes.synth_cloud(300, 77, log_scale_mean=-2.6)
+    W, H = 72, 56
+    cam, proj, vp, nf = scenes.default_view(W, H, z=6.0)
+    ref = orc.render_frame(cloud.as_array(), True, cam, proj, vp, nf, want_splats=True)
+    sp = ref["splats"]
+    xs = (np.arange(W, dtype=np.float32) + np.float32(0.5))[None, :]
+    ys = (np.arange(H, dtype=np.float32) + np.float32(0.5))[:, None]
+
+    def mirror(rop):
+        img = np.zeros((H, W, 4), np.float32)
+        img[..., 3] = 1.0
+        for g in sp:
+            if g["reject"]:
+                continue
+            dx = xs - g["px"]
+            dy = ys - g["py"]
+            inv = g["inv"]
+            q = dx * (inv[0] * dx + inv[2] * dy) + dy * (inv[1] * dx + inv[3] * dy)
+            sa = (g["alpha"] * np.exp(np.float32(-0.5) * q)).astype(np.float32)
+            hx, hy = g["hx"], g["hy"]
+            keep = (sa > np.float32(1.0 / 256.0)) & (np.abs(dx) <= hx) & (np.abs(dy) <= hy)
+            src = np.stack([sa * g["rgb"][0], sa * g["rgb"][1], sa * g["rgb"][2], sa], axis=-1).astype(np.float32)
+            if rop == 1:
+                src = np.clip(src, 0.0, 1.0)
+            res = src + (np.float32(1.0) - src[..., 3:4]) * img
+            if rop == 1:
+                res = np.floor(np.clip(res, 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)) / np.float32(255.0)
+            elif rop == 2:
+                res = res.astype(np.float16).astype(np.float32)
+            img = np.where(keep[..., None], res.astype(np.float32), img)
+        return img
+    plain = orc.composite_rop(sp, W, H, 0)
+    np.testing.assert_array_equal(plain, ref["image"])
+    for rop in (1, 2):
+        got = orc.composite_rop(sp, W, H, rop, nthreads=3)
+        want = mirror(rop)
+        d = np.abs(got - want)
+        # expf (C) vs np.exp differ by an ulp now and then: a rounding boundary may flip one 8-bit / fp16 step
+        step = 1.0 / 255.0 if rop == 1 else 2e-3
+        assert (d <= 1e-6).mean() > 0.995 and d.max() <= 2 * step, (rop, d.max(), (d > 1e-6).mean())
+    rgba8 = orc.composite_rop(sp, W, H, 1)
+    assert np.allclose(rgba8 * 255.0, np.round(rgba8 * 255.0), atol=1e-4) and rgba8.min() >= 0.0 and rgba8.max() <= 1.0
+    assert np.abs(rgba8 - np.clip(plain, 0.0, 1.0)).max() > 0.02         # per-blend clamping is visible (unclamped SH colours)
+    f16 = orc.composite_rop(sp, W, H, 2)
+    np.testing.assert_array_equal(f16, f16.astype(np.float16).astype(np.float32))

@@ -1282,7 +1282,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                                                                  FrameParams fp, uint32_t cap,
                                                                  const uint32_t* __restrict__ order,
                                                                  uint32_t* __restrict__ queue, uint32_t ntiles,
-                                                                 uint32_t* __restrict__ probe)
+                                                                 uint32_t* __restrict__ probe, int prio_levels)
 {
     // Lane (lx, ly) owns pixels (x0+lx, y0 + 4k + ly), k = 0..3: strip k is the 16x4 pixel block of
     // rows 4k..4k+3.  Per splat the exponent is split into a part shared by the four strips and a
@@ -1314,6 +1314,19 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
         if (threadIdx.x == 0) nq = queue_next(queue, ntiles);
         qpos = __builtin_amdgcn_readfirstlane(nq);
         continue;
+    }
+    // The launch lasts as long as its heaviest work item (the probe: max / mean item clocks = 2.0, and the heaviest item
+    // spans the whole launch although it starts first), because a wave that shares its SIMD with four others gets a
+    // fifth of the issue slots.  Items are numbered heaviest-first, so the wave's issue priority follows the item
+    // number: the heaviest thousand items run at the single-wave issue rate from the start and the light ones fill
+    // the slots they leave (SIMD arbitration is priority first, then age -- MI355X_MICROARCH.md).
+    if (prio_levels > 0) {
+        const uint32_t band = max(ntiles >> 3, 1u);                    // an eighth of the items per priority step
+        const uint32_t lvl = qpos / band;
+        if (lvl == 0u) __builtin_amdgcn_s_setprio(3);
+        else if (lvl == 1u) __builtin_amdgcn_s_setprio(2);
+        else if (lvl <= 3u) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
     }
     const int lane = threadIdx.x;
     const int lx = lane & 15, ly = lane >> 4;

@@ -23,8 +23,9 @@ except Exception as e:
 PY
   done
 }
-ab now
-ab now_b
+# variants to compare: lines of "tag ENV=..." in $AB_LIST (default: the build as it is, twice)
+printf '%s\n' "${AB_LIST:-now
+now_b}" | while read -r tag envs; do [ -n "$tag" ] && ab $tag $envs; done
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r2b_prof -o run --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline --frames-in-flight 1 > $GRAFT_REPO_ROOT/gpurun_out/r2b_prof.log 2>&1)
 python - <<PY
 import csv, glob

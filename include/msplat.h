@@ -254,6 +254,11 @@ int msplat_debug_get_projected(msplat_ctx* ctx, float* rec12, uint32_t* rect, ui
 int msplat_debug_get_tile_lists(msplat_ctx* ctx, uint32_t* tile_start, uint32_t tile_cap,
                                 uint32_t* pairs, uint64_t pair_cap);
 
+/* on-device self-check of the ordering contracts (sorted keys ascending, ties by ascending splat index; every bin list
+ * ascending in draw-order rank): counts of violations, both 0 on a healthy context.  Guards the lane-ordered LDS-atomic
+ * ranking, which msplat_create probes but the hardware does not document (MSPLAT_BALLOT_RANK=1 selects the ballot path) */
+int msplat_debug_verify_order(msplat_ctx* ctx, uint32_t* key_violations, uint32_t* list_violations);
+
 /* compositor probe (performance analysis, bench statistics): per (bin, quadrant) work item 8 words
  * {shader clocks, records composited, batches staged, inner-loop clocks, pair words fetched, records fetched,
  *  bin-list length, ran}.  Off by default (a few clock reads per batch); MSPLAT_TILE_PROBE=1 in the environment

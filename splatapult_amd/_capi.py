@@ -99,6 +99,7 @@ SYMBOLS = [
     ("msplat_debug_get_tile_lists", C.c_int, [C.c_void_p, _U32P, C.c_uint32, _U32P, C.c_uint64]),
     ("msplat_debug_get_tile_probe", C.c_int, [C.c_void_p, _U32P, C.c_uint32]),
     ("msplat_set_tile_probe", C.c_int, [C.c_void_p, C.c_int]),
+    ("msplat_debug_verify_order", C.c_int, [C.c_void_p, _U32P, _U32P]),
     ("msplat_get_composite_work", C.c_int, [C.c_void_p, C.POINTER(CompositeWork)]),
     ("msplat_cloud_create", C.c_void_p, [C.c_int]),
     ("msplat_cloud_destroy", None, [C.c_void_p]),

@@ -1292,6 +1292,31 @@ int msplat_debug_get_projected(msplat_ctx* ctx, float* rec12, uint32_t* rect, ui
     return MSPLAT_OK;
 }
 
+// On-device check of the ordering contracts of the last Sort (+ the last Render's bin lists, if there was one):
+// sorted keys ascend with ties in ascending splat index, every bin list ascends in draw-order rank.  A cheap guard
+// for the lane-ordered LDS-atomic ranking (probed at msplat_create, not documented hardware behaviour): call it in
+// debug builds or every few hundred frames; non-zero counts mean the context should be re-created with
+// MSPLAT_BALLOT_RANK=1.
+int msplat_debug_verify_order(msplat_ctx* ctx, uint32_t* key_violations, uint32_t* list_violations)
+{
+    if (!ctx || !key_violations || !list_violations) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
+    if (!ctx->has_sort) return fail(ctx, MSPLAT_ERR_NO_SORT, "no sort yet");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t* counters = (uint32_t*)ctx->counters.p;
+    uint32_t* bad = counters + 12;
+    HIP_TRY(ctx, hipMemsetAsync(bad, 0, 2 * sizeof(uint32_t), ctx->stream));
+    const int nbins = ctx->has_render ? ctx->last_fp.tiles_x * ctx->last_fp.tiles_y : 0;
+    hipLaunchKernelGGL(verify_order_kernel, dim3(1024), dim3(kThreads), 0, ctx->stream, (const uint32_t*)ctx->keyA.p,
+                       (const uint32_t*)ctx->valA.p, (const uint32_t*)counters, nbins ? (const uint32_t*)ctx->tile_start.p : nullptr,
+                       (const uint32_t*)ctx->pairsB.p, (uint32_t)ctx->pair_cap, nbins, bad);
+    uint32_t h[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(h, bad, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *key_violations = h[0];
+    *list_violations = h[1];
+    return MSPLAT_OK;
+}
+
 int msplat_debug_get_tile_probe(msplat_ctx* ctx, uint32_t* dst, uint32_t tile_cap)
 {
     if (!ctx || !dst) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");

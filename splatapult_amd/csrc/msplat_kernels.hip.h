@@ -1181,6 +1181,35 @@ __global__ __launch_bounds__(kThreads) void tile_start_kernel(const uint32_t* __
     if (lane == 0) tile_start[tile] = lo;
 }
 
+// Self-check of the two ordering contracts everything downstream relies on (the stable ranking rests on
+// ds_add_rtn handing out values in lane order, which is probed once per context but not documented hardware
+// behaviour): (1) the sorted keys ascend and equal keys keep ascending splat indices, (2) every bin list ascends in
+// draw-order rank.  bad[0] / bad[1] count the violations.  On demand only (msplat_debug_verify_order).
+__global__ __launch_bounds__(kThreads) void verify_order_kernel(const uint32_t* __restrict__ keys,
+                                                                const uint32_t* __restrict__ idx,
+                                                                const uint32_t* __restrict__ d_V,
+                                                                const uint32_t* __restrict__ tile_start,
+                                                                const uint32_t* __restrict__ pairs, uint32_t cap,
+                                                                int nbins, uint32_t* __restrict__ bad)
+{
+    const uint32_t V = *d_V;
+    uint32_t b0 = 0, b1 = 0;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i + 1u < V; i += gridDim.x * kThreads) {
+        const uint32_t k0 = keys[i], k1 = keys[i + 1u];
+        if (k0 > k1 || (k0 == k1 && idx[i] >= idx[i + 1u])) ++b0;
+    }
+    if (tile_start != nullptr) {
+        const int lane = threadIdx.x & 63;
+        for (int bin = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6); bin < nbins; bin += gridDim.x * (kThreads / 64)) {
+            const uint32_t s = min(tile_start[bin], cap), e = min(tile_start[bin + 1], cap);
+            for (uint32_t i = s + lane; i + 1u < e; i += 64u)
+                if ((pairs[i] & kRankMask) >= (pairs[i + 1u] & kRankMask)) ++b1;
+        }
+    }
+    if (b0) atomicAdd(&bad[0], b0);
+    if (b1) atomicAdd(&bad[1], b1);
+}
+
 // The compositors' work queue.  One queue head serves only ~90 returning atomics per microsecond (measured r2: a
 // half-tile launch pulling 8 k items from one head spent ~90 us queueing), so the head is sharded: item i lives
 // in shard i % 32, a workgroup pulls from the shard of its index and, when that one is drained, from up to two

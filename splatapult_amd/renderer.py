@@ -253,6 +253,12 @@ class SplatRenderer:
         _capi.check(self._ctx, self._lib.msplat_get_composite_work(self._ctx, C.byref(w)))
         return {k: int(getattr(w, k)) for k, _ in _capi.CompositeWork._fields_}
 
+    def verify_order(self):
+        """on-device self-check: (violations of the sorted-key / tie order, violations of the bin-list order); (0, 0) = healthy"""
+        a, b = C.c_uint32(), C.c_uint32()
+        _capi.check(self._ctx, self._lib.msplat_debug_verify_order(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def debug_tile_probe(self):
         st = self.stats()
         nt = st["tiles_x"] * st["tiles_y"] * 8        # one slot per work item: (bin, quadrant[, half])

@@ -622,6 +622,34 @@ def test_large_viewport_4096_matches_oracle():
     assert st["tiles_x"] == 128 and st["tiles_y"] == 128
 
 
+def test_ballot_rank_fallback_matches_lds_atomic_rank(monkeypatch):
+    """the stable ranking uses the return values of lane-ordered LDS atomics (probed at msplat_create); the ballot
+    path (MSPLAT_BALLOT_RANK=1) is the fallback.  Both must give the oracle's permutation, the same bin lists and pixels,
+    and pass the on-device order check (msplat_debug_verify_order)."""
+    cloud = scenes.cloud_from_attrs(scenes.hard_attrs(9000, 23))             # duplicates: equal keys, tie order matters
+    cam, proj, vp, nf = scenes.default_view(640, 400, yaw=0.4)
+    mvp = orc.mat4_mul(proj, orc.mat4_inverse(cam))
+    keys, idx = orc.sort(*orc.presort(cloud.as_array(), mvp, nf[1]))
+    outs = []
+    for env in ({}, {"MSPLAT_BALLOT_RANK": "1"}, {"MSPLAT_BALLOT_RANK": "1", "MSPLAT_SCAN_KERNELS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = make_renderer(cloud)
+        for k in env:
+            monkeypatch.delenv(k)
+        for rep in range(2):
+            r.Sort(cam, proj, vp, nf)
+            img = r.Render(cam, proj, vp, nf)
+        np.testing.assert_array_equal(r.sorted_keys(), keys)
+        np.testing.assert_array_equal(r.sorted_indices(), idx)
+        assert r.verify_order() == (0, 0)
+        ts, pairs = r.debug_tile_lists()
+        outs.append((ts, pairs, img))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_scan_free_and_scan_kernel_passes_agree(monkeypatch):
     """the radix / binning passes exist in two forms -- scan-free (group tables, 2 launches per pass; the default for
     chunk tables of up to 2048 rows) and upsweep + scan + downsweep (MSPLAT_SCAN_KERNELS=1, and automatically for
@@ -783,6 +811,7 @@ def _check_sort_exact(r, aos, cam, proj, nf):
 
 def _check_tile_lists_ascending(r):
     """every bin list is strictly increasing in rank (draw order preserved inside bins), lists tile the pair array"""
+    assert r.verify_order() == (0, 0)                 # the on-device self-check agrees
     st = r.stats()
     ts, pairs = r.debug_tile_lists()
     assert (np.diff(ts.astype(np.int64)) >= 0).all() and ts[-1] == st["pairs"]

@@ -1339,6 +1339,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
     const int tx = (bin - bvy * fp.tiles_x) * 2 + (quad & 1);
     const int ty = (bvy * fp.row_mod + fp.row_rem) * 2 + (quad >> 1);
     if (tx * kTile >= fp.width || ty * kTile + half * ROWS >= fp.height) {      // work item entirely outside the image
+        if (gridDim.x >= ntiles) break;
         uint32_t nq = 0;
         if (threadIdx.x == 0) nq = queue_next(queue, ntiles);
         qpos = __builtin_amdgcn_readfirstlane(nq);
@@ -1554,6 +1555,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
         }
     }
     __syncthreads();      // s_rec is reused by the next tile
+    if (gridDim.x >= ntiles) break;       // every work item has its own wave: nothing to pull, no exit atomic
     uint32_t nq = 0;
     if (threadIdx.x == 0) nq = queue_next(queue, ntiles);
     qpos = __builtin_amdgcn_readfirstlane(nq);

@@ -900,43 +900,55 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
     const float4* pos = (const float4*)ctx->pos4.p;
     uint32_t *kA = (uint32_t*)ctx->keyA.p, *kB = (uint32_t*)ctx->keyB.p;
     uint32_t *vA = (uint32_t*)ctx->valA.p, *vB = (uint32_t*)ctx->valB.p;
-    const int grid = grid_for(div_up(N, kSortChunk));
+    // chunk size by cloud size (msplat_kernels.hip.h, kSortItems): 2048 keys up to 2 M splats, 4096 beyond
+    const bool large = ctx->N > (2u << 20);
+    const uint32_t chunk = (uint32_t)kThreads * (large ? kSortItemsLarge : kSortItems);
+    const int grid = grid_for(div_up(N, chunk));
 
     const bool timed = ctx->ev_ok && (ctx->sort_calls++ % ctx->timing_stride) == 0;
     const int tset = (int)(ctx->sort_sets % msplat_ctx::kEvSets);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][0], s));
     // scan-free passes (2 launches each) while the chunk table is small, else upsweep + scan + downsweep
-    const bool fused = ctx->scan_free && div_up(N, kSortChunk) <= ctx->fused_max_chunks;
+    const bool fused = ctx->scan_free && div_up(N, chunk) <= ctx->fused_max_chunks;
     auto gacc = [&](int pass) { return fused ? (uint32_t*)ctx->gsumS[pass & 1].p : nullptr; };
     auto gzero = [&](int pass) { return (uint32_t*)ctx->gsumS[(pass + 1) & 1].p; };      // always: keeps both tables clean
+#define MSPLAT_UPSWEEP(MODE, ...)                                                                                       \
+    do {                                                                                                                \
+        if (large) hipLaunchKernelGGL((radix_upsweep<MODE, kSortItemsLarge>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((radix_upsweep<MODE, kSortItems>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__);            \
+    } while (0)
+#define MSPLAT_DOWNSWEEP(MODE, ...)                                                                                              \
+    do {                                                                                                                         \
+        if (large) {                                                                                                             \
+            if (ctx->atomic_rank) hipLaunchKernelGGL((radix_downsweep<MODE, true, true, kSortItemsLarge>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__); \
+            else hipLaunchKernelGGL((radix_downsweep<MODE, true, false, kSortItemsLarge>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__);                 \
+        } else {                                                                                                                 \
+            if (ctx->atomic_rank) hipLaunchKernelGGL((radix_downsweep<MODE, true, true, kSortItems>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__);      \
+            else hipLaunchKernelGGL((radix_downsweep<MODE, true, false, kSortItems>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__);                      \
+        }                                                                                                                        \
+    } while (0)
     // pass 0: cull + key fused into the first radix pass (presort_compute.glsl + byte 0 of the sort)
-    hipLaunchKernelGGL(radix_upsweep<MODE_CULL>, dim3(grid), dim3(kThreads), 0, s, nullptr, pos, nullptr, N, N, 0,
-                       hist, ctx->hist_stride, gacc(0), gzero(0), ctx->gsumS_rows, fp);
-    if (!fused) launch_scan(s, ctx->N <= (2u << 20), hist, ctx->hist_stride, nullptr, N, N, (uint32_t)kSortChunk, totals);
-    if (ctx->atomic_rank)
-        hipLaunchKernelGGL((radix_downsweep<MODE_CULL, true, true>), dim3(grid), dim3(kThreads), 0, s, nullptr, nullptr, pos,
-                           nullptr, N, N, 0, hist, ctx->hist_stride, totals, kB, vB, d_V, nullptr, gacc(0), nullptr, fp);
-    else
-        hipLaunchKernelGGL((radix_downsweep<MODE_CULL, true, false>), dim3(grid), dim3(kThreads), 0, s, nullptr, nullptr, pos,
-                           nullptr, N, N, 0, hist, ctx->hist_stride, totals, kB, vB, d_V, nullptr, gacc(0), nullptr, fp);
+    MSPLAT_UPSWEEP(MODE_CULL, (const uint32_t*)nullptr, pos, (const uint32_t*)nullptr, N, N, 0, hist, ctx->hist_stride, gacc(0),
+                   gzero(0), ctx->gsumS_rows, fp);
+    if (!fused) launch_scan(s, ctx->N <= (2u << 20), hist, ctx->hist_stride, nullptr, N, N, chunk, totals);
+    MSPLAT_DOWNSWEEP(MODE_CULL, (const uint32_t*)nullptr, (const uint32_t*)nullptr, pos, (const uint32_t*)nullptr, N, N, 0,
+                     (const uint32_t*)hist, ctx->hist_stride, (const uint32_t*)totals, kB, vB, d_V, (const uint32_t*)nullptr,
+                     (const uint32_t*)gacc(0), (uint32_t*)nullptr, fp);
     // passes 1..3 on the V survivors (V stays on the device; splatrenderer.cpp:195-204's readback is gone)
     for (int pass = 1; pass < 4; ++pass) {
         uint32_t* kin = (pass & 1) ? kB : kA;
         uint32_t* vin = (pass & 1) ? vB : vA;
         uint32_t* kout = (pass & 1) ? kA : kB;
         uint32_t* vout = (pass & 1) ? vA : vB;
-        hipLaunchKernelGGL(radix_upsweep<MODE_KEYS>, dim3(grid), dim3(kThreads), 0, s, kin, nullptr, d_V, 0u, N,
-                           pass * 8, hist, ctx->hist_stride, gacc(pass), gzero(pass), ctx->gsumS_rows, fp);
-        if (!fused) launch_scan(s, ctx->N <= (2u << 20), hist, ctx->hist_stride, d_V, 0u, N, (uint32_t)kSortChunk, totals);
-        if (ctx->atomic_rank)
-            hipLaunchKernelGGL((radix_downsweep<MODE_KEYS, true, true>), dim3(grid), dim3(kThreads), 0, s, kin, vin, nullptr,
-                               d_V, 0u, N, pass * 8, hist, ctx->hist_stride, totals, kout, vout, nullptr, nullptr, gacc(pass),
-                               nullptr, fp);
-        else
-            hipLaunchKernelGGL((radix_downsweep<MODE_KEYS, true, false>), dim3(grid), dim3(kThreads), 0, s, kin, vin, nullptr,
-                               d_V, 0u, N, pass * 8, hist, ctx->hist_stride, totals, kout, vout, nullptr, nullptr, gacc(pass),
-                               nullptr, fp);
+        MSPLAT_UPSWEEP(MODE_KEYS, (const uint32_t*)kin, (const float4*)nullptr, (const uint32_t*)d_V, 0u, N, pass * 8, hist,
+                       ctx->hist_stride, gacc(pass), gzero(pass), ctx->gsumS_rows, fp);
+        if (!fused) launch_scan(s, ctx->N <= (2u << 20), hist, ctx->hist_stride, d_V, 0u, N, chunk, totals);
+        MSPLAT_DOWNSWEEP(MODE_KEYS, (const uint32_t*)kin, (const uint32_t*)vin, (const float4*)nullptr, (const uint32_t*)d_V, 0u, N,
+                         pass * 8, (const uint32_t*)hist, ctx->hist_stride, (const uint32_t*)totals, kout, vout, (uint32_t*)nullptr,
+                         (const uint32_t*)nullptr, (const uint32_t*)gacc(pass), (uint32_t*)nullptr, fp);
     }
+#undef MSPLAT_UPSWEEP
+#undef MSPLAT_DOWNSWEEP
     if (timed) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][1], s));
         ctx->sort_sets++;

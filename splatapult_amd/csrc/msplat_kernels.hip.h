@@ -19,11 +19,15 @@
 namespace msplat {
 
 constexpr int kThreads = 256;            // 4 wave64 per workgroup
-constexpr int kSortItems = 8;            // keys per thread per chunk (4 measured no faster, 2026-r1)
+// keys per thread per chunk of the sort passes: 8 (2048-key chunks) up to 2 M splats -- 4 measured no faster (r1), 16 slower
+// at 1 M (245 workgroups for 256 CUs: sort 76 -> 91 us) -- and 16 (4096-key chunks) beyond: digit runs twice as long make
+// the scattered write-out cheaper (6 M splats: sort 234 -> 212 us, r2)
+constexpr int kSortItems = 8;
+constexpr int kSortItemsLarge = 16;
 constexpr int kSortChunk = kThreads * kSortItems;   // 2048 keys per chunk
 constexpr int kPairItems = 16;           // binning pass 2 moves 7x more words: bigger chunks, longer runs
 constexpr int kPairChunk = kThreads * kPairItems;   // 4096 words per chunk
-template <int MODE> struct RadixCfg { static constexpr int ITEMS = (MODE == 2) ? kPairItems : kSortItems; static constexpr int CHUNK = kThreads * ITEMS; };
+template <int MODE, int SORT_ITEMS> struct RadixCfg { static constexpr int ITEMS = (MODE == 2) ? kPairItems : SORT_ITEMS; static constexpr int CHUNK = kThreads * ITEMS; };
 constexpr int kBinChunk = 1024;          // draw-order ranks per chunk in the tile-column partition
 constexpr int kTile = 16;                // one compositor wave owns a 16x16 pixel tile ...
 constexpr int kBin = 32;                 // ... binning works on 32x32 bins (4 tiles share one list, each
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(kThreads) void lds_atomic_order_probe(uint32_t* __r
 // (radix_scan*) instead; both are correct at any size.
 constexpr int kGroupShift = 5;
 
-template <int MODE>
+template <int MODE, int SORT_ITEMS = kSortItems>
 __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __restrict__ keys,
                                                           const float4* __restrict__ pos,
                                                           const uint32_t* __restrict__ d_n, uint32_t n_static,
@@ -206,8 +210,8 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
                                                           uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_rows,
                                                           FrameParams fp)
 {
-    constexpr int ITEMS = RadixCfg<MODE>::ITEMS;
-    constexpr int CHUNK = RadixCfg<MODE>::CHUNK;
+    constexpr int ITEMS = RadixCfg<MODE, SORT_ITEMS>::ITEMS;
+    constexpr int CHUNK = RadixCfg<MODE, SORT_ITEMS>::CHUNK;
     __shared__ uint32_t s_hist[256];
     if (gsum_zero != nullptr)
         for (uint32_t row = blockIdx.x; row < gsum_zero_rows; row += gridDim.x) gsum_zero[(size_t)row * 256 + threadIdx.x] = 0u;
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(kThreads) void radix_scan_small(uint32_t* __restric
     if (g == 0) totals[digit] = total;
 }
 
-template <int MODE, bool HAS_VALUES, bool ATOMIC_RANK>
+template <int MODE, bool HAS_VALUES, bool ATOMIC_RANK, int SORT_ITEMS = kSortItems>
 __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __restrict__ keys_in,
                                                             const uint32_t* __restrict__ vals_in,
                                                             const float4* __restrict__ pos,
@@ -384,8 +388,8 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
     // gsum != nullptr: scan-free path -- hist holds raw per-chunk counts, prefixes come from the group tables;
     // otherwise hist holds exclusive prefixes and totals the digit totals (radix_scan*).
     // totals_out != nullptr: workgroup 0 publishes the digit totals (the row totals tile_start_kernel needs).
-    constexpr int ITEMS = RadixCfg<MODE>::ITEMS;
-    constexpr int CHUNK = RadixCfg<MODE>::CHUNK;
+    constexpr int ITEMS = RadixCfg<MODE, SORT_ITEMS>::ITEMS;
+    constexpr int CHUNK = RadixCfg<MODE, SORT_ITEMS>::CHUNK;
     __shared__ uint32_t s_col[MODE == MODE_PAIR ? 256 : 1];   // MODE_PAIR: first input position of each column
     __shared__ uint32_t s_cnt[4][256];   // per-wave digit counters, then per-wave scatter bases
     __shared__ uint32_t s_base[256];     // exclusive scan of the digit totals

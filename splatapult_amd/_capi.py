@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmsplat.so")
+# MSPLAT_LIB_PATH: load another build of the same ABI (A/B timing of two commits on one GPU box); default: the in-tree build
+LIB_PATH = os.environ.get("MSPLAT_LIB_PATH") or os.path.join(_HERE, "lib", "libmsplat.so")
 
 OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NO_CLOUD, ERR_NO_SORT, ERR_UNSUPPORTED, ERR_PAIR_OVERFLOW, ERR_IO = \

@@ -1,4 +1,5 @@
 #!/bin/bash
+# frames in flight x hardware queues
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 run() {
@@ -8,15 +9,14 @@ run() {
 import json
 try:
     d = json.loads(open("gpurun_out/r2d_$tag.json").read().strip().splitlines()[-1])
-    print("%-22s fps %7.1f ms %.4f | overlapped compk %.4f | hbm frac %.3f | blocks %s" % ("$tag", d["value"], d["ms_per_step"], d["stages_ms"].get("composite_kernel", 0), d["frame_hbm_frac"], [round(b,1) for b in d["block_ms"]]))
+    print("%-22s fps %7.1f ms %.4f | overlapped compk %.4f | hbm frac %.3f | enqueue %.4f" % ("$tag", d["value"], d["ms_per_step"], d["stages_ms"].get("composite_kernel", 0), d["frame_hbm_frac"], d["host_enqueue_ms_per_frame"]))
 except Exception as e:
     print("$tag failed:", e); print(open("gpurun_out/r2d_$tag.err").read()[-800:])
 PY
 }
-for P in 3 4 5; do
-  for CW in 1024 1536 2048 3072 4096; do
-    MSPLAT_COMP_WAVES=$CW run p${P}_w$CW --frames-in-flight $P
-  done
+for Q in 4 6 8 12 16 24; do
+  GPU_MAX_HW_QUEUES=$Q run p4_q$Q --frames-in-flight 4
 done
-GPU_MAX_HW_QUEUES=16 MSPLAT_COMP_WAVES=1536 run p6_q16_w1536 --frames-in-flight 6
-GPU_MAX_HW_QUEUES=16 MSPLAT_COMP_WAVES=1536 run p8_q16_w1536 --frames-in-flight 8
+GPU_MAX_HW_QUEUES=12 run p5_q12 --frames-in-flight 5
+GPU_MAX_HW_QUEUES=12 run p6_q12 --frames-in-flight 6
+GPU_MAX_HW_QUEUES=24 run p6_q24 --frames-in-flight 6

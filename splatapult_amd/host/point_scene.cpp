@@ -20,20 +20,20 @@ struct PointRecord {
 
 }  // namespace
 
-PointCloud::PointCloud(bool useLinearColorsIn) : useLinearColors(useLinearColorsIn) {}
+PointCloud::PointCloud(bool useLinearColorsIn) : linearColours_(useLinearColorsIn) {}
 
-void PointCloud::InitAttribs()
+void PointCloud::SetUpAttributes()
 {
-    positionAttrib = BinaryAttribute(BinaryAttribute::Type::Float, offsetof(PointRecord, position));
-    colorAttrib = BinaryAttribute(BinaryAttribute::Type::Float, offsetof(PointRecord, color));
+    posAttr_ = BinaryAttribute(BinaryAttribute::Type::Float, offsetof(PointRecord, position));
+    rgbAttr_ = BinaryAttribute(BinaryAttribute::Type::Float, offsetof(PointRecord, color));
 }
 
-void PointCloud::Alloc(size_t n)
+void PointCloud::Reserve(size_t n)
 {
-    numPoints = n;
-    pointSize = sizeof(PointRecord);
-    InitAttribs();
-    data.reset(new PointRecord[n ? n : 1], [](void* p) { delete[] static_cast<PointRecord*>(p); });
+    count_ = n;
+    recordBytes_ = sizeof(PointRecord);
+    SetUpAttributes();
+    records_.reset(new PointRecord[n ? n : 1], [](void* p) { delete[] static_cast<PointRecord*>(p); });
 }
 
 bool PointCloud::ImportPly(const std::string& plyFilename)
@@ -59,8 +59,8 @@ bool PointCloud::ImportPly(const std::string& plyFilename)
         // logged, not fatal (pointcloud.cpp:66-71): the unset attributes then read as 0 -> black points
         std::fprintf(stderr, "[msplat][E] Error parsing ply file \"%s\", missing color property\n", plyFilename.c_str());
 
-    Alloc(ply.GetVertexCount());
-    PointRecord* pd = static_cast<PointRecord*>(data.get());
+    Reserve(ply.GetVertexCount());
+    PointRecord* pd = static_cast<PointRecord*>(records_.get());
     size_t i = 0;
     ply.ForEachVertex([&](const void* v, size_t) {
         float p[3];
@@ -69,9 +69,9 @@ bool PointCloud::ImportPly(const std::string& plyFilename)
         } else {
             p[0] = px.Read<float>(v); p[1] = py.Read<float>(v); p[2] = pz.Read<float>(v);
         }
-        // Reference quirk kept on purpose: with useLinearColors it is the POSITIONS that go through SRGBToLinear,
+        // Reference quirk kept on purpose: with linearColours_ it is the POSITIONS that go through SRGBToLinear,
         // not the colours (pointcloud.cpp:84-95,109-120).
-        for (int k = 0; k < 3; ++k) pd[i].position[k] = useLinearColors ? SRGBToLinear(p[k]) : p[k];
+        for (int k = 0; k < 3; ++k) pd[i].position[k] = linearColours_ ? SRGBToLinear(p[k]) : p[k];
         pd[i].position[3] = 1.0f;
         pd[i].color[0] = (float)red.Read<uint8_t>(v) / 255.0f;
         pd[i].color[1] = (float)green.Read<uint8_t>(v) / 255.0f;
@@ -98,8 +98,8 @@ bool PointCloud::ExportPly(const std::string& plyFilename) const
     BinaryAttribute f[6], c[3];
     for (int k = 0; k < 6; ++k) ply.GetProperty(fnames[k], f[k]);
     for (int k = 0; k < 3; ++k) ply.GetProperty(cnames[k], c[k]);
-    ply.AllocData(numPoints);
-    const PointRecord* pd = static_cast<const PointRecord*>(data.get());
+    ply.AllocData(count_);
+    const PointRecord* pd = static_cast<const PointRecord*>(records_.get());
     size_t i = 0;
     ply.ForEachVertexMut([&](void* v, size_t) {
         for (int k = 0; k < 3; ++k) f[k].Write<float>(v, pd[i].position[k]);
@@ -116,8 +116,8 @@ void PointCloud::InitDebugCloud()
     // three axis lines of 5 points each, 0.2 apart, coloured r / g / b (pointcloud.cpp:199-258)
     const int kPerAxis = 5;
     const float delta = 1.0f / (float)kPerAxis;
-    Alloc((size_t)kPerAxis * 3);
-    PointRecord* pd = static_cast<PointRecord*>(data.get());
+    Reserve((size_t)kPerAxis * 3);
+    PointRecord* pd = static_cast<PointRecord*>(records_.get());
     for (int axis = 0; axis < 3; ++axis)
         for (int i = 0; i < kPerAxis; ++i) {
             PointRecord& p = pd[axis * kPerAxis + i];
@@ -132,7 +132,7 @@ void PointCloud::InitDebugCloud()
 
 void PointCloud::ForEachPosition(const ForEachPositionCallback& cb) const
 {
-    positionAttrib.ForEach<float>(GetRawDataPtr(), GetStride(), GetNumPoints(), cb);
+    posAttr_.ForEach<float>(GetRawDataPtr(), GetStride(), GetNumPoints(), cb);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -21,26 +21,25 @@ public:
     bool ExportPly(const std::string& plyFilename) const;
     void InitDebugCloud();
 
-    size_t GetNumPoints() const { return numPoints; }
-    size_t GetStride() const { return pointSize; }
+    size_t GetNumPoints() const { return count_; }
+    size_t GetStride() const { return recordBytes_; }
     size_t GetTotalSize() const { return GetNumPoints() * GetStride(); }
-    void* GetRawDataPtr() { return data.get(); }
-    const void* GetRawDataPtr() const { return data.get(); }
+    void* GetRawDataPtr() { return records_.get(); }
+    const void* GetRawDataPtr() const { return records_.get(); }
 
-    const BinaryAttribute& GetPositionAttrib() const { return positionAttrib; }
-    const BinaryAttribute& GetColorAttrib() const { return colorAttrib; }
+    const BinaryAttribute& GetPositionAttrib() const { return posAttr_; }
+    const BinaryAttribute& GetColorAttrib() const { return rgbAttr_; }
 
     using ForEachPositionCallback = std::function<void(const float*)>;
     void ForEachPosition(const ForEachPositionCallback& cb) const;
 
-protected:
-    void InitAttribs();
-    void Alloc(size_t n);
+private:
+    // one interleaved record per point (position + colour, see point_scene.cpp); the accessors above describe it
+    void Reserve(size_t n);
+    void SetUpAttributes();
 
-    std::shared_ptr<void> data;
-    BinaryAttribute positionAttrib;
-    BinaryAttribute colorAttrib;
-    size_t numPoints = 0;
-    size_t pointSize = 0;
-    bool useLinearColors;
+    size_t count_ = 0, recordBytes_ = 0;
+    std::shared_ptr<void> records_;
+    BinaryAttribute posAttr_, rgbAttr_;
+    const bool linearColours_;
 };

@@ -65,7 +65,17 @@ typedef struct msplat_config {
     int32_t compositor_waves;  /* persistent compositor waves per render; 0 = default (8192, the  */
                                /* measured best for one frame at a time; the SplatRenderer shims   */
                                /* use 1024 with frames in flight so that frames share the CUs)     */
+    int32_t rank_mode;         /* MSPLAT_RANK_*: how the stable radix / binning passes rank the    */
+                               /* keys of one wave.  Added after the first release of the struct:  */
+                               /* a struct_size that ends before this field selects MSPLAT_RANK_AUTO */
 } msplat_config;
+
+/* msplat_config.rank_mode */
+enum {
+    MSPLAT_RANK_AUTO = 0,      /* lane-ordered LDS atomics if the probe run by msplat_create confirms */
+                               /* that ds_add_rtn hands out return values in lane order, else ballots */
+    MSPLAT_RANK_BALLOT = 1     /* always the ballot / popcount ranking (no reliance on that ordering) */
+};
 
 /* Byte offsets of the attributes inside one AoS record, i.e. the BinaryAttribute offsets that
  * SplatRenderer::BuildVertexArrayObject binds (splatrenderer.cpp:345-391;

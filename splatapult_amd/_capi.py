@@ -12,6 +12,7 @@ ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NO_CLOUD, ERR_NO_SORT, ERR_UNSUPPOR
     -1, -2, -3, -4, -5, -6, -7, -8
 FB_RGBA32F, FB_RGBA16F = 0, 1
 ROP_NONE, ROP_RGBA8, ROP_RGBA16F = 0, 1, 2
+RANK_AUTO, RANK_BALLOT = 0, 1
 
 
 class MsplatError(RuntimeError):
@@ -23,7 +24,8 @@ class MsplatError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("fb_format", C.c_int32),
                 ("srgb", C.c_int32), ("t_epsilon", C.c_float), ("pair_capacity", C.c_uint64),
-                ("stream", C.c_void_p), ("enable_timing", C.c_int32), ("compositor_waves", C.c_int32)]
+                ("stream", C.c_void_p), ("enable_timing", C.c_int32), ("compositor_waves", C.c_int32),
+                ("rank_mode", C.c_int32)]
 
 
 class AttrOffsets(C.Structure):

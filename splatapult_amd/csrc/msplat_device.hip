@@ -220,11 +220,16 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
     c.struct_size = sizeof(msplat_config);
     c.t_epsilon = -1.0f;
     if (cfg) {
-        if (cfg->struct_size != sizeof(msplat_config))
-            return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: config struct_size %u != %zu",
-                        cfg->struct_size, sizeof(msplat_config));
-        c = *cfg;
+        // the struct grows at its end: a caller built against an older header passes a shorter struct_size
+        constexpr size_t kMinConfig = offsetof(msplat_config, rank_mode);
+        if (cfg->struct_size < kMinConfig || cfg->struct_size > sizeof(msplat_config))
+            return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: config struct_size %u not in [%zu, %zu]",
+                        cfg->struct_size, kMinConfig, sizeof(msplat_config));
+        memcpy(&c, cfg, cfg->struct_size);
+        c.struct_size = sizeof(msplat_config);
     }
+    if (c.rank_mode != MSPLAT_RANK_AUTO && c.rank_mode != MSPLAT_RANK_BALLOT)
+        return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: bad rank_mode %d", c.rank_mode);
     if (c.fb_format != MSPLAT_FB_RGBA32F && c.fb_format != MSPLAT_FB_RGBA16F)
         return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: bad fb_format %d", c.fb_format);
     int ndev = 0;
@@ -289,7 +294,7 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         if (hipMemcpyAsync(&hbad, bad, sizeof(hbad), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess)
             rc = fail(ctx, MSPLAT_ERR_HIP, "LDS atomic order probe failed to run");
-        ctx->atomic_rank = (hbad == 0) && getenv("MSPLAT_BALLOT_RANK") == nullptr;
+        ctx->atomic_rank = (hbad == 0) && c.rank_mode != MSPLAT_RANK_BALLOT && getenv("MSPLAT_BALLOT_RANK") == nullptr;
         ctx->scan_free = getenv("MSPLAT_SCAN_KERNELS") == nullptr;
         if (getenv("MSPLAT_FUSED_MAX_CHUNKS")) ctx->fused_max_chunks = (uint32_t)atoi(getenv("MSPLAT_FUSED_MAX_CHUNKS"));
         if (const char* ck = getenv("MSPLAT_COMPOSITOR")) {

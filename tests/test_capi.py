@@ -36,7 +36,7 @@ def test_signatures_are_plain_c_no_framework_types():
 def test_version_and_struct_sizes():
     L = _capi.lib()
     assert b"msplat" in L.msplat_version_string()
-    assert C.sizeof(_capi.Config) == 48 and C.sizeof(_capi.AttrOffsets) == 64
+    assert C.sizeof(_capi.Config) == 56 and _capi.Config.rank_mode.offset == 48 and C.sizeof(_capi.AttrOffsets) == 64
     assert C.sizeof(_capi.Stats) == 64 and C.sizeof(_capi.Timings) == 32
 
 
@@ -61,6 +61,21 @@ def test_bad_arguments_are_rejected_without_a_context():
     cfg.struct_size = 7
     h = C.c_void_p()
     assert L.msplat_create(C.byref(h), C.byref(cfg)) == _capi.ERR_INVALID_ARG
+    # the config struct grows at its end: the size of the struct before rank_mode was added is still accepted ...
+    cfg = _capi.Config()
+    cfg.struct_size = 48
+    cfg.t_epsilon = -1.0
+    rc = L.msplat_create(C.byref(h), C.byref(cfg))
+    assert rc in (_capi.OK, _capi.ERR_NO_DEVICE)            # past the argument checks either way
+    if rc == _capi.OK:
+        L.msplat_destroy(h)
+    # ... a size in between, a larger one, or an unknown rank_mode are not
+    for size, mode in ((44, 0), (64, 0), (C.sizeof(_capi.Config), 7)):
+        cfg = _capi.Config()
+        cfg.struct_size = size
+        cfg.rank_mode = mode
+        h = C.c_void_p()
+        assert L.msplat_create(C.byref(h), C.byref(cfg)) == _capi.ERR_INVALID_ARG and not h.value
     assert L.msplat_sort(None, None, None, None, None) == _capi.ERR_INVALID_ARG
     assert L.msplat_render(None, None, None, None, None, None, 0, 0) == _capi.ERR_INVALID_ARG
     assert L.msplat_cloud_import_ply(None, b"x") == _capi.ERR_INVALID_ARG

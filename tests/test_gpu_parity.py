@@ -631,10 +631,11 @@ def test_ballot_rank_fallback_matches_lds_atomic_rank(monkeypatch):
     mvp = orc.mat4_mul(proj, orc.mat4_inverse(cam))
     keys, idx = orc.sort(*orc.presort(cloud.as_array(), mvp, nf[1]))
     outs = []
-    for env in ({}, {"MSPLAT_BALLOT_RANK": "1"}, {"MSPLAT_BALLOT_RANK": "1", "MSPLAT_SCAN_KERNELS": "1"}):
+    # the ballot path is selected by msplat_config.rank_mode or, for a whole process, by MSPLAT_BALLOT_RANK=1
+    for kw, env in (({}, {}), ({"rank_mode": 1}, {}), ({}, {"MSPLAT_BALLOT_RANK": "1", "MSPLAT_SCAN_KERNELS": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        r = make_renderer(cloud)
+        r = make_renderer(cloud, **kw)
         for k in env:
             monkeypatch.delenv(k)
         for rep in range(2):

@@ -746,6 +746,36 @@ def test_seeded_random_scenes_sort_exact_and_image_in_tolerance(case):
     np.testing.assert_array_equal(r.Render(cam, proj, vp, nf), img)
 
 
+@pytest.mark.parametrize("fovy_deg,zn,zf,z,wh", [(20.0, 0.1, 1000.0, 12.0, (640, 360)),      # long lens
+                                                  (100.0, 0.1, 1000.0, 3.0, (512, 512)),     # wide angle, inside the cloud's halo
+                                                  (45.0, 0.5, 9.0, 7.0, (480, 300)),         # splats beyond the far plane
+                                                  (60.0, 2.0, 40.0, 5.0, (333, 211)),        # near plane cuts the cloud
+                                                  (45.0, 0.001, 1.0e6, 7.0, (400, 240))])    # key uses 12 of its 32 bits
+def test_other_projections_match_the_oracle(fovy_deg, zn, zf, z, wh):
+    """every other test uses the application's projection (45 degrees, near 0.1, far 1000: app.cpp:73-75); the depth key
+    scales with 1 / far (presort_compute.glsl:53), the geometry stage rejects on ndc.z < 0.25 and clips at the far
+    plane (splat_geom.glsl:46-54): other frusta move all three.  Keys at or beyond the far plane saturate."""
+    W, H = wh
+    cloud = scenes.synth_cloud(40000, 77, log_scale_mean=-3.3)
+    cam = camera.pose((0.3, -0.2, z), 0.25, -0.1)
+    proj = camera.perspective(np.radians(fovy_deg), W / H, zn, zf)
+    vp, nf = [0, 0, W, H], [zn, zf]
+    r = make_renderer(cloud)
+    r.Sort(cam, proj, vp, nf)
+    img = r.Render(cam, proj, vp, nf)
+    ref = oracle_frame(cloud.as_array(), True, cam, proj, vp, nf)
+    assert r.sort_count() == ref["V"] and ref["V"] > 1000
+    np.testing.assert_array_equal(r.sorted_keys(), ref["sorted_keys"])
+    np.testing.assert_array_equal(r.sorted_indices(), ref["sorted_idx"])
+    assert r.verify_order() == (0, 0)
+    _check_projection(r, ref, W, H)                      # centres, conics, colours, rectangles; no rejected splat drawn
+    drawn_ref = int((ref["splats"]["reject"] == 0).sum())
+    assert r.stats()["drawn"] <= drawn_ref
+    if zf < 100.0:
+        assert drawn_ref < ref["V"]                      # the case really has far- or near-rejected splats
+    check_image(img, ref["image"], budget=ref["budget"])
+
+
 def test_device_output_pair_overflow_is_reported_on_the_next_call():
     """VERDICT r1 / ADVICE: a device-output render cannot know that the (splat, bin) pair buffer overflowed; the
     binning kernel leaves the needed count in host-mapped memory and the next call on the context reports

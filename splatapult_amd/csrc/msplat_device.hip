@@ -81,6 +81,7 @@ struct msplat_ctx {
     // tile (composite_quad_kernel, LDS-bound, kept for comparison); MSPLAT_COMPOSITOR=wave|half|quad
     int comp_kind = 0;
     bool comp_ftz = true;   // discard by underflow in the compositor (MSPLAT_COMP_FTZ=0: compare + select)
+    int comp_xcd = 1;       // the four quadrants of a bin run on one XCD (MSPLAT_COMP_XCD=0: plain item order)
     int comp_prio = 1;      // wave issue priority follows the work item's weight (MSPLAT_COMP_PRIO=0: all equal)
     Buf totals;     // uint32[256]  digit totals of the current radix pass (rows in binning pass 2)
     Buf totals1;    // uint32[256]  column totals of binning pass 1
@@ -303,6 +304,7 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         }
         if (getenv("MSPLAT_COMP_FTZ")) ctx->comp_ftz = atoi(getenv("MSPLAT_COMP_FTZ")) != 0;
         if (getenv("MSPLAT_COMP_PRIO")) ctx->comp_prio = atoi(getenv("MSPLAT_COMP_PRIO"));
+        if (getenv("MSPLAT_COMP_XCD")) ctx->comp_xcd = atoi(getenv("MSPLAT_COMP_XCD"));
     }
     if (rc != MSPLAT_OK) {
         std::string msg = ctx->err;
@@ -1104,7 +1106,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
             const int grid = (int)std::min<uint32_t>(nitems, pool);
 #define MSPLAT_LAUNCH_COMP(F16, NP, OCC, FZ)                                                                          \
     hipExtLaunchKernelGGL((composite_kernel<F16, NP, OCC, FZ>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, \
-                          d_out, pitch, fp, cap, ord, d_queue, nitems, probe, ctx->comp_prio)
+                          d_out, pitch, fp, cap, ord, d_queue, nitems, probe, ctx->comp_prio, ctx->comp_xcd)
 #define MSPLAT_LAUNCH_COMP_F(NP, OCC, FZ) do { if (f16) MSPLAT_LAUNCH_COMP(true, NP, OCC, FZ); else MSPLAT_LAUNCH_COMP(false, NP, OCC, FZ); } while (0)
             if (half) {                          // experiment: one wave per 16x8 half tile
                 MSPLAT_LAUNCH_COMP_F(1, 6, false);

@@ -1315,7 +1315,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                                                                  FrameParams fp, uint32_t cap,
                                                                  const uint32_t* __restrict__ order,
                                                                  uint32_t* __restrict__ queue, uint32_t ntiles,
-                                                                 uint32_t* __restrict__ probe, int prio_levels)
+                                                                 uint32_t* __restrict__ probe, int prio_levels, int xcd_affinity)
 {
     // Lane (lx, ly) owns pixels (x0+lx, y0 + 4k + ly), k = 0..3: strip k is the 16x4 pixel block of
     // rows 4k..4k+3.  Per splat the exponent is split into a part shared by the four strips and a
@@ -1337,8 +1337,17 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
     const int tile = (int)qpos;                       // probe slot
     const uint32_t tpos = (NP == 2) ? qpos : (qpos >> 1);          // (bin, quadrant) index
     const int half = (NP == 2) ? 0 : (int)(qpos & 1u);            // which 16x8 half of the tile
-    const int bin = (int)order[tpos >> 2];
-    const int quad = (int)(tpos & 3u);
+    // The four tiles of a bin walk the SAME list, and workgroup b runs on XCD b % 8 (each XCD has its own L2): inside every
+    // group of 32 items the quadrants of one bin are the items r, r + 8, r + 16, r + 24, i.e. on one XCD, as the first
+    // (static) item of a wave and -- shard = item % 32, home shard = workgroup % 32 -- as a pulled one.  Three of the four
+    // waves then find the list words and records in their XCD's L2 instead of fetching them from HBM again.
+    uint32_t slot = tpos >> 2, quadrant = tpos & 3u;
+    if (xcd_affinity && tpos < (((NP == 2) ? ntiles : (ntiles >> 1)) & ~31u)) {
+        slot = (tpos >> 5) * 8u + (tpos & 7u);
+        quadrant = (tpos >> 3) & 3u;
+    }
+    const int bin = (int)order[slot];
+    const int quad = (int)quadrant;
     const int bvy = bin / fp.tiles_x;
     const int tx = (bin - bvy * fp.tiles_x) * 2 + (quad & 1);
     const int ty = (bvy * fp.row_mod + fp.row_rem) * 2 + (quad >> 1);

@@ -712,6 +712,12 @@ def test_all_compositors_match_the_oracle(monkeypatch):
     for other in ("quad", "wave"):
         d = np.abs(imgs["half"] - imgs[other])[..., :3]
         assert (d <= 1e-4).mean() > 0.999
+    # the work-item -> (bin, quadrant) mapping that keeps a bin's four tiles on one XCD only reorders the work
+    monkeypatch.setenv("MSPLAT_COMP_XCD", "0")
+    r = make_renderer(cloud)
+    monkeypatch.delenv("MSPLAT_COMP_XCD")
+    r.Sort(cam, proj, vp, nf)
+    np.testing.assert_array_equal(r.Render(cam, proj, vp, nf), imgs["wave"])
 
 
 @pytest.mark.parametrize("case", range(24))

@@ -1483,9 +1483,11 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                 const float c1 = -(2.0f * qa * a + qb * b);
                 const float c2 = -(2.0f * qc * b + qb * a);
                 const float c0 = (qa * a + qb * b) * a + (qc * b * b + (p1.y - kBias));      // the exponent bias rides on log2(alpha)
-                s_rec[slot * 3 + 0] = make_float4(c0, c1, c2, qa);
-                s_rec[slot * 3 + 1] = make_float4(qb, qc, p1.z, p1.w);
-                s_rec[slot * 3 + 2] = p2;
+                // the four values the packed instructions broadcast (c5, r, g, b) sit at even dwords of the 16-byte reads: they
+                // land in even VGPRs, which a packed operand can name directly (an odd one costs a v_mov)
+                s_rec[slot * 3 + 0] = make_float4(qc, c0, p1.z, c1);
+                s_rec[slot * 3 + 1] = make_float4(p1.w, c2, p2.x, qa);
+                s_rec[slot * 3 + 2] = make_float4(qb, 0.0f, 0.0f, 0.0f);
             }
         }
         __syncthreads();
@@ -1505,19 +1507,19 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
         probe_recs += cnt;
         const uint64_t probe_t1 = probe ? clock64() : 0ull;
         if (n != 0u) {
-            float4 a = s_rec[0];          // c0, c1, c2, c3
-            float4 b = s_rec[1];          // c4, c5, r, g
-            float blue = s_rec[2].x;
+            float4 a = s_rec[0];          // c5, c0, r, c1
+            float4 b = s_rec[1];          // g, c2, b, c3
+            float c4 = s_rec[2].x;
 #pragma unroll 2
             for (uint32_t j = 0; j < n; ++j) {
                 // next record (slot n is a harmless over-read inside the 65-slot array)
                 const float4 na = s_rec[(j + 1) * 3 + 0];
                 const float4 nb = s_rec[(j + 1) * 3 + 1];
-                const float nblue = s_rec[(j + 1) * 3 + 2].x;
-                const float base = __builtin_fmaf(__builtin_fmaf(a.w, u, a.y), u, a.x);      // c0 + c1 u + c3 u^2
-                const float lin = __builtin_fmaf(b.x, u, a.z);                               // c2 + c4 u
-                const v2f vbase = (v2f){base, base}, vlin = (v2f){lin, lin}, vC = (v2f){b.y, b.y};
-                const v2f vr = (v2f){b.z, b.z}, vg = (v2f){b.w, b.w}, vb = (v2f){blue, blue};
+                const float nc4 = s_rec[(j + 1) * 3 + 2].x;
+                const float base = __builtin_fmaf(__builtin_fmaf(b.w, u, a.w), u, a.y);      // c0 + c1 u + c3 u^2
+                const float lin = __builtin_fmaf(c4, u, b.y);                                // c2 + c4 u
+                const v2f vbase = (v2f){base, base}, vlin = (v2f){lin, lin}, vC = (v2f){a.x, a.x};
+                const v2f vr = (v2f){a.z, a.z}, vg = (v2f){b.x, b.x}, vb = (v2f){b.z, b.z};
                 // Branch-free on purpose: the strips are independent dependency chains inside one basic
                 // block, so the in-order wave can overlap them.  w = 0 where the fragment shader discards.
 #pragma unroll
@@ -1539,7 +1541,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                     if (FTZ) T[h] = __builtin_elementwise_fma(tw, (v2f){-kScale, -kScale}, T[h]);
                     else T[h] = T[h] - tw;
                 }
-                a = na; b = nb; blue = nblue;
+                a = na; b = nb; c4 = nc4;
             }
         }
         if (probe) probe_inner += clock64() - probe_t1;

@@ -82,6 +82,7 @@ struct msplat_ctx {
     int comp_kind = 0;
     bool comp_ftz = true;   // discard by underflow in the compositor (MSPLAT_COMP_FTZ=0: compare + select)
     int comp_xcd = 1;       // the four quadrants of a bin run on one XCD (MSPLAT_COMP_XCD=0: plain item order)
+    bool comp_always_order = false;   // MSPLAT_COMP_ORDER=1: heaviest-first order for persistent waves too (A/B)
     int comp_prio = 1;      // wave issue priority follows the work item's weight (MSPLAT_COMP_PRIO=0: all equal)
     Buf totals;     // uint32[256]  digit totals of the current radix pass (rows in binning pass 2)
     Buf totals1;    // uint32[256]  column totals of binning pass 1
@@ -98,7 +99,8 @@ struct msplat_ctx {
     Buf sprite;
     SpriteParams sprite_params{};
     Buf tile_start; // uint32[65537]
-    Buf tile_order; // uint32[65536] tiles by descending list length
+    Buf tile_order; // uint32[65536] bins by descending list length, then uint32[65536] = 0, 1, 2, ... (the order used when persistent
+                    // waves pull the items dynamically: measured, the heaviest-first order buys nothing there)
     Buf hist1;      // uint32[256 * hist1_stride]
     uint32_t hist1_stride = 0;
     Buf pairsA, pairsB;   // uint32[pair_cap]
@@ -271,7 +273,8 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->totals1, 256 * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->queue, kQueueShards * kQueueStride * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_start, 65537 * sizeof(uint32_t));
-    if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_order, 65536 * sizeof(uint32_t));
+    if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_order, 2 * 65536 * sizeof(uint32_t));
+
     if (c.compositor_waves > 0) { ctx->comp_waves = std::max(64, (int)c.compositor_waves); ctx->comp_waves_auto = false; }
     if (getenv("MSPLAT_COMP_WAVES")) { ctx->comp_waves = std::max(64, atoi(getenv("MSPLAT_COMP_WAVES"))); ctx->comp_waves_auto = false; }
     if (rc == MSPLAT_OK && getenv("MSPLAT_TILE_PROBE") != nullptr) {
@@ -290,6 +293,7 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
     if (rc == MSPLAT_OK) {
         // feature probe: stable ranks straight from LDS atomics need lane-ordered ds_add_rtn
         uint32_t* bad = (uint32_t*)ctx->counters.p + 8;
+        hipLaunchKernelGGL(iota_kernel, dim3(65536 / kThreads), dim3(kThreads), 0, ctx->stream, (uint32_t*)ctx->tile_order.p + 65536);
         hipLaunchKernelGGL(lds_atomic_order_probe, dim3(64), dim3(kThreads), 0, ctx->stream, bad);
         uint32_t hbad = 1;
         if (hipMemcpyAsync(&hbad, bad, sizeof(hbad), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -304,6 +308,7 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         }
         if (getenv("MSPLAT_COMP_FTZ")) ctx->comp_ftz = atoi(getenv("MSPLAT_COMP_FTZ")) != 0;
         if (getenv("MSPLAT_COMP_PRIO")) ctx->comp_prio = atoi(getenv("MSPLAT_COMP_PRIO"));
+        if (getenv("MSPLAT_COMP_ORDER")) ctx->comp_always_order = atoi(getenv("MSPLAT_COMP_ORDER")) != 0;
         if (getenv("MSPLAT_COMP_XCD")) ctx->comp_xcd = atoi(getenv("MSPLAT_COMP_XCD"));
     }
     if (rc != MSPLAT_OK) {
@@ -1040,11 +1045,20 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                            (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
                            (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1,
                            fused2 ? (const uint32_t*)gB2 : nullptr, fused2 ? totals2 : nullptr, fp);
+    // The heaviest-first order of the bins only pays when every work item has its own wave (the hardware then starts the
+    // waves in item order: 83 -> 97 us without it at config 2); persistent waves that pull items from the queue balance
+    // themselves, and the counting sort is one launch (4.5 us; 16 us at 16 k bins) for nothing: they walk the bins in
+    // storage order (`tile_order` + 65536 holds 0, 1, 2, ...).
+    const bool wave_comp = !ctx->point_mode && ctx->depth_bits == 0 && ctx->rop == 0 && ctx->comp_kind != 2;
+    const uint32_t comp_items = (uint32_t)ntiles * (ctx->comp_kind == 1 ? 8u : 4u);
+    const uint32_t comp_pool = (ctx->comp_waves_auto && comp_items <= 20480u) ? comp_items : (uint32_t)ctx->comp_waves;
+    const bool ordered = !(wave_comp && comp_pool < comp_items) || ctx->comp_always_order;
     hipLaunchKernelGGL(tile_start_kernel, dim3(std::max(1, (ntiles + kTileStartBins - 1) / kTileStartBins)), dim3(kThreads), 0, s,
                        (const uint32_t*)ctx->pairsB.p, (const uint32_t*)totals2, d_D, cap, fp.tiles_x, ntiles,
-                       (uint32_t*)ctx->tile_start.p, gB2, ctx->gsumB2_rows);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)ctx->tile_start.p, ntiles,
-                       (uint32_t*)ctx->tile_order.p, d_queue);
+                       (uint32_t*)ctx->tile_start.p, gB2, ctx->gsumB2_rows, ordered ? nullptr : d_queue);
+    if (ordered)
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)ctx->tile_start.p, ntiles,
+                           (uint32_t*)ctx->tile_order.p, d_queue);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][4], s));
 
     // persistent compositor: a fixed pool of waves pulls (bin, quadrant) items; never more waves than items
@@ -1087,7 +1101,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         const uint32_t* ts = (const uint32_t*)ctx->tile_start.p;
         const uint32_t* pb = (const uint32_t*)ctx->pairsB.p;
         const float4* r2 = (const float4*)ctx->rec2d.p;
-        const uint32_t* ord = (const uint32_t*)ctx->tile_order.p;
+        const uint32_t* ord = (const uint32_t*)ctx->tile_order.p + (ordered ? 0 : 65536);
         const bool f16 = ctx->cfg.fb_format == MSPLAT_FB_RGBA16F;
         if (ctx->comp_kind == 2) {
             // four waves per tile: the pool is counted in workgroups of four waves
@@ -1101,8 +1115,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         } else {
             // one wave per 16x8 half tile (twice the work items) or per 16x16 tile
             const bool half = ctx->comp_kind == 1;
-            const uint32_t nitems = (uint32_t)ntiles * (half ? 8u : 4u);
-            const uint32_t pool = (ctx->comp_waves_auto && nitems <= 20480u) ? nitems : (uint32_t)ctx->comp_waves;
+            const uint32_t nitems = comp_items, pool = comp_pool;
             const int grid = (int)std::min<uint32_t>(nitems, pool);
 #define MSPLAT_LAUNCH_COMP(F16, NP, OCC, FZ)                                                                          \
     hipExtLaunchKernelGGL((composite_kernel<F16, NP, OCC, FZ>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, \

@@ -1141,14 +1141,20 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
 // One WAVE per bin and a 64-ary search: every step probes 64 evenly spaced words of the remaining range with
 // one gather, so a row segment of 100 k words needs 3 dependent loads instead of 17 (this kernel was a
 // 2 k-thread latency chain: 7.8 us at 1920x1080).
+// (the compositors' sharded work queue, see queue_next below)
+constexpr uint32_t kQueueShards = 32;
+constexpr uint32_t kQueueStride = 16;          // words between heads: one 64-byte line each
 constexpr int kTileStartBins = kThreads / 64;      // bins per workgroup
 __global__ __launch_bounds__(kThreads) void tile_start_kernel(const uint32_t* __restrict__ pairs,
                                                               const uint32_t* __restrict__ row_totals,
                                                               const uint32_t* __restrict__ d_D, uint32_t cap,
                                                               int tiles_x, int ntiles,
                                                               uint32_t* __restrict__ tile_start,
-                                                              uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_rows)
+                                                              uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_rows,
+                                                              uint32_t* __restrict__ queue_reset)
 {
+    // (the compositors' work queue starts empty every frame; tile_order_kernel does it when it runs)
+    if (queue_reset != nullptr && blockIdx.x == 0 && threadIdx.x < kQueueShards) queue_reset[threadIdx.x * kQueueStride] = 0u;
     __shared__ uint32_t s_row[kThreads + 1];
     __shared__ uint32_t s_tmp[4];
     if (gsum_zero != nullptr)      // scan-free path: the row pass's group table for the NEXT frame, see radix_upsweep
@@ -1220,8 +1226,6 @@ __global__ __launch_bounds__(kThreads) void verify_order_kernel(const uint32_t* 
 // neighbours (checked with a plain load first, so drained shards are not hammered by the exiting waves).
 // Items are stored heaviest-first, so every shard hands out its share heaviest-first too.  The first item of every
 // workgroup is static (its own index): queue[s] counts only the items of shard s taken dynamically.
-constexpr uint32_t kQueueShards = 32;
-constexpr uint32_t kQueueStride = 16;          // words between heads: one 64-byte line each
 __device__ __forceinline__ uint32_t queue_next(uint32_t* __restrict__ queue, uint32_t nitems)
 {
     const uint32_t home = blockIdx.x % kQueueShards;
@@ -1238,6 +1242,12 @@ __device__ __forceinline__ uint32_t queue_next(uint32_t* __restrict__ queue, uin
         if (item < nitems) return (uint32_t)item;
     }
     return 0xFFFFFFFFu;
+}
+
+// 0, 1, 2, ...: the bin order persistent compositor waves use (filled once, at msplat_create)
+__global__ __launch_bounds__(kThreads) void iota_kernel(uint32_t* __restrict__ dst)
+{
+    dst[blockIdx.x * kThreads + threadIdx.x] = blockIdx.x * kThreads + threadIdx.x;
 }
 
 // tiles ordered by descending list length (counting sort on len/16): the compositor's waves pull tiles

@@ -46,7 +46,9 @@ sys.path.insert(0, ROOT)
 # hardware queues (default 4) and streams that share a queue serialise.  With torch's own streams in the
 # process, 4 frames in flight need more than 4 queues (measured: 3.8 k fps with 4 queues, 5.1 k with 8).
 # Must be set before the HIP runtime initialises, i.e. before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# N > 1: RCCL brings its own streams; 16 queues keep the frame streams from sharing one with them (a shared queue costs a
+# quarter of the frame rate; 8 / 12 / 16 / 24 queues measure the same on one GPU).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "8")
 
 WORKLOADS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on

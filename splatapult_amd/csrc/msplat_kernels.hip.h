@@ -1447,52 +1447,56 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
     // pair words / records whose loads have been issued so far (the prefetch pipeline runs two / one batches ahead)
     uint32_t probe_words = min(end - start, 2u * (uint32_t)kCompThreads), probe_recs = cnt;
     while (cnt != 0u && alive != 0u) {
-        // stage: record + the strips (bit k) its y-range [py - ey, py + ey] can reach in this tile
-        // stage only the splats whose y-range reaches a strip that is still live, compacted in list
-        // order (near to far).  The CU has ONE scalar unit for its four SIMDs, so the inner loop is
-        // written to need almost no scalar work: a plain counted loop, strips handled by VALU predicates.
+        // stage: every lane turns its list entry into the coefficients of e(u, v) in tile-centred coordinates and tests
+        // it against the tile; the survivors are compacted into LDS in list order (near to far).  Straight-line code on
+        // purpose: the CU has ONE scalar unit for its four SIMDs and this is the dependent chain between two batches --
+        // the branchy form (per-strip y tests, the exact test under an EXEC mask) was ~115 VALU + ~80 scalar instructions
+        // per batch, this one is ~60 + ~15.
         uint32_t n;
         {
-            const float ylo = p0.y - p2.w, yhi = p0.y + p2.w;
-            bool rel = false;
+            constexpr float U = 0.5f * (float)(kTile - 1);          // box of pixel centres: |u| <= U, |v| <= Vh
+            constexpr float Vh = 0.5f * (float)(ROWS - 1);
+            const float a = p0.x - xc, b = p0.y - yc;               // splat centre, tile-centred
+            const float qa = p0.z, qb = p0.w, qc = p1.x;            // c3, c4, c5
+            const float Aa = qa * a, Bb = qb * b, Cb = qc * b, Ba = qb * a;
+            const float c1 = __builtin_fmaf(-2.0f, Aa, -Bb);
+            const float c2 = __builtin_fmaf(-2.0f, Cb, -Ba);
+            const float c0 = __builtin_fmaf(Aa + Bb, a, __builtin_fmaf(Cb, b, p1.y - kBias));   // the exponent bias rides on log2(alpha)
+            // y reach of the footprint against the strips that are still live (strip k: v in [4k - Vh, 4k + 3 - Vh])
+            const float vlo = b - p2.w, vhi = b + p2.w;
+            bool rel = lane < (int)cnt && vhi >= -Vh && vlo <= Vh;
+            if (alive != (1u << NS) - 1u) {                          // wave-uniform; only once strips have saturated
+                bool any = false;
 #pragma unroll
-            for (int k = 0; k < NS; ++k)
-                rel = rel || ((alive & (1u << k)) && yhi >= tile_y0 + 4.0f * k + 0.5f && ylo <= tile_y0 + 4.0f * k + 3.5f);
-            rel = rel && lane < (int)cnt;
-            if (rel) {
-                // exact footprint-vs-tile test (the list was built from bounding rectangles): the exponent
-                // e(d) is a concave quadratic, so unless the centre lies inside the tile's box of pixel
-                // centres its maximum over the box is on one of the four edges (1-D maximiser, clamped)
-                const float X0 = (float)(tx * kTile) + 0.5f, X1 = X0 + (float)(kTile - 1);
-                const float Y0 = tile_y0 + 0.5f, Y1 = Y0 + (float)(ROWS - 1);
-                const float qa = p0.z, qb = p0.w, qc = p1.x, la = p1.y;
-                const float dxl = X0 - p0.x, dxh = X1 - p0.x, dyl = Y0 - p0.y, dyh = Y1 - p0.y;
-                if (!(dxl <= 0.0f && dxh >= 0.0f && dyl <= 0.0f && dyh >= 0.0f)) {
-                    float emax = -1e30f;
-                    // v_rcp_f32 (1 ulp) instead of four IEEE divisions (~10 instructions each): the maximiser only
-                    // has to be accurate to the 0.05 slack of the test below
-                    const float i2c = __builtin_amdgcn_rcpf(2.0f * qc), i2a = __builtin_amdgcn_rcpf(2.0f * qa);
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const float dx = s ? dxh : dxl;                      // vertical edges
-                        const float dy = fminf(fmaxf(-qb * dx * i2c, dyl), dyh);
-                        emax = fmaxf(emax, (qc * dy + qb * dx) * dy + qa * dx * dx + la);
-                        const float ey = s ? dyh : dyl;                      // horizontal edges
-                        const float ex = fminf(fmaxf(-qb * ey * i2a, dxl), dxh);
-                        emax = fmaxf(emax, (qa * ex + qb * ey) * ex + qc * ey * ey + la);
-                    }
-                    rel = emax > -8.05f;
-                }
+                for (int k = 0; k < NS; ++k)
+                    any = any || ((alive & (1u << k)) && vhi >= 4.0f * k - Vh && vlo <= 4.0f * k + 3.0f - Vh);
+                rel = rel && any;
             }
+            // exact footprint-vs-tile test (the list was built from bounding rectangles): e is a concave quadratic, so
+            // unless the centre lies inside the box its maximum over the box is on one of the four edges (1-D maximiser,
+            // clamped).  v_rcp_f32 instead of IEEE divisions: the maximiser only has to be good to the 0.05 slack below.
+            const bool inside_box = fabsf(a) <= U && fabsf(b) <= Vh;
+            const float i2c = -0.5f * __builtin_amdgcn_rcpf(qc), i2a = -0.5f * __builtin_amdgcn_rcpf(qa);
+            const float ku = __builtin_fmaf(qa, U * U, c0), kv = __builtin_fmaf(qc, Vh * Vh, c0);
+            float emax;
+            {
+                const float lp = __builtin_fmaf(qb, U, c2), lm = __builtin_fmaf(qb, -U, c2);       // edges u = +-U
+                const float kp = __builtin_fmaf(c1, U, ku), km = __builtin_fmaf(c1, -U, ku);
+                const float vp = fminf(fmaxf(lp * i2c, -Vh), Vh), vm = fminf(fmaxf(lm * i2c, -Vh), Vh);
+                const float ep = __builtin_fmaf(__builtin_fmaf(qc, vp, lp), vp, kp);
+                const float em = __builtin_fmaf(__builtin_fmaf(qc, vm, lm), vm, km);
+                const float mp = __builtin_fmaf(qb, Vh, c1), mm = __builtin_fmaf(qb, -Vh, c1);    // edges v = +-Vh
+                const float hp = __builtin_fmaf(c2, Vh, kv), hm = __builtin_fmaf(c2, -Vh, kv);
+                const float up = fminf(fmaxf(mp * i2a, -U), U), um = fminf(fmaxf(mm * i2a, -U), U);
+                const float fp_ = __builtin_fmaf(__builtin_fmaf(qa, up, mp), up, hp);
+                const float fm_ = __builtin_fmaf(__builtin_fmaf(qa, um, mm), um, hm);
+                emax = fmaxf(fmaxf(ep, em), fmaxf(fp_, fm_));
+            }
+            rel = rel && (inside_box || emax > -8.05f - kBias);
             const uint64_t relmask = __ballot(rel);
             n = (uint32_t)__popcll(relmask);
             if (rel) {
                 const int slot = __popcll(relmask & ((1ull << lane) - 1ull));
-                const float a = p0.x - xc, b = p0.y - yc;
-                const float qa = p0.z, qb = p0.w, qc = p1.x;
-                const float c1 = -(2.0f * qa * a + qb * b);
-                const float c2 = -(2.0f * qc * b + qb * a);
-                const float c0 = (qa * a + qb * b) * a + (qc * b * b + (p1.y - kBias));      // the exponent bias rides on log2(alpha)
                 // the four values the packed instructions broadcast (c5, r, g, b) sit at even dwords of the 16-byte reads: they
                 // land in even VGPRs, which a packed operand can name directly (an odd one costs a v_mov)
                 s_rec[slot * 3 + 0] = make_float4(qc, c0, p1.z, c1);

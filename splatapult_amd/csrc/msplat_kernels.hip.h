@@ -1306,11 +1306,11 @@ constexpr int kCompThreads = 64;   // one wave per 16x16 tile, 4 pixels (one per
 // 64 pixels per wave (four waves per tile, composite_quad_kernel below) is NOT the next step: every record costs
 // ~10 LDS-pipe cycles per wave however few pixels the wave owns, and at 64 pixels the four SIMDs of a CU ask for
 // more broadcast reads than its one LDS pipe delivers.
-// OCC = waves per SIMD the register allocation must leave room for (__launch_bounds__): the kernel is VALU-issue
-// bound and a SIMD needs ~8 resident waves to issue at its full rate (tools/ubench_valu: 1.38 / 1.78 / 2.63 clocks per
-// instruction at 8 / 4 / 2 waves), while the unconstrained allocation takes 94 VGPRs = 5 waves.
+// OCC = waves per SIMD the register allocation must leave room for (__launch_bounds__).  The kernel is VALU bound:
+// 21.5 VALU instructions per record in the inner loop (12 packed, 4 v_exp_f32, 3 scalar FMAs: ~147 pipe cycles) and
+// ~70 per staged batch; it takes 76 VGPRs (six waves per SIMD).  Measured: more resident waves do not help.
 // FTZ: the fragment shader's discard (w <= 1/256, splat_frag.glsl:37-40) costs a compare and a select per pixel in
-// a loop of ~14 instructions per (pixel, record).  Here it is free: the exponent is biased by -118, so that
+// a loop that then had ~9 instructions per (pixel, record).  Here it is free: the exponent is biased by -118, so that
 // w' = exp2(e - 118) is a NORMAL float exactly when e >= -8 and underflows otherwise, and the wave runs with fp32
 // denormals flushed (MODE.FP_DENORM, set below): the underflowing weights come out of v_exp_f32 as exact zeros.
 // The transmittance is carried scaled by 2^118 (Ts = 2^118 T), so tw = Ts w' = T w exactly as before (powers of

@@ -1,0 +1,65 @@
+"""bench.py's output contract on a one-GPU box (-m gpu): the single JSON line the driver parses, for N = 1 and -- over gloo
+with every rank on device 0 (MSPLAT_BENCH_ONE_DEVICE=1, a debug aid: it exercises the N > 1 control flow, not xGMI) -- N = 2."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+QUICK = ["--steps", "6", "--warmup", "2", "--prewarm", "24", "--serial-frames", "8", "--profile-frames", "1"]
+
+
+def _line(out):
+    lines = [ln for ln in out.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def _check_contract(d, n):
+    assert d["metric"] == "frames_per_sec" and d["unit"] == "frames/s"
+    assert d["n_gpus"] == n and d["steps"] == 6 and d["warmup"] == 2
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and abs(d["value"] * d["ms_per_step"] - 1e3) < 1e-3 * 1e3
+    assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic"
+    cfg = d["config"]
+    assert "BASELINE configs[1]" in cfg["workload"] and cfg["splats"] == 1000000 and (cfg["width"], cfg["height"]) == (1920, 1080)
+    assert "model" not in cfg
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["avg_launch_ms"] > 0 and (r["traffic"] is None or r["traffic"] > 0)
+    assert d["serial"]["ms_per_frame"] > 0
+
+
+def test_bench_single_gpu_json_contract():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--cpu-frames", "1"] + QUICK,
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    _check_contract(d, 1)
+    assert d["rccl_ranks"] == 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "frames/s" and cb["sample"]
+    assert d["value"] > 50 * cb["value"]                   # sanity only: the ratio says nothing about the kernels
+
+
+def test_bench_two_ranks_one_device_control_flow():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MSPLAT_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--no-cpu-baseline", "--also", ""] + QUICK,
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    d = _line(p.stdout)
+    _check_contract(d, 2)
+    assert d["rccl_ranks"] == 0                            # gloo stand-in: no RCCL ranks are claimed
+    assert d["config"]["sharding"].endswith("% 2 == rank")
+    assert d["gather"]["bytes_into_rank0_per_frame"] > 0

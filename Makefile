@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 CXX ?= g++
 LIB = splatapult_amd/lib/libmsplat.so
-SRC = splatapult_amd/csrc/msplat_device.hip splatapult_amd/host/gaussian_scene.cpp splatapult_amd/host/scene_config.cpp \
+SRC = splatapult_amd/csrc/msplat_device.hip splatapult_amd/csrc/msplat_group.hip splatapult_amd/host/gaussian_scene.cpp splatapult_amd/host/scene_config.cpp \
       splatapult_amd/host/point_scene.cpp
 HDR = splatapult_amd/csrc/msplat_kernels.hip.h splatapult_amd/host/gaussian_scene.hpp splatapult_amd/host/scene_config.hpp \
       splatapult_amd/host/point_scene.hpp include/msplat.h
@@ -11,7 +11,7 @@ all: $(LIB) examples
 
 $(LIB): $(SRC) $(HDR)
 	mkdir -p splatapult_amd/lib
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -Wno-unused-function -o $@ $(SRC)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -Wno-unused-function -o $@ $(SRC) -lpthread
 
 examples: build/example_render build/example_points
 

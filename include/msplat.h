@@ -171,6 +171,17 @@ int msplat_download_cloud(msplat_ctx* ctx, void* aos_out, uint64_t cap_bytes);
  * row_mod = 1 (default) = whole image.  The framebuffer handed to msplat_render is always the
  * full W x H image; only rows owned by the band are written. */
 int msplat_set_band(msplat_ctx* ctx, int32_t row_mod, int32_t row_rem);
+/* The general form (r3): the context owns blocks of `block` consecutive bin rows starting at first_row,
+ * first_row + stride, first_row + 2 stride, ... (stride >= block), at most row_count rows in total (0 = as many as the
+ * image has).  Contiguous band g of G over R rows (the north star's "tiles row-sharded"): (g R / G, (g+1) R / G - g R / G,
+ * that count, anything >= it); interleaved rows: (g, 0, 1, G); blocks of k rows dealt round-robin: (g k, 0, k, G k).
+ * msplat_band_plan computes these.  Pixels are bit-identical to the unbanded frame for every layout. */
+int msplat_set_band_layout(msplat_ctx* ctx, int32_t first_row, int32_t row_count, int32_t block, int32_t stride);
+enum { MSPLAT_BANDS_CONTIGUOUS = 0, MSPLAT_BANDS_INTERLEAVED = 1, MSPLAT_BANDS_BLOCK_INTERLEAVED = 2 };
+/* layout parameters of rank `rank` of `world` for `rows_full` = ceil(H / msplat_tile_size()) bin rows; block_rows is
+ * only read for MSPLAT_BANDS_BLOCK_INTERLEAVED.  Host arithmetic only (works without a GPU). */
+int msplat_band_plan(int32_t kind, int32_t rows_full, int32_t world, int32_t rank, int32_t block_rows, int32_t* first_row,
+                     int32_t* row_count, int32_t* block, int32_t* stride);
 /* Band-restricted cull: with a band set, msplat_sort additionally drops splats whose
  * footprint (conservative bound) cannot reach a row owned by this context, so sort / projection / binning
  * shrink with the number of ranks.  Pixels are unchanged, but msplat_sort_count and the sorted list then
@@ -244,6 +255,45 @@ int msplat_stream_wait(msplat_ctx* ctx, void* stream);
 /* the reverse join: the context's stream waits for `event` (a hipEvent_t the caller recorded, e.g. after
  * the consumer of a framebuffer that the next frame issued on this context will overwrite) */
 int msplat_wait_event(msplat_ctx* ctx, void* event);
+
+/* the hipStream_t the context launches on (the one given in msplat_config.stream, or the library's own) */
+void* msplat_get_stream(msplat_ctx* ctx);
+
+/* ---- several GPUs, one process (no reference counterpart: the reference is one single-threaded C++ process
+ * calling Sort / Render, src/app.cpp:1067-1068, and this keeps that shape) ------------------------------------------------
+ * One group = one context per listed device.  The cloud is replicated, the screen's bin rows are partitioned over the
+ * devices (msplat_group_set_layout; default MSPLAT_BANDS_CONTIGUOUS, the north star's "tiles row-sharded"), every device
+ * runs the whole pipeline on its rows, and the ONLY exchange is the row gather: with out_is_device != 0 `rgba` is memory of
+ * devices[0] and every other device's compositor stores its rows straight into it through the peer mapping (xGMI, one
+ * direct link per device, no staging, no RCCL); where no peer mapping exists the rows are staged locally and copied.
+ * Pixels are bit-identical to one context rendering the whole frame.  msplat_group_render returns once every device's work
+ * has been ISSUED; the stream of context 0 (msplat_get_stream(msplat_group_context(g, 0))) waits for the others, so
+ * synchronising it -- or msplat_group_synchronize -- means the frame is complete.  Calls on one group are serialised by
+ * the caller (like a context); devices beyond the first are driven by the library's own worker threads.
+ * devices may repeat an ordinal (several contexts on one GPU: tests).  cfg: as msplat_create (device is ignored; stream
+ * must be NULL when n > 1). */
+typedef struct msplat_group msplat_group;
+int msplat_group_create(msplat_group** out, const int32_t* devices, uint32_t n, const msplat_config* cfg);
+void msplat_group_destroy(msplat_group* g);
+const char* msplat_group_last_error(const msplat_group* g);     /* g may be NULL */
+uint32_t msplat_group_size(const msplat_group* g);
+msplat_ctx* msplat_group_context(msplat_group* g, uint32_t i);  /* borrowed: stats, timings, parity taps of rank i */
+int msplat_group_peer_store(const msplat_group* g, uint32_t i); /* 1: rank i writes device 0's framebuffer directly */
+/* replicated uploads (msplat_upload_cloud / msplat_upload_gaussian_cloud / msplat_upload_ply on every device) */
+int msplat_group_upload_cloud(msplat_group* g, const void* aos, uint64_t n, uint32_t stride_bytes,
+                              const msplat_attr_offsets* off, int full_sh);
+int msplat_group_upload_gaussian_cloud(msplat_group* g, const msplat_cloud* c);
+int msplat_group_upload_ply(msplat_group* g, const char* path, int import_full_sh);
+/* MSPLAT_BANDS_*; block_rows only for MSPLAT_BANDS_BLOCK_INTERLEAVED */
+int msplat_group_set_layout(msplat_group* g, int32_t kind, int32_t block_rows);
+/* msplat_set_band_cull on every context: mono rendering only (every Render uses its Sort's camera) */
+int msplat_group_set_band_cull(msplat_group* g, int enable);
+/* SplatRenderer::Sort / Render over the group: same arguments as msplat_sort / msplat_render */
+int msplat_group_sort(msplat_group* g, const float cameraMat[16], const float projMat[16], const float viewport[4],
+                      const float nearFar[2]);
+int msplat_group_render(msplat_group* g, const float cameraMat[16], const float projMat[16], const float viewport[4],
+                        const float nearFar[2], void* rgba, uint64_t pitch_bytes, int out_is_device);
+int msplat_group_synchronize(msplat_group* g);
 
 /* sortCount of the last Sort (splatrenderer.cpp:198-199); synchronises */
 int msplat_sort_count(msplat_ctx* ctx, uint32_t* v);

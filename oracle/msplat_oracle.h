@@ -135,6 +135,17 @@ uint32_t orc_render_frame(size_t n, const float* aos, size_t stride_floats, int 
                           float* rgba, uint32_t* sorted_idx_out, uint32_t* sorted_keys_out,
                           orc_splat2d* splats_out, int nthreads);
 
+/* The TIMED CPU baseline (msplat_cpu_tiled.c): the same frame with parallel cull / stable radix
+ * sort / projection, 16x16-tile binning and a front-to-back compositor that stops a pixel at T < t_eps, on
+ * `nthreads` host threads.  stage_ms (may be NULL) receives {cull, sort, project, bin, composite, total} in ms.
+ * Rows [row0, row1) are produced.  Returns V (0xFFFFFFFF: out of memory). */
+uint32_t orc_render_frame_tiled(size_t n, const float* aos, size_t stride_floats, int full_sh, int srgb,
+                                const float sortCameraMat[16], const float sortProjMat[16],
+                                const float renderCameraMat[16], const float renderProjMat[16],
+                                const float viewport[4], const float nearFar[2], float* rgba,
+                                uint32_t* sorted_idx_out, uint32_t* sorted_keys_out, float t_eps, int nthreads,
+                                int row0, int row1, double* stage_ms);
+
 /* pixel-splat evaluations performed by the last orc_composite call (for baselines) */
 uint64_t orc_last_fragment_count(void);
 

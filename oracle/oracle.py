@@ -75,6 +75,9 @@ def lib():
                                    fp, u32p, u32p, C.c_void_p, C.c_int]
     L.orc_render_frame.restype = C.c_uint32
     L.orc_last_fragment_count.restype = C.c_uint64
+    L.orc_render_frame_tiled.argtypes = [C.c_size_t, fp, C.c_size_t, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, fp, u32p, u32p,
+                                         C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.orc_render_frame_tiled.restype = C.c_uint32
     _LIB = L
     return L
 
@@ -261,6 +264,33 @@ def render_frame(aos, full_sh, sort_cam, sort_proj, viewport, nearFar, render_ca
     return dict(V=v, image=img, sorted_idx=sidx[:v].copy(), sorted_keys=skeys[:v].copy(),
                 splats=splats[:v] if want_splats else None,
                 fragments=int(lib().orc_last_fragment_count()) if want_image else 0)
+
+
+def render_frame_tiled(aos, full_sh, sort_cam, sort_proj, viewport, nearFar, render_cam=None, render_proj=None,
+                       srgb=False, nthreads=1, t_eps=2.0 ** -14, row0=0, row1=None, image=None):
+    """The timed CPU baseline (msplat_cpu_tiled.c): tile-binned, front-to-back, multi-threaded Sort()+Render().
+    Returns dict(V, image, sorted_idx, sorted_keys, stages_ms).  `image` may be a preallocated (H, W, 4) float32 array."""
+    aos, pa = _f(aos)
+    n, stride = aos.shape
+    if render_cam is None:
+        render_cam = sort_cam
+    if render_proj is None:
+        render_proj = sort_proj
+    sc, p_sc = _f(sort_cam); sp, p_sp = _f(sort_proj); rc, p_rc = _f(render_cam); rp, p_rp = _f(render_proj)
+    vp, p_vp = _f(viewport); nf, p_nf = _f(nearFar)
+    W, H = int(viewport[2]), int(viewport[3])
+    img = np.zeros((H, W, 4), np.float32) if image is None else image
+    assert img.dtype == np.float32 and img.shape == (H, W, 4) and img.flags.c_contiguous
+    sidx = np.empty(max(n, 1), np.uint32)
+    skeys = np.empty(max(n, 1), np.uint32)
+    st = (C.c_double * 6)()
+    v = lib().orc_render_frame_tiled(n, pa, stride, int(bool(full_sh)), int(bool(srgb)), p_sc, p_sp, p_rc, p_rp, p_vp, p_nf,
+                                     img.ctypes.data_as(C.POINTER(C.c_float)), _u(sidx), _u(skeys), float(t_eps),
+                                     int(nthreads), int(row0), int(H if row1 is None else row1), st)
+    if v == 0xFFFFFFFF:
+        raise MemoryError("orc_render_frame_tiled: out of memory")
+    return dict(V=v, image=img, sorted_idx=sidx[:v].copy(), sorted_keys=skeys[:v].copy(),
+                stages_ms=dict(zip(("cull", "sort", "project", "bin", "composite", "total"), list(st))))
 
 
 # ---- reference PLY parser (oracle/_ref, built from /root/reference sources) ------------------

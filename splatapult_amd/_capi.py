@@ -13,6 +13,8 @@ ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NO_CLOUD, ERR_NO_SORT, ERR_UNSUPPOR
 FB_RGBA32F, FB_RGBA16F = 0, 1
 ROP_NONE, ROP_RGBA8, ROP_RGBA16F = 0, 1, 2
 RANK_AUTO, RANK_BALLOT = 0, 1
+BANDS_CONTIGUOUS, BANDS_INTERLEAVED, BANDS_BLOCK_INTERLEAVED = 0, 1, 2
+BAND_KINDS = {"contiguous": BANDS_CONTIGUOUS, "interleaved": BANDS_INTERLEAVED, "block": BANDS_BLOCK_INTERLEAVED}
 
 
 class MsplatError(RuntimeError):
@@ -73,6 +75,23 @@ SYMBOLS = [
     ("msplat_download_cloud", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     ("msplat_set_band", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     ("msplat_set_band_cull", C.c_int, [C.c_void_p, C.c_int]),
+    ("msplat_set_band_layout", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    ("msplat_band_plan", C.c_int, [C.c_int32] * 5 + [C.POINTER(C.c_int32)] * 4),
+    ("msplat_get_stream", C.c_void_p, [C.c_void_p]),
+    ("msplat_group_create", C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(Config)]),
+    ("msplat_group_destroy", None, [C.c_void_p]),
+    ("msplat_group_last_error", C.c_char_p, [C.c_void_p]),
+    ("msplat_group_size", C.c_uint32, [C.c_void_p]),
+    ("msplat_group_context", C.c_void_p, [C.c_void_p, C.c_uint32]),
+    ("msplat_group_peer_store", C.c_int, [C.c_void_p, C.c_uint32]),
+    ("msplat_group_upload_cloud", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(AttrOffsets), C.c_int]),
+    ("msplat_group_upload_gaussian_cloud", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("msplat_group_upload_ply", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    ("msplat_group_set_layout", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    ("msplat_group_set_band_cull", C.c_int, [C.c_void_p, C.c_int]),
+    ("msplat_group_sort", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16]),
+    ("msplat_group_render", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16, C.c_void_p, C.c_uint64, C.c_int]),
+    ("msplat_group_synchronize", C.c_int, [C.c_void_p]),
     ("msplat_sort", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16]),
     ("msplat_render", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16, C.c_void_p, C.c_uint64, C.c_int]),
     ("msplat_synchronize", C.c_int, [C.c_void_p]),
@@ -154,3 +173,25 @@ def check(ctx, rc):
     if rc != OK:
         msg = lib().msplat_last_error(ctx)
         raise MsplatError(rc, msg.decode() if msg else "")
+
+
+def band_plan(kind, rows_full, world, rank, block_rows=1):
+    """(first_row, row_count, block, stride) of rank `rank` of `world` over rows_full bin rows; kind = "contiguous" |
+    "interleaved" | "block" (blocks of block_rows rows dealt round-robin).  Host arithmetic (msplat_band_plan)."""
+    out = [C.c_int32() for _ in range(4)]
+    rc = lib().msplat_band_plan(BAND_KINDS[kind] if isinstance(kind, str) else int(kind), rows_full, world, rank, block_rows,
+                                *[C.byref(o) for o in out])
+    check(None, rc)
+    return tuple(o.value for o in out)
+
+
+def band_rows(first, count, block, stride, rows_full=None):
+    """the bin rows a layout owns, ascending (what msplat_set_band_layout's parameters mean)"""
+    rows, v = [], 0
+    while True:
+        t = first + (v // block) * stride + (v % block)
+        if (count and v >= count) or (rows_full is not None and t >= rows_full) or (not count and rows_full is None):
+            break
+        rows.append(t)
+        v += 1
+    return rows

@@ -75,6 +75,16 @@ struct msplat_ctx {
     Buf gsumS[2];   // sort passes alternate between the two
     Buf gsumB1, gsumB2;     // binning: column pass / row pass
     uint32_t gsumS_rows = 0, gsumB1_rows = 0, gsumB2_rows = 0;
+    // wide-digit 3-pass sort (r3, msplat_kernels.hip.h ws_*): histogram rows of up to 2048 digits per chunk, one group
+    // table per pass, one visibility bit per splat, the visible set's minimum key per frame parity (counters[10..11])
+    Buf wsHist, wsGsum[3], vmask;
+    uint32_t ws_items = 8, ws_gshift = 4, ws_gsum_words = 0;
+    bool wide_sort = true;      // MSPLAT_SORT=lsd8 (or no lane-ordered LDS atomics): the four 8-bit passes
+    uint32_t sort_parity = 0;
+    bool tables_dirty = false;  // a launch failed: clear every self-cleaning table before the next frame
+    // per-bin pair counts taken by the row pass's upsweep (r3): list offsets + work order without tile_start_kernel
+    Buf bincnt;
+    bool bin_counts = true;     // MSPLAT_TILE_TABLE=search: tile_start_kernel / tile_order_kernel as in r2
     bool scan_free = true;  // MSPLAT_SCAN_KERNELS=1 forces the 3-kernel (upsweep, scan, downsweep) passes
     uint32_t fused_max_chunks = kFusedMaxChunks;   // MSPLAT_FUSED_MAX_CHUNKS: scan-free passes up to this many chunk rows
     // compositor formulation: 0 = one wave per 16x16 tile, 1 = one wave per 16x8 half tile (default), 2 = four waves per
@@ -115,7 +125,10 @@ struct msplat_ctx {
     uint32_t* h_flags = nullptr;   // host view   [0] = pairs needed by an overflowed device-output render
     uint32_t* d_flags = nullptr;   // device view of the same words
     // band
-    int row_mod = 1, row_rem = 0;
+    // owned bin rows: blocks of band_block rows starting at band_first, band_first + band_stride, ..., at most band_count
+    // rows (0 = as many as the image has); banded == false: the whole image (msplat_set_band_layout)
+    bool banded = false;
+    int band_first = 0, band_block = 1, band_stride = 1, band_count = 0;
     bool band_cull = false;
     // last frame
     FrameParams last_fp{};
@@ -272,7 +285,9 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->counters, 16 * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->totals1, 256 * sizeof(uint32_t));
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->queue, kQueueShards * kQueueStride * sizeof(uint32_t));
-    if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_start, 65537 * sizeof(uint32_t));
+    if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_start, (65536 + 1024 + 16) * sizeof(uint32_t));
+    if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->bincnt, (65536 + 1024 + 16) * sizeof(uint32_t));
+    if (rc == MSPLAT_OK && hipMemsetAsync(ctx->bincnt.p, 0, ctx->bincnt.bytes, ctx->stream) != hipSuccess) rc = MSPLAT_ERR_HIP;
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_order, 2 * 65536 * sizeof(uint32_t));
 
     if (c.compositor_waves > 0) { ctx->comp_waves = std::max(64, (int)c.compositor_waves); ctx->comp_waves_auto = false; }
@@ -290,6 +305,8 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
     }
     if (rc == MSPLAT_OK && hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(uint32_t), ctx->stream) != hipSuccess)
         rc = MSPLAT_ERR_HIP;
+    if (rc == MSPLAT_OK && hipMemsetAsync((uint32_t*)ctx->counters.p + 10, 0xFF, 2 * sizeof(uint32_t), ctx->stream) != hipSuccess)
+        rc = MSPLAT_ERR_HIP;      // minimum key of the visible set, one word per frame parity
     if (rc == MSPLAT_OK) {
         // feature probe: stable ranks straight from LDS atomics need lane-ordered ds_add_rtn
         uint32_t* bad = (uint32_t*)ctx->counters.p + 8;
@@ -301,6 +318,21 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
             rc = fail(ctx, MSPLAT_ERR_HIP, "LDS atomic order probe failed to run");
         ctx->atomic_rank = (hbad == 0) && c.rank_mode != MSPLAT_RANK_BALLOT && getenv("MSPLAT_BALLOT_RANK") == nullptr;
         ctx->scan_free = getenv("MSPLAT_SCAN_KERNELS") == nullptr;
+        if (const char* sk = getenv("MSPLAT_SORT")) ctx->wide_sort = std::string(sk) != "lsd8";
+        if (!ctx->atomic_rank) ctx->wide_sort = false;       // the wide kernels rank with lane-ordered LDS atomics only
+        if (const char* tk = getenv("MSPLAT_TILE_TABLE")) ctx->bin_counts = std::string(tk) != "search";
+        if (ctx->wide_sort) {
+            // ws_downsweep needs 72 / 104 KB of dynamic LDS: above the 64 KB a kernel gets without asking
+            static const bool lds_ok = [] {
+                bool ok = true;
+                ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&ws_downsweep<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_downsweep_lds(8)) == hipSuccess;
+                ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&ws_downsweep<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_downsweep_lds(8)) == hipSuccess;
+                ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&ws_downsweep<true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_downsweep_lds(16)) == hipSuccess;
+                ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&ws_downsweep<false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_downsweep_lds(16)) == hipSuccess;
+                return ok;
+            }();
+            if (!lds_ok) { (void)hipGetLastError(); ctx->wide_sort = false; }
+        }
         if (getenv("MSPLAT_FUSED_MAX_CHUNKS")) ctx->fused_max_chunks = (uint32_t)atoi(getenv("MSPLAT_FUSED_MAX_CHUNKS"));
         if (const char* ck = getenv("MSPLAT_COMPOSITOR")) {
             const std::string k = ck;
@@ -333,7 +365,8 @@ void msplat_destroy(msplat_ctx* ctx)
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     Buf* all[] = {&ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist, &ctx->gsumS[0], &ctx->gsumS[1], &ctx->gsumB1, &ctx->gsumB2,
                   &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->totals1, &ctx->tile_start, &ctx->tile_order,
-                  &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe, &ctx->zq, &ctx->sprite, &ctx->queue};
+                  &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe, &ctx->zq, &ctx->sprite, &ctx->queue,
+                  &ctx->wsHist, &ctx->wsGsum[0], &ctx->wsGsum[1], &ctx->wsGsum[2], &ctx->vmask, &ctx->bincnt};
     for (Buf* b : all) buf_free(ctx, *b);
     if (ctx->ev_ok)
         for (auto& set : ctx->ev)
@@ -449,6 +482,8 @@ int msplat_attach_cloud(msplat_ctx* ctx, msplat_ctx* owner)
     return MSPLAT_OK;
 }
 
+void* msplat_get_stream(msplat_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
 // Makes `stream` (a hipStream_t, NULL = the legacy default stream) wait for everything enqueued so far on
 // the context's stream, without blocking the host.
 int msplat_stream_wait(msplat_ctx* ctx, void* stream)
@@ -552,6 +587,22 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
     if ((rc = alloc_group_table(ctx, ctx->gsumS[0], rows_s0, ctx->hist_stride))) return rc;
     if ((rc = alloc_group_table(ctx, ctx->gsumS[1], ctx->gsumS_rows, ctx->hist_stride))) return rc;
     ctx->gsumS_rows = std::min(ctx->gsumS_rows, rows_s0);
+    if (ctx->wide_sort) {
+        // 4096-key chunks up to 2 M splats, 8192 beyond (MSPLAT_WS_ITEMS = 8 | 16 overrides); groups of 16 chunk rows while
+        // there are at most 512 rows, else of 32 (a downsweep sums <= nchunks / G + G - 1 rows)
+        ctx->ws_items = n > (2u << 20) ? 16u : 8u;
+        if (const char* wi = getenv("MSPLAT_WS_ITEMS")) ctx->ws_items = atoi(wi) == 16 ? 16u : 8u;
+        const uint32_t nch = std::max(1u, div_up(n, (uint64_t)kWsThreads * ctx->ws_items));
+        ctx->ws_gshift = nch <= 512u ? 4u : 5u;
+        if ((rc = buf_alloc(ctx, ctx->wsHist, (size_t)nch * kWsMaxBins * 4))) return rc;
+        const size_t gwords = (size_t)((nch >> ctx->ws_gshift) + 2) * kWsMaxBins;
+        for (auto& g : ctx->wsGsum) {
+            if ((rc = buf_alloc(ctx, g, gwords * 4))) return rc;
+            HIP_TRY(ctx, hipMemsetAsync(g.p, 0, g.bytes, ctx->stream));
+        }
+        ctx->ws_gsum_words = (uint32_t)gwords;
+        if ((rc = buf_alloc(ctx, ctx->vmask, (size_t)div_up(alloc_n, 64) * 8 + 64))) return rc;
+    }
     if ((rc = buf_alloc(ctx, ctx->rec2d, alloc_n * 48))) return rc;
     if ((rc = buf_alloc(ctx, ctx->rect, alloc_n * 4))) return rc;
     if (ctx->depth_bits != 0 && (rc = buf_alloc(ctx, ctx->zq, alloc_n * 4))) return rc;
@@ -827,13 +878,62 @@ int msplat_set_band_cull(msplat_ctx* ctx, int enable)
     return MSPLAT_OK;
 }
 
+int msplat_set_band_layout(msplat_ctx* ctx, int32_t first_row, int32_t row_count, int32_t block, int32_t stride)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if (first_row < 0 || row_count < 0 || block < 1 || stride < block)
+        return fail(ctx, MSPLAT_ERR_INVALID_ARG,
+                    "msplat_set_band_layout: need first_row >= 0, row_count >= 0, block >= 1 and stride >= block (got %d, %d, %d, %d)",
+                    first_row, row_count, block, stride);
+    ctx->banded = true;
+    ctx->band_first = first_row;
+    ctx->band_count = row_count;
+    ctx->band_block = block;
+    ctx->band_stride = stride;
+    return MSPLAT_OK;
+}
+
 int msplat_set_band(msplat_ctx* ctx, int32_t row_mod, int32_t row_rem)
 {
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if (row_mod < 1 || row_rem < 0 || row_rem >= row_mod)
         return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_set_band: need row_mod >= 1 and 0 <= row_rem < row_mod");
-    ctx->row_mod = row_mod;
-    ctx->row_rem = row_rem;
+    if (row_mod == 1) {          // the whole image
+        ctx->banded = false;
+        ctx->band_first = 0; ctx->band_count = 0; ctx->band_block = 1; ctx->band_stride = 1;
+        return MSPLAT_OK;
+    }
+    return msplat_set_band_layout(ctx, row_rem, 0, 1, row_mod);       // rows t with t % row_mod == row_rem
+}
+
+// The standard partitions of `rows_full` bin rows over `world` ranks: pure arithmetic, no context needed.
+int msplat_band_plan(int32_t kind, int32_t rows_full, int32_t world, int32_t rank, int32_t block_rows, int32_t* first_row,
+                     int32_t* row_count, int32_t* block, int32_t* stride)
+{
+    if (!first_row || !row_count || !block || !stride) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_plan: NULL output");
+    if (rows_full < 0 || world < 1 || rank < 0 || rank >= world)
+        return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_plan: need rows_full >= 0, world >= 1, 0 <= rank < world");
+    auto owned_below = [](int R, int first, int blk, int str) {      // owned rows t < R
+        if (R <= first) return 0;
+        const int d = R - first, k = d / str, j = d - k * str;
+        return k * blk + std::min(j, blk);
+    };
+    if (kind == MSPLAT_BANDS_CONTIGUOUS) {
+        const int a = (int)(((int64_t)rows_full * rank) / world), b = (int)(((int64_t)rows_full * (rank + 1)) / world);
+        // (row_count == 0 means "no limit" to msplat_set_band_layout: an empty band starts past the last row instead)
+        *first_row = b > a ? a : rows_full; *row_count = b - a; *block = std::max(1, b - a);
+        *stride = std::max(1, std::max(rows_full, b - a));
+        return MSPLAT_OK;
+    }
+    int k = 1;
+    if (kind == MSPLAT_BANDS_BLOCK_INTERLEAVED) {
+        if (block_rows < 1) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_plan: block_rows must be >= 1");
+        k = block_rows;
+    } else if (kind != MSPLAT_BANDS_INTERLEAVED) {
+        return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_plan: unknown kind %d", kind);
+    }
+    *first_row = rank * k; *block = k; *stride = world * k;
+    *row_count = owned_below(rows_full, rank * k, k, world * k);
     return MSPLAT_OK;
 }
 
@@ -860,14 +960,24 @@ static int make_frame_params(msplat_ctx* ctx, const float cameraMat[16], const f
                     fp.width, fp.height);
     fp.tiles_x = (fp.width + kBin - 1) / kBin;
     const int rows_full = (fp.height + kBin - 1) / kBin;
-    fp.row_mod = ctx->row_mod;
-    fp.row_rem = ctx->row_rem;
-    // owned rows: vy*mod + rem < rows_full
-    fp.tiles_y = (rows_full > ctx->row_rem) ? (rows_full - ctx->row_rem + ctx->row_mod - 1) / ctx->row_mod : 0;
+    fp.banded = ctx->banded ? 1 : 0;
+    fp.band_first = ctx->band_first;
+    fp.band_block = ctx->band_block;
+    fp.band_stride = ctx->band_stride;
+    fp.tiles_y = rows_full;
+    if (ctx->banded) {           // owned rows below rows_full, at most band_count of them
+        int owned = 0;
+        if (rows_full > ctx->band_first) {
+            const int d = rows_full - ctx->band_first, k = d / ctx->band_stride, j = d - k * ctx->band_stride;
+            owned = k * ctx->band_block + std::min(j, ctx->band_block);
+        }
+        if (ctx->band_count > 0) owned = std::min(owned, ctx->band_count);
+        fp.tiles_y = owned;
+    }
     fp.full_sh = ctx->full_sh ? 1 : 0;
     fp.srgb = ctx->cfg.srgb ? 1 : 0;
     fp.t_eps = ctx->cfg.t_epsilon;
-    fp.band_cull = (ctx->band_cull && ctx->row_mod > 1 && !ctx->point_mode) ? 1 : 0;   // points carry no footprint bound
+    fp.band_cull = (ctx->band_cull && ctx->banded && !ctx->point_mode) ? 1 : 0;   // points carry no footprint bound
     fp.depth_bits = ctx->depth_bits;
     fp.rop = ctx->rop;
     fp.view_scale2 = 0.0f;
@@ -889,6 +999,23 @@ static void launch_scan(hipStream_t s, bool small, uint32_t* hist, uint32_t hist
     else
         hipLaunchKernelGGL(radix_scan, dim3(256), dim3(kThreads), 0, s, hist, hist_stride, d_n, n_static, n_cap, chunk,
                            totals);
+}
+
+// The scan-free passes keep their tables clean for the NEXT frame from inside the frame (every group table is zeroed by a
+// later kernel of the same frame, the bin counts by their consumer, the minimum-key words by the other parity's pass 0), so
+// a frame whose launches did not all go out leaves them in an unknown state: after any launch error the context is marked
+// dirty and the next msplat_sort restores every table with memsets before it issues its kernels.
+static int clear_frame_tables(msplat_ctx* ctx)
+{
+    hipStream_t s = ctx->stream;
+    Buf* zero[] = {&ctx->gsumS[0], &ctx->gsumS[1], &ctx->gsumB1, &ctx->gsumB2, &ctx->wsGsum[0], &ctx->wsGsum[1], &ctx->wsGsum[2],
+                   &ctx->bincnt};
+    for (Buf* b : zero)
+        if (b->p) HIP_TRY(ctx, hipMemsetAsync(b->p, 0, b->bytes, s));
+    HIP_TRY(ctx, hipMemsetAsync((uint32_t*)ctx->counters.p + 10, 0xFF, 2 * sizeof(uint32_t), s));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->queue.p, 0, ctx->queue.bytes, s));
+    ctx->tables_dirty = false;
+    return MSPLAT_OK;
 }
 
 int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[16],
@@ -917,9 +1044,60 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
     const uint32_t chunk = (uint32_t)kThreads * (large ? kSortItemsLarge : kSortItems);
     const int grid = grid_for(div_up(N, chunk));
 
+    if (ctx->tables_dirty) {
+        rc = clear_frame_tables(ctx);
+        if (rc) return rc;
+    }
     const bool timed = ctx->ev_ok && (ctx->sort_calls++ % ctx->timing_stride) == 0;
     const int tset = (int)(ctx->sort_sets % msplat_ctx::kEvSets);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][0], s));
+    if (ctx->wide_sort) {
+        // three passes of 10 + (8..11) + (8..11) key bits (msplat_kernels.hip.h, ws_*): 6 launches.
+        // pass 0: positions -> raw keys + visibility bits in keyB / vmask -> (keyA, valA); pass 1: A -> B; pass 2: B -> A
+        uint32_t* mk_cur = counters + 10 + (ctx->sort_parity & 1u);
+        uint32_t* mk_next = counters + 10 + ((ctx->sort_parity ^ 1u) & 1u);
+        ctx->sort_parity ^= 1u;
+        uint32_t* whist = (uint32_t*)ctx->wsHist.p;
+        unsigned long long* vm = (unsigned long long*)ctx->vmask.p;
+        const int gsh = (int)ctx->ws_gshift;
+        const uint32_t gw = ctx->ws_gsum_words;
+        auto gt = [&](int pass) { return (uint32_t*)ctx->wsGsum[(pass + 3) % 3].p; };
+        const uint32_t wchunk = (uint32_t)kWsThreads * ctx->ws_items;
+        const int wgrid = grid_for(div_up(N, wchunk));
+        const uint32_t* dV = d_V;
+#define MSPLAT_WS(KERNEL, CULLF, LDS, ...)                                                                              \
+    do {                                                                                                                \
+        if (ctx->ws_items == 16) hipLaunchKernelGGL((KERNEL<CULLF, 16>), dim3(wgrid), dim3(kWsThreads), LDS(16), s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<CULLF, 8>), dim3(wgrid), dim3(kWsThreads), LDS(8), s, __VA_ARGS__);                       \
+    } while (0)
+#define MSPLAT_NO_LDS(I) 0
+        MSPLAT_WS(ws_upsweep, true, MSPLAT_NO_LDS, (const uint32_t*)nullptr, pos, kB, vm, (const uint32_t*)nullptr, N, N, 0, mk_cur,
+                  mk_next, whist, gt(0), gsh, gt(-1), gw, fp);
+        MSPLAT_WS(ws_downsweep, true, ws_downsweep_lds, (const uint32_t*)kB, (const uint32_t*)nullptr, (const unsigned long long*)vm,
+                  (const uint32_t*)nullptr, N, N, 0, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(0), gsh, kA, vA,
+                  d_V);
+        MSPLAT_WS(ws_upsweep, false, MSPLAT_NO_LDS, (const uint32_t*)kA, (const float4*)nullptr, (uint32_t*)nullptr,
+                  (unsigned long long*)nullptr, dV, 0u, N, 1, mk_cur, mk_next, whist, gt(1), gsh, gt(0), gw, fp);
+        MSPLAT_WS(ws_downsweep, false, ws_downsweep_lds, (const uint32_t*)kA, (const uint32_t*)vA, (const unsigned long long*)nullptr, dV,
+                  0u, N, 1, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(1), gsh, kB, vB, (uint32_t*)nullptr);
+        MSPLAT_WS(ws_upsweep, false, MSPLAT_NO_LDS, (const uint32_t*)kB, (const float4*)nullptr, (uint32_t*)nullptr,
+                  (unsigned long long*)nullptr, dV, 0u, N, 2, mk_cur, mk_next, whist, gt(2), gsh, gt(1), gw, fp);
+        MSPLAT_WS(ws_downsweep, false, ws_downsweep_lds, (const uint32_t*)kB, (const uint32_t*)vB, (const unsigned long long*)nullptr, dV,
+                  0u, N, 2, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(2), gsh, kA, vA, (uint32_t*)nullptr);
+#undef MSPLAT_NO_LDS
+#undef MSPLAT_WS
+        if (timed) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][1], s));
+            ctx->sort_sets++;
+        }
+        if (hipGetLastError() != hipSuccess) {
+            ctx->tables_dirty = true;
+            return fail(ctx, MSPLAT_ERR_HIP, "msplat_sort: a kernel launch failed");
+        }
+        ctx->has_sort = true;
+        if (pending) return fail(ctx, pending, "%s", pending_msg.c_str());
+        return MSPLAT_OK;
+    }
     // scan-free passes (2 launches each) while the chunk table is small, else upsweep + scan + downsweep
     const bool fused = ctx->scan_free && div_up(N, chunk) <= ctx->fused_max_chunks;
     auto gacc = [&](int pass) { return fused ? (uint32_t*)ctx->gsumS[pass & 1].p : nullptr; };
@@ -965,7 +1143,10 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
         HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][1], s));
         ctx->sort_sets++;
     }
-    HIP_TRY(ctx, hipGetLastError());
+    if (hipGetLastError() != hipSuccess) {
+        ctx->tables_dirty = true;
+        return fail(ctx, MSPLAT_ERR_HIP, "msplat_sort: a kernel launch failed");
+    }
     ctx->has_sort = true;
     if (pending) return fail(ctx, pending, "%s", pending_msg.c_str());
     return MSPLAT_OK;
@@ -1012,8 +1193,9 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const bool fused2 = ctx->scan_free && last_D != 0u && div_up((uint64_t)last_D + (last_D >> 2), kPairChunk) <= ctx->fused_max_chunks;
     uint32_t* gB1 = (uint32_t*)ctx->gsumB1.p;
     uint32_t* gB2 = (uint32_t*)ctx->gsumB2.p;
+    // (bin1_upsweep also clears the row pass's group table: its consumer, the previous frame's row downsweep, is long done)
     hipLaunchKernelGGL(bin1_upsweep, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
-                       (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_overflow, fused1 ? gB1 : nullptr, (uint32_t*)nullptr, 0u);
+                       (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_overflow, fused1 ? gB1 : nullptr, gB2, ctx->gsumB2_rows);
     if (!fused1)
         launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V, 0u, N, (uint32_t)kBinChunk, totals1);
     if (ctx->atomic_rank)
@@ -1027,38 +1209,46 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                            (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags, async_overflow_flag ? 1 : 0,
                            fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr);
     // pass 2: stable partition by tile row (one generic radix pass on the top byte); words become (tx<<24)|rank
-    const int g2 = grid_for(div_up(cap, kPairChunk));
-    hipLaunchKernelGGL(radix_upsweep<MODE_PAIR>, dim3(g2), dim3(kThreads), 0, s, (const uint32_t*)ctx->pairsA.p,
-                       nullptr, d_D, 0u, cap, 24, (uint32_t*)ctx->hist2.p, ctx->hist2_stride, fused2 ? gB2 : nullptr, gB1,
-                       ctx->gsumB1_rows, fp);
-    if (!fused2)
-        launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist2.p, ctx->hist2_stride, d_D, 0u, cap, (uint32_t)kPairChunk, totals2);
-    if (ctx->atomic_rank)
-        hipLaunchKernelGGL((radix_downsweep<MODE_PAIR, false, true>), dim3(g2), dim3(kThreads), 0, s,
-                           (const uint32_t*)ctx->pairsA.p, nullptr, nullptr, d_D, 0u, cap, 24,
-                           (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
-                           (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1,
-                           fused2 ? (const uint32_t*)gB2 : nullptr, fused2 ? totals2 : nullptr, fp);
-    else
-        hipLaunchKernelGGL((radix_downsweep<MODE_PAIR, false, false>), dim3(g2), dim3(kThreads), 0, s,
-                           (const uint32_t*)ctx->pairsA.p, nullptr, nullptr, d_D, 0u, cap, 24,
-                           (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
-                           (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1,
-                           fused2 ? (const uint32_t*)gB2 : nullptr, fused2 ? totals2 : nullptr, fp);
     // The heaviest-first order of the bins only pays when every work item has its own wave (the hardware then starts the
     // waves in item order: 83 -> 97 us without it at config 2); persistent waves that pull items from the queue balance
-    // themselves, and the counting sort is one launch (4.5 us; 16 us at 16 k bins) for nothing: they walk the bins in
-    // storage order (`tile_order` + 65536 holds 0, 1, 2, ...).
+    // themselves: they walk the bins in storage order (`tile_order` + 65536 holds 0, 1, 2, ...).
     const bool wave_comp = !ctx->point_mode && ctx->depth_bits == 0 && ctx->rop == 0 && ctx->comp_kind != 2;
     const uint32_t comp_items = (uint32_t)ntiles * (ctx->comp_kind == 1 ? 8u : 4u);
     const uint32_t comp_pool = (ctx->comp_waves_auto && comp_items <= 20480u) ? comp_items : (uint32_t)ctx->comp_waves;
     const bool ordered = !(wave_comp && comp_pool < comp_items) || ctx->comp_always_order;
-    hipLaunchKernelGGL(tile_start_kernel, dim3(std::max(1, (ntiles + kTileStartBins - 1) / kTileStartBins)), dim3(kThreads), 0, s,
-                       (const uint32_t*)ctx->pairsB.p, (const uint32_t*)totals2, d_D, cap, fp.tiles_x, ntiles,
-                       (uint32_t*)ctx->tile_start.p, gB2, ctx->gsumB2_rows, ordered ? nullptr : d_queue);
-    if (ordered)
-        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)ctx->tile_start.p, ntiles,
-                           (uint32_t*)ctx->tile_order.p, d_queue);
+    // r3: the upsweep of the row pass also counts the pairs per bin, and one extra workgroup of its downsweep turns the
+    // counts into the list offsets (+ the heaviest-first order when it is wanted): tile_start_kernel / tile_order_kernel
+    // are not launched (MSPLAT_TILE_TABLE=search brings them back for comparison)
+    uint32_t* bincnt = ctx->bin_counts ? (uint32_t*)ctx->bincnt.p : nullptr;
+    const int g2 = grid_for(div_up(cap, kPairChunk));
+    hipLaunchKernelGGL(radix_upsweep<MODE_PAIR>, dim3(g2), dim3(kThreads), 0, s, (const uint32_t*)ctx->pairsA.p,
+                       nullptr, d_D, 0u, cap, 24, (uint32_t*)ctx->hist2.p, ctx->hist2_stride, fused2 ? gB2 : nullptr, gB1,
+                       ctx->gsumB1_rows, fp, (const uint32_t*)totals1, bincnt);
+    if (!fused2)
+        launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist2.p, ctx->hist2_stride, d_D, 0u, cap, (uint32_t)kPairChunk, totals2);
+    const int g2d = g2 + (bincnt ? 1 : 0);
+    if (ctx->atomic_rank)
+        hipLaunchKernelGGL((radix_downsweep<MODE_PAIR, false, true>), dim3(g2d), dim3(kThreads), 0, s,
+                           (const uint32_t*)ctx->pairsA.p, nullptr, nullptr, d_D, 0u, cap, 24,
+                           (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
+                           (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1,
+                           fused2 ? (const uint32_t*)gB2 : nullptr, fused2 ? totals2 : nullptr, fp, bincnt,
+                           (uint32_t*)ctx->tile_start.p, (uint32_t*)ctx->tile_order.p, d_queue, ntiles, ordered ? 1 : 0);
+    else
+        hipLaunchKernelGGL((radix_downsweep<MODE_PAIR, false, false>), dim3(g2d), dim3(kThreads), 0, s,
+                           (const uint32_t*)ctx->pairsA.p, nullptr, nullptr, d_D, 0u, cap, 24,
+                           (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
+                           (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1,
+                           fused2 ? (const uint32_t*)gB2 : nullptr, fused2 ? totals2 : nullptr, fp, bincnt,
+                           (uint32_t*)ctx->tile_start.p, (uint32_t*)ctx->tile_order.p, d_queue, ntiles, ordered ? 1 : 0);
+    if (!bincnt) {
+        hipLaunchKernelGGL(tile_start_kernel, dim3(std::max(1, (ntiles + kTileStartBins - 1) / kTileStartBins)), dim3(kThreads), 0, s,
+                           (const uint32_t*)ctx->pairsB.p, (const uint32_t*)totals2, d_D, cap, fp.tiles_x, ntiles,
+                           (uint32_t*)ctx->tile_start.p, gB2, ctx->gsumB2_rows, ordered ? nullptr : d_queue);
+        if (ordered)
+            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)ctx->tile_start.p, ntiles,
+                               (uint32_t*)ctx->tile_order.p, d_queue);
+    }
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][4], s));
 
     // persistent compositor: a fixed pool of waves pulls (bin, quadrant) items; never more waves than items
@@ -1140,7 +1330,10 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         if (ctx->comp_kernel_timed) ctx->comp_kernel_sets_mask |= 1u << tset; else ctx->comp_kernel_sets_mask &= ~(1u << tset);
         ctx->render_sets++;
     }
-    HIP_TRY(ctx, hipGetLastError());
+    if (hipGetLastError() != hipSuccess) {
+        ctx->tables_dirty = true;
+        return fail(ctx, MSPLAT_ERR_HIP, "msplat_render: a kernel launch failed");
+    }
     return MSPLAT_OK;
 }
 
@@ -1163,6 +1356,7 @@ int msplat_render(msplat_ctx* ctx, const float cameraMat[16], const float projMa
         return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_render: pitch %llu too small / misaligned for width %d",
                     (unsigned long long)pitch_bytes, fp.width);
     ctx->last_fp = fp;
+    if (ctx->tables_dirty && (rc = clear_frame_tables(ctx))) return rc;
     if (ctx->point_mode && !ctx->sprite.p && (rc = build_sprite(ctx, nullptr, 0, 0))) return rc;   // built-in sphere sprite
     std::string pending_msg;
     const int pending = poll_async_overflow(ctx, pending_msg);     // an EARLIER frame; this one is still rendered
@@ -1184,12 +1378,15 @@ int msplat_render(msplat_ctx* ctx, const float cameraMat[16], const float projMa
         HIP_TRY(ctx, hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (cnt[2] == 0) {
-            if (ctx->row_mod > 1) {
+            if (ctx->banded) {
                 // band mode: only the owned bin rows are written to the caller's buffer (as documented for
                 // msplat_set_band), so several bands can be assembled in one host image
-                for (int vy = 0; vy < fp.tiles_y; ++vy) {
-                    const int y0 = (vy * ctx->row_mod + ctx->row_rem) * kBin;
-                    const int rows = std::min(kBin, fp.height - y0);
+                for (int vy = 0; vy < fp.tiles_y;) {
+                    const int y0 = band_real_row(fp, vy) * kBin;
+                    int run = 1;                  // consecutive owned rows leave in one copy
+                    while (vy + run < fp.tiles_y && band_real_row(fp, vy + run) == band_real_row(fp, vy) + run) ++run;
+                    vy += run;
+                    const int rows = std::min(kBin * run, fp.height - y0);
                     if (rows <= 0) break;
                     HIP_TRY(ctx, hipMemcpy2D((char*)rgba + (size_t)y0 * pitch_bytes, pitch_bytes,
                                              (const char*)ctx->fb.p + (size_t)y0 * tight, tight, tight, rows,

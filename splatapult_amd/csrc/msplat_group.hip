@@ -1,0 +1,354 @@
+// msplat_group.hip -- single-process multi-GPU rendering behind the C ABI (include/msplat.h, msplat_group_*).
+//
+// The reference is ONE single-threaded C++ process that calls SplatRenderer::Sort / Render once per frame
+// (/root/reference/src/sdl_main.cpp:49-204, src/app.cpp:1067-1068).  A maintainer who wants the frame spread over the
+// GPUs of a node keeps that shape: one msplat_group = one context per device, the cloud replicated, the screen's bin rows
+// partitioned over the devices, msplat_group_sort / msplat_group_render with the arguments of
+// msplat_sort / msplat_render.  The only exchange step is the row gather, and it is zero-copy where the hardware allows:
+// device i's compositor stores its rows STRAIGHT into device 0's framebuffer through the peer mapping
+// (hipDeviceEnablePeerAccess: every band travels over its own direct xGMI link, 7 links into device 0 concurrently, no
+// ring), else its rows are staged locally and moved with one hipMemcpy2DAsync per run of consecutive rows.  No RCCL
+// communicator is needed inside one process; bench.py's one-process-per-GPU form (torch.distributed over RCCL) remains for
+// the driver's launcher.
+//
+// Host side: launching ~12 kernels on each of 8 devices from one thread costs more host time than the frame lasts on the
+// GPUs, so every device beyond the first has a worker thread that issues its context's calls; the caller's thread drives
+// device 0 and then waits for the workers to have ISSUED their work (the GPUs keep running asynchronously; device 0's
+// stream is made to wait for the others' streams, so "synchronise device 0's stream" = "the frame is complete").
+// Uses only the public C ABI of the single-device library plus HIP runtime calls.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/msplat.h"
+
+namespace {
+
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> task;
+    bool has_task = false, done = true, quit = false;
+    int rc = MSPLAT_OK;
+
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return has_task || quit; });
+            if (quit) return;
+            std::function<int()> t = std::move(task);
+            has_task = false;
+            lk.unlock();
+            const int r = t();
+            lk.lock();
+            rc = r;
+            done = true;
+            cv.notify_all();
+        }
+    }
+    void post(std::function<int()> t)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        task = std::move(t);
+        has_task = true;
+        done = false;
+        cv.notify_all();
+    }
+    int wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+        return rc;
+    }
+};
+
+}  // namespace
+
+struct msplat_group {
+    std::vector<int> devices;
+    std::vector<msplat_ctx*> ctx;
+    std::vector<std::unique_ptr<Worker>> workers;      // [i - 1] drives ctx[i]
+    std::vector<bool> peer_store;                      // ctx[i] may store into device 0's memory directly
+    std::vector<void*> stage;                          // per-rank staging framebuffer when it may not
+    std::vector<size_t> stage_bytes;
+    int fb_format = MSPLAT_FB_RGBA32F;
+    int kind = MSPLAT_BANDS_CONTIGUOUS, block_rows = 1;
+    bool band_cull = false;
+    int planned_rows = -1;                             // rows_full the contexts' layouts were set for
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_group_error;
+
+int gfail(msplat_group* g, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_group_error = buf;
+    if (g) g->err = buf;
+    return code;
+}
+
+// runs f(i) for every rank: ranks >= 1 on their worker threads, rank 0 on the caller's; returns the first real error
+// (MSPLAT_ERR_PAIR_OVERFLOW -- a deferred report about an EARLIER frame -- only if nothing worse happened)
+int for_all(msplat_group* g, const std::function<int(uint32_t)>& f)
+{
+    const uint32_t n = (uint32_t)g->ctx.size();
+    for (uint32_t i = 1; i < n; ++i) g->workers[i - 1]->post([&f, i] { return f(i); });
+    std::vector<int> rc(n, MSPLAT_OK);
+    rc[0] = f(0);
+    for (uint32_t i = 1; i < n; ++i) rc[i] = g->workers[i - 1]->wait();
+    int soft = MSPLAT_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (rc[i] == MSPLAT_OK) continue;
+        if (rc[i] == MSPLAT_ERR_PAIR_OVERFLOW) { if (!soft) { soft = rc[i]; g->err = msplat_last_error(g->ctx[i]); } continue; }
+        g->err = std::string("device ") + std::to_string(g->devices[i]) + ": " + msplat_last_error(g->ctx[i]);
+        g_group_error = g->err;
+        return rc[i];
+    }
+    if (soft) g_group_error = g->err;
+    return soft;
+}
+
+// (re)assigns the bin rows when the viewport's row count changes
+int plan_rows(msplat_group* g, const float viewport[4])
+{
+    if (!viewport) return gfail(g, MSPLAT_ERR_INVALID_ARG, "NULL viewport");
+    const int H = (int)viewport[3], T = msplat_tile_size();
+    if (H < 1) return gfail(g, MSPLAT_ERR_INVALID_ARG, "viewport height %d", H);
+    const int rows = (H + T - 1) / T;
+    const uint32_t n = (uint32_t)g->ctx.size();
+    if (rows == g->planned_rows) return MSPLAT_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        int rc;
+        if (n == 1) {
+            rc = msplat_set_band(g->ctx[i], 1, 0);
+        } else {
+            int32_t first, count, block, stride;
+            rc = msplat_band_plan(g->kind, rows, (int32_t)n, (int32_t)i, g->block_rows, &first, &count, &block, &stride);
+            if (rc) return gfail(g, rc, "%s", msplat_last_error(nullptr));
+            rc = msplat_set_band_layout(g->ctx[i], first, count, block, stride);
+            if (!rc) rc = msplat_set_band_cull(g->ctx[i], g->band_cull ? 1 : 0);
+        }
+        if (rc) return gfail(g, rc, "%s", msplat_last_error(g->ctx[i]));
+    }
+    g->planned_rows = rows;
+    return MSPLAT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* msplat_group_last_error(const msplat_group* g) { return g ? g->err.c_str() : g_group_error.c_str(); }
+
+int msplat_group_create(msplat_group** out, const int32_t* devices, uint32_t n, const msplat_config* cfg)
+{
+    if (!out) return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_group_create: out is NULL");
+    *out = nullptr;
+    if (!devices || n < 1 || n > 64) return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_group_create: need 1..64 devices");
+    if (cfg && cfg->stream && n > 1)
+        return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_group_create: a caller stream can only be used with one device");
+    msplat_config c{};
+    c.struct_size = sizeof(c);
+    c.t_epsilon = -1.0f;
+    if (cfg) {
+        if (cfg->struct_size > sizeof(c) || cfg->struct_size < 16)
+            return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_group_create: bad config struct_size %u", cfg->struct_size);
+        std::memcpy(&c, cfg, cfg->struct_size);
+        c.struct_size = sizeof(c);
+    }
+    msplat_group* g = new msplat_group;
+    g->fb_format = c.fb_format;
+    for (uint32_t i = 0; i < n; ++i) {
+        c.device = devices[i];
+        msplat_ctx* h = nullptr;
+        const int rc = msplat_create(&h, &c);
+        if (rc) {
+            gfail(nullptr, rc, "msplat_group_create: device %d: %s", devices[i], msplat_last_error(nullptr));
+            msplat_group_destroy(g);
+            return rc;
+        }
+        g->ctx.push_back(h);
+        g->devices.push_back(devices[i]);
+    }
+    g->peer_store.assign(n, true);
+    g->stage.assign(n, nullptr);
+    g->stage_bytes.assign(n, 0);
+    // peer mapping towards device 0: the other devices' compositors then write their rows into its framebuffer directly
+    for (uint32_t i = 1; i < n; ++i) {
+        if (devices[i] == devices[0]) continue;            // same device (tests): plain device memory
+        int can = 0;
+        bool ok = hipSetDevice(devices[i]) == hipSuccess && hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can;
+        if (ok) {
+            const hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+            ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+        }
+        (void)hipGetLastError();
+        g->peer_store[i] = ok;
+    }
+    if (getenv("MSPLAT_GROUP_EXCHANGE") && std::string(getenv("MSPLAT_GROUP_EXCHANGE")) == "copy")
+        for (uint32_t i = 1; i < n; ++i) g->peer_store[i] = false;       // force the staged form (comparison / debugging)
+    for (uint32_t i = 1; i < n; ++i) {
+        g->workers.emplace_back(new Worker);
+        Worker* w = g->workers.back().get();
+        w->th = std::thread([w] { w->run(); });
+    }
+    *out = g;
+    return MSPLAT_OK;
+}
+
+void msplat_group_destroy(msplat_group* g)
+{
+    if (!g) return;
+    for (auto& w : g->workers) {
+        { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; w->cv.notify_all(); }
+        if (w->th.joinable()) w->th.join();
+    }
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        if (g->ctx[i]) (void)msplat_synchronize(g->ctx[i]);
+        if (i < g->stage.size() && g->stage[i]) { (void)hipSetDevice(g->devices[i]); (void)hipFree(g->stage[i]); }
+        msplat_destroy(g->ctx[i]);
+    }
+    delete g;
+}
+
+uint32_t msplat_group_size(const msplat_group* g) { return g ? (uint32_t)g->ctx.size() : 0u; }
+
+msplat_ctx* msplat_group_context(msplat_group* g, uint32_t i) { return (g && i < g->ctx.size()) ? g->ctx[i] : nullptr; }
+
+int msplat_group_peer_store(const msplat_group* g, uint32_t i) { return (g && i < g->ctx.size() && g->peer_store[i]) ? 1 : 0; }
+
+int msplat_group_upload_cloud(msplat_group* g, const void* aos, uint64_t n, uint32_t stride_bytes, const msplat_attr_offsets* off,
+                              int full_sh)
+{
+    if (!g) return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "group is NULL");
+    return for_all(g, [&](uint32_t i) { return msplat_upload_cloud(g->ctx[i], aos, n, stride_bytes, off, full_sh); });
+}
+
+int msplat_group_upload_gaussian_cloud(msplat_group* g, const msplat_cloud* c)
+{
+    if (!g) return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "group is NULL");
+    return for_all(g, [&](uint32_t i) { return msplat_upload_gaussian_cloud(g->ctx[i], c); });
+}
+
+int msplat_group_upload_ply(msplat_group* g, const char* path, int import_full_sh)
+{
+    if (!g) return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "group is NULL");
+    return for_all(g, [&](uint32_t i) { return msplat_upload_ply(g->ctx[i], path, import_full_sh); });
+}
+
+int msplat_group_set_layout(msplat_group* g, int32_t kind, int32_t block_rows)
+{
+    if (!g) return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "group is NULL");
+    if (kind != MSPLAT_BANDS_CONTIGUOUS && kind != MSPLAT_BANDS_INTERLEAVED && kind != MSPLAT_BANDS_BLOCK_INTERLEAVED)
+        return gfail(g, MSPLAT_ERR_INVALID_ARG, "msplat_group_set_layout: unknown kind %d", kind);
+    if (kind == MSPLAT_BANDS_BLOCK_INTERLEAVED && block_rows < 1)
+        return gfail(g, MSPLAT_ERR_INVALID_ARG, "msplat_group_set_layout: block_rows must be >= 1");
+    g->kind = kind;
+    g->block_rows = std::max(1, block_rows);
+    g->planned_rows = -1;
+    return MSPLAT_OK;
+}
+
+int msplat_group_set_band_cull(msplat_group* g, int enable)
+{
+    if (!g) return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "group is NULL");
+    g->band_cull = enable != 0;
+    g->planned_rows = -1;
+    return MSPLAT_OK;
+}
+
+int msplat_group_sort(msplat_group* g, const float cameraMat[16], const float projMat[16], const float viewport[4],
+                      const float nearFar[2])
+{
+    if (!g) return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "group is NULL");
+    int rc = plan_rows(g, viewport);
+    if (rc) return rc;
+    return for_all(g, [&](uint32_t i) { return msplat_sort(g->ctx[i], cameraMat, projMat, viewport, nearFar); });
+}
+
+int msplat_group_render(msplat_group* g, const float cameraMat[16], const float projMat[16], const float viewport[4],
+                        const float nearFar[2], void* rgba, uint64_t pitch_bytes, int out_is_device)
+{
+    if (!g) return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "group is NULL");
+    if (!rgba) return gfail(g, MSPLAT_ERR_INVALID_ARG, "msplat_group_render: rgba is NULL");
+    int rc = plan_rows(g, viewport);
+    if (rc) return rc;
+    const uint32_t n = (uint32_t)g->ctx.size();
+    const int W = (int)viewport[2], H = (int)viewport[3], T = msplat_tile_size();
+    const size_t bpp = g->fb_format == MSPLAT_FB_RGBA16F ? 8 : 16;
+    const size_t tight = (size_t)W * bpp;
+    if (pitch_bytes == 0) pitch_bytes = tight;
+    if (!out_is_device)         // host image: every context copies its own rows into it (msplat_render's band rule)
+        return for_all(g, [&](uint32_t i) { return msplat_render(g->ctx[i], cameraMat, projMat, viewport, nearFar, rgba, pitch_bytes, 0); });
+
+    void* stream0 = msplat_get_stream(g->ctx[0]);
+    rc = for_all(g, [&](uint32_t i) -> int {
+        msplat_ctx* c = g->ctx[i];
+        if (i == 0 || g->peer_store[i]) {
+            // zero-copy: this device's compositor writes its rows where they belong in device 0's framebuffer
+            int r = msplat_render(c, cameraMat, projMat, viewport, nearFar, rgba, pitch_bytes, 1);
+            if (r && r != MSPLAT_ERR_PAIR_OVERFLOW) return r;
+            if (i != 0) { const int j = msplat_stream_wait(c, stream0); if (j) return j; }
+            return r;
+        }
+        // no peer mapping: render into a local image, then one copy per run of consecutive owned rows
+        if (hipSetDevice(g->devices[i]) != hipSuccess) return gfail(g, MSPLAT_ERR_HIP, "hipSetDevice(%d) failed", g->devices[i]);
+        const size_t need = tight * (size_t)H;
+        if (g->stage_bytes[i] < need) {
+            (void)msplat_synchronize(c);
+            if (g->stage[i]) (void)hipFree(g->stage[i]);
+            g->stage[i] = nullptr;
+            g->stage_bytes[i] = 0;
+            if (hipMalloc(&g->stage[i], need) != hipSuccess) return gfail(g, MSPLAT_ERR_HIP, "staging framebuffer: out of device memory");
+            g->stage_bytes[i] = need;
+        }
+        int r = msplat_render(c, cameraMat, projMat, viewport, nearFar, g->stage[i], tight, 1);
+        if (r && r != MSPLAT_ERR_PAIR_OVERFLOW) return r;
+        int32_t first, count, block, stride;
+        const int rows_full = (H + T - 1) / T;
+        int pr = msplat_band_plan(g->kind, rows_full, (int32_t)n, (int32_t)i, g->block_rows, &first, &count, &block, &stride);
+        if (pr) return pr;
+        hipStream_t s = (hipStream_t)msplat_get_stream(c);
+        for (int v = 0; v < count;) {
+            const int k = v / block, row = first + k * stride + (v - k * block);
+            const int run = std::min(block - (v - k * block), count - v);          // the rest of this block
+            const int y0 = row * T, nrows = std::min(run * T, H - y0);
+            v += run;
+            if (nrows <= 0) break;
+            if (hipMemcpy2DAsync((char*)rgba + (size_t)y0 * pitch_bytes, pitch_bytes, (const char*)g->stage[i] + (size_t)y0 * tight,
+                                 tight, tight, (size_t)nrows, hipMemcpyDeviceToDevice, s) != hipSuccess)
+                return gfail(g, MSPLAT_ERR_HIP, "hipMemcpy2DAsync (device %d -> %d) failed", g->devices[i], g->devices[0]);
+        }
+        const int j = msplat_stream_wait(c, stream0);
+        return j ? j : r;
+    });
+    return rc;
+}
+
+int msplat_group_synchronize(msplat_group* g)
+{
+    if (!g) return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "group is NULL");
+    return for_all(g, [&](uint32_t i) { return msplat_synchronize(g->ctx[i]); });
+}
+
+}  // extern "C"

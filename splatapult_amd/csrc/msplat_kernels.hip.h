@@ -32,6 +32,9 @@ constexpr int kBinChunk = 1024;          // draw-order ranks per chunk in the ti
 constexpr int kTile = 16;                // one compositor wave owns a 16x16 pixel tile ...
 constexpr int kBin = 32;                 // ... binning works on 32x32 bins (4 tiles share one list, each
                                          // wave filters it for its own quadrant): 2.2-2.9x fewer pairs
+// the compositors' sharded work queue (queue_next): 32 heads, one 64-byte line each
+constexpr uint32_t kQueueShards = 32;
+constexpr uint32_t kQueueStride = 16;          // words between heads
 constexpr uint32_t kRectEmpty = 0x000000FFu;   // tx0=255 > tx1=0
 constexpr uint32_t kRankMask = 0x00FFFFFFu;
 
@@ -46,8 +49,11 @@ struct FrameParams {
     float W, H, X0, Y0, zn, zf;
     float t_eps;
     int width, height;
-    int tiles_x, tiles_y;       // tiles_y = number of OWNED tile rows (band mode) else ceil(H/16)
-    int row_mod, row_rem;       // owned tile rows: ty = vy * row_mod + row_rem
+    int tiles_x, tiles_y;       // tiles_y = number of OWNED bin rows (band mode) else ceil(H / 32)
+    // Band (multi-GPU): the owned bin rows are blocks of band_block consecutive rows that start at
+    // band_first, band_first + band_stride, ...; they are numbered vy = 0 .. tiles_y - 1 in ascending order ("virtual rows":
+    // what the pair words, the bin lists and the compositor's work items carry).  banded == 0: every row, vy == row.
+    int banded, band_first, band_block, band_stride;
     int full_sh, srgb;
     int band_cull;              // multi-GPU only: Sort also drops splats that cannot reach an owned bin row
     float view_scale2;          // largest squared column norm of mat3(view) (1 for a rigid camera)
@@ -58,6 +64,30 @@ struct FrameParams {
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
+
+// band geometry (see FrameParams): real bin row of virtual row vy
+__host__ __device__ __forceinline__ int band_real_row(const FrameParams& fp, int vy)
+{
+    if (!fp.banded) return vy;
+    const int k = vy / fp.band_block;
+    return fp.band_first + k * fp.band_stride + (vy - k * fp.band_block);
+}
+// virtual index of the first owned row >= t (>= tiles_y: there is none)
+__host__ __device__ __forceinline__ int band_first_owned_from(const FrameParams& fp, int t)
+{
+    if (!fp.banded) return t < 0 ? 0 : t;
+    if (t <= fp.band_first) return 0;
+    const int d = t - fp.band_first, k = d / fp.band_stride, j = d - k * fp.band_stride;
+    return j < fp.band_block ? k * fp.band_block + j : (k + 1) * fp.band_block;
+}
+// virtual index of the last owned row <= t (-1: there is none; may be >= tiles_y: clamp)
+__host__ __device__ __forceinline__ int band_last_owned_upto(const FrameParams& fp, int t)
+{
+    if (!fp.banded) return t;
+    if (t < fp.band_first) return -1;
+    const int d = t - fp.band_first, k = d / fp.band_stride, j = d - k * fp.band_stride;
+    return k * fp.band_block + (j < fp.band_block ? j : fp.band_block - 1);
+}
 
 // inclusive scan of one uint32 per thread across a 256-thread workgroup.
 __device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* s_tmp4, uint32_t& total)
@@ -123,8 +153,8 @@ __device__ __forceinline__ bool cull_key(const float4 p, const FrameParams& fp, 
             const float y0 = fmaxf(cy - ey, 0.0f), y1 = fminf(cy + ey, fp.H - 1.0f);
             if (!(y0 <= y1)) return false;
             const int r0 = (int)y0 / kBin, r1 = (int)y1 / kBin;
-            const int first = r0 + ((fp.row_rem - r0 % fp.row_mod) + fp.row_mod) % fp.row_mod;   // first owned row >= r0
-            if (first > r1) return false;
+            const int v0 = band_first_owned_from(fp, r0), v1 = min(band_last_owned_upto(fp, r1), fp.tiles_y - 1);
+            if (v0 > v1) return false;                 // no owned row in [r0, r1]
         }
         float f = __fmul_rn(__fdiv_rn(depth, fp.zf), 4294967296.0f);
         uint32_t q = (f >= 4294967296.0f) ? 0xFFFFFFFFu : (uint32_t)f;
@@ -208,20 +238,60 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
                                                           uint32_t* __restrict__ hist, uint32_t hist_stride,
                                                           uint32_t* __restrict__ gsum_acc,
                                                           uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_rows,
-                                                          FrameParams fp)
+                                                          FrameParams fp,
+                                                          const uint32_t* __restrict__ col_totals = nullptr,
+                                                          uint32_t* __restrict__ bincnt = nullptr)
 {
+    // MODE_PAIR with bincnt != nullptr (r3): the input is ordered by (column, rank) and carries the row in its top byte, so
+    // counting the words per (row, column) here gives every bin's list length before the partition has run: the
+    // downsweep's extra workgroup turns the counts into the bins' list offsets (tile_table_role) and the two launches
+    // that used to derive them from the partitioned array (tile_start_kernel's searches, tile_order_kernel) are gone.
+    // A chunk of 4096 words lies inside one or two columns: counts go to an LDS table of the first kPairCols columns the
+    // chunk touches (one LDS atomic per word, as before) and leave the workgroup as one global atomic per non-empty
+    // (row, column); words further right (tiny scenes: columns shorter than a chunk) use a global atomic each.
     constexpr int ITEMS = RadixCfg<MODE, SORT_ITEMS>::ITEMS;
     constexpr int CHUNK = RadixCfg<MODE, SORT_ITEMS>::CHUNK;
+    constexpr int kPairCols = 4;
     __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_bin[MODE == MODE_PAIR ? kPairCols * 256 : 1];
+    __shared__ uint32_t s_col[MODE == MODE_PAIR ? 257 : 1];       // first input position of each column
+    __shared__ uint32_t s_tmp4[4];
     if (gsum_zero != nullptr)
         for (uint32_t row = blockIdx.x; row < gsum_zero_rows; row += gridDim.x) gsum_zero[(size_t)row * 256 + threadIdx.x] = 0u;
     uint32_t n = d_n ? *d_n : n_static;
     if (n > n_cap) n = n_cap;
     const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
+    const bool count_bins = MODE == MODE_PAIR && bincnt != nullptr;
+    if (count_bins) {
+        const uint32_t t = col_totals[threadIdx.x];
+        uint32_t tot;
+        const uint32_t incl = block_incl_scan(t, s_tmp4, tot);
+        s_col[threadIdx.x] = incl - t;
+        if (threadIdx.x == 255) s_col[256] = 0xFFFFFFFFu;
+        __syncthreads();
+    }
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         s_hist[threadIdx.x] = 0;
+        if (count_bins)
+#pragma unroll
+            for (int j = 0; j < kPairCols; ++j) s_bin[j * 256 + threadIdx.x] = 0u;
         __syncthreads();
         const uint32_t base = chunk * CHUNK;
+        uint32_t c0 = 0;
+        bool one_col = false;      // the whole chunk lies in column c0 (almost every chunk: a column holds ~D / tiles_x words)
+        if (count_bins) {          // columns of the chunk's first and last word: last c with s_col[c] <= position
+            const uint32_t last = min(base + (uint32_t)CHUNK, n) - 1u;
+            uint32_t lo = 0, hi = 255, lo1 = 0, hi1 = 255;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const uint32_t mid = (lo + hi + 1u) >> 1, mid1 = (lo1 + hi1 + 1u) >> 1;
+                if (s_col[mid] <= base) lo = mid; else hi = mid - 1u;
+                if (s_col[mid1] <= last) lo1 = mid1; else hi1 = mid1 - 1u;
+            }
+            c0 = lo;
+            one_col = lo1 == lo;
+        }
+        uint32_t cw = c0;          // the positions of a thread ascend with r: its column only moves right
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const uint32_t i = base + r * kThreads + threadIdx.x;
@@ -230,11 +300,35 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
                 bool ok = true;
                 if (MODE == MODE_CULL) ok = cull_key(pos[i], fp, key);
                 else key = keys[i];
-                if (ok) atomicAdd(&s_hist[digit_of<MODE>(key, shift)], 1u);
+                if (count_bins && one_col) {
+                    atomicAdd(&s_bin[key >> 24], 1u);          // s_bin[0][row]
+                } else if (count_bins) {
+                    while (s_col[cw + 1u] <= i) ++cw;          // s_col[256] is a sentinel
+                    const uint32_t row = key >> 24, j = cw - c0;
+                    if (j < (uint32_t)kPairCols) {
+                        atomicAdd(&s_bin[j * 256u + row], 1u);
+                    } else {
+                        atomicAdd(&s_hist[row], 1u);
+                        (void)__hip_atomic_fetch_add(&bincnt[row * (uint32_t)fp.tiles_x + cw], 1u, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else if (ok) {
+                    atomicAdd(&s_hist[digit_of<MODE>(key, shift)], 1u);
+                }
             }
         }
         __syncthreads();
-        const uint32_t c = s_hist[threadIdx.x];
+        uint32_t c = s_hist[threadIdx.x];
+        if (count_bins) {
+#pragma unroll
+            for (int j = 0; j < kPairCols; ++j) {
+                const uint32_t v = s_bin[j * 256 + threadIdx.x];
+                c += v;
+                if (v != 0u)
+                    (void)__hip_atomic_fetch_add(&bincnt[threadIdx.x * (uint32_t)fp.tiles_x + c0 + j], v, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         hist[(size_t)chunk * 256 + threadIdx.x] = c;
         if (gsum_acc != nullptr && c != 0u)
             (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(chunk >> kGroupShift) * 256 + threadIdx.x], c, __ATOMIC_RELAXED,
@@ -369,6 +463,56 @@ __global__ __launch_bounds__(kThreads) void radix_scan_small(uint32_t* __restric
     if (g == 0) totals[digit] = total;
 }
 
+// The bins' list offsets and the compositors' work order from the per-bin pair counts (r3; see radix_upsweep<MODE_PAIR>).
+// Run by ONE extra workgroup of the row pass's downsweep, beside the workgroups that move the pairs: the final pair
+// array is ordered by (row, column) = bin index, so the offset of a bin's list is the exclusive prefix sum of the
+// counts -- no search in the partitioned array -- and the counting sort of the bins by list length (heaviest first,
+// what tile_order_kernel did in its own launch) reads the same numbers.  Clears the counts for the next frame and
+// resets the compositors' queue heads.  tile_start gets ceil((ntiles + 1) / 1024) * 1024 entries (the tail = D).
+__device__ __forceinline__ void tile_table_role(uint32_t* __restrict__ bincnt, int ntiles,
+                                                uint32_t* __restrict__ tile_start, uint32_t* __restrict__ order,
+                                                uint32_t* __restrict__ queue, int do_order,
+                                                uint32_t* s_cnt256, uint32_t* s_off256, uint32_t* s_tmp4)
+{
+    if (threadIdx.x < kQueueShards) queue[threadIdx.x * kQueueStride] = 0u;
+    const uint32_t nblk = ((uint32_t)ntiles + 1u + 1023u) / 1024u;
+    uint32_t running = 0;
+    for (uint32_t b = 0; b < nblk; ++b) {
+        const uint32_t i0 = b * 1024u + threadIdx.x * 4u;
+        uint4 v = *reinterpret_cast<const uint4*>(bincnt + i0);
+        if (i0 + 0u >= (uint32_t)ntiles) v.x = 0u;           // (entries past the last bin are zero anyway)
+        if (i0 + 1u >= (uint32_t)ntiles) v.y = 0u;
+        if (i0 + 2u >= (uint32_t)ntiles) v.z = 0u;
+        if (i0 + 3u >= (uint32_t)ntiles) v.w = 0u;
+        const uint32_t local = v.x + v.y + v.z + v.w;
+        uint32_t total;
+        const uint32_t e = running + block_incl_scan(local, s_tmp4, total) - local;
+        *reinterpret_cast<uint4*>(tile_start + i0) = make_uint4(e, e + v.x, e + v.x + v.y, e + v.x + v.y + v.z);
+        *reinterpret_cast<uint4*>(bincnt + i0) = make_uint4(0u, 0u, 0u, 0u);
+        running += total;
+    }
+    if (!do_order) return;
+    // bins by descending list length (counting sort on len / 16): the compositor's waves take them heaviest first
+    s_cnt256[threadIdx.x] = 0u;
+    __syncthreads();                 // also: this workgroup's tile_start stores are visible to all its threads
+    for (int i = threadIdx.x; i < ntiles; i += kThreads) {
+        const uint32_t len = tile_start[i + 1] - tile_start[i];
+        atomicAdd(&s_cnt256[255u - min(len >> 4, 255u)], 1u);
+    }
+    __syncthreads();
+    {
+        const uint32_t c = s_cnt256[threadIdx.x];
+        uint32_t total;
+        s_off256[threadIdx.x] = block_incl_scan(c, s_tmp4, total) - c;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntiles; i += kThreads) {
+        const uint32_t len = tile_start[i + 1] - tile_start[i];
+        const uint32_t pos = atomicAdd(&s_off256[255u - min(len >> 4, 255u)], 1u);
+        order[pos] = (uint32_t)i;      // order inside a bucket is irrelevant (tiles are independent)
+    }
+}
+
 template <int MODE, bool HAS_VALUES, bool ATOMIC_RANK, int SORT_ITEMS = kSortItems>
 __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __restrict__ keys_in,
                                                             const uint32_t* __restrict__ vals_in,
@@ -383,11 +527,18 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
                                                             const uint32_t* __restrict__ col_totals,
                                                             const uint32_t* __restrict__ gsum,
                                                             uint32_t* __restrict__ totals_out,
-                                                            FrameParams fp)
+                                                            FrameParams fp,
+                                                            uint32_t* __restrict__ bincnt = nullptr,
+                                                            uint32_t* __restrict__ tile_start = nullptr,
+                                                            uint32_t* __restrict__ tile_order = nullptr,
+                                                            uint32_t* __restrict__ queue = nullptr,
+                                                            int ntiles = 0, int do_order = 0)
 {
     // gsum != nullptr: scan-free path -- hist holds raw per-chunk counts, prefixes come from the group tables;
     // otherwise hist holds exclusive prefixes and totals the digit totals (radix_scan*).
     // totals_out != nullptr: workgroup 0 publishes the digit totals (the row totals tile_start_kernel needs).
+    // bincnt != nullptr (MODE_PAIR, r3): workgroup 0 of the grid does not move pairs, it builds the bins' list
+    // offsets and work order from the counts the upsweep took (tile_table_role); the others are the workers.
     constexpr int ITEMS = RadixCfg<MODE, SORT_ITEMS>::ITEMS;
     constexpr int CHUNK = RadixCfg<MODE, SORT_ITEMS>::CHUNK;
     __shared__ uint32_t s_col[MODE == MODE_PAIR ? 256 : 1];   // MODE_PAIR: first input position of each column
@@ -399,6 +550,15 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
     __shared__ uint8_t s_dig[CHUNK];
     __shared__ uint32_t s_tmp[4];
 
+    uint32_t nworkers = gridDim.x, wb = blockIdx.x;      // worker count / this workgroup's worker index
+    if (MODE == MODE_PAIR && bincnt != nullptr) {
+        if (blockIdx.x == 0u) {                  // workgroup-uniform; dispatched first
+            tile_table_role(bincnt, ntiles, tile_start, tile_order, queue, do_order, s_cnt[0], s_base, s_tmp);
+            return;
+        }
+        nworkers = gridDim.x - 1u;
+        wb = blockIdx.x - 1u;
+    }
     uint32_t n = d_n ? *d_n : n_static;
     if (n > n_cap) n = n_cap;
     const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
@@ -412,8 +572,8 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
         uint32_t tot;
         const uint32_t incl = block_incl_scan(t, s_tmp, tot);
         s_base[threadIdx.x] = incl - t;
-        if (d_count_out != nullptr && blockIdx.x == 0 && threadIdx.x == 255) *d_count_out = incl;
-        if (totals_out != nullptr && blockIdx.x == 0) totals_out[threadIdx.x] = t;
+        if (d_count_out != nullptr && wb == 0 && threadIdx.x == 255) *d_count_out = incl;
+        if (totals_out != nullptr && wb == 0) totals_out[threadIdx.x] = t;
     }
     if (MODE == MODE_PAIR) {
         const uint32_t t = col_totals[threadIdx.x];
@@ -423,7 +583,7 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
     }
     __syncthreads();
 
-    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    for (uint32_t chunk = wb; chunk < nchunks; chunk += nworkers) {
         // this chunk's exclusive prefix per digit (thread = digit): issued first, consumed after the local ranking
         const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk, reinterpret_cast<uint4*>(s_keys))
                                                      : hist[(size_t)chunk * 256 + threadIdx.x];
@@ -538,6 +698,323 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
                 const uint32_t dst = p + s_gdelta[s_dig[p]];
                 keys_out[dst] = s_keys[p];
                 if (HAS_VALUES) vals_out[dst] = s_vals[p];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Wide-digit sort (round 3): THREE stable LSD passes over the 32-bit depth key instead of four.
+//
+// Contract kept: stable ascending 32-bit key, values = splat indices (splatrenderer.cpp:165-169,223-264; the
+// reference itself tried and rejected a 24-bit key, :165-167).  What changes is only how the 32 bits are cut:
+//   pass 0 sorts key bits [0, 10) -- fused with the presort cull as before -- and while it computes the keys it
+//   also takes the minimum key of the visible set (one atomicMin per workgroup).  key = 0xFFFFFFFF - q with
+//   q = trunc(depth / far * 2^32), so with B = bit length of the largest q every key has its top 32 - B bits set:
+//   only B bits can differ.  Passes 1 and 2 read that word and split the remaining max(B - 10, 16) bits in two
+//   digits of 8..11 bits.  A scene whose depths stay below far / 64 (B <= 26: every BASELINE workload) is sorted
+//   with digits of 10 + 8 + 8 bits; the general case (depth up to far and beyond: the key saturates at 0) with
+//   10 + 11 + 11.  Exact for every input: the ignored bits are provably constant.
+// One pass = upsweep + downsweep (scan-free, group tables: see radix_upsweep), so Sort = 6 launches instead of 8.
+// Differences from the 8-bit kernels above, all following from the wider digit:
+//   * 512 threads and 4096 / 8192-key chunks: a histogram row has up to 2048 entries, so rows must be rarer;
+//   * per-wave rank counters are 16-bit halves of packed words (a wave ranks at most 64 * ITEMS <= 1024 keys per
+//     digit and a chunk position is < 8192): 8 waves x 2048 digits fit in 32 KB of LDS.  The rank of a key is
+//     still the return value of ONE lane-ordered LDS atomic (ds_add_rtn_u32 of 1 or 1 << 16);
+//   * the digit is recomputed from the key at write-out (no digit array in LDS);
+//   * pass 0's upsweep writes the key and a visibility bit per splat, so the downsweep reads 4 bytes + 1 bit per
+//     splat instead of re-reading the 16-byte position and recomputing the cull (r2: 1.48x traffic in pass 0).
+// Needs the lane-ordered LDS atomics (probed at msplat_create); without them the 8-bit ballot kernels are used.
+// ------------------------------------------------------------------------------------------
+constexpr int kWsThreads = 512;
+constexpr int kWsWaves = kWsThreads / 64;
+constexpr int kWsBits0 = 10;                 // digit of pass 0: key bits [0, 10)
+constexpr int kWsMinBits = 8, kWsMaxBits = 11;
+constexpr int kWsMaxBins = 1 << kWsMaxBits;
+
+// digit of pass `pass`: bits [shift, shift + bits) of the key.  minkey = smallest key of the visible set (pass >= 1)
+__device__ __forceinline__ void ws_digit_range(int pass, uint32_t minkey, int& shift, int& bits)
+{
+    if (pass == 0) { shift = 0; bits = kWsBits0; return; }
+    const uint32_t q = ~minkey;                          // largest quantised depth among the visible splats
+    const int B = q ? 32 - __clz((int)q) : 0;            // keys differ in their low B bits only
+    int rem = B - kWsBits0;
+    if (rem < 2 * kWsMinBits) rem = 2 * kWsMinBits;      // at least 8 bits per pass (constant high bits sort trivially)
+    const int b1 = (rem + 1) >> 1;                       // <= 11 since B <= 32
+    if (pass == 1) { shift = kWsBits0; bits = b1; }
+    else { shift = kWsBits0 + b1; bits = rem - b1; }
+}
+
+// inclusive scan of one uint32 per thread across a 512-thread workgroup (s_tmp: 8 words); ends with a barrier
+__device__ __forceinline__ uint32_t ws_block_incl_scan(uint32_t v, uint32_t* s_tmp, uint32_t& total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    if (lane == 63) s_tmp[w] = v;
+    __syncthreads();
+    uint32_t off = 0;
+    total = 0;
+#pragma unroll
+    for (int k = 0; k < kWsWaves; ++k) {
+        const uint32_t s = s_tmp[k];
+        if (k < w) off += s;
+        total += s;
+    }
+    __syncthreads();
+    return v + off;
+}
+
+// Sum of n0 rows at rows0 plus n1 rows at rows1 (rows of `nbins` uint32, nbins = 256..2048), as quads: thread t < nbins / 4
+// receives the sums of digits 4t .. 4t+3.  A row is nbins / 4 16-byte quads; thread t loads quad t % Q of the rows
+// t / Q, t / Q + 512 / Q, ... (coalesced), partial sums meet in s_part (512 uint4).  Two barriers: call from all threads.
+__device__ __forceinline__ uint4 ws_row_sum(const uint32_t* __restrict__ rows0, uint32_t n0,
+                                            const uint32_t* __restrict__ rows1, uint32_t n1, uint32_t nbins, int bits,
+                                            uint4* s_part)
+{
+    const uint32_t Q = nbins >> 2, RL = (uint32_t)kWsThreads >> (bits - 2);
+    const uint32_t q = threadIdx.x & (Q - 1u), rl = threadIdx.x >> (bits - 2);
+    uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 4
+    for (uint32_t r = rl; r < n0; r += RL) {
+        const uint4 x = *reinterpret_cast<const uint4*>(rows0 + (size_t)r * nbins + q * 4u);
+        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+    }
+#pragma unroll 4
+    for (uint32_t r = rl; r < n1; r += RL) {
+        const uint4 x = *reinterpret_cast<const uint4*>(rows1 + (size_t)r * nbins + q * 4u);
+        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+    }
+    s_part[threadIdx.x] = acc;                 // == s_part[rl * Q + q]
+    __syncthreads();
+    uint4 sum = make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x < Q)
+        for (uint32_t k = 0; k < RL; ++k) {
+            const uint4 x = s_part[k * Q + threadIdx.x];
+            sum.x += x.x; sum.y += x.y; sum.z += x.z; sum.w += x.w;
+        }
+    __syncthreads();
+    return sum;
+}
+
+// CULL: pass 0.  keys are computed from the positions (presort_compute.glsl:38-55 via cull_key), written to raw_keys
+// together with one visibility bit per splat (vmask: one uint64 per 64 splats), and their minimum goes to *minkey_cur.
+template <bool CULL, int ITEMS>
+__global__ __launch_bounds__(kWsThreads) void ws_upsweep(const uint32_t* __restrict__ keys_in,
+                                                         const float4* __restrict__ pos,
+                                                         uint32_t* __restrict__ raw_keys,
+                                                         unsigned long long* __restrict__ vmask,
+                                                         const uint32_t* __restrict__ d_n, uint32_t n_static, uint32_t n_cap,
+                                                         int pass, uint32_t* __restrict__ minkey_cur,
+                                                         uint32_t* __restrict__ minkey_next,
+                                                         uint32_t* __restrict__ hist,
+                                                         uint32_t* __restrict__ gsum_acc, int gshift,
+                                                         uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_words,
+                                                         FrameParams fp)
+{
+    constexpr int CHUNK = kWsThreads * ITEMS;
+    __shared__ uint32_t s_hist[kWsMaxBins];
+    __shared__ uint32_t s_min[kWsWaves];
+    // the group table of the pass before this one (its consumer finished one launch ago) is cleared for the next frame
+    if (gsum_zero != nullptr)
+        for (uint32_t i = blockIdx.x * kWsThreads + threadIdx.x; i < gsum_zero_words; i += gridDim.x * kWsThreads) gsum_zero[i] = 0u;
+    if (CULL && blockIdx.x == 0 && threadIdx.x == 0) *minkey_next = 0xFFFFFFFFu;      // the other frame parity's word
+    uint32_t n = d_n ? *d_n : n_static;
+    if (n > n_cap) n = n_cap;
+    int shift, bits;
+    ws_digit_range(pass, CULL ? 0u : *minkey_cur, shift, bits);
+    const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
+    const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
+    uint32_t mk = 0xFFFFFFFFu;
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        for (uint32_t d = threadIdx.x; d < nbins; d += kWsThreads) s_hist[d] = 0u;
+        __syncthreads();
+        const uint32_t base = chunk * CHUNK;
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const uint32_t i = base + r * kWsThreads + threadIdx.x;
+            uint32_t key = 0u;
+            bool ok = false;
+            if (i < n) {
+                if (CULL) ok = cull_key(pos[i], fp, key);
+                else { key = keys_in[i]; ok = true; }
+            }
+            if (CULL) {
+                const unsigned long long m = __ballot(ok);
+                if (i < n) {
+                    raw_keys[i] = key;
+                    if ((threadIdx.x & 63) == 0) vmask[i >> 6] = m;        // i is a multiple of 64 here
+                    if (ok) mk = min(mk, key);
+                }
+            }
+            if (ok) atomicAdd(&s_hist[(key >> shift) & dmask], 1u);
+        }
+        __syncthreads();
+        for (uint32_t d = threadIdx.x; d < nbins; d += kWsThreads) {
+            const uint32_t c = s_hist[d];
+            hist[(size_t)chunk * nbins + d] = c;
+            if (c != 0u)
+                (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(chunk >> gshift) * nbins + d], c, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+    if (CULL) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mk = min(mk, (uint32_t)__shfl_xor((int)mk, d, 64));
+        if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = mk;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t m = s_min[0];
+#pragma unroll
+            for (int k = 1; k < kWsWaves; ++k) m = min(m, s_min[k]);
+            if (m != 0xFFFFFFFFu) (void)atomicMin(minkey_cur, m);
+        }
+    }
+}
+
+// dynamic LDS of ws_downsweep<., ITEMS>: keys + values of the chunk, packed per-wave counters, per-digit deltas, scan scratch
+constexpr size_t ws_downsweep_lds(int items)
+{
+    return (size_t)kWsThreads * items * 8 + (size_t)kWsWaves * (kWsMaxBins / 2) * 4 + (size_t)kWsMaxBins * 4 + 64;
+}
+
+template <bool CULL, int ITEMS>
+__global__ __launch_bounds__(kWsThreads, ITEMS == 8 ? 2 : 1) void ws_downsweep(const uint32_t* __restrict__ keys_in,
+                                                           const uint32_t* __restrict__ vals_in,
+                                                           const unsigned long long* __restrict__ vmask,
+                                                           const uint32_t* __restrict__ d_n, uint32_t n_static, uint32_t n_cap,
+                                                           int pass, const uint32_t* __restrict__ minkey_cur,
+                                                           const uint32_t* __restrict__ hist,
+                                                           const uint32_t* __restrict__ gsum, int gshift,
+                                                           uint32_t* __restrict__ keys_out,
+                                                           uint32_t* __restrict__ vals_out,
+                                                           uint32_t* __restrict__ d_count_out)
+{
+    constexpr int CHUNK = kWsThreads * ITEMS;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    uint32_t* s_keys = s_dyn;                                   // CHUNK
+    uint32_t* s_vals = s_keys + CHUNK;                          // CHUNK
+    uint32_t* s_cnt = s_vals + CHUNK;                           // kWsWaves x (nbins / 2) packed 16-bit counters, then bases
+    uint32_t* s_gd = s_cnt + kWsWaves * (kWsMaxBins / 2);       // nbins: global position minus chunk-local position
+    uint32_t* s_tmp = s_gd + kWsMaxBins;                        // 8 words
+    uint4* s_part = reinterpret_cast<uint4*>(s_keys);           // 8 KB scratch of the row sums (s_keys not live yet)
+
+    uint32_t n = d_n ? *d_n : n_static;
+    if (n > n_cap) n = n_cap;
+    int shift, bits;
+    ws_digit_range(pass, CULL ? 0u : *minkey_cur, shift, bits);
+    const uint32_t nbins = 1u << bits, dmask = nbins - 1u, Q = nbins >> 2, half = nbins >> 1;
+    const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+
+    // digit totals = sum of all group rows; their exclusive scan = where each digit's run starts (kept in registers)
+    uint32_t gbase[4];
+    {
+        const uint32_t ng = (nchunks + (1u << gshift) - 1u) >> gshift;
+        const uint4 tot = ws_row_sum(gsum, ng, gsum, 0u, nbins, bits, s_part);
+        const uint32_t tsum = tot.x + tot.y + tot.z + tot.w;          // 0 for t >= Q
+        uint32_t total;
+        const uint32_t e = ws_block_incl_scan(tsum, s_tmp, total) - tsum;
+        gbase[0] = e; gbase[1] = e + tot.x; gbase[2] = gbase[1] + tot.y; gbase[3] = gbase[2] + tot.z;
+        if (d_count_out != nullptr && blockIdx.x == 0 && t == 0) *d_count_out = total;
+    }
+
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        // this chunk's exclusive prefix per digit: the group rows before its group + the chunk rows before it in the group
+        const uint32_t g = chunk >> gshift;
+        const uint4 pre = ws_row_sum(gsum, g, hist + (size_t)(g << gshift) * nbins, chunk - (g << gshift), nbins, bits, s_part);
+        for (uint32_t i = t; i < nbins; i += kWsThreads) reinterpret_cast<uint4*>(s_cnt)[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+
+        uint32_t key[ITEMS], val[ITEMS], lrank[ITEMS];
+        bool valid[ITEMS];
+        // wave w owns the contiguous sub-chunk [w * 64 * ITEMS, (w + 1) * 64 * ITEMS): keeps the sort stable
+        const uint32_t base = chunk * CHUNK + (uint32_t)w * (64 * ITEMS);
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const uint32_t i = base + r * 64 + lane;
+            valid[r] = i < n;
+            key[r] = 0u;
+            val[r] = 0u;
+            if (CULL) {
+                // (the key load does not wait for the visibility word: both are issued for every splat of the chunk)
+                unsigned long long m = 0ull;
+                if (base + r * 64 < n) m = vmask[(base + r * 64) >> 6];          // wave-uniform
+                if (valid[r]) { key[r] = keys_in[i]; val[r] = i; }
+                valid[r] = valid[r] && ((m >> lane) & 1ull);
+            } else if (valid[r]) {
+                key[r] = keys_in[i];
+                val[r] = vals_in[i];
+            }
+        }
+        uint32_t* wcnt = s_cnt + (uint32_t)w * half;
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            // ds_add_rtn_u32 serves the lanes of one wave instruction in ascending lane order and a wave's DS instructions
+            // in program order (lds_atomic_order_probe), so the returned half-word IS the stable rank inside the wave
+            const uint32_t d = (key[r] >> shift) & dmask, sh = (d & 1u) << 4;
+            lrank[r] = 0u;
+            if (valid[r]) lrank[r] = (atomicAdd(&wcnt[d >> 1], 1u << sh) >> sh) & 0xFFFFu;
+        }
+        __syncthreads();
+        // per digit: counts of the 8 waves -> chunk-local exclusive positions -> per-wave bases (16 bit: < CHUNK <= 8192)
+        uint32_t chunk_count;
+        {
+            uint32_t c[kWsWaves][4];
+            uint32_t tot[4] = {0u, 0u, 0u, 0u};
+            if ((uint32_t)t < Q) {
+#pragma unroll
+                for (int k = 0; k < kWsWaves; ++k) {
+                    const uint2 x = *reinterpret_cast<const uint2*>(s_cnt + (uint32_t)k * half + 2u * t);
+                    c[k][0] = x.x & 0xFFFFu; c[k][1] = x.x >> 16; c[k][2] = x.y & 0xFFFFu; c[k][3] = x.y >> 16;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tot[j] += c[k][j];
+                }
+            }
+            const uint32_t tsum = tot[0] + tot[1] + tot[2] + tot[3];
+            const uint32_t e = ws_block_incl_scan(tsum, s_tmp, chunk_count) - tsum;
+            if ((uint32_t)t < Q) {
+                uint32_t run[4] = {e, e + tot[0], e + tot[0] + tot[1], e + tot[0] + tot[1] + tot[2]};
+                const uint32_t pr[4] = {pre.x, pre.y, pre.z, pre.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s_gd[4u * t + j] = gbase[j] + pr[j] - run[j];
+#pragma unroll
+                for (int k = 0; k < kWsWaves; ++k) {
+                    uint2 x;
+                    x.x = run[0] | (run[1] << 16);
+                    x.y = run[2] | (run[3] << 16);
+                    *reinterpret_cast<uint2*>(s_cnt + (uint32_t)k * half + 2u * t) = x;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) run[j] += c[k][j];
+                }
+            }
+        }
+        __syncthreads();
+        // local sort through LDS, then a coalesced write-out: position p of the chunk's digit-sorted order goes to
+        // p + s_gd[digit], so neighbouring threads write neighbouring words of a digit run
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            if (valid[r]) {
+                const uint32_t d = (key[r] >> shift) & dmask, sh = (d & 1u) << 4;
+                const uint32_t p = ((wcnt[d >> 1] >> sh) & 0xFFFFu) + lrank[r];
+                s_keys[p] = key[r];
+                s_vals[p] = val[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const uint32_t p = k * kWsThreads + t;
+            if (p < chunk_count) {
+                const uint32_t kk = s_keys[p];
+                const uint32_t dst = p + s_gd[(kk >> shift) & dmask];
+                keys_out[dst] = kk;
+                vals_out[dst] = s_vals[p];
             }
         }
         __syncthreads();
@@ -840,12 +1317,11 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
         if (x0f <= x1f && y0f <= y1f) {
             const int tx0 = (int)x0f / kBin, tx1 = (int)x1f / kBin;
             int ty0 = (int)y0f / kBin, ty1 = (int)y1f / kBin;
-            // band mode: keep only owned tile rows, renumbered vy = (ty - rem) / mod
-            if (fp.row_mod > 1) {
-                int a = ty0 - fp.row_rem, bq = ty1 - fp.row_rem;
-                // ceil(a/mod) for possibly negative a
-                ty0 = (a >= 0) ? (a + fp.row_mod - 1) / fp.row_mod : 0;
-                ty1 = (bq >= 0) ? bq / fp.row_mod : -1;
+            // band mode: keep only the owned bin rows, as their virtual numbers (a contiguous range: vy ascends with the row)
+            if (fp.banded) {
+                const int v0 = band_first_owned_from(fp, ty0), v1 = min(band_last_owned_upto(fp, ty1), fp.tiles_y - 1);
+                ty0 = v0;
+                ty1 = v1;
             }
             if (ty0 <= ty1) {
                 rect = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
@@ -893,7 +1369,10 @@ __global__ __launch_bounds__(kThreads) void count_drawn_kernel(const uint32_t* _
         const float y0 = fmaxf(ceilf(a.y - q.w - 0.5f), 0.0f), y1 = fminf(floorf(a.y + q.w - 0.5f), (float)(fp.height - 1));
         if (x0 <= x1 && y0 <= y1) {
             int ty0 = (int)y0 / kTile, ty1 = (int)y1 / kTile, rows = 0;
-            for (int ty = ty0; ty <= ty1; ++ty) rows += ((ty / (kBin / kTile)) % fp.row_mod) == fp.row_rem;
+            for (int ty = ty0; ty <= ty1; ++ty) {
+                const int br = ty / (kBin / kTile), v = band_first_owned_from(fp, br);
+                rows += (v < fp.tiles_y && band_real_row(fp, v) == br) ? 1 : 0;
+            }
             p16 += (unsigned long long)((int)x1 / kTile - (int)x0 / kTile + 1) * (unsigned long long)rows;
         }
     }
@@ -1142,8 +1621,6 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
 // one gather, so a row segment of 100 k words needs 3 dependent loads instead of 17 (this kernel was a
 // 2 k-thread latency chain: 7.8 us at 1920x1080).
 // (the compositors' sharded work queue, see queue_next below)
-constexpr uint32_t kQueueShards = 32;
-constexpr uint32_t kQueueStride = 16;          // words between heads: one 64-byte line each
 constexpr int kTileStartBins = kThreads / 64;      // bins per workgroup
 __global__ __launch_bounds__(kThreads) void tile_start_kernel(const uint32_t* __restrict__ pairs,
                                                               const uint32_t* __restrict__ row_totals,
@@ -1360,7 +1837,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
     const int quad = (int)quadrant;
     const int bvy = bin / fp.tiles_x;
     const int tx = (bin - bvy * fp.tiles_x) * 2 + (quad & 1);
-    const int ty = (bvy * fp.row_mod + fp.row_rem) * 2 + (quad >> 1);
+    const int ty = band_real_row(fp, bvy) * 2 + (quad >> 1);
     if (tx * kTile >= fp.width || ty * kTile + half * ROWS >= fp.height) {      // work item entirely outside the image
         if (gridDim.x >= ntiles) break;
         uint32_t nq = 0;
@@ -1658,7 +2135,7 @@ __global__ __launch_bounds__(kQuadThreads) void composite_quad_kernel(const uint
         const int quad = (int)(qpos & 3u);
         const int bvy = bin / fp.tiles_x;
         const int tx = (bin - bvy * fp.tiles_x) * 2 + (quad & 1);
-        const int ty = (bvy * fp.row_mod + fp.row_rem) * 2 + (quad >> 1);
+        const int ty = band_real_row(fp, bvy) * 2 + (quad >> 1);
         const bool tile_in_image = tx * kTile < fp.width && ty * kTile < fp.height;
         if (tile_in_image) {
             const int x = tx * kTile + sbx * 8 + lx, y = ty * kTile + sby * 8 + ly;
@@ -1882,7 +2359,7 @@ __global__ __launch_bounds__(kCompThreads) void composite_depth_kernel(const uin
         const int quad = (int)(qpos & 3u);
         const int bvy = bin / fp.tiles_x;
         const int tx = (bin - bvy * fp.tiles_x) * 2 + (quad & 1);
-        const int ty = (bvy * fp.row_mod + fp.row_rem) * 2 + (quad >> 1);
+        const int ty = band_real_row(fp, bvy) * 2 + (quad >> 1);
         if (tx * kTile < fp.width && ty * kTile < fp.height) {
             const int x = tx * kTile + lx, ybase = ty * kTile + ly;
             const float fx = (float)x + 0.5f;
@@ -2053,10 +2530,10 @@ __global__ __launch_bounds__(kProjThreads) void point_project_kernel(const uint3
         if (x0f <= x1f && y0f <= y1f) {
             const int tx0 = (int)x0f / kBin, tx1 = (int)x1f / kBin;
             int ty0 = (int)y0f / kBin, ty1 = (int)y1f / kBin;
-            if (fp.row_mod > 1) {
-                const int a = ty0 - fp.row_rem, bq = ty1 - fp.row_rem;
-                ty0 = (a >= 0) ? (a + fp.row_mod - 1) / fp.row_mod : 0;
-                ty1 = (bq >= 0) ? bq / fp.row_mod : -1;
+            if (fp.banded) {
+                const int v0 = band_first_owned_from(fp, ty0), v1 = min(band_last_owned_upto(fp, ty1), fp.tiles_y - 1);
+                ty0 = v0;
+                ty1 = v1;
             }
             if (ty0 <= ty1) rect = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
         }
@@ -2121,7 +2598,7 @@ __global__ __launch_bounds__(kCompThreads) void composite_points_kernel(const ui
         const int quad = (int)(qpos & 3u);
         const int bvy = bin / fp.tiles_x;
         const int tx = (bin - bvy * fp.tiles_x) * 2 + (quad & 1);
-        const int ty = (bvy * fp.row_mod + fp.row_rem) * 2 + (quad >> 1);
+        const int ty = band_real_row(fp, bvy) * 2 + (quad >> 1);
         if (tx * kTile < fp.width && ty * kTile < fp.height) {
             const int x = tx * kTile + lx, ybase = ty * kTile + ly;
             const float fx = (float)x + 0.5f;

@@ -1,40 +1,65 @@
 """Multi-GPU tile-row sharding (one process per GPU, torch.distributed = RCCL over xGMI on ROCm).
 
-The path shards by screen tiles: rank g of G renders bin rows t with t % G == g
-(rows of msplat_tile_size() = 32 pixels, interleaved for load balance; per-pixel results are bit-identical to single-GPU
-rendering because every bin still sees its splats in global depth order).  The only exchange is the final row
-gather to rank 0, and it moves every band exactly once:
+The path shards by screen tiles: rank g of G renders a set of bin rows (rows of msplat_tile_size() = 32
+pixels) given by a layout -- "contiguous" bands [g R / G, (g+1) R / G) (the north star's "tiles row-sharded"), "interleaved"
+rows (t % G == g) or "block": blocks of k rows dealt round-robin (msplat_band_plan; per-pixel results are bit-identical
+to single-GPU rendering for every layout because every bin still sees its splats in global depth order).  The only
+exchange is the final row gather to rank 0, and it moves every band exactly once:
 
   * every rank renders into a full-size framebuffer (it writes only its own bin rows);
-  * rank 0's framebuffer IS the final image: it posts one receive per foreign bin row, straight into that row's
-    place (a bin row is a contiguous block of tile x W pixels), and the other ranks send their rows from where the
-    compositor left them -- no pack, no staging buffer, no unpack;
+  * rank 0's framebuffer IS the final image: it posts one receive per RUN of consecutive foreign bin rows, straight into
+    the run's place (a run is one contiguous block of pixels), and the other ranks send their runs from where the
+    compositor left them -- no pack, no staging buffer, no unpack.  Contiguous bands: ONE message per rank and frame;
   * all of a frame's sends/receives are issued as ONE group (ncclGroupStart/End via batch_isend_irecv), so
     each rank's band travels over its own direct xGMI link concurrently (7 links into rank 0), not around a ring.
 
-No collective is used anywhere else."""
+No collective is used anywhere else.  (One process driving several GPUs uses msplat_group_* instead: the other devices'
+compositors store into device 0's framebuffer through the peer mapping and there is no message at all.)"""
 import torch.distributed as dist
+
+
+def owned_rows(kind, tiles_y, world, rank, block_rows=1):
+    """the bin rows rank `rank` owns under the layout (the ownership rule of msplat_band_plan, restated in Python so
+    that the gather plan needs no library call): ascending list"""
+    if kind == "contiguous":
+        return list(range((tiles_y * rank) // world, (tiles_y * (rank + 1)) // world))
+    k = 1 if kind == "interleaved" else int(block_rows)
+    assert kind in ("interleaved", "block") and k >= 1
+    return [t for t in range(tiles_y) if (t // k) % world == rank]
+
+
+def row_runs(rows):
+    """[(first_row, count)] of the maximal runs of consecutive rows"""
+    runs = []
+    for t in rows:
+        if runs and runs[-1][0] + runs[-1][1] == t:
+            runs[-1] = (runs[-1][0], runs[-1][1] + 1)
+        else:
+            runs.append((t, 1))
+    return runs
 
 
 class BandGather:
     """Gathers the owned bin rows of every rank's full-size framebuffer into rank `dst`'s framebuffer.
 
     fb layout on every rank: (tiles_y * tile, W, 4) (height padded to a multiple of the bin size);
-    rank g has written rows of bins g, g+G, ... only.  On `dst` the call returns fb itself, completed."""
+    rank g has written its own bin rows only.  On `dst` the call returns fb itself, completed."""
 
-    def __init__(self, tiles_y, width, dtype, device, rank, world, dst=0, tile=32):
+    def __init__(self, tiles_y, width, dtype, device, rank, world, dst=0, tile=32, layout="interleaved", block_rows=1):
         self.tiles_y, self.W, self.rank, self.world, self.dst, self.tile = tiles_y, width, rank, world, dst, tile
-        self.dtype, self.device = dtype, device
-        # bin rows this rank sends, or (on dst) receives from each peer -- fixed for the lifetime of the object
+        self.dtype, self.device, self.layout, self.block_rows = dtype, device, layout, block_rows
+        self.rows = owned_rows(layout, tiles_y, world, rank, block_rows)
+        # runs of bin rows this rank sends, or (on dst) receives from each peer -- fixed for the lifetime of the object
         if rank == dst:
-            self.plan = [(t, src) for src in range(world) if src != dst for t in range(src, tiles_y, world)]
+            self.plan = [(t, c, src) for src in range(world) if src != dst
+                         for t, c in row_runs(owned_rows(layout, tiles_y, world, src, block_rows))]
         else:
-            self.plan = [(t, dst) for t in range(rank, tiles_y, world)]
-        self.bytes_per_frame = len(self.plan) * tile * width * 4 * (2 if str(dtype).endswith("float16") else 4)
+            self.plan = [(t, c, dst) for t, c in row_runs(self.rows)]
+        self.bytes_per_frame = sum(c for _, c, _ in self.plan) * tile * width * 4 * (2 if str(dtype).endswith("float16") else 4)
 
     def owned(self, fb):
-        """view of this rank's bin rows inside a (tiles_y*tile, W, 4) framebuffer"""
-        return fb.view(self.tiles_y, self.tile, self.W, 4)[self.rank::self.world]
+        """this rank's bin rows inside a (tiles_y*tile, W, 4) framebuffer (a copy when they are not evenly strided)"""
+        return fb.view(self.tiles_y, self.tile, self.W, 4)[self.rows]
 
     def __call__(self, fb):
         """returns the assembled (tiles_y*tile, W, 4) image on rank dst (fb itself), None elsewhere.
@@ -44,14 +69,14 @@ class BandGather:
         if fb.is_cuda and dist.get_backend() == "gloo":
             # debug path only (bench.py MSPLAT_BENCH_ONE_DEVICE=1: several ranks on one GPU, no RCCL): gloo moves host
             # memory, so the rows are staged through the CPU here; RCCL sends / receives the device rows in place
-            host = {t: rows[t].cpu() for t, _ in self.plan}
-            for req in dist.batch_isend_irecv([dist.P2POp(op, host[t], peer) for t, peer in self.plan]) if self.plan else []:
+            host = {t: rows[t:t + c].cpu() for t, c, _ in self.plan}
+            for req in dist.batch_isend_irecv([dist.P2POp(op, host[t], peer) for t, _, peer in self.plan]) if self.plan else []:
                 req.wait()
             if self.rank == self.dst:
-                for t, _ in self.plan:
-                    rows[t].copy_(host[t])
+                for t, c, _ in self.plan:
+                    rows[t:t + c].copy_(host[t])
             return fb if self.rank == self.dst else None
-        ops = [dist.P2POp(op, rows[t], peer) for t, peer in self.plan]
+        ops = [dist.P2POp(op, rows[t:t + c], peer) for t, c, peer in self.plan]      # contiguous slices of fb, in place
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()

@@ -47,6 +47,21 @@ public:
         cfg.t_epsilon = tEpsilon;
     }
 
+    // optional, before Init: render on several GPUs from this one process (msplat_group_* in msplat.h).  The
+    // cloud is replicated, the screen's bin rows are partitioned over `devices` (MSPLAT_BANDS_*: contiguous bands by
+    // default) and every device writes its rows into the render target, which must be host memory or memory of
+    // devices[0] (the other devices reach it through the xGMI peer mapping).  Sort / Render are unchanged.
+    // bandCull: Sort also drops splats that cannot reach a device's rows (mono rendering only: every Render must use its
+    // Sort's camera).  Frames in flight are not combined with a device group.
+    void ConfigureDevices(const std::vector<int>& devicesIn, int bandKind = MSPLAT_BANDS_CONTIGUOUS, int blockRows = 1,
+                          bool bandCull = false)
+    {
+        groupDevices.assign(devicesIn.begin(), devicesIn.end());
+        groupKind = bandKind;
+        groupBlockRows = blockRows;
+        groupBandCull = bandCull;
+    }
+
     // optional, before Init: number of frames in flight (default 1).  With depth > 1 every Sort moves on to
     // the next of `depth` contexts (own stream + per-frame buffers, one shared cloud), so successive frames
     // overlap on the GPU the way a GL driver overlaps queued frames; the following Render(s) use the context
@@ -63,6 +78,7 @@ public:
         DestroyContexts();
         cfg.struct_size = sizeof(cfg);
         cfg.srgb = isFramebufferSRGBEnabledIn ? 1 : 0;
+        if (groupDevices.size() > 1) return InitGroup(*gaussianCloud);
         msplat_config c = cfg;
         if (framesInFlight > 1) {
             c.stream = nullptr;
@@ -116,6 +132,12 @@ public:
     void Sort(const Mat4& cameraMat, const Mat4& projMat, const Vec4& viewport, const Vec2& nearFar)
     {
         static_assert(sizeof(Mat4) == 64 && sizeof(Vec4) == 16 && sizeof(Vec2) == 8, "glm-compatible layout expected");
+        if (group) {
+            if (msplat_group_sort(group, reinterpret_cast<const float*>(&cameraMat), reinterpret_cast<const float*>(&projMat),
+                                  reinterpret_cast<const float*>(&viewport), reinterpret_cast<const float*>(&nearFar)) != MSPLAT_OK)
+                std::fprintf(stderr, "[msplat][E] Sort: %s\n", msplat_group_last_error(group));
+            return;
+        }
         if (ctxs.empty()) return;
         cur = (cur + 1) % (int)ctxs.size();
         ctx = ctxs[cur];
@@ -131,6 +153,13 @@ public:
         static_assert(sizeof(Mat4) == 64 && sizeof(Vec4) == 16 && sizeof(Vec2) == 8, "glm-compatible layout expected");
         if (!target) {
             std::fprintf(stderr, "[msplat][E] Render: no render target set (SetRenderTarget)\n");
+            return;
+        }
+        if (group) {
+            if (msplat_group_render(group, reinterpret_cast<const float*>(&cameraMat), reinterpret_cast<const float*>(&projMat),
+                                    reinterpret_cast<const float*>(&viewport), reinterpret_cast<const float*>(&nearFar), target,
+                                    targetPitch, targetIsDevice ? 1 : 0) != MSPLAT_OK)
+                std::fprintf(stderr, "[msplat][E] Render: %s\n", msplat_group_last_error(group));
             return;
         }
         if (msplat_render(ctx, reinterpret_cast<const float*>(&cameraMat), reinterpret_cast<const float*>(&projMat),
@@ -163,6 +192,8 @@ public:
     // (also where a pair-buffer overflow of an earlier device-target Render is reported, see msplat_render)
     void Synchronize()
     {
+        if (group && msplat_group_synchronize(group) != MSPLAT_OK)
+            std::fprintf(stderr, "[msplat][E] Synchronize: %s\n", msplat_group_last_error(group));
         for (msplat_ctx* h : ctxs)
             if (msplat_synchronize(h) != MSPLAT_OK) std::fprintf(stderr, "[msplat][E] Synchronize: %s\n", msplat_last_error(h));
     }
@@ -180,18 +211,59 @@ public:
     }
     int GetFrameSlot() const { return cur; }
 
-    msplat_ctx* GetContext() { return ctx; }   // the context of the latest Sort
+    msplat_ctx* GetContext() { return group ? msplat_group_context(group, 0) : ctx; }   // the context of the latest Sort
+    msplat_group* GetGroup() { return group; }
 
 public:
     uint32_t numBlocksPerWorkgroup = 1024;   // accepted and ignored (splatrenderer.h:39)
 
 protected:
+    bool InitGroup(GaussianCloud& cloud)
+    {
+        std::vector<int32_t> devs(groupDevices.begin(), groupDevices.end());
+        if (msplat_group_create(&group, devs.data(), (uint32_t)devs.size(), &cfg) != MSPLAT_OK) {
+            std::fprintf(stderr, "[msplat][E] %s\n", msplat_group_last_error(nullptr));
+            group = nullptr;
+            return false;
+        }
+        msplat_group_set_layout(group, groupKind, groupBlockRows);
+        msplat_group_set_band_cull(group, groupBandCull ? 1 : 0);
+        msplat_attr_offsets off{};
+        off.pos_with_alpha = (uint32_t)cloud.GetPosWithAlphaAttrib().offset;
+        off.r_sh0 = (uint32_t)cloud.GetR_SH0Attrib().offset;
+        off.g_sh0 = (uint32_t)cloud.GetG_SH0Attrib().offset;
+        off.b_sh0 = (uint32_t)cloud.GetB_SH0Attrib().offset;
+        off.cov3_col0 = (uint32_t)cloud.GetCov3_Col0Attrib().offset;
+        off.cov3_col1 = (uint32_t)cloud.GetCov3_Col1Attrib().offset;
+        off.cov3_col2 = (uint32_t)cloud.GetCov3_Col2Attrib().offset;
+        if (cloud.HasFullSH()) {
+            off.r_sh1 = (uint32_t)cloud.GetR_SH1Attrib().offset; off.r_sh2 = (uint32_t)cloud.GetR_SH2Attrib().offset;
+            off.r_sh3 = (uint32_t)cloud.GetR_SH3Attrib().offset; off.g_sh1 = (uint32_t)cloud.GetG_SH1Attrib().offset;
+            off.g_sh2 = (uint32_t)cloud.GetG_SH2Attrib().offset; off.g_sh3 = (uint32_t)cloud.GetG_SH3Attrib().offset;
+            off.b_sh1 = (uint32_t)cloud.GetB_SH1Attrib().offset; off.b_sh2 = (uint32_t)cloud.GetB_SH2Attrib().offset;
+            off.b_sh3 = (uint32_t)cloud.GetB_SH3Attrib().offset;
+        }
+        if (msplat_group_upload_cloud(group, cloud.GetRawDataPtr(), cloud.GetNumGaussians(), (uint32_t)cloud.GetStride(), &off,
+                                      cloud.HasFullSH() ? 1 : 0) != MSPLAT_OK) {
+            std::fprintf(stderr, "[msplat][E] %s\n", msplat_group_last_error(group));
+            return false;
+        }
+        return true;
+    }
+
     void DestroyContexts()
     {
+        if (group) msplat_group_destroy(group);
+        group = nullptr;
         for (msplat_ctx* h : ctxs) msplat_destroy(h);
         ctxs.clear();
         ctx = nullptr;
     }
+
+    msplat_group* group = nullptr;       // set when ConfigureDevices named more than one device
+    std::vector<int> groupDevices;
+    int groupKind = MSPLAT_BANDS_CONTIGUOUS, groupBlockRows = 1;
+    bool groupBandCull = false;
 
     std::vector<msplat_ctx*> ctxs;       // one per frame in flight; ctxs[0] owns the cloud
     msplat_ctx* ctx = nullptr;           // == ctxs[cur]

@@ -155,9 +155,22 @@ class SplatRenderer:
 
     # -- extensions -------------------------------------------------------------------------
     def set_band(self, row_mod, row_rem, band_cull=False):
+        """interleaved rows: this renderer owns the bin rows t with t % row_mod == row_rem"""
         for h in self._ctxs:
             _capi.check(h, self._lib.msplat_set_band(h, row_mod, row_rem))
             _capi.check(h, self._lib.msplat_set_band_cull(h, 1 if band_cull else 0))
+
+    def set_band_layout(self, first_row, row_count, block, stride, band_cull=False):
+        """general form (msplat_set_band_layout): blocks of `block` bin rows at first_row, first_row + stride, ..."""
+        for h in self._ctxs:
+            _capi.check(h, self._lib.msplat_set_band_layout(h, first_row, row_count, block, stride))
+            _capi.check(h, self._lib.msplat_set_band_cull(h, 1 if band_cull else 0))
+
+    def set_band_plan(self, kind, rows_full, world, rank, block_rows=1, band_cull=False):
+        """rank `rank` of `world` under the layout `kind` ("contiguous" | "interleaved" | "block"); returns the parameters"""
+        lay = _capi.band_plan(kind, rows_full, world, rank, block_rows)
+        self.set_band_layout(*lay, band_cull=band_cull)
+        return lay
 
     def set_depth_test(self, depth_bits):
         """emulated depth buffer: 0 = colour-only target (default), 24 = default back buffer,
@@ -278,3 +291,105 @@ class SplatRenderer:
             self._ctx, ts.ctypes.data_as(C.POINTER(C.c_uint32)), ts.shape[0],
             pairs.ctypes.data_as(C.POINTER(C.c_uint32)), pairs.shape[0]))
         return ts, pairs[:int(st["pairs"])]
+
+
+class SplatRendererGroup:
+    """Several GPUs, one process: the Python mirror of msplat_group_* (include/msplat.h).  Same Init / Sort / Render
+    surface as SplatRenderer; the screen's bin rows are partitioned over `devices`, every device renders its rows, and
+    with a device framebuffer (memory of devices[0]) the other devices' compositors write into it directly over xGMI."""
+
+    def __init__(self, devices, fb_format="fp32", t_epsilon=-1.0, layout="contiguous", block_rows=1, band_cull=False,
+                 enable_timing=False):
+        self._lib = _capi.lib()
+        self._g = None
+        self._devices = [int(d) for d in devices]
+        self._fb_format = {"fp32": _capi.FB_RGBA32F, "fp16": _capi.FB_RGBA16F}[fb_format]
+        self._t_eps = t_epsilon
+        self._layout, self._block_rows, self._band_cull = layout, int(block_rows), bool(band_cull)
+        self._timing = enable_timing
+        self._err = ""
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        g, self._g = getattr(self, "_g", None), None
+        if g:
+            self._lib.msplat_group_destroy(g)
+
+    def last_error(self):
+        return self._lib.msplat_group_last_error(self._g).decode() if self._g else self._err
+
+    def _check(self, rc):
+        if rc != _capi.OK:
+            raise _capi.MsplatError(rc, self._lib.msplat_group_last_error(self._g).decode())
+
+    def Init(self, gaussianCloud, isFramebufferSRGBEnabled=False, useRgcSortOverride=False):
+        del useRgcSortOverride
+        self.close()
+        cfg = _capi.Config()
+        cfg.struct_size = C.sizeof(_capi.Config)
+        cfg.fb_format = self._fb_format
+        cfg.srgb = 1 if isFramebufferSRGBEnabled else 0
+        cfg.t_epsilon = self._t_eps
+        cfg.enable_timing = int(self._timing)
+        devs = (C.c_int32 * len(self._devices))(*self._devices)
+        g = C.c_void_p()
+        rc = self._lib.msplat_group_create(C.byref(g), devs, len(self._devices), C.byref(cfg))
+        if rc != _capi.OK:
+            self._err = self._lib.msplat_group_last_error(None).decode()
+            return False
+        self._g = g
+        self._check(self._lib.msplat_group_set_layout(g, _capi.BAND_KINDS[self._layout], self._block_rows))
+        self._check(self._lib.msplat_group_set_band_cull(g, 1 if self._band_cull else 0))
+        if isinstance(gaussianCloud, GaussianCloud):
+            rc = self._lib.msplat_group_upload_gaussian_cloud(g, gaussianCloud.handle)
+        else:
+            aos = np.ascontiguousarray(gaussianCloud, np.float32)
+            assert aos.shape[1] in (25, 61)
+            off = _capi.AttrOffsets(0, 16, 32, 48, 64, 76, 88, 100, 116, 132, 148, 164, 180, 196, 212, 228)
+            rc = self._lib.msplat_group_upload_cloud(g, aos.ctypes.data, aos.shape[0], aos.shape[1] * 4, C.byref(off),
+                                                     1 if aos.shape[1] == 61 else 0)
+        if rc != _capi.OK:
+            self._err = self._lib.msplat_group_last_error(g).decode()
+            return False
+        return True
+
+    @property
+    def size(self):
+        return int(self._lib.msplat_group_size(self._g))
+
+    def peer_store(self, i):
+        return bool(self._lib.msplat_group_peer_store(self._g, i))
+
+    def context(self, i):
+        """borrowed msplat_ctx handle of rank i (for the C-ABI getters)"""
+        return C.c_void_p(self._lib.msplat_group_context(self._g, i))
+
+    def sort_count(self, i):
+        v = C.c_uint32()
+        h = self.context(i)
+        _capi.check(h, self._lib.msplat_sort_count(h, C.byref(v)))
+        return v.value
+
+    def Sort(self, cameraMat, projMat, viewport, nearFar):
+        _, c = _m(cameraMat, 16); _, p = _m(projMat, 16); _, v = _m(viewport, 4); _, nf = _m(nearFar, 2)
+        self._check(self._lib.msplat_group_sort(self._g, c, p, v, nf))
+
+    def Render(self, cameraMat, projMat, viewport, nearFar, out=None, out_ptr=None, pitch_bytes=0):
+        """out_ptr: device pointer ON devices[0] (asynchronous; synchronize() or wait on context 0's stream);
+        otherwise a host array is filled / returned"""
+        _, c = _m(cameraMat, 16); _, p = _m(projMat, 16); vp, v = _m(viewport, 4); _, nf = _m(nearFar, 2)
+        if out_ptr is not None:
+            self._check(self._lib.msplat_group_render(self._g, c, p, v, nf, C.c_void_p(out_ptr), pitch_bytes, 1))
+            return None
+        W, H = int(vp[2]), int(vp[3])
+        dt = np.float16 if self._fb_format == _capi.FB_RGBA16F else np.float32
+        if out is None:
+            out = np.zeros((H, W, 4), dt)
+        assert out.dtype == dt and out.shape == (H, W, 4) and out.flags["C_CONTIGUOUS"]
+        self._check(self._lib.msplat_group_render(self._g, c, p, v, nf, out.ctypes.data, 0, 0))
+        return out
+
+    def synchronize(self):
+        self._check(self._lib.msplat_group_synchronize(self._g))

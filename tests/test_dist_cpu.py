@@ -1,5 +1,5 @@
-"""N > 1 path on CPU: two / three gloo ranks shard an image by interleaved bin rows (the exact ownership
-rule of msplat_set_band) and rank 0 receives the foreign rows straight into its own framebuffer with
+"""N > 1 path on CPU: two / three gloo ranks shard an image by bin rows -- contiguous bands, interleaved rows or blocks of
+rows dealt round-robin (the ownership rules of msplat_band_plan) -- and rank 0 receives the foreign rows straight into its own framebuffer with
 splatapult_amd.dist.BandGather (grouped send/recv, no pack or unpack copy) -- the one exchange step of the
 multi-GPU path.  The per-band pixels come from the oracle (no GPU here)."""
 import os
@@ -22,13 +22,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, W, H, q):
+def _worker(rank, world, port, W, H, q, layout, block_rows):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as orc
     from splatapult_amd import synthetic
-    from splatapult_amd.dist import BandGather
+    from splatapult_amd import _capi
+    from splatapult_amd.dist import BandGather, owned_rows, row_runs
     from tests import scenes
     cloud = synthetic.make_cloud(1500, seed=5, log_scale_mean=-3.0)
     cam, proj, vp, nf = scenes.default_view(W, H)
@@ -36,11 +37,13 @@ def _worker(rank, world, port, W, H, q):
     T = 32                                   # msplat_tile_size()
     tiles_y = (H + T - 1) // T
     fb = np.zeros((tiles_y * T, W, 4), np.float32)
-    # this rank "renders" only its own tile rows (rows of tile t with t % world == rank)
-    for t in range(rank, tiles_y, world):
+    # this rank "renders" only its own bin rows; the Python ownership rule must be the library's (msplat_band_plan)
+    mine = owned_rows(layout, tiles_y, world, rank, block_rows)
+    assert mine == _capi.band_rows(*_capi.band_plan(layout, tiles_y, world, rank, block_rows), rows_full=tiles_y)
+    for t in mine:
         y0, y1 = t * T, min(t * T + T, H)
         fb[y0:y1] = orc.composite(res["splats"], W, H, row0=y0, row1=y1)[y0:y1]
-    g = BandGather(tiles_y, W, torch.float32, torch.device("cpu"), rank, world, tile=T)
+    g = BandGather(tiles_y, W, torch.float32, torch.device("cpu"), rank, world, tile=T, layout=layout, block_rows=block_rows)
     own = fb.copy()
     t_fb = torch.from_numpy(fb)
     for frame in range(2):                   # the object is reused frame after frame
@@ -52,17 +55,19 @@ def _worker(rank, world, port, W, H, q):
     else:
         assert out is None
         assert np.array_equal(fb, own)                          # senders' framebuffers are untouched
-    assert len(g.plan) == (sum(len(range(s, tiles_y, world)) for s in range(1, world)) if rank == 0
-                           else len(range(rank, tiles_y, world)))
+    nruns = [len(row_runs(owned_rows(layout, tiles_y, world, r, block_rows))) for r in range(world)]
+    assert len(g.plan) == (sum(nruns[1:]) if rank == 0 else nruns[rank])
+    if layout == "contiguous":
+        assert all(n <= 1 for n in nruns)                        # one message per rank and frame
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(world, W, H):
+def _run(world, W, H, layout="interleaved", block_rows=1):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, q, layout, block_rows)) for r in range(world)]
     for p in procs:
         p.start()
     ok = q.get(timeout=120)
@@ -78,3 +83,45 @@ def test_two_ranks_reassemble_the_frame_bit_exact():
 
 def test_three_ranks_uneven_bands():
     assert _run(3, 96, 208)         # 7 tile rows over 3 ranks: 3 + 2 + 2
+
+
+def test_contiguous_bands_one_message_per_rank():
+    assert _run(3, 96, 208, layout="contiguous")          # 7 rows: 2 + 2 + 3
+
+
+def test_block_interleaved_bands():
+    assert _run(2, 64, 300, layout="block", block_rows=2)   # 10 rows, blocks of 2: ragged last row, 5 blocks over 2 ranks
+
+
+def test_band_plan_partitions_every_row_exactly_once():
+    """msplat_band_plan / msplat_set_band_layout arithmetic (host only): for every layout the ranks' rows are disjoint,
+    cover 0..R-1, and agree with the Python restatement the gather plan uses"""
+    sys.path.insert(0, ROOT)
+    from splatapult_amd import _capi
+    from splatapult_amd.dist import owned_rows
+    for R in (0, 1, 7, 34, 128, 256):
+        for world in (1, 2, 3, 8, 9):
+            for kind, k in (("contiguous", 1), ("interleaved", 1), ("block", 2), ("block", 5), ("block", 32)):
+                seen = []
+                for rank in range(world):
+                    first, count, block, stride = _capi.band_plan(kind, R, world, rank, k)
+                    rows = _capi.band_rows(first, count, block, stride, rows_full=R)
+                    assert len(rows) == count and rows == owned_rows(kind, R, world, rank, k), (R, world, kind, k, rank)
+                    assert block >= 1 and stride >= block
+                    seen += rows
+                assert sorted(seen) == list(range(R)), (R, world, kind, k)
+    # argument checks
+    import ctypes as C
+    L = _capi.lib()
+    o = [C.c_int32() for _ in range(4)]
+    refs = [C.byref(x) for x in o]
+    assert L.msplat_band_plan(0, 8, 0, 0, 1, *refs) == _capi.ERR_INVALID_ARG
+    assert L.msplat_band_plan(0, 8, 2, 2, 1, *refs) == _capi.ERR_INVALID_ARG
+    assert L.msplat_band_plan(2, 8, 2, 0, 0, *refs) == _capi.ERR_INVALID_ARG
+    assert L.msplat_band_plan(7, 8, 2, 0, 1, *refs) == _capi.ERR_INVALID_ARG
+    assert L.msplat_set_band_layout(None, 0, 0, 1, 1) == _capi.ERR_INVALID_ARG
+    assert L.msplat_group_create(None, None, 0, None) == _capi.ERR_INVALID_ARG
+    g = C.c_void_p()
+    assert L.msplat_group_create(C.byref(g), None, 2, None) == _capi.ERR_INVALID_ARG and not g.value
+    assert L.msplat_group_sort(None, None, None, None, None) == _capi.ERR_INVALID_ARG
+    L.msplat_group_destroy(None)

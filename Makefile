@@ -22,7 +22,18 @@ build/example_%: splatapult_amd/host/example_%.cpp $(LIB) splatapult_amd/host/ms
 oracle:
 	$(MAKE) -C oracle
 
+# ASan + UBSan over the host half of the library (PLY / JSON / PNG parsers behind the C ABI): no GPU, no hipcc.
+# tests/sanitize/host_sanitize_driver.cpp stubs the device entry points and replays the golden files + hostile inputs.
+SAN = build/host_sanitize
+HOSTSRC = splatapult_amd/host/gaussian_scene.cpp splatapult_amd/host/scene_config.cpp splatapult_amd/host/point_scene.cpp
+sanitize: $(HOSTSRC) tests/sanitize/host_sanitize_driver.cpp include/msplat.h
+	mkdir -p build build/sanitize_scratch
+	$(CXX) -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined -I. \
+	    $(HOSTSRC) tests/sanitize/host_sanitize_driver.cpp -o $(SAN)
+	ASAN_OPTIONS=detect_leaks=1:allocator_may_return_null=1 UBSAN_OPTIONS=print_stacktrace=1 $(SAN) tests/golden build/sanitize_scratch
+	rm -rf build/sanitize_scratch
+
 clean:
 	rm -rf build $(LIB)
 
-.PHONY: all examples oracle clean
+.PHONY: all examples oracle clean sanitize

@@ -61,8 +61,16 @@ WORKLOADS = {
                  desc="6M synthetic Gaussians, SH3, 4096x4096 fp32 (BASELINE configs[3])"),
     "cfg5": dict(n=1_000_000, seed=0x5EED1234, pos_sigma=1.5, W=2016, H=2240, cam_z=7.0, fb="fp16", views=2,
                  desc="1M synthetic Gaussians, stereo 2x2016x2240 fp16, one sort (BASELINE configs[4])"),
+    # configs[2] again, scene-LIKE (r3): surface-concentrated positions, heavy-tailed anisotropic scales, 1 % background splats
+    # that span a quarter of the view, bimodal opacity, cameras INSIDE the cloud; written as an Inria-style PLY + cameras.json and
+    # replayed through the file path (Ply::Parse -> GPU ingest, CamerasConfig::ImportJson: camerasconfig.cpp:20-67)
+    "cfg3s": dict(n=6_000_000, seed=0x5CE11E, scene=True, W=1920, H=1080, cam_z=0.0, fb="fp32", views=1,
+                  desc="6M scene-like synthetic splats (surfaces, log-scale sigma 1.2, 1% background, camera inside), SH3, "
+                       "1920x1080 fp32, PLY + cameras.json replay (BASELINE configs[2] stand-in)"),
     "tiny": dict(n=20_000, seed=7, pos_sigma=1.5, W=640, H=360, cam_z=7.0, fb="fp32", views=1,
                  desc="20k synthetic Gaussians, 640x360 (debug)"),
+    "tinys": dict(n=60_000, seed=0x5CE11E, scene=True, W=640, H=360, cam_z=0.0, fb="fp32", views=1,
+                  desc="60k scene-like synthetic splats, 640x360, PLY + cameras.json replay (debug)"),
 }
 HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md
 VALU_PEAK = 157.3e12     # fp32 vector FLOP/s, MI355X_MICROARCH.md
@@ -85,13 +93,25 @@ def measure(E, args, key, ply=None, primary=True):
     wl = dict(WORKLOADS[key])
     W, H, views = wl["W"], wl["H"], wl["views"]
     scene_cams = None
+    scene_dir = None
+    if wl.get("scene") and not ply:
+        # the scene-like workload goes through the FILE path: attributes -> PLY + cameras.json in a scratch directory
+        import tempfile
+        scene_dir = tempfile.mkdtemp(prefix="msplat_scene_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        ply = os.path.join(scene_dir, "point_cloud", "iteration_30000", "point_cloud.ply")
+        if rank == 0 or world == 1 or True:       # every rank writes its own copy (ranks do not share the scratch directory)
+            os.makedirs(os.path.dirname(ply))
+            synthetic.write_ply(ply, synthetic.generate_scene(wl["n"], seed=wl["seed"]))
+            synthetic.write_cameras_json(os.path.join(scene_dir, "cameras.json"), synthetic.scene_cameras(64), W, H, camera.FOVY)
+    from_file = ply is not None
     if ply:
         from splatapult_amd import GaussianCloud
         cloud = GaussianCloud()
         if not cloud.ImportPly(ply):
             raise SystemExit("cannot import " + ply)
         wl["n"] = cloud.GetNumGaussians()
-        wl["desc"] = "%s (%d splats), %dx%d %s" % (os.path.basename(ply), wl["n"], W, H, wl["fb"])
+        if not wl.get("scene"):
+            wl["desc"] = "%s (%d splats), %dx%d %s" % (os.path.basename(ply), wl["n"], W, H, wl["fb"])
         cj = camera.find_config_file(ply, "cameras.json")          # app.cpp:418-461
         if cj:
             scene_cams = [m for m, _ in camera.load_cameras_json(cj)]
@@ -102,14 +122,30 @@ def measure(E, args, key, ply=None, primary=True):
     P = max(1, args.frames_in_flight)
     r = SplatRenderer(device=E.local_rank, fb_format=wl["fb"], stream=stream.cuda_stream,
                       enable_timing=args.timing_stride, frames_in_flight=P)
-    if not r.Init(cloud, False, False):
-        raise SystemExit("Init failed: " + r.last_error())
-    if world > 1:
-        # mono workloads may also restrict the cull to the band (every Render uses its Sort's camera)
-        r.set_band(world, rank, band_cull=(views == 1))
 
+    def init(rr):
+        # a file is rendered the way the app would: Ply::Parse on the host + GaussianCloud::ImportPly's math on the GPU
+        ok = rr.InitFromPly(ply, True, False) if from_file else rr.Init(cloud, False, False)
+        if not ok:
+            raise SystemExit("Init failed: " + rr.last_error())
+
+    init(r)
+    pair_cap0 = int(max(4 << 20, 32 * n))           # the library's initial (splat, bin) pair capacity: max(4 M, 32 N)
     TILE = _capi.lib().msplat_tile_size()
     tiles_y = (H + TILE - 1) // TILE
+    # bin-row layout over the ranks (msplat_band_plan): "contiguous" | "interleaved" | "block:k"; auto = blocks of
+    # ~rows / (4 ranks) rows dealt round-robin -- four blocks per rank balance the load of a centred scene while the
+    # band-restricted cull still drops most of the splats of the other ranks' rows (profiles/r03_cfg4_bands.json)
+    lay = args.layout
+    if lay == "auto":
+        lay = "block:%d" % max(1, tiles_y // (4 * world))
+    lay_kind, lay_k = (lay.split(":")[0], int(lay.split(":")[1])) if ":" in lay else (lay, 1)
+    if lay_kind == "block" and lay_k == 1:
+        lay_kind = "interleaved"
+    if world > 1:
+        # mono workloads may also restrict the cull to the band (every Render uses its Sort's camera)
+        r.set_band_plan(lay_kind, tiles_y, world, rank, block_rows=lay_k, band_cull=(views == 1))
+
     Hpad = tiles_y * TILE
     fdt = torch.float16 if wl["fb"] == "fp16" else torch.float32
     bpp = 8 if wl["fb"] == "fp16" else 16
@@ -134,7 +170,7 @@ def measure(E, args, key, ply=None, primary=True):
     gathers = None
     if world > 1:
         from splatapult_amd.dist import BandGather
-        gathers = [BandGather(tiles_y, W, fdt, dev, rank, world, tile=TILE) for _ in range(views)]
+        gathers = [BandGather(tiles_y, W, fdt, dev, rank, world, tile=TILE, layout=lay_kind, block_rows=lay_k) for _ in range(views)]
     state = {"fbs": fb_sets[0]}
 
     def frame(step, rr=r, sets=fb_sets):
@@ -206,10 +242,9 @@ def measure(E, args, key, ply=None, primary=True):
     else:
         rs = SplatRenderer(device=E.local_rank, fb_format=wl["fb"], stream=stream.cuda_stream, enable_timing=4,
                            frames_in_flight=1)     # stage events on every 4th frame: they cost a few us each
-        if not rs.Init(cloud, False, False):
-            raise SystemExit("Init (serial renderer) failed: " + rs.last_error())
+        init(rs)
         if world > 1:
-            rs.set_band(world, rank, band_cull=(views == 1))
+            rs.set_band_plan(lay_kind, tiles_y, world, rank, block_rows=lay_k, band_cull=(views == 1))
         rs_sets = [fb_sets[0]]
     for s in range(24):
         frame(s, rs, rs_sets)
@@ -242,6 +277,9 @@ def measure(E, args, key, ply=None, primary=True):
         if views == 1:
             works.append(rs.composite_work())
     rs.set_tile_probe(False)
+    ts_last, _ = rs.debug_tile_lists(want_pairs=False)
+    longest_list = int(np.diff(ts_last.astype(np.int64)).max()) if ts_last.shape[0] > 1 else 0
+    pair_cap_end = int(rs.stats()["pair_capacity"])
     V, D = float(np.mean(Vs)), float(np.mean(Ds))
     work = {k: float(np.mean([w[k] for w in works])) for k in works[0]} if works else None
     if world > 1:
@@ -272,7 +310,7 @@ def measure(E, args, key, ply=None, primary=True):
     # (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE in their own passes, gfx950 x2 correction on FETCH_SIZE);
     # the committed summary is only quoted for the workload it was measured on
     traffic, tsrc = None, None
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, key))
         if world == 1 and os.path.exists(tpath):
             try:
@@ -317,10 +355,13 @@ def measure(E, args, key, ply=None, primary=True):
         "gsplats_per_sec": n * fps / 1e9,
         "rccl_ranks": world if (world > 1 and not E.one_dev) else (0 if world > 1 else 1),
         "config": {"workload": wl["desc"], "key": key, "splats": n, "width": W, "height": H,
-                   "views": views, "framebuffer": wl["fb"], "sharding": "bin rows, row %% %d == rank" % world,
+                   "views": views, "framebuffer": wl["fb"],
+                   "sharding": ("bin rows of %d px over %d ranks, layout %s" % (TILE, world, lay)) if world > 1 else "none (one GPU)",
                    "frames_in_flight": P, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                    "visible_V": V, "pairs_D": D_total, "pairs_binned_32px": float(np.mean(Dbin)),
-                   "drawn": float(np.mean(drawn))},
+                   "drawn": float(np.mean(drawn)), "D_over_N": D_total / max(1, n),
+                   "longest_bin_list": longest_list, "pair_capacity": pair_cap_end, "pair_capacity_initial": pair_cap0,
+                   "cameras": ("cameras.json, %d poses" % len(scene_cams)) if scene_cams else "64-step orbit"},
         "timed_blocks": len(blocks), "block_ms": [1e3 * b for b in blocks],
         "serial": {"frames_per_sec": 1e3 / serial_ms, "ms_per_frame": serial_ms, "frames": SER,
                    "single_frame_latency_ms_host_to_host": latency_ms, "stages_ms": prof_serial},
@@ -339,13 +380,16 @@ def measure(E, args, key, ply=None, primary=True):
         out["gather"]["bytes_into_rank0_per_frame"] = float(t.item())
 
     if rank == 0 and world == 1 and primary and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cloud, wl, cams_for, projs, vp, nf, args.cpu_frames)
+        out["cpu_baseline"], out["cpu_baseline_literal"] = cpu_baseline(cloud, wl, cams_for, projs, vp, nf, args.cpu_frames)
     if rank == 0 and primary and args.save_image:
         img = state["fbs"][0][:H].float().cpu().numpy()
         camera.write_image(args.save_image, img)
     if rs is not r:
         rs.close()
     r.close()
+    if scene_dir:
+        import shutil
+        shutil.rmtree(scene_dir, ignore_errors=True)
     return out
 
 
@@ -359,6 +403,8 @@ def main():
                     "embedded under \"also\" (default: cfg4 when --gpus > 1 -- the row-sharded BASELINE configs[3])")
     ap.add_argument("--ply", default=None, help="render a real scene instead of the synthetic workload (BASELINE configs[2]: "
                     "Inria point_cloud.ply); cameras.json next to it (or up to two directories above) is replayed")
+    ap.add_argument("--layout", default="auto", help="N > 1: how the bin rows are dealt to the ranks: contiguous | interleaved | "
+                    "block:k (blocks of k rows round-robin) | auto")
     ap.add_argument("--save-image", default=None, help="write the last frame of rank 0 as PNG")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="CPU baseline frames (0 = auto, about 10-30 s)")
@@ -425,30 +471,50 @@ def main():
 
 
 def cpu_baseline(cloud, wl, cams_for, projs, vp, nf, frames):
-    """The oracle (C restatement of the reference shaders; the reference has no CPU path of its own)
-    timed on the host cores on a bounded sample: `frames` whole frames of the same workload."""
+    """The CPU-side sort + raster path on the host cores (the reference has none of its own: src/sdl_main.cpp:28 is a
+    commented-out define): oracle/msplat_cpu_tiled.c -- parallel cull / stable radix sort / projection, 16x16-tile binning,
+    front-to-back compositor with early termination -- timed on a bounded sample of the same workload; next to it the
+    literal oracle (the reference shaders restated one to one, back-to-front over every pixel row band) on one frame."""
     from oracle import oracle as orc
     cores = os.cpu_count() or 1
     aos = cloud.as_array()
     views = wl["views"]
+    W, H = int(vp[2]), int(vp[3])
+    img = np.zeros((H, W, 4), np.float32)
 
-    def one(step):
+    def one(step, stages=None):
         cams = cams_for(step)
         t = time.perf_counter()
         for v in range(views):
-            orc.render_frame(aos, True, cams[0], projs[0], vp, nf, render_cam=cams[v], render_proj=projs[v],
-                             nthreads=cores)
+            r = orc.render_frame_tiled(aos, True, cams[0], projs[0], vp, nf, render_cam=cams[v], render_proj=projs[v],
+                                       nthreads=cores, image=img)
+            if stages is not None:
+                stages.append(r["stages_ms"])
         return time.perf_counter() - t
 
+    one(0)                                            # first touch of the work buffers
     t_first = one(0)
     if frames <= 0:
-        frames = int(max(1, min(8, 15.0 // max(t_first, 1e-3))))
-    times = [t_first] + [one(s) for s in range(1, frames)]
+        frames = int(max(3, min(64, 12.0 // max(t_first, 1e-3))))
+    stages = []
+    times = [one(s, stages) for s in range(frames)]
     sec = float(np.median(times))
-    return {"value": 1.0 / sec, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d frame(s) of the same workload (orbit steps 0..%d), median, all %d host threads, "
-                      "oracle/msplat_oracle.c via OpenMP row bands" % (len(times), len(times) - 1, cores),
-            "sec_per_frame": sec, "gsplats_per_sec": wl["n"] / sec / 1e9}
+    st = {k: float(np.median([s[k] for s in stages])) for k in stages[0]}
+    out = {"value": 1.0 / sec, "unit": "frames/s", "cores": cores, "kind": "port-tiled",
+           "sample": "%d frame(s) of the same workload (orbit steps 0..%d), median, %d host threads (OpenMP), "
+                     "oracle/msplat_cpu_tiled.c: tile-binned, front-to-back, early termination at T < 2^-14"
+                     % (len(times), len(times) - 1, cores),
+           "sec_per_frame": sec, "gsplats_per_sec": wl["n"] / sec / 1e9, "stages_ms": st}
+    # the literal restatement of the reference shaders (what cpu_baseline was in rounds 1-2): one frame
+    cams = cams_for(0)
+    t = time.perf_counter()
+    for v in range(views):
+        orc.render_frame(aos, True, cams[0], projs[0], vp, nf, render_cam=cams[v], render_proj=projs[v], nthreads=cores)
+    lit = time.perf_counter() - t
+    return out, {"value": 1.0 / lit, "unit": "frames/s", "cores": cores, "kind": "port",
+                 "sample": "1 frame (orbit step 0), %d host threads, oracle/msplat_oracle.c via OpenMP row bands (every band "
+                           "walks all visible splats back to front; single-threaded sort)" % cores,
+                 "sec_per_frame": lit}
 
 
 if __name__ == "__main__":

@@ -36,7 +36,12 @@ enum {
     MSPLAT_ERR_UNSUPPORTED = -6,   /* e.g. viewport larger than 8192x8192                    */
     MSPLAT_ERR_PAIR_OVERFLOW = -7, /* (splat,bin) pair buffer too small: host-output renders grow it and retry,   */
                                    /* device-output renders report it on the NEXT call (see msplat_render)     */
-    MSPLAT_ERR_IO = -8             /* PLY open/parse failure                                 */
+    MSPLAT_ERR_IO = -8,            /* PLY open/parse failure                                 */
+    MSPLAT_ERR_PAIR_OVERFLOW_EARLIER = -9  /* msplat_sort / msplat_render: THIS call did its work (the sort ran, the image
+                                      was written), but an EARLIER device-output render on the context had overflowed the
+                                      pair buffer (that frame lacks splats; the buffer has been grown unless its capacity is
+                                      fixed).  A warning about a past frame, not a failure of the call.  msplat_synchronize
+                                      reports the same event as MSPLAT_ERR_PAIR_OVERFLOW. */
 };
 
 enum { MSPLAT_FB_RGBA32F = 0, MSPLAT_FB_RGBA16F = 1 };
@@ -109,8 +114,8 @@ typedef struct msplat_composite_work {
     uint64_t list_entries;        /* sum of the bin-list lengths: what it would fetch without early-out   */
     uint64_t pair_words_fetched;  /* 4-byte list entries whose loads were issued                          */
     uint64_t records_fetched;     /* 48-byte projected records whose loads were issued                    */
-    uint64_t records_composited;  /* records that passed the exact footprint test of their work item: a 16x8  */
-                                  /* half tile (default), a 16x16 tile or an 8x8 sub-block (MSPLAT_COMPOSITOR) */
+    uint64_t records_composited;  /* records that passed the exact footprint test of their work item: a 16x16 */
+                                  /* tile (default), a 16x8 half tile or an 8x8 sub-block (MSPLAT_COMPOSITOR)  */
     uint64_t pixel_evals;         /* (pixel, splat) evaluations = 128 / 256 / 64 per composited record    */
     uint64_t batches;             /* 64-entry batches staged                                              */
     uint64_t clocks_sum, clocks_max, inner_clocks_sum;   /* shader clocks per work item (probe overhead included) */
@@ -226,7 +231,8 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
  * host-output render grows the buffer and retries before it returns.  A device-output render cannot know:
  * the binning kernel leaves the needed pair count in host-mapped memory, and the NEXT msplat_sort /
  * msplat_render / msplat_synchronize on the context (which still does its own work) grows the buffer -- unless
- * msplat_config.pair_capacity fixed it -- and returns MSPLAT_ERR_PAIR_OVERFLOW once: the frame that overflowed
+ * msplat_config.pair_capacity fixed it -- and reports it once (msplat_synchronize: MSPLAT_ERR_PAIR_OVERFLOW; msplat_sort /
+ * msplat_render, whose own work is still done: MSPLAT_ERR_PAIR_OVERFLOW_EARLIER): the frame that overflowed
  * lacks splats in its last bin columns and should be re-rendered.
  * Limits: at most 2^24 splats per cloud (24-bit rank field in the pair words) and viewports up to 8192 x 8192
  * (256 x 256 bins of 32 px); beyond them msplat_upload_* / msplat_sort return MSPLAT_ERR_UNSUPPORTED. */
@@ -324,7 +330,9 @@ int msplat_debug_verify_order(msplat_ctx* ctx, uint32_t* key_violations, uint32_
  *  bin-list length, ran}.  Off by default (a few clock reads per batch); MSPLAT_TILE_PROBE=1 in the environment
  * turns it on at msplat_create. */
 int msplat_set_tile_probe(msplat_ctx* ctx, int enable);
-int msplat_debug_get_tile_probe(msplat_ctx* ctx, uint32_t* dst8, uint32_t tile_cap);
+/* (the getter carries the record size in its name: an out-of-tree caller built for the 4-word records of the first
+ * release fails to link instead of overrunning its buffer) */
+int msplat_debug_get_tile_probe8(msplat_ctx* ctx, uint32_t* dst8, uint32_t tile_cap);
 int msplat_get_composite_work(msplat_ctx* ctx, msplat_composite_work* out);
 
 /* ---- scene data: GaussianCloud / Ply surface (gaussiancloud.h:17-91, ply.h:19-46) -------- */

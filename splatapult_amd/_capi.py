@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get("MSPLAT_LIB_PATH") or os.path.join(_HERE, "lib", "libm
 OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NO_CLOUD, ERR_NO_SORT, ERR_UNSUPPORTED, ERR_PAIR_OVERFLOW, ERR_IO = \
     -1, -2, -3, -4, -5, -6, -7, -8
+ERR_PAIR_OVERFLOW_EARLIER = -9      # the call did its work; an EARLIER device-output frame had overflowed the pair buffer
 FB_RGBA32F, FB_RGBA16F = 0, 1
 ROP_NONE, ROP_RGBA8, ROP_RGBA16F = 0, 1, 2
 RANK_AUTO, RANK_BALLOT = 0, 1
@@ -119,7 +120,7 @@ SYMBOLS = [
     ("msplat_get_timings", C.c_int, [C.c_void_p, C.POINTER(Timings)]),
     ("msplat_debug_get_projected", C.c_int, [C.c_void_p, _F16, _U32P, C.c_uint32]),
     ("msplat_debug_get_tile_lists", C.c_int, [C.c_void_p, _U32P, C.c_uint32, _U32P, C.c_uint64]),
-    ("msplat_debug_get_tile_probe", C.c_int, [C.c_void_p, _U32P, C.c_uint32]),
+    ("msplat_debug_get_tile_probe8", C.c_int, [C.c_void_p, _U32P, C.c_uint32]),
     ("msplat_set_tile_probe", C.c_int, [C.c_void_p, C.c_int]),
     ("msplat_debug_verify_order", C.c_int, [C.c_void_p, _U32P, _U32P]),
     ("msplat_get_composite_work", C.c_int, [C.c_void_p, C.POINTER(CompositeWork)]),
@@ -169,7 +170,17 @@ def lib():
     return _LIB
 
 
+class EarlierFrameOverflow(UserWarning):
+    """msplat_sort / msplat_render succeeded, but an earlier device-output render on the context had overflowed the pair
+    buffer (MSPLAT_ERR_PAIR_OVERFLOW_EARLIER): that frame lacks splats and should be rendered again"""
+
+
 def check(ctx, rc):
+    if rc == ERR_PAIR_OVERFLOW_EARLIER:          # a warning about a past frame: this call's result is valid
+        import warnings
+        msg = lib().msplat_last_error(ctx)
+        warnings.warn(EarlierFrameOverflow(msg.decode() if msg else "an earlier frame overflowed the pair buffer"), stacklevel=3)
+        return
     if rc != OK:
         msg = lib().msplat_last_error(ctx)
         raise MsplatError(rc, msg.decode() if msg else "")

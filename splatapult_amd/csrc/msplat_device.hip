@@ -87,13 +87,13 @@ struct msplat_ctx {
     bool bin_counts = true;     // MSPLAT_TILE_TABLE=search: tile_start_kernel / tile_order_kernel as in r2
     bool scan_free = true;  // MSPLAT_SCAN_KERNELS=1 forces the 3-kernel (upsweep, scan, downsweep) passes
     uint32_t fused_max_chunks = kFusedMaxChunks;   // MSPLAT_FUSED_MAX_CHUNKS: scan-free passes up to this many chunk rows
-    // compositor formulation: 0 = one wave per 16x16 tile, 1 = one wave per 16x8 half tile (default), 2 = four waves per
+    // compositor formulation: 0 = one wave per 16x16 tile (default), 1 = one wave per 16x8 half tile, 2 = four waves per
     // tile (composite_quad_kernel, LDS-bound, kept for comparison); MSPLAT_COMPOSITOR=wave|half|quad
     int comp_kind = 0;
     bool comp_ftz = true;   // discard by underflow in the compositor (MSPLAT_COMP_FTZ=0: compare + select)
     int comp_xcd = 1;       // the four quadrants of a bin run on one XCD (MSPLAT_COMP_XCD=0: plain item order)
     bool comp_always_order = false;   // MSPLAT_COMP_ORDER=1: heaviest-first order for persistent waves too (A/B)
-    int comp_prio = 1;      // wave issue priority follows the work item's weight (MSPLAT_COMP_PRIO=0: all equal)
+    int comp_prio = -1;     // wave issue priority follows the work item's weight: -1 auto, 0 off, 1 by item number, 2 by list length
     Buf totals;     // uint32[256]  digit totals of the current radix pass (rows in binning pass 2)
     Buf totals1;    // uint32[256]  column totals of binning pass 1
     Buf counters;   // uint32[16]: 0=V, 1=D, 2=overflow, 4=drawn, 6..7=pairs16 (u64), 8=probe
@@ -460,6 +460,9 @@ int msplat_set_target_emulation(msplat_ctx* ctx, int rop)
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if (rop != MSPLAT_ROP_NONE && rop != MSPLAT_ROP_RGBA8 && rop != MSPLAT_ROP_RGBA16F)
         return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_set_target_emulation: rop must be MSPLAT_ROP_NONE, _RGBA8 or _RGBA16F (got %d)", rop);
+    if (rop != MSPLAT_ROP_NONE && ctx->point_mode)
+        return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "msplat_set_target_emulation: the point-cloud sprite compositor has no render-target "
+                    "emulation (the context holds a point cloud)");
     ctx->rop = rop;
     return MSPLAT_OK;
 }
@@ -817,6 +820,9 @@ int msplat_upload_points(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t 
     if (stride_bytes % 4 != 0 || position_offset + 16u > stride_bytes || color_offset + 16u > stride_bytes)
         return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_upload_points: bad stride / offsets (%u, %u, %u)", stride_bytes,
                     position_offset, color_offset);
+    if (ctx->rop != MSPLAT_ROP_NONE)
+        return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "msplat_upload_points: render-target emulation is set on this context and the "
+                    "sprite compositor has none (msplat_set_target_emulation(ctx, MSPLAT_ROP_NONE) first)");
     ctx->point_mode = true;
     int rc = prepare_cloud_buffers(ctx, n, false, nullptr);
     if (rc) { ctx->point_mode = false; return rc; }
@@ -1095,7 +1101,7 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
             return fail(ctx, MSPLAT_ERR_HIP, "msplat_sort: a kernel launch failed");
         }
         ctx->has_sort = true;
-        if (pending) return fail(ctx, pending, "%s", pending_msg.c_str());
+        if (pending) return fail(ctx, MSPLAT_ERR_PAIR_OVERFLOW_EARLIER, "%s", pending_msg.c_str());
         return MSPLAT_OK;
     }
     // scan-free passes (2 launches each) while the chunk table is small, else upsweep + scan + downsweep
@@ -1148,7 +1154,7 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
         return fail(ctx, MSPLAT_ERR_HIP, "msplat_sort: a kernel launch failed");
     }
     ctx->has_sort = true;
-    if (pending) return fail(ctx, pending, "%s", pending_msg.c_str());
+    if (pending) return fail(ctx, MSPLAT_ERR_PAIR_OVERFLOW_EARLIER, "%s", pending_msg.c_str());
     return MSPLAT_OK;
 }
 
@@ -1255,6 +1261,9 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const int cgrid = std::min(ntiles * 4, ctx->comp_waves);     // work items = (bin, quadrant)
     // (frames in flight: serialising the compositor launches of the contexts sharing a cloud with an event
     //  gate was measured r1 -- no gain over letting the hardware queues interleave them, dropped)
+    if (ntiles > 0 && ctx->probe_on && ctx->probe.p && (ctx->point_mode || ctx->depth_bits != 0 || ctx->rop != 0))
+        // the draw-order compositors do not write the probe: leave zeros, not an earlier frame's counters
+        HIP_TRY(ctx, hipMemsetAsync(ctx->probe.p, 0, (size_t)ntiles * 8 * kProbeWords * sizeof(uint32_t), s));
     if (ntiles > 0 && ctx->point_mode) {
         // sprites in draw order (optionally against the emulated depth buffer)
         const uint32_t* zqp = ctx->depth_bits ? (const uint32_t*)ctx->zq.p : nullptr;
@@ -1306,10 +1315,14 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
             // one wave per 16x8 half tile (twice the work items) or per 16x16 tile
             const bool half = ctx->comp_kind == 1;
             const uint32_t nitems = comp_items, pool = comp_pool;
+            // wave issue priority: by item number where the items are numbered heaviest-first, by the bin's list length where
+            // persistent waves walk the bins in storage order (the item number says nothing there);
+            // MSPLAT_COMP_PRIO = 0 none, 1 item number, 2 list length, unset: automatic
+            const int prio_mode = ctx->comp_prio < 0 ? (ordered ? 1 : 2) : ctx->comp_prio;
             const int grid = (int)std::min<uint32_t>(nitems, pool);
 #define MSPLAT_LAUNCH_COMP(F16, NP, OCC, FZ)                                                                          \
     hipExtLaunchKernelGGL((composite_kernel<F16, NP, OCC, FZ>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, \
-                          d_out, pitch, fp, cap, ord, d_queue, nitems, probe, ctx->comp_prio, ctx->comp_xcd)
+                          d_out, pitch, fp, cap, ord, d_queue, nitems, probe, prio_mode, ctx->comp_xcd)
 #define MSPLAT_LAUNCH_COMP_F(NP, OCC, FZ) do { if (f16) MSPLAT_LAUNCH_COMP(true, NP, OCC, FZ); else MSPLAT_LAUNCH_COMP(false, NP, OCC, FZ); } while (0)
             if (half) {                          // experiment: one wave per 16x8 half tile
                 MSPLAT_LAUNCH_COMP_F(1, 6, false);
@@ -1366,7 +1379,7 @@ int msplat_render(msplat_ctx* ctx, const float cameraMat[16], const float projMa
         rc = launch_render(ctx, fp, rgba, pitch_bytes, true);
         if (rc) return rc;
         ctx->has_render = true;
-        if (pending) return fail(ctx, pending, "%s", pending_msg.c_str());
+        if (pending) return fail(ctx, MSPLAT_ERR_PAIR_OVERFLOW_EARLIER, "%s", pending_msg.c_str());
         return MSPLAT_OK;
     }
     // host output: render into an internal device framebuffer, copy back, grow the pair buffer on overflow
@@ -1396,7 +1409,7 @@ int msplat_render(msplat_ctx* ctx, const float cameraMat[16], const float projMa
                 HIP_TRY(ctx, hipMemcpy2D(rgba, pitch_bytes, ctx->fb.p, tight, tight, fp.height, hipMemcpyDeviceToHost));
             }
             ctx->has_render = true;
-            if (pending) return fail(ctx, pending, "%s", pending_msg.c_str());
+            if (pending) return fail(ctx, MSPLAT_ERR_PAIR_OVERFLOW_EARLIER, "%s", pending_msg.c_str());
             return MSPLAT_OK;
         }
         // overflow: cnt[2] holds the required pair count
@@ -1549,7 +1562,7 @@ int msplat_debug_verify_order(msplat_ctx* ctx, uint32_t* key_violations, uint32_
     return MSPLAT_OK;
 }
 
-int msplat_debug_get_tile_probe(msplat_ctx* ctx, uint32_t* dst, uint32_t tile_cap)
+int msplat_debug_get_tile_probe8(msplat_ctx* ctx, uint32_t* dst, uint32_t tile_cap)
 {
     if (!ctx || !dst) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
     if (!ctx->probe.p || !ctx->probe_on)
@@ -1580,7 +1593,7 @@ int msplat_get_composite_work(msplat_ctx* ctx, msplat_composite_work* out)
     } catch (const std::exception&) {
         return fail(ctx, MSPLAT_ERR_HIP, "out of host memory");
     }
-    int rc = msplat_debug_get_tile_probe(ctx, h.data(), items);
+    int rc = msplat_debug_get_tile_probe8(ctx, h.data(), items);
     if (rc) return rc;
     for (uint32_t t = 0; t < items; ++t) {
         const uint32_t* p = &h[(size_t)t * kProbeWords];

@@ -108,7 +108,7 @@ int gfail(msplat_group* g, int code, const char* fmt, ...)
 }
 
 // runs f(i) for every rank: ranks >= 1 on their worker threads, rank 0 on the caller's; returns the first real error
-// (MSPLAT_ERR_PAIR_OVERFLOW -- a deferred report about an EARLIER frame -- only if nothing worse happened)
+// (MSPLAT_ERR_PAIR_OVERFLOW[_EARLIER] -- a deferred report about an EARLIER frame -- only if nothing worse happened)
 int for_all(msplat_group* g, const std::function<int(uint32_t)>& f)
 {
     const uint32_t n = (uint32_t)g->ctx.size();
@@ -119,7 +119,10 @@ int for_all(msplat_group* g, const std::function<int(uint32_t)>& f)
     int soft = MSPLAT_OK;
     for (uint32_t i = 0; i < n; ++i) {
         if (rc[i] == MSPLAT_OK) continue;
-        if (rc[i] == MSPLAT_ERR_PAIR_OVERFLOW) { if (!soft) { soft = rc[i]; g->err = msplat_last_error(g->ctx[i]); } continue; }
+        if (rc[i] == MSPLAT_ERR_PAIR_OVERFLOW || rc[i] == MSPLAT_ERR_PAIR_OVERFLOW_EARLIER) {
+            if (!soft) { soft = rc[i]; g->err = msplat_last_error(g->ctx[i]); }
+            continue;
+        }
         g->err = std::string("device ") + std::to_string(g->devices[i]) + ": " + msplat_last_error(g->ctx[i]);
         g_group_error = g->err;
         return rc[i];
@@ -307,7 +310,7 @@ int msplat_group_render(msplat_group* g, const float cameraMat[16], const float 
         if (i == 0 || g->peer_store[i]) {
             // zero-copy: this device's compositor writes its rows where they belong in device 0's framebuffer
             int r = msplat_render(c, cameraMat, projMat, viewport, nearFar, rgba, pitch_bytes, 1);
-            if (r && r != MSPLAT_ERR_PAIR_OVERFLOW) return r;
+            if (r && r != MSPLAT_ERR_PAIR_OVERFLOW_EARLIER) return r;
             if (i != 0) { const int j = msplat_stream_wait(c, stream0); if (j) return j; }
             return r;
         }
@@ -323,7 +326,7 @@ int msplat_group_render(msplat_group* g, const float cameraMat[16], const float 
             g->stage_bytes[i] = need;
         }
         int r = msplat_render(c, cameraMat, projMat, viewport, nearFar, g->stage[i], tight, 1);
-        if (r && r != MSPLAT_ERR_PAIR_OVERFLOW) return r;
+        if (r && r != MSPLAT_ERR_PAIR_OVERFLOW_EARLIER) return r;
         int32_t first, count, block, stride;
         const int rows_full = (H + T - 1) / T;
         int pr = msplat_band_plan(g->kind, rows_full, (int32_t)n, (int32_t)i, g->block_rows, &first, &count, &block, &stride);

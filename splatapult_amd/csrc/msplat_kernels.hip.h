@@ -1701,8 +1701,9 @@ __global__ __launch_bounds__(kThreads) void verify_order_kernel(const uint32_t* 
 // half-tile launch pulling 8 k items from one head spent ~90 us queueing), so the head is sharded: item i lives
 // in shard i % 32, a workgroup pulls from the shard of its index and, when that one is drained, from up to two
 // neighbours (checked with a plain load first, so drained shards are not hammered by the exiting waves).
-// Items are stored heaviest-first, so every shard hands out its share heaviest-first too.  The first item of every
-// workgroup is static (its own index): queue[s] counts only the items of shard s taken dynamically.
+// Where the items are numbered heaviest-first (every item on its own wave, or MSPLAT_COMP_ORDER=1) every shard hands out its
+// share heaviest-first too; persistent waves otherwise walk the bins in storage order (`tile_order` + 65536).  The first item
+// of every workgroup is static (its own index): queue[s] counts only the items of shard s taken dynamically.
 __device__ __forceinline__ uint32_t queue_next(uint32_t* __restrict__ queue, uint32_t nitems)
 {
     const uint32_t home = blockIdx.x % kQueueShards;
@@ -1850,7 +1851,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
     // fifth of the issue slots.  Items are numbered heaviest-first, so the wave's issue priority follows the item
     // number: the heaviest thousand items run at the single-wave issue rate from the start and the light ones fill
     // the slots they leave (SIMD arbitration is priority first, then age -- MI355X_MICROARCH.md).
-    if (prio_levels > 0) {
+    if (prio_levels == 1) {
         const uint32_t band = max(ntiles >> 3, 1u);                    // an eighth of the items per priority step
         const uint32_t lvl = qpos / band;
         if (lvl == 0u) __builtin_amdgcn_s_setprio(3);
@@ -1868,6 +1869,15 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
     uint32_t start = tile_start[bin], end = tile_start[bin + 1];
     if (start > cap) start = cap;
     if (end > cap) end = cap;
+    if (prio_levels == 2) {
+        // items in storage order (persistent waves): the weight is the bin's list length against the mean list length
+        const uint32_t nbins = (uint32_t)(fp.tiles_x * fp.tiles_y);
+        const uint32_t mean = tile_start[nbins] / max(nbins, 1u), len = end - start;
+        if (len >= 2u * mean) __builtin_amdgcn_s_setprio(3);
+        else if (4u * len >= 5u * mean) __builtin_amdgcn_s_setprio(2);
+        else if (4u * len >= 3u * mean) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
 
     // Accumulators are kept as strip PAIRS (0,1) and (2,3): gfx950 executes a plain wave64 fp32 VALU
     // op in ~4 cycles but a packed v_pk_{fma,mul,add}_f32 does two per lane in the same slot (measured:

@@ -278,14 +278,18 @@ class SplatRenderer:
         st = self.stats()
         nt = st["tiles_x"] * st["tiles_y"] * 8        # one slot per work item: (bin, quadrant[, half])
         out = np.zeros((max(nt, 1), 8), np.uint32)
-        _capi.check(self._ctx, self._lib.msplat_debug_get_tile_probe(
+        _capi.check(self._ctx, self._lib.msplat_debug_get_tile_probe8(
             self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.shape[0]))
         return out[out[:, 7] > 0]
 
-    def debug_tile_lists(self):
+    def debug_tile_lists(self, want_pairs=True):
         st = self.stats()
         nt = st["tiles_x"] * st["tiles_y"]
         ts = np.zeros(nt + 1, np.uint32)
+        if not want_pairs:          # only the list offsets
+            _capi.check(self._ctx, self._lib.msplat_debug_get_tile_lists(
+                self._ctx, ts.ctypes.data_as(C.POINTER(C.c_uint32)), ts.shape[0], None, 0))
+            return ts, None
         pairs = np.zeros(max(int(st["pairs"]), 1), np.uint32)
         _capi.check(self._ctx, self._lib.msplat_debug_get_tile_lists(
             self._ctx, ts.ctypes.data_as(C.POINTER(C.c_uint32)), ts.shape[0],
@@ -321,6 +325,10 @@ class SplatRendererGroup:
         return self._lib.msplat_group_last_error(self._g).decode() if self._g else self._err
 
     def _check(self, rc):
+        if rc == _capi.ERR_PAIR_OVERFLOW_EARLIER:
+            import warnings
+            warnings.warn(_capi.EarlierFrameOverflow(self._lib.msplat_group_last_error(self._g).decode()), stacklevel=3)
+            return
         if rc != _capi.OK:
             raise _capi.MsplatError(rc, self._lib.msplat_group_last_error(self._g).decode())
 

@@ -534,6 +534,32 @@ def test_row_bands_reassemble_bit_exact():
         acc[rows] = part[rows]
     np.testing.assert_array_equal(acc, full)
     assert max(vs) < 0.8 * r.sort_count(), (vs, r.sort_count())
+    # the general layouts (msplat_set_band_layout / msplat_band_plan): contiguous bands, blocks of rows dealt round-robin;
+    # 360 px = 11.25 bin rows, so bands are uneven and the last row is ragged; with and without the band cull
+    from splatapult_amd import _capi
+    R = (360 + bin_px() - 1) // bin_px()
+    for kind, k, G, cull in (("contiguous", 1, 3, False), ("contiguous", 1, 8, True), ("block", 2, 3, True),
+                             ("block", 4, 2, False), ("interleaved", 1, 5, True), ("contiguous", 1, 16, True)):
+        acc = np.zeros_like(full)
+        covered = np.zeros(360, bool)
+        for g in range(G):
+            rb = make_renderer(cloud)
+            lay = rb.set_band_plan(kind, R, G, g, block_rows=k, band_cull=cull)
+            mine = _capi.band_rows(*lay, rows_full=R)
+            rb.Sort(cam, proj, vp, nf)
+            part = rb.Render(cam, proj, vp, nf)
+            rows = np.isin(np.arange(360) // bin_px(), mine)
+            assert (part[~rows] == 0).all() and not (covered & rows).any()
+            covered |= rows
+            acc[rows] = part[rows]
+            if kind == "contiguous" and cull and 0 < len(mine) <= 2:
+                assert rb.sort_count() < 0.7 * r.sort_count()
+        assert covered.all()
+        np.testing.assert_array_equal(acc, full)
+    # back to the whole image on the same context
+    rb.set_band(1, 0)
+    rb.Sort(cam, proj, vp, nf)
+    np.testing.assert_array_equal(rb.Render(cam, proj, vp, nf), full)
 
 
 def test_frames_in_flight_bit_identical_to_serial_frames():
@@ -785,7 +811,9 @@ def test_other_projections_match_the_oracle(fovy_deg, zn, zf, z, wh):
 def test_device_output_pair_overflow_is_reported_on_the_next_call():
     """VERDICT r1 / ADVICE: a device-output render cannot know that the (splat, bin) pair buffer overflowed; the
     binning kernel leaves the needed count in host-mapped memory and the next call on the context reports
-    MSPLAT_ERR_PAIR_OVERFLOW once, after growing the buffer (unless msplat_config.pair_capacity fixed it)"""
+    it once, after growing the buffer (unless msplat_config.pair_capacity fixed it): msplat_synchronize fails with
+    MSPLAT_ERR_PAIR_OVERFLOW, msplat_sort / msplat_render -- whose own work is done -- return the warning code
+    MSPLAT_ERR_PAIR_OVERFLOW_EARLIER"""
     import torch
     from splatapult_amd import MsplatError, _capi
     # screen-filling splats: ~10 M pairs at 1024x1024 (32 x 32 bins), above the 4 M-pair minimum capacity
@@ -821,9 +849,8 @@ def test_device_output_pair_overflow_is_reported_on_the_next_call():
     r.Sort(cam, proj, vp, nf)
     r.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)
     torch.cuda.synchronize()
-    with pytest.raises(MsplatError) as e:
-        r.Sort(cam, proj, vp, nf)
-    assert e.value.code == _capi.ERR_PAIR_OVERFLOW
+    with pytest.warns(_capi.EarlierFrameOverflow, match="earlier device-output render"):
+        r.Sort(cam, proj, vp, nf)          # MSPLAT_ERR_PAIR_OVERFLOW_EARLIER: a warning, the sort itself is valid
     r.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)      # uses the sort that just ran
     r.synchronize()
     np.testing.assert_array_equal(fb.cpu().numpy(), expect)
@@ -894,9 +921,11 @@ def _check_tile_lists_ascending(r):
 
 def _check_window(img, aos, W, H, cam, proj, nf, y0, y1, render_cam=None, render_proj=None, fp16=False):
     """bounded oracle comparison at full workload: rows [y0, y1) of the frame"""
+    import os
+    nt = max(32, min(128, os.cpu_count() or 32)) if y1 - y0 > 512 else 32         # whole frames: more row bands
     ref = orc.render_frame(aos, True, cam, proj, [0, 0, W, H], nf, render_cam=render_cam, render_proj=render_proj,
                            nthreads=32, want_image=False, want_splats=True)
-    win, bud = orc.composite_flip(ref["splats"], W, H, nthreads=32, row0=y0, row1=y1)
+    win, bud = orc.composite_flip(ref["splats"], W, H, nthreads=nt, row0=y0, row1=y1)
     if fp16:
         check_fp16_image(img[y0:y1], win[y0:y1], bud[y0:y1])
     else:
@@ -918,7 +947,25 @@ def test_full_size_config2_sort_and_properties(cloud_1m):
     assert np.isfinite(img).all() and (img[..., 3] == 1).all()
     # idempotence: rendering again from the same sort is bit-identical
     np.testing.assert_array_equal(r.Render(cam, proj, vp, nf), img)
-    _check_window(img, aos, W, H, cam, proj, nf, 412, 668)
+    _check_window(img, aos, W, H, cam, proj, nf, 0, H)          # the WHOLE frame, incl. the ragged top bin row (33.75 bins)
+
+
+@pytest.mark.parametrize("step", [17, 40])
+def test_full_size_config2_whole_frame_at_rotated_orbit_poses(cloud_1m, step):
+    """BASELINE configs[1] at bench.py's orbit steps 17 and 40 (rotated view matrices): exact sort, ordered bin lists and
+    the whole 1920x1080 frame against the oracle"""
+    import math
+    W, H = 1920, 1080
+    cam = camera.orbit(7.0, 2.0 * math.pi * step / 64.0)
+    proj, vp, nf = camera.perspective(camera.FOVY, W / H), [0, 0, W, H], scenes.NF
+    r = make_renderer(cloud_1m)
+    r.Sort(cam, proj, vp, nf)
+    aos = cloud_1m.as_array()
+    V = _check_sort_exact(r, aos, cam, proj, nf)
+    img = r.Render(cam, proj, vp, nf)
+    st = _check_tile_lists_ascending(r)
+    assert st["sort_count"] == V
+    _check_window(img, aos, W, H, cam, proj, nf, 0, H)
 
 
 def test_full_size_config3_6m_1080p(cloud_6m):
@@ -936,6 +983,7 @@ def test_full_size_config3_6m_1080p(cloud_6m):
     assert st["sort_count"] == V and st["pairs"] > st["drawn"] > 4_000_000
     assert np.isfinite(img).all() and (img[..., 3] == 1).all()
     _check_window(img, aos, W, H, cam, proj, nf, 412, 668)
+    _check_window(img, aos, W, H, cam, proj, nf, 1056, 1080)      # the ragged top bin row (1080 = 33.75 bins)
 
 
 def test_full_size_config4_6m_4096_and_8_bands(cloud_6m):
@@ -951,19 +999,23 @@ def test_full_size_config4_6m_4096_and_8_bands(cloud_6m):
     assert st["tiles_x"] == 128 and st["tiles_y"] == 128 and st["pairs"] > 20_000_000
     assert np.isfinite(full).all() and (full[..., 3] == 1).all()
     _check_window(full, cloud_6m.as_array(), W, H, cam, proj, nf, 1984, 2112)
+    _check_window(full, cloud_6m.as_array(), W, H, cam, proj, nf, 4064, 4096)     # the top bin row
+    from splatapult_amd import _capi
     G = 8
-    acc = np.zeros_like(full)
     part = np.zeros_like(full)
-    vs = []
-    for g in range(G):
-        r.set_band(G, g, band_cull=True)
-        r.Sort(cam, proj, vp, nf)
-        vs.append(r.sort_count())
-        r.Render(cam, proj, vp, nf, out=part)
-        rows = np.arange(H) // bin_px() % G == g
-        acc[rows] = part[rows]
-    np.testing.assert_array_equal(acc, full)
-    assert max(vs) < 0.6 * V, (vs, V)          # the band cull really shrinks the per-rank sort (measured: 0.50 V at G = 8)
+    for kind, k, vmax in (("interleaved", 1, 0.6), ("contiguous", 1, 0.45), ("block", 4, 0.5)):
+        acc = np.zeros_like(full)
+        vs = []
+        for g in range(G):
+            lay = r.set_band_plan(kind, 128, G, g, block_rows=k, band_cull=True)
+            r.Sort(cam, proj, vp, nf)
+            vs.append(r.sort_count())
+            r.Render(cam, proj, vp, nf, out=part)
+            rows = np.isin(np.arange(H) // bin_px(), _capi.band_rows(*lay, rows_full=128))
+            acc[rows] = part[rows]
+        np.testing.assert_array_equal(acc, full)
+        # the band cull really shrinks the per-rank sort (r2 measured 0.50 V at G = 8 for interleaved rows)
+        assert max(vs) < vmax * V, (kind, vs, V)
 
 
 def test_full_size_config5_stereo_fp16(cloud_1m):
@@ -983,6 +1035,7 @@ def test_full_size_config5_stereo_fp16(cloud_1m):
         assert img.dtype == np.float16 and img.shape == (H, W, 4)
         _check_tile_lists_ascending(r)
         _check_window(img, aos, W, H, eyes[0], projs[0], nf, 992, 1248, render_cam=eyes[e], render_proj=projs[e], fp16=True)
+        _check_window(img, aos, W, H, eyes[0], projs[0], nf, 2208, 2240, render_cam=eyes[e], render_proj=projs[e], fp16=True)
 
 
 def test_large_cloud_uses_the_wide_scan_path():
@@ -1112,3 +1165,153 @@ def test_gpu_ingest_test_ply_and_errors(golden_dir, tmp_path):
     bad = tmp_path / "bad.ply"
     bad.write_bytes(b"ply\nformat ascii 1.0\nelement vertex 0\nend_header\n")
     assert not SplatRenderer().InitFromPly(str(bad))
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3: the three-pass sort chooses its digit widths from the visible set's largest quantised depth
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("zf,z,n", [(8.0, 7.0, 30000),        # depth up to and beyond far: keys saturate at 0 -> 10 + 11 + 11 bits
+                                    (40.0, 7.0, 30000),       # q up to 2^30: 10 + 10 + 10
+                                    (1.0e6, 7.0, 30000),      # tiny q (B < 26): the minimum widths 10 + 8 + 8
+                                    (1000.0, 7.0, 5000),      # the reference's far plane
+                                    (64.0, 30.0, 200000)])    # many chunks, B = 31
+def test_sort_exact_for_every_key_range(zf, z, n):
+    cloud = scenes.synth_cloud(n, 1234 + int(zf))
+    cam, proj, vp, _ = scenes.default_view(640, 480, z=z, yaw=0.4)
+    nf = [0.1, zf]
+    proj = camera.perspective(camera.FOVY, 640 / 480, 0.1, zf)
+    r = make_renderer(cloud)
+    for _ in range(2):                      # twice: the second frame runs on the tables the first one left behind
+        r.Sort(cam, proj, vp, nf)
+        mvp = orc.mat4_mul(proj, orc.mat4_inverse(cam))
+        keys, idx = orc.sort(*orc.presort(cloud.as_array(), mvp, nf[1]))
+        assert r.sort_count() == keys.shape[0] > 0
+        np.testing.assert_array_equal(r.sorted_keys(), keys)
+        np.testing.assert_array_equal(r.sorted_indices(), idx)
+    assert r.verify_order()[0] == 0
+
+
+def test_wide_sort_and_legacy_sort_and_tile_tables_agree(monkeypatch):
+    """MSPLAT_SORT=lsd8 (four 8-bit passes) and MSPLAT_TILE_TABLE=search (tile_start_kernel / tile_order_kernel) are the r2
+    paths kept for comparison: bit-identical keys, permutation, bin lists and pixels"""
+    cloud = scenes.synth_cloud(150000, 77, log_scale_mean=-3.6)
+    cam, proj, vp, nf = scenes.default_view(800, 450, yaw=-0.3)
+    res = []
+    for env in ({}, {"MSPLAT_SORT": "lsd8"}, {"MSPLAT_TILE_TABLE": "search"}, {"MSPLAT_WS_ITEMS": "16"}):
+        for k in ("MSPLAT_SORT", "MSPLAT_TILE_TABLE", "MSPLAT_WS_ITEMS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = make_renderer(cloud)
+        r.Sort(cam, proj, vp, nf)
+        img = r.Render(cam, proj, vp, nf)
+        ts, pairs = r.debug_tile_lists()
+        res.append((r.sorted_keys(), r.sorted_indices(), ts, pairs, img))
+        assert r.verify_order() == (0, 0)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            np.testing.assert_array_equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3: several GPUs, one process (msplat_group_*).  On a one-GPU box the group runs with one context, and with two
+# contexts on the same device -- the band plan, the worker threads, the joins and both exchange forms execute; only
+# the xGMI peer mapping itself needs a second GPU.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("devices,layout,k,cull", [([0], "contiguous", 1, False), ([0, 0], "contiguous", 1, True),
+                                                   ([0, 0, 0], "block", 2, True), ([0, 0], "interleaved", 1, False)])
+def test_device_group_renders_the_single_context_frame(devices, layout, k, cull, monkeypatch):
+    import torch
+    from splatapult_amd import SplatRendererGroup
+    cloud = scenes.synth_cloud(40000, 55, log_scale_mean=-3.3)
+    W, H = 640, 360
+    cam, proj, vp, nf = scenes.default_view(W, H, yaw=0.2)
+    r = make_renderer(cloud)
+    r.Sort(cam, proj, vp, nf)
+    full = r.Render(cam, proj, vp, nf)
+    for exchange in ("peer", "copy"):
+        if exchange == "copy":
+            monkeypatch.setenv("MSPLAT_GROUP_EXCHANGE", "copy")
+        else:
+            monkeypatch.delenv("MSPLAT_GROUP_EXCHANGE", raising=False)
+        g = SplatRendererGroup(devices, layout=layout, block_rows=k, band_cull=cull)
+        assert g.Init(cloud), g.last_error()
+        assert g.size == len(devices) and g.peer_store(0)
+        if len(devices) > 1:
+            assert g.peer_store(1) == (exchange == "peer")
+        # host framebuffer
+        g.Sort(cam, proj, vp, nf)
+        np.testing.assert_array_equal(g.Render(cam, proj, vp, nf), full)
+        if cull and len(devices) > 1:
+            assert max(g.sort_count(i) for i in range(g.size)) < r.sort_count()
+        # device framebuffer on devices[0]: complete once context 0's stream is (msplat_group_synchronize)
+        fb = torch.full((H, W, 4), -1.0, dtype=torch.float32, device="cuda:0")
+        for _ in range(3):
+            g.Sort(cam, proj, vp, nf)
+            g.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)
+        g.synchronize()
+        np.testing.assert_array_equal(fb.cpu().numpy(), full)
+        # another viewport: the rows are re-planned
+        vp2 = [0, 0, 333, 211]
+        proj2 = camera.perspective(camera.FOVY, 333 / 211)
+        r.Sort(cam, proj2, vp2, nf)
+        g.Sort(cam, proj2, vp2, nf)
+        np.testing.assert_array_equal(g.Render(cam, proj2, vp2, nf), r.Render(cam, proj2, vp2, nf))
+        r.Sort(cam, proj, vp, nf)
+        g.close()
+
+
+def test_device_group_errors():
+    from splatapult_amd import SplatRendererGroup, _capi
+    g = SplatRendererGroup([0, 99])
+    assert g.Init(np.zeros((4, 61), np.float32)) is False and "99" in g.last_error()
+    g = SplatRendererGroup([0, 0])
+    assert g.Init(np.zeros((0, 61), np.float32))           # an empty cloud is a cloud
+    cam, proj, vp, nf = scenes.default_view(64, 48)
+    with pytest.raises(_capi.MsplatError):
+        g.Render(cam, proj, vp, nf)                         # no sort yet
+    g.Sort(cam, proj, vp, nf)
+    img = g.Render(cam, proj, vp, nf)
+    assert (img[..., :3] == 0).all() and (img[..., 3] == 1).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3: a scene-LIKE 6 M workload (bench.py cfg3s): surfaces, heavy-tailed anisotropic scales, 1 % background splats a
+# quarter of the view wide, bimodal opacity, cameras inside the cloud -- through the FILE path (PLY + cameras.json)
+# ------------------------------------------------------------------------------------------------
+def test_scene_like_6m_file_replay_matches_the_oracle(tmp_path):
+    from splatapult_amd import synthetic
+    from splatapult_amd.scene import GaussianCloud
+    n, W, H = 6_000_000, 1920, 1080
+    ply = str(tmp_path / "point_cloud" / "iteration_30000" / "point_cloud.ply")
+    import os
+    os.makedirs(os.path.dirname(ply))
+    synthetic.write_ply(ply, synthetic.generate_scene(n, seed=0x5CE11E))
+    synthetic.write_cameras_json(str(tmp_path / "cameras.json"), synthetic.scene_cameras(64), W, H, camera.FOVY)
+    cj = camera.find_config_file(ply, "cameras.json")            # app.cpp:418-461: two directories above the PLY
+    assert cj == str(tmp_path / "cameras.json")
+    cams = [m for m, _ in camera.load_cameras_json(cj)]
+    assert len(cams) == 64
+    r = SplatRenderer(device=0)
+    assert r.InitFromPly(ply, True, False), r.last_error()      # Ply::Parse + GaussianCloud::ImportPly's math on the GPU
+    host = GaussianCloud()
+    assert host.ImportPly(ply)                                   # the same file through the host importer, for the oracle
+    aos = host.as_array()
+    assert aos.shape == (n, 61)
+    proj, vp, nf = camera.perspective(camera.FOVY, W / H), [0, 0, W, H], scenes.NF
+    cap0 = r.stats()["pair_capacity"]
+    for k, (y0, y1) in ((0, (500, 564)), (23, (1040, 1080))):   # a mid-frame window; the ragged top bin row at another pose
+        cam = cams[k]
+        r.Sort(cam, proj, vp, nf)
+        V = _check_sort_exact(r, aos, cam, proj, nf)
+        assert 1_000_000 < V < n                                 # the camera is inside: much of the cloud is behind it
+        img = r.Render(cam, proj, vp, nf)
+        st = _check_tile_lists_ascending(r)
+        assert st["sort_count"] == V
+        ts, _ = r.debug_tile_lists(want_pairs=False)
+        longest = int(np.diff(ts.astype(np.int64)).max())
+        print("scene-like 6M pose %d: V %d  drawn %d  pairs(32 px bins) %d = %.1f per splat  longest bin list %d  pair capacity %d -> %d"
+              % (k, V, st["drawn"], st["pairs"], st["pairs"] / n, longest, cap0, st["pair_capacity"]))
+        assert st["pairs"] > 5 * st["drawn"]                      # big footprints: many bins per splat
+        assert np.isfinite(img).all() and (img[..., 3] == 1).all()
+        _check_window(img, aos, W, H, cam, proj, nf, y0, y1)

@@ -239,3 +239,21 @@ def test_hostile_inputs_fail_without_throwing_across_the_c_abi(tmp_path):
     pj.write_text("[" * 10000 + "]" * 10000)
     with pytest.raises(Exception):
         camera.load_cameras_json(str(pj))
+
+
+def test_host_library_is_clean_under_asan_ubsan(tmp_path):
+    """the PLY / JSON / PNG parsers behind the never-throwing C ABI, built with -fsanitize=address,undefined and
+    driven with the golden files + hostile inputs (tests/sanitize/host_sanitize_driver.cpp; `make sanitize`)"""
+    import shutil
+    import subprocess
+    from tests.conftest import ROOT
+    probe = tmp_path / "probe.cpp"
+    probe.write_text("int main() { return 0; }\n")
+    if shutil.which("g++") is None or subprocess.run(["g++", "-fsanitize=address,undefined", str(probe), "-o", str(tmp_path / "probe")],
+                                                     capture_output=True).returncode != 0:
+        pytest.skip("g++ with libasan / libubsan is not available")
+    p = subprocess.run(["make", "-C", ROOT, "sanitize", "SAN=" + str(tmp_path / "host_sanitize")], capture_output=True, text=True,
+                       errors="replace")
+    tail = (p.stdout + p.stderr)[-3000:]
+    assert p.returncode == 0, tail
+    assert "0 failed expectation(s)" in p.stdout and "ERROR: AddressSanitizer" not in tail and "runtime error" not in tail

@@ -130,3 +130,27 @@ def test_png_and_ppm_writer(tmp_path):
     b = open(ppm, "rb").read()
     assert b.startswith(b"P6\n53 37\n255\n") and len(b) == len(b"P6\n53 37\n255\n") + 53 * 37 * 3
     np.testing.assert_array_equal(np.frombuffer(b[-53 * 37 * 3:], np.uint8).reshape(37, 53, 3), exp[..., :3])
+
+
+def test_scene_like_generator_and_cameras_json_writer(tmp_path):
+    """synthetic.generate_scene / scene_cameras / write_cameras_json (bench.py cfg3s): deterministic, chunk-independent,
+    and the written cameras.json comes back through CamerasConfig::ImportJson as the matrices that were written"""
+    import numpy as np
+    from splatapult_amd import synthetic
+    a = synthetic.generate_scene(5000, seed=11, chunk=1024, workers=1)
+    b = synthetic.generate_scene(5000, seed=11, chunk=4096, workers=3)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+    assert np.isfinite(a["xyz"]).all() and abs(np.linalg.norm(a["rot"], axis=1) - 1).max() < 1e-5
+    r = np.linalg.norm(a["xyz"], axis=1)
+    assert (r > 24).mean() > 0.003 and (np.abs(a["xyz"][:, 1] + 1) < 0.1).mean() > 0.2        # background shell, ground plane
+    assert a["log_scale"].max() > 0.0 and a["log_scale"].min() < -7.0                           # heavy tail both ways
+    cams = synthetic.scene_cameras(9)
+    p = str(tmp_path / "cameras.json")
+    synthetic.write_cameras_json(p, cams, 1920, 1080, camera.FOVY)
+    back = camera.load_cameras_json(p)
+    assert len(back) == 9
+    for (m, fov), c in zip(back, cams):
+        np.testing.assert_allclose(m, c, atol=1e-6)
+        R = m.reshape(4, 4)[:3, :3]
+        np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-5)                                # a rotation

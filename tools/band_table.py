@@ -1,0 +1,111 @@
+#!/usr/bin/env python
+"""Predicted multi-GPU frame from ONE GPU: every rank's share of a workload, rendered in turn, for several bin-row layouts.
+
+  python tools/band_table.py --workload cfg4 --world 8 --out gpurun_out/r03_cfg4_bands.json
+
+For each layout (contiguous bands, interleaved rows, blocks of k rows dealt round-robin) and each rank it sets the rank's band
+(msplat_band_plan + band-restricted cull), renders serial frames on one stream and records V, the (splat, bin) pairs, the stage
+times and the frame time; then the max over the ranks (= the frame a node of `world` GPUs would take before the gather), the
+messages / bytes that reach rank 0, and the gather modelled at 153 GB/s per xGMI link (every rank has its own link to rank 0,
+MI355X_MICROARCH.md).  The exchange itself needs the real node; this table is what chooses the layout bench.py defaults to."""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+XGMI_LINK = 153e9
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="cfg4")
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--layouts", default="contiguous,interleaved,block:2,block:4,block:8")
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    import torch
+    import bench
+    from splatapult_amd import SplatRenderer, camera, synthetic, _capi
+    from splatapult_amd.dist import owned_rows, row_runs
+
+    wl = bench.WORKLOADS[args.workload]
+    W, H, G = wl["W"], wl["H"], args.world
+    cloud = synthetic.make_cloud(wl["n"], seed=wl["seed"], full_sh=True, pos_sigma=wl["pos_sigma"])
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    r = SplatRenderer(device=0, fb_format=wl["fb"], stream=stream.cuda_stream, enable_timing=1, frames_in_flight=1)
+    assert r.Init(cloud, False, False), r.last_error()
+    T = _capi.lib().msplat_tile_size()
+    R = (H + T - 1) // T
+    bpp = 8 if wl["fb"] == "fp16" else 16
+    fb = torch.zeros((R * T, W, 4), dtype=torch.float16 if bpp == 8 else torch.float32, device=dev)
+    proj = camera.perspective(camera.FOVY, W / H)
+    vp, nf = [0, 0, W, H], [camera.Z_NEAR, camera.Z_FAR]
+
+    def frames(n, first=0):
+        for s in range(n):
+            cam = camera.orbit(wl["cam_z"], 2.0 * math.pi * ((first + s) % 64) / 64.0)
+            r.Sort(cam, proj, vp, nf)
+            r.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * bpp)
+
+    def measure():
+        frames(6)
+        torch.cuda.synchronize()
+        r.timings()
+        t0 = time.perf_counter()
+        frames(args.frames, 6)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / args.frames
+        tm = r.timings()
+        st = r.stats()
+        return dict(frame_ms=ms, sort_ms=tm["sort_total"], project_ms=tm["project"], binning_ms=tm["binning"],
+                    composite_ms=tm["composite"], V=st["sort_count"], pairs=st["pairs"])
+
+    r.set_band(1, 0)
+    whole = measure()
+    out = {"workload": wl["desc"], "world": G, "bin_rows": R, "bin_px": T, "single_gpu": whole, "layouts": {},
+           "xgmi_link_GBps": XGMI_LINK / 1e9, "frames_per_point": args.frames}
+    print("single GPU: frame %.3f ms  V %d  pairs %d" % (whole["frame_ms"], whole["V"], whole["pairs"]))
+    for lay in args.layouts.split(","):
+        kind, k = (lay.split(":")[0], int(lay.split(":")[1])) if ":" in lay else (lay, 1)
+        if kind == "block" and k == 1:
+            kind = "interleaved"
+        ranks = []
+        for g in range(G):
+            r.set_band_plan(kind, R, G, g, block_rows=k, band_cull=True)
+            m = measure()
+            rows = owned_rows(kind, R, G, g, k)
+            runs = row_runs(rows)
+            px_rows = sum(min(T * c, max(0, H - t * T)) for t, c in runs)
+            m.update(rows=len(rows), messages=len(runs) if g else 0, bytes=px_rows * W * bpp if g else 0)
+            ranks.append(m)
+        mx = max(x["frame_ms"] for x in ranks)
+        gather_ms = 1e3 * max(x["bytes"] for x in ranks) / XGMI_LINK       # every rank's rows on its own link, concurrently
+        out["layouts"][lay] = {
+            "ranks": ranks, "max_rank_frame_ms": mx, "mean_rank_frame_ms": float(np.mean([x["frame_ms"] for x in ranks])),
+            "max_V_frac": max(x["V"] for x in ranks) / max(1, whole["V"]),
+            "messages_into_rank0": sum(x["messages"] for x in ranks), "bytes_into_rank0": sum(x["bytes"] for x in ranks),
+            "modelled_gather_ms": gather_ms, "predicted_frame_ms_overlapped": max(mx, gather_ms),
+            "predicted_frame_ms_serialised": mx + gather_ms,
+            "speedup_vs_single_gpu": whole["frame_ms"] / max(mx, gather_ms)}
+        L = out["layouts"][lay]
+        print("%-12s max-rank frame %.3f ms (mean %.3f)  max V %.2f  msgs %d  gather %.3f ms  -> x%.2f" % (
+            lay, mx, L["mean_rank_frame_ms"], L["max_V_frac"], L["messages_into_rank0"], gather_ms, L["speedup_vs_single_gpu"]))
+        for g, x in enumerate(ranks):
+            print("    rank %d: frame %.3f  sort %.3f  proj %.3f  bin %.3f  comp %.3f  V %d  pairs %d  rows %d" % (
+                g, x["frame_ms"], x["sort_ms"], x["project_ms"], x["binning_ms"], x["composite_ms"], x["V"], x["pairs"], x["rows"]))
+    if args.out:
+        json.dump(out, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

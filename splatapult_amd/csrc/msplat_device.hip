@@ -85,6 +85,9 @@ struct msplat_ctx {
     // per-bin pair counts taken by the row pass's upsweep (r3): list offsets + work order without tile_start_kernel
     Buf bincnt;
     bool bin_counts = true;     // MSPLAT_TILE_TABLE=search: tile_start_kernel / tile_order_kernel as in r2
+    int xcd_map = 1;            // MSPLAT_XCD_MAP bit 0: sort downsweeps (default on: 6 M splats 196 -> 185 us, no change at 1 M), bit 1: the
+                                // column pass's downsweep (off: 6 M / 4096^2 453 -> 509 us) take XCD-contiguous chunk ranges
+    uint32_t bin_chunk = 1024;  // ranks per chunk of the column pass (kBinChunk / kBinChunkLarge by cloud size)
     bool scan_free = true;  // MSPLAT_SCAN_KERNELS=1 forces the 3-kernel (upsweep, scan, downsweep) passes
     uint32_t fused_max_chunks = kFusedMaxChunks;   // MSPLAT_FUSED_MAX_CHUNKS: scan-free passes up to this many chunk rows
     // compositor formulation: 0 = one wave per 16x16 tile (default), 1 = one wave per 16x8 half tile, 2 = four waves per
@@ -321,6 +324,7 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         if (const char* sk = getenv("MSPLAT_SORT")) ctx->wide_sort = std::string(sk) != "lsd8";
         if (!ctx->atomic_rank) ctx->wide_sort = false;       // the wide kernels rank with lane-ordered LDS atomics only
         if (const char* tk = getenv("MSPLAT_TILE_TABLE")) ctx->bin_counts = std::string(tk) != "search";
+        if (getenv("MSPLAT_XCD_MAP")) ctx->xcd_map = atoi(getenv("MSPLAT_XCD_MAP"));
         if (ctx->wide_sort) {
             // ws_downsweep needs 72 / 104 KB of dynamic LDS: above the 64 KB a kernel gets without asking
             static const bool lds_ok = [] {
@@ -609,6 +613,8 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
     if ((rc = buf_alloc(ctx, ctx->rec2d, alloc_n * 48))) return rc;
     if ((rc = buf_alloc(ctx, ctx->rect, alloc_n * 4))) return rc;
     if (ctx->depth_bits != 0 && (rc = buf_alloc(ctx, ctx->zq, alloc_n * 4))) return rc;
+    ctx->bin_chunk = (uint32_t)kBinChunk;      // r3: 2048-rank chunks measured at 6 M: binning 183 -> 191 us (1080p), 459 -> 453 us (4096^2)
+    if (const char* bc = getenv("MSPLAT_BIN_CHUNK")) ctx->bin_chunk = atoi(bc) == kBinChunkLarge ? (uint32_t)kBinChunkLarge : (uint32_t)kBinChunk;
     ctx->hist1_stride = std::max(1u, div_up(n, kBinChunk));
     if ((rc = buf_alloc(ctx, ctx->hist1, (size_t)256 * ctx->hist1_stride * 4))) return rc;
     if ((rc = alloc_group_table(ctx, ctx->gsumB1, ctx->gsumB1_rows, ctx->hist1_stride))) return rc;
@@ -1071,6 +1077,7 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
         const uint32_t wchunk = (uint32_t)kWsThreads * ctx->ws_items;
         const int wgrid = grid_for(div_up(N, wchunk));
         const uint32_t* dV = d_V;
+        const int wsx = (ctx->xcd_map & 1) ? 1 : 0;
 #define MSPLAT_WS(KERNEL, CULLF, LDS, ...)                                                                              \
     do {                                                                                                                \
         if (ctx->ws_items == 16) hipLaunchKernelGGL((KERNEL<CULLF, 16>), dim3(wgrid), dim3(kWsThreads), LDS(16), s, __VA_ARGS__); \
@@ -1081,15 +1088,15 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
                   mk_next, whist, gt(0), gsh, gt(-1), gw, fp);
         MSPLAT_WS(ws_downsweep, true, ws_downsweep_lds, (const uint32_t*)kB, (const uint32_t*)nullptr, (const unsigned long long*)vm,
                   (const uint32_t*)nullptr, N, N, 0, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(0), gsh, kA, vA,
-                  d_V);
+                  d_V, wsx);
         MSPLAT_WS(ws_upsweep, false, MSPLAT_NO_LDS, (const uint32_t*)kA, (const float4*)nullptr, (uint32_t*)nullptr,
                   (unsigned long long*)nullptr, dV, 0u, N, 1, mk_cur, mk_next, whist, gt(1), gsh, gt(0), gw, fp);
         MSPLAT_WS(ws_downsweep, false, ws_downsweep_lds, (const uint32_t*)kA, (const uint32_t*)vA, (const unsigned long long*)nullptr, dV,
-                  0u, N, 1, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(1), gsh, kB, vB, (uint32_t*)nullptr);
+                  0u, N, 1, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(1), gsh, kB, vB, (uint32_t*)nullptr, wsx);
         MSPLAT_WS(ws_upsweep, false, MSPLAT_NO_LDS, (const uint32_t*)kB, (const float4*)nullptr, (uint32_t*)nullptr,
                   (unsigned long long*)nullptr, dV, 0u, N, 2, mk_cur, mk_next, whist, gt(2), gsh, gt(1), gw, fp);
         MSPLAT_WS(ws_downsweep, false, ws_downsweep_lds, (const uint32_t*)kB, (const uint32_t*)vB, (const unsigned long long*)nullptr, dV,
-                  0u, N, 2, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(2), gsh, kA, vA, (uint32_t*)nullptr);
+                  0u, N, 2, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(2), gsh, kA, vA, (uint32_t*)nullptr, wsx);
 #undef MSPLAT_NO_LDS
 #undef MSPLAT_WS
         if (timed) {
@@ -1188,32 +1195,39 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     // pass 1: stable partition by tile column, enumerated from the rank-ordered rectangles
     uint32_t* totals1 = (uint32_t*)ctx->totals1.p;
     uint32_t* totals2 = (uint32_t*)ctx->totals.p;
-    const int g1 = grid_for(div_up(N, kBinChunk));
+    const uint32_t bchunk = ctx->bin_chunk;
+    const int g1 = grid_for(div_up(N, bchunk));
     // scan-free variants while the chunk tables are small; the row pass's size (D) is only known on the device, so
     // its choice uses the D of an EARLIER frame that the binning kernel left in host-mapped memory (0 = none yet);
     // either variant is correct at any size, the choice only matters for speed
     // (the column pass's chunks are half the size of the sort's: its table is scanned by a kernel from 4096 rows on --
     //  measured at 6 M splats: 5860 rows cost the scan-free downsweep +28 us, the scan kernel 20 us)
-    const bool fused1 = ctx->scan_free && div_up(N, kBinChunk) <= ctx->fused_max_chunks / 2;
+    const bool fused1 = ctx->scan_free && div_up(N, bchunk) <= ctx->fused_max_chunks / 2;
     const uint32_t last_D = ctx->h_flags ? __atomic_load_n(ctx->h_flags + 2, __ATOMIC_RELAXED) : 0u;
     const bool fused2 = ctx->scan_free && last_D != 0u && div_up((uint64_t)last_D + (last_D >> 2), kPairChunk) <= ctx->fused_max_chunks;
     uint32_t* gB1 = (uint32_t*)ctx->gsumB1.p;
     uint32_t* gB2 = (uint32_t*)ctx->gsumB2.p;
     // (bin1_upsweep also clears the row pass's group table: its consumer, the previous frame's row downsweep, is long done)
-    hipLaunchKernelGGL(bin1_upsweep, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
-                       (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_overflow, fused1 ? gB1 : nullptr, gB2, ctx->gsumB2_rows);
-    if (!fused1)
-        launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V, 0u, N, (uint32_t)kBinChunk, totals1);
-    if (ctx->atomic_rank)
-        hipLaunchKernelGGL(bin1_downsweep<true>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
-                           (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,
-                           (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags, async_overflow_flag ? 1 : 0,
-                           fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr);
-    else
-        hipLaunchKernelGGL(bin1_downsweep<false>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,
-                           (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,
-                           (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags, async_overflow_flag ? 1 : 0,
-                           fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr);
+#define MSPLAT_BIN1(CH)                                                                                                       \
+    do {                                                                                                                      \
+        hipLaunchKernelGGL(bin1_upsweep<CH>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,               \
+                           (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_overflow, fused1 ? gB1 : nullptr, gB2, ctx->gsumB2_rows); \
+        if (!fused1)                                                                                                          \
+            launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V, 0u, N, bchunk, totals1);     \
+        if (ctx->atomic_rank)                                                                                                 \
+            hipLaunchKernelGGL((bin1_downsweep<true, CH>), dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V, \
+                               (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,                    \
+                               (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags, async_overflow_flag ? 1 : 0,      \
+                               fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, (ctx->xcd_map & 2) ? 1 : 0); \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((bin1_downsweep<false, CH>), dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V, \
+                               (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,                    \
+                               (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags, async_overflow_flag ? 1 : 0,      \
+                               fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, (ctx->xcd_map & 2) ? 1 : 0); \
+    } while (0)
+    // (bin1_upsweep also clears the row pass's group table: its consumer, the previous frame's row downsweep, is long done)
+    if (bchunk == (uint32_t)kBinChunkLarge) MSPLAT_BIN1(kBinChunkLarge); else MSPLAT_BIN1(kBinChunk);
+#undef MSPLAT_BIN1
     // pass 2: stable partition by tile row (one generic radix pass on the top byte); words become (tx<<24)|rank
     // The heaviest-first order of the bins only pays when every work item has its own wave (the hardware then starts the
     // waves in item order: 83 -> 97 us without it at config 2); persistent waves that pull items from the queue balance
@@ -1317,8 +1331,9 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
             const uint32_t nitems = comp_items, pool = comp_pool;
             // wave issue priority: by item number where the items are numbered heaviest-first, by the bin's list length where
             // persistent waves walk the bins in storage order (the item number says nothing there);
-            // MSPLAT_COMP_PRIO = 0 none, 1 item number, 2 list length, unset: automatic
-            const int prio_mode = ctx->comp_prio < 0 ? (ordered ? 1 : 2) : ctx->comp_prio;
+            // MSPLAT_COMP_PRIO = 0 none, 1 item number, 2 list length; unset: by item number for ordered items, none for
+            // persistent waves (r3, 4 frames in flight at config 2: 0 / 1 / 2 -> 5.82 / 5.76 / 5.79 k frames/s, i.e. no effect)
+            const int prio_mode = ctx->comp_prio < 0 ? (ordered ? 1 : 0) : ctx->comp_prio;
             const int grid = (int)std::min<uint32_t>(nitems, pool);
 #define MSPLAT_LAUNCH_COMP(F16, NP, OCC, FZ)                                                                          \
     hipExtLaunchKernelGGL((composite_kernel<F16, NP, OCC, FZ>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, \

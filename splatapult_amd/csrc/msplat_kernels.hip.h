@@ -28,7 +28,8 @@ constexpr int kSortChunk = kThreads * kSortItems;   // 2048 keys per chunk
 constexpr int kPairItems = 16;           // binning pass 2 moves 7x more words: bigger chunks, longer runs
 constexpr int kPairChunk = kThreads * kPairItems;   // 4096 words per chunk
 template <int MODE, int SORT_ITEMS> struct RadixCfg { static constexpr int ITEMS = (MODE == 2) ? kPairItems : SORT_ITEMS; static constexpr int CHUNK = kThreads * ITEMS; };
-constexpr int kBinChunk = 1024;          // draw-order ranks per chunk in the tile-column partition (512 / 2048 measured: binning 64 -> 70 us)
+constexpr int kBinChunk = 1024;          // draw-order ranks per chunk in the tile-column partition (512 / 2048 measured at 1 M: binning 64 -> 70 us)
+constexpr int kBinChunkLarge = 2048;     // MSPLAT_BIN_CHUNK=2048: a (chunk, column) run of pair words twice as long; measured r3 at 6 M splats: no gain
 constexpr int kTile = 16;                // one compositor wave owns a 16x16 pixel tile ...
 constexpr int kBin = 32;                 // ... binning works on 32x32 bins (4 tiles share one list, each
                                          // wave filters it for its own quadrant): 2.2-2.9x fewer pairs
@@ -291,18 +292,15 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
             c0 = lo;
             one_col = lo1 == lo;
         }
-        uint32_t cw = c0;          // the positions of a thread ascend with r: its column only moves right
+        if (count_bins && !one_col) {
+            // general form (a chunk that spans columns: tiny scenes, column boundaries): the positions of a thread ascend
+            // with r, so its column only moves right
+            uint32_t cw = c0;
 #pragma unroll
-        for (int r = 0; r < ITEMS; ++r) {
-            const uint32_t i = base + r * kThreads + threadIdx.x;
-            if (i < n) {
-                uint32_t key;
-                bool ok = true;
-                if (MODE == MODE_CULL) ok = cull_key(pos[i], fp, key);
-                else key = keys[i];
-                if (count_bins && one_col) {
-                    atomicAdd(&s_bin[key >> 24], 1u);          // s_bin[0][row]
-                } else if (count_bins) {
+            for (int r = 0; r < ITEMS; ++r) {
+                const uint32_t i = base + r * kThreads + threadIdx.x;
+                if (i < n) {
+                    const uint32_t key = keys[i];
                     while (s_col[cw + 1u] <= i) ++cw;          // s_col[256] is a sentinel
                     const uint32_t row = key >> 24, j = cw - c0;
                     if (j < (uint32_t)kPairCols) {
@@ -312,8 +310,32 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
                         (void)__hip_atomic_fetch_add(&bincnt[row * (uint32_t)fp.tiles_x + cw], 1u, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_AGENT);
                     }
-                } else if (ok) {
-                    atomicAdd(&s_hist[digit_of<MODE>(key, shift)], 1u);
+                }
+            }
+        } else {
+            // straight-line form: every load of the chunk is in flight before the first LDS atomic (one_col: the counts land
+            // in s_bin[0][row], i.e. column c0)
+            if (MODE == MODE_CULL) {
+#pragma unroll
+                for (int r = 0; r < ITEMS; ++r) {
+                    const uint32_t i = base + r * kThreads + threadIdx.x;
+                    uint32_t key;
+                    if (i < n && cull_key(pos[i], fp, key)) atomicAdd(&s_hist[digit_of<MODE>(key, shift)], 1u);
+                }
+            } else {
+                // unconditional (clamped) loads first: under `if (i < n)` the compiler waits for every load before it
+                // issues the next one (seen in the ISA: global_load, s_waitcnt vmcnt(0), ds_add, 16 times in a row)
+                uint32_t kk[ITEMS];
+#pragma unroll
+                for (int r = 0; r < ITEMS; ++r) kk[r] = keys[min(base + r * kThreads + threadIdx.x, n - 1u)];
+                if (MODE == MODE_PAIR && count_bins) {
+#pragma unroll
+                    for (int r = 0; r < ITEMS; ++r)
+                        if (base + r * kThreads + threadIdx.x < n) atomicAdd(&s_bin[kk[r] >> 24], 1u);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < ITEMS; ++r)
+                        if (base + r * kThreads + threadIdx.x < n) atomicAdd(&s_hist[digit_of<MODE>(kk[r], shift)], 1u);
                 }
             }
         }
@@ -347,16 +369,33 @@ __device__ __forceinline__ uint32_t coop_row_sum(const uint32_t* __restrict__ ro
 {
     const uint32_t q = threadIdx.x & 63u, rg = threadIdx.x >> 6;
     uint4 acc = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll 4
-    for (uint32_t r = rg; r < n0; r += 4u) {
-        const uint4 x = *reinterpret_cast<const uint4*>(rows0 + (size_t)r * 256 + q * 4u);
-        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-    }
-#pragma unroll 4
-    for (uint32_t r = rg; r < n1; r += 4u) {
-        const uint4 x = *reinterpret_cast<const uint4*>(rows1 + (size_t)r * 256 + q * 4u);
-        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-    }
+    // four rows per step with their loads issued together, and a tail of up to three rows loaded together too (r3: the
+    // remainder iterations of an unrolled loop compile to load, wait, add, load, wait, ... -- up to six memory latencies
+    // on the critical path of every downsweep)
+    auto sum_rows = [&](const uint32_t* __restrict__ rows, uint32_t n) {
+        const uint32_t* p = rows + q * 4u;
+        uint32_t r = rg;
+        for (; r + 12u < n; r += 16u) {
+            const uint4 x0 = *reinterpret_cast<const uint4*>(p + (size_t)r * 256);
+            const uint4 x1 = *reinterpret_cast<const uint4*>(p + (size_t)(r + 4u) * 256);
+            const uint4 x2 = *reinterpret_cast<const uint4*>(p + (size_t)(r + 8u) * 256);
+            const uint4 x3 = *reinterpret_cast<const uint4*>(p + (size_t)(r + 12u) * 256);
+            acc.x += (x0.x + x1.x) + (x2.x + x3.x); acc.y += (x0.y + x1.y) + (x2.y + x3.y);
+            acc.z += (x0.z + x1.z) + (x2.z + x3.z); acc.w += (x0.w + x1.w) + (x2.w + x3.w);
+        }
+        const uint32_t r1 = r + 4u, r2 = r + 8u;
+        const bool h1 = r1 < n, h2 = r2 < n;
+        if (r < n) {
+            const uint4 x0 = *reinterpret_cast<const uint4*>(p + (size_t)r * 256);
+            const uint4 x1 = *reinterpret_cast<const uint4*>(p + (size_t)(h1 ? r1 : r) * 256);
+            const uint4 x2 = *reinterpret_cast<const uint4*>(p + (size_t)(h2 ? r2 : r) * 256);
+            const uint32_t m1 = h1 ? 0xFFFFFFFFu : 0u, m2 = h2 ? 0xFFFFFFFFu : 0u;
+            acc.x += x0.x + (x1.x & m1) + (x2.x & m2); acc.y += x0.y + (x1.y & m1) + (x2.y & m2);
+            acc.z += x0.z + (x1.z & m1) + (x2.z & m2); acc.w += x0.w + (x1.w & m1) + (x2.w & m2);
+        }
+    };
+    sum_rows(rows0, n0);
+    sum_rows(rows1, n1);
     s_part[rg * 64u + q] = acc;
     __syncthreads();
     const uint32_t* sp = reinterpret_cast<const uint32_t*>(s_part);
@@ -779,16 +818,33 @@ __device__ __forceinline__ uint4 ws_row_sum(const uint32_t* __restrict__ rows0, 
     const uint32_t Q = nbins >> 2, RL = (uint32_t)kWsThreads >> (bits - 2);
     const uint32_t q = threadIdx.x & (Q - 1u), rl = threadIdx.x >> (bits - 2);
     uint4 acc = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll 4
-    for (uint32_t r = rl; r < n0; r += RL) {
-        const uint4 x = *reinterpret_cast<const uint4*>(rows0 + (size_t)r * nbins + q * 4u);
-        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-    }
-#pragma unroll 4
-    for (uint32_t r = rl; r < n1; r += RL) {
-        const uint4 x = *reinterpret_cast<const uint4*>(rows1 + (size_t)r * nbins + q * 4u);
-        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-    }
+    // four rows per step, their loads issued together (a plain `for (r += RL)` loop compiles to load, wait, add, load, ...:
+    // one memory latency per row on the critical path of every downsweep)
+    auto sum_rows = [&](const uint32_t* __restrict__ rows, uint32_t n) {
+        const uint32_t* p = rows + q * 4u;
+        uint32_t r = rl;
+        for (; r + 3u * RL < n; r += 4u * RL) {
+            const uint4 x0 = *reinterpret_cast<const uint4*>(p + (size_t)r * nbins);
+            const uint4 x1 = *reinterpret_cast<const uint4*>(p + (size_t)(r + RL) * nbins);
+            const uint4 x2 = *reinterpret_cast<const uint4*>(p + (size_t)(r + 2u * RL) * nbins);
+            const uint4 x3 = *reinterpret_cast<const uint4*>(p + (size_t)(r + 3u * RL) * nbins);
+            acc.x += (x0.x + x1.x) + (x2.x + x3.x); acc.y += (x0.y + x1.y) + (x2.y + x3.y);
+            acc.z += (x0.z + x1.z) + (x2.z + x3.z); acc.w += (x0.w + x1.w) + (x2.w + x3.w);
+        }
+        // tail: up to three rows, loaded together (the clamped row is added with weight 0)
+        const uint32_t r1 = r + RL, r2 = r + 2u * RL;
+        const bool h0 = r < n, h1 = r1 < n, h2 = r2 < n;
+        if (h0) {
+            const uint4 x0 = *reinterpret_cast<const uint4*>(p + (size_t)r * nbins);
+            const uint4 x1 = *reinterpret_cast<const uint4*>(p + (size_t)(h1 ? r1 : r) * nbins);
+            const uint4 x2 = *reinterpret_cast<const uint4*>(p + (size_t)(h2 ? r2 : r) * nbins);
+            const uint32_t m1 = h1 ? 0xFFFFFFFFu : 0u, m2 = h2 ? 0xFFFFFFFFu : 0u;
+            acc.x += x0.x + (x1.x & m1) + (x2.x & m2); acc.y += x0.y + (x1.y & m1) + (x2.y & m2);
+            acc.z += x0.z + (x1.z & m1) + (x2.z & m2); acc.w += x0.w + (x1.w & m1) + (x2.w & m2);
+        }
+    };
+    sum_rows(rows0, n0);
+    sum_rows(rows1, n1);
     s_part[threadIdx.x] = acc;                 // == s_part[rl * Q + q]
     __syncthreads();
     uint4 sum = make_uint4(0u, 0u, 0u, 0u);
@@ -834,14 +890,24 @@ __global__ __launch_bounds__(kWsThreads) void ws_upsweep(const uint32_t* __restr
         for (uint32_t d = threadIdx.x; d < nbins; d += kWsThreads) s_hist[d] = 0u;
         __syncthreads();
         const uint32_t base = chunk * CHUNK;
+        // unconditional (clamped) loads first, so that all of them are in flight together: under `if (i < n)` the
+        // compiler waits for each load before it issues the next (r3, seen in the ISA)
+        float4 pp[CULL ? ITEMS : 1];
+        uint32_t kk[CULL ? 1 : ITEMS];
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const uint32_t ic = min(base + r * kWsThreads + threadIdx.x, n - 1u);          // n >= 1 inside this loop
+            if (CULL) pp[r] = pos[ic];
+            else kk[r] = keys_in[ic];
+        }
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const uint32_t i = base + r * kWsThreads + threadIdx.x;
             uint32_t key = 0u;
             bool ok = false;
             if (i < n) {
-                if (CULL) ok = cull_key(pos[i], fp, key);
-                else { key = keys_in[i]; ok = true; }
+                if (CULL) ok = cull_key(pp[r], fp, key);
+                else { key = kk[r]; ok = true; }
             }
             if (CULL) {
                 const unsigned long long m = __ballot(ok);
@@ -884,7 +950,7 @@ constexpr size_t ws_downsweep_lds(int items)
 }
 
 template <bool CULL, int ITEMS>
-__global__ __launch_bounds__(kWsThreads, ITEMS == 8 ? 2 : 1) void ws_downsweep(const uint32_t* __restrict__ keys_in,
+__global__ __launch_bounds__(kWsThreads, ITEMS == 8 ? 4 : 2) void ws_downsweep(const uint32_t* __restrict__ keys_in,
                                                            const uint32_t* __restrict__ vals_in,
                                                            const unsigned long long* __restrict__ vmask,
                                                            const uint32_t* __restrict__ d_n, uint32_t n_static, uint32_t n_cap,
@@ -893,8 +959,11 @@ __global__ __launch_bounds__(kWsThreads, ITEMS == 8 ? 2 : 1) void ws_downsweep(c
                                                            const uint32_t* __restrict__ gsum, int gshift,
                                                            uint32_t* __restrict__ keys_out,
                                                            uint32_t* __restrict__ vals_out,
-                                                           uint32_t* __restrict__ d_count_out)
+                                                           uint32_t* __restrict__ d_count_out, int xcd_map)
 {
+    // xcd_map: workgroup b runs on XCD b % 8; chunk = xcd_contiguous(b) gives every XCD a contiguous range of chunks, so
+    // the digit runs that neighbouring chunks write next to each other meet in ONE L2 instead of being written to HBM
+    // as partial lines by several (the per-XCD L2s are not coherent; every one writes back its own bytes of a shared line)
     constexpr int CHUNK = kWsThreads * ITEMS;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     uint32_t* s_keys = s_dyn;                                   // CHUNK
@@ -924,7 +993,8 @@ __global__ __launch_bounds__(kWsThreads, ITEMS == 8 ? 2 : 1) void ws_downsweep(c
         if (d_count_out != nullptr && blockIdx.x == 0 && t == 0) *d_count_out = total;
     }
 
-    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    for (uint32_t cidx = blockIdx.x; cidx < nchunks; cidx += gridDim.x) {
+        const uint32_t chunk = (xcd_map && (gridDim.x >= nchunks || (gridDim.x & 7u) == 0u)) ? xcd_contiguous(cidx, nchunks) : cidx;
         // this chunk's exclusive prefix per digit: the group rows before its group + the chunk rows before it in the group
         const uint32_t g = chunk >> gshift;
         const uint4 pre = ws_row_sum(gsum, g, hist + (size_t)(g << gshift) * nbins, chunk - (g << gshift), nbins, bits, s_part);
@@ -935,21 +1005,22 @@ __global__ __launch_bounds__(kWsThreads, ITEMS == 8 ? 2 : 1) void ws_downsweep(c
         bool valid[ITEMS];
         // wave w owns the contiguous sub-chunk [w * 64 * ITEMS, (w + 1) * 64 * ITEMS): keeps the sort stable
         const uint32_t base = chunk * CHUNK + (uint32_t)w * (64 * ITEMS);
+        // unconditional (clamped) loads, all in flight together (see ws_upsweep); n >= 1 inside this loop
+        unsigned long long vm[CULL ? ITEMS : 1];
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const uint32_t ic = min(base + r * 64 + lane, n - 1u);
+            key[r] = keys_in[ic];
+            if (CULL) vm[r] = vmask[min(base + r * 64, n - 1u) >> 6];          // wave-uniform address
+            else val[r] = vals_in[ic];
+        }
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const uint32_t i = base + r * 64 + lane;
             valid[r] = i < n;
-            key[r] = 0u;
-            val[r] = 0u;
             if (CULL) {
-                // (the key load does not wait for the visibility word: both are issued for every splat of the chunk)
-                unsigned long long m = 0ull;
-                if (base + r * 64 < n) m = vmask[(base + r * 64) >> 6];          // wave-uniform
-                if (valid[r]) { key[r] = keys_in[i]; val[r] = i; }
-                valid[r] = valid[r] && ((m >> lane) & 1ull);
-            } else if (valid[r]) {
-                key[r] = keys_in[i];
-                val[r] = vals_in[i];
+                valid[r] = valid[r] && ((vm[r] >> lane) & 1ull);
+                val[r] = i;
             }
         }
         uint32_t* wcnt = s_cnt + (uint32_t)w * half;
@@ -1398,6 +1469,7 @@ __global__ __launch_bounds__(kThreads) void count_drawn_kernel(const uint32_t* _
 //                     row the words are ascending and tile_start_kernel can binary-search them.
 // ------------------------------------------------------------------------------------------
 
+template <int BIN_CHUNK>
 __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restrict__ rect,
                                                          const uint32_t* __restrict__ d_V,
                                                          uint32_t* __restrict__ hist, uint32_t hist_stride,
@@ -1412,16 +1484,19 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
     __shared__ uint32_t s_diff[kThreads + 1];
     __shared__ uint32_t s_tmp[4];
     const uint32_t V = *d_V;
-    const uint32_t nchunks = (V + kBinChunk - 1) / kBinChunk;
+    const uint32_t nchunks = (V + BIN_CHUNK - 1) / BIN_CHUNK;
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         s_diff[threadIdx.x] = 0;
         if (threadIdx.x == 0) s_diff[kThreads] = 0;
         __syncthreads();
+        uint32_t rcs[BIN_CHUNK / kThreads];          // clamped loads, all in flight together (V >= 1 here)
 #pragma unroll
-        for (int k = 0; k < kBinChunk / kThreads; ++k) {
-            const uint32_t r = chunk * kBinChunk + k * kThreads + threadIdx.x;
+        for (int k = 0; k < BIN_CHUNK / kThreads; ++k) rcs[k] = rect[min(chunk * BIN_CHUNK + k * kThreads + threadIdx.x, V - 1u)];
+#pragma unroll
+        for (int k = 0; k < BIN_CHUNK / kThreads; ++k) {
+            const uint32_t r = chunk * BIN_CHUNK + k * kThreads + threadIdx.x;
             if (r < V) {
-                const uint32_t rc = rect[r];
+                const uint32_t rc = rcs[k];
                 const uint32_t tx0 = rc & 255u, ty0 = (rc >> 8) & 255u, tx1 = (rc >> 16) & 255u, ty1 = rc >> 24;
                 if (tx0 <= tx1) {
                     // pairs per column = sum of row counts of the rectangles covering it: difference array
@@ -1446,7 +1521,7 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
 // order, weight = number of tile rows; wave w takes a contiguous quarter of the chunk's items, so
 // (wave, round, lane) order == item order.  Ranking inside a wave: ballot-match on the column byte,
 // weighted prefix from 9 ballots over the bits of the weight (rows <= 256).
-template <bool ATOMIC_RANK>
+template <bool ATOMIC_RANK, int BIN_CHUNK>
 __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __restrict__ rect,
                                                            const uint32_t* __restrict__ d_V,
                                                            const uint32_t* __restrict__ hist, uint32_t hist_stride,
@@ -1456,25 +1531,26 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
                                                            uint32_t* __restrict__ d_overflow,
                                                            uint32_t* __restrict__ host_words, int report_overflow,
                                                            const uint32_t* __restrict__ gsum,
-                                                           uint32_t* __restrict__ totals_out)
+                                                           uint32_t* __restrict__ totals_out, int xcd_map)
 {
     // gsum != nullptr: scan-free path (hist = raw per-chunk column counts, see radix_upsweep); workgroup 0 then also
     // publishes the column totals in totals_out for the row pass.  host_words (host-mapped): [0] pairs needed by an
     // overflowed device-output frame, [1] V and [2] D of the latest frame (read by the host without synchronising,
     // only to choose between the scan-free and the 3-kernel path for the NEXT frame's row pass)
-    constexpr int PER = kBinChunk / kThreads;          // rectangles per thread (blocked)
-    __shared__ uint32_t s_off[kBinChunk + 1];          // exclusive scan of the rectangle widths
-    __shared__ uint32_t s_rect[kBinChunk];
+    constexpr int PER = BIN_CHUNK / kThreads;          // rectangles per thread (blocked)
+    __shared__ uint32_t s_off[BIN_CHUNK + 1];          // exclusive scan of the rectangle widths
+    __shared__ uint32_t s_rect[BIN_CHUNK];
     __shared__ uint32_t s_cnt[4][256];                 // per-wave column weights, then per-wave cursors
     __shared__ uint32_t s_base[kThreads];
     __shared__ uint32_t s_tmp[4];
     // item -> owner rectangle table (chunks with at most kOwnerCap items; larger ones binary-search s_off):
     // one LDS read per item instead of a 10-step dependent search, twice per item
-    constexpr uint32_t kOwnerCap = 8192;
+    constexpr uint32_t kOwnerCap = 8u * BIN_CHUNK;       // 8192 / 16384 items: 16 / 32 KB
     __shared__ __attribute__((aligned(16))) uint16_t s_owner[kOwnerCap];
+    __shared__ uint32_t s_emit[4][3][64];              // per wave: {first word, destination, base word} of a batch's items
     uint4* s_part = reinterpret_cast<uint4*>(s_owner);      // 16 KB, not live while the row sums run
     const uint32_t V = *d_V;
-    const uint32_t nchunks = (V + kBinChunk - 1) / kBinChunk;
+    const uint32_t nchunks = (V + BIN_CHUNK - 1) / BIN_CHUNK;
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -1502,9 +1578,11 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
     }
     __syncthreads();
 
-    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    for (uint32_t cidx = blockIdx.x; cidx < nchunks; cidx += gridDim.x) {
+        // (xcd_map: see ws_downsweep -- the (chunk, column) runs of neighbouring chunks are adjacent in memory)
+        const uint32_t chunk = (xcd_map && (gridDim.x >= nchunks || (gridDim.x & 7u) == 0u)) ? xcd_contiguous(cidx, nchunks) : cidx;
         const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk, s_part) : hist[(size_t)chunk * 256 + threadIdx.x];
-        const uint32_t rbase = chunk * kBinChunk;
+        const uint32_t rbase = chunk * BIN_CHUNK;
         uint32_t rc[PER], woff[PER], wsum = 0;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -1520,7 +1598,7 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
             s_off[threadIdx.x * PER + k] = incl - wsum + woff[k];
             s_rect[threadIdx.x * PER + k] = rc[k];
         }
-        if (threadIdx.x == 0) s_off[kBinChunk] = M;
+        if (threadIdx.x == 0) s_off[BIN_CHUNK] = M;
 #pragma unroll
         for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
         const bool owner_table = M <= kOwnerCap;              // block-uniform
@@ -1539,12 +1617,12 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
 
         // item k -> (owner rectangle j, column tx, rows, first row)
         auto locate = [&](uint32_t k, uint32_t& tx, uint32_t& rows, uint32_t& ty0, uint32_t& rank) {
-            uint32_t lo = 0, hi = kBinChunk - 1;      // last j with s_off[j] <= k (1024 candidates: 10 steps)
+            uint32_t lo = 0, hi = BIN_CHUNK - 1;      // last j with s_off[j] <= k (BIN_CHUNK candidates: 10 / 11 steps)
             if (owner_table) {
                 lo = s_owner[k];
             } else {
 #pragma unroll
-                for (int s = 0; (1 << s) < kBinChunk; ++s) {
+                for (int s = 0; (1 << s) < BIN_CHUNK; ++s) {
                     const uint32_t mid = (lo + hi + 1u) >> 1;
                     if (s_off[mid] <= k) lo = mid; else hi = mid - 1u;
                 }
@@ -1606,9 +1684,38 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
                 __builtin_amdgcn_wave_barrier();
                 pos = prev + pre;
             }
-            if (valid) {
-                for (uint32_t q = 0; q < rows; ++q)
+            // emit: item j writes `rows` consecutive words.  With small footprints (rows <= 2 everywhere in the batch) every
+            // lane writes its own; otherwise one screen-high splat would keep its lane busy for up to 256 iterations while
+            // the other 63 idle (scene-like clouds, r3: this kernel was 330 us of a 765 us frame), so the wave expands the
+            // batch cooperatively: word x of the batch's concatenated output belongs to the item whose exclusive row prefix
+            // covers x (6-step search in a wave-private LDS table), and consecutive lanes write consecutive words.
+            const uint32_t nrows = valid ? rows : 0u;
+            if (__ballot(nrows > 2u) == 0ull) {
+                for (uint32_t q = 0; q < nrows; ++q)
                     if (pos + q < cap) pairs_out[pos + q] = ((ty0 + q) << 24) | rank;
+            } else {
+                uint32_t incl = nrows;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t t = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += t;
+                }
+                const uint32_t total = __shfl(incl, 63, 64);
+                s_emit[w][0][lane] = incl - nrows;                  // first word of the item inside the batch
+                s_emit[w][1][lane] = pos;
+                s_emit[w][2][lane] = (ty0 << 24) | rank;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (uint32_t x = lane; x < total; x += 64u) {
+                    uint32_t lo = 0;                                 // last item j with excl[j] <= x
+#pragma unroll
+                    for (int st = 32; st >= 1; st >>= 1)
+                        if (s_emit[w][0][lo + st] <= x) lo += st;
+                    const uint32_t q = x - s_emit[w][0][lo], p = s_emit[w][1][lo] + q;
+                    if (p < cap) pairs_out[p] = s_emit[w][2][lo] + (q << 24);
+                }
+                __builtin_amdgcn_wave_barrier();                     // the table is rewritten by the next batch
             }
         }
         __syncthreads();
@@ -1795,6 +1902,9 @@ constexpr int kCompThreads = 64;   // one wave per 16x16 tile, 4 pixels (one per
 // two), colours accumulate unchanged and Ts -= 2^118 tw.  The bias costs 4 bits of the exponent's absolute
 // precision (|e - 118| ~ 2^7 instead of <= 2^3): a relative error of 3e-6 in w.  Only e == -8 exactly (w == 1/256,
 // which the reference discards) is kept: a measure-zero threshold flip.
+// (r3, measured and removed: a per-record mask of the strip PAIRS its y reach touches, with a scalar branch over the other
+//  pair's packed instructions -- 80 -> 105 us at config 2, 404 -> 530 us at config 4: the two pairs are independent
+//  dependency chains inside one basic block that the in-order wave overlaps; a branch per pair serialises them.  DESIGN.md 4.)
 template <bool HALF, int NP, int OCC, bool FTZ>
 __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint32_t* __restrict__ tile_start,
                                                                  const uint32_t* __restrict__ pairs,

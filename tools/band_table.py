@@ -61,16 +61,20 @@ def main():
         frames(6)
         torch.cuda.synchronize()
         r.timings()
-        t0 = time.perf_counter()
-        frames(args.frames, 6)
-        torch.cuda.synchronize()
-        ms = 1e3 * (time.perf_counter() - t0) / args.frames
+        blocks = []
+        for b in range(3):          # the fastest of three blocks: the runtime's one-off stalls (pool growth) must not count
+            t0 = time.perf_counter()
+            frames(args.frames, 6 + b * args.frames)
+            torch.cuda.synchronize()
+            blocks.append(1e3 * (time.perf_counter() - t0) / args.frames)
+        ms = min(blocks)
         tm = r.timings()
         st = r.stats()
         return dict(frame_ms=ms, sort_ms=tm["sort_total"], project_ms=tm["project"], binning_ms=tm["binning"],
                     composite_ms=tm["composite"], V=st["sort_count"], pairs=st["pairs"])
 
     r.set_band(1, 0)
+    frames(300)                 # get past the runtime's start-up stall (bench.py --prewarm)
     whole = measure()
     out = {"workload": wl["desc"], "world": G, "bin_rows": R, "bin_px": T, "single_gpu": whole, "layouts": {},
            "xgmi_link_GBps": XGMI_LINK / 1e9, "frames_per_point": args.frames}

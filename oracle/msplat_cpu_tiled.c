@@ -65,6 +65,54 @@ static inline void pixel_range(float centre, float half, int lo_clip, int hi_cli
     *hi = (int)b;
 }
 
+/* exp(x) for x <= 0, branch-free so that the compositor's row loop vectorises: Cody-Waite range reduction and the degree-5
+ * polynomial of the classic single-precision expf (relative error ~1e-7: the baseline need not be bit-identical to the
+ * literal oracle, tests/test_oracle.py holds it to the framebuffer tolerance) */
+static inline float exp_neg(float x)
+{
+    x = x < -87.0f ? -87.0f : x;
+    const float t = x * 1.44269504088896341f;
+    const int n = (int)(t - 0.5f);                           /* nearest integer for t <= 0 */
+    const float fn = (float)n;
+    float r = x - fn * 0.693359375f;
+    r = r - fn * -2.12194440e-4f;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    p = p * r * r + r + 1.0f;
+    union { int32_t i; float f; } s;
+    s.i = (n + 127) << 23;
+    return p * s.f;
+}
+
+/* one pixel row segment of one splat inside a tile: n <= 16 pixels starting at tile-local index p0, first pixel centre
+ * offset (dx0, dy) from the splat centre.  splat_frag.glsl:20-41 + the front-to-back blend; discarded fragments and
+ * saturated pixels get weight 0 (no branches). */
+__attribute__((target_clones("avx2", "default")))
+static void blend_row(float* __restrict__ T, float* __restrict__ cr, float* __restrict__ cg, float* __restrict__ cb, int n,
+                      float dx0, float dy, float i0, float i1, float i2, float i3, float alpha, float r, float g, float b, float t_eps)
+{
+#pragma omp simd
+    for (int k = 0; k < n; ++k) {
+        const float dx = dx0 + (float)k;
+        const float mx = i0 * dx + i2 * dy;
+        const float my = i1 * dx + i3 * dy;
+        const float q = dx * mx + dy * my;
+        const float sa = alpha * exp_neg(-0.5f * q);
+        const float t = T[k];
+        const int keep = (sa > (1.0f / 256.0f)) & (t >= t_eps);
+        const float w = keep ? sa : 0.0f;
+        const float tw = t * w;
+        cr[k] += tw * r;
+        cg[k] += tw * g;
+        cb[k] += tw * b;
+        T[k] = t - tw;
+    }
+}
+
 /* stable LSD radix sort of (key, idx), 4 x 8 bit, `nb` blocks of contiguous input; a pass whose digit is the same for
  * every key is skipped.  Result in keyA / idxA. */
 static void par_sort(uint32_t v, uint32_t** pk, uint32_t** pi, uint32_t** pk2, uint32_t** pi2, int nb)
@@ -268,32 +316,27 @@ uint32_t orc_render_frame_tiled(size_t n, const float* aos, size_t stride, int f
         const int x1 = x0 + TILE < W ? x0 + TILE : W, y1 = y0 + TILE < H ? y0 + TILE : H;
         float T[TILE * TILE], cr[TILE * TILE], cg[TILE * TILE], cb[TILE * TILE];
         for (int k = 0; k < TILE * TILE; ++k) { T[k] = 1.0f; cr[k] = 0.0f; cg[k] = 0.0f; cb[k] = 0.0f; }
-        int live = (x1 - x0) * (y1 - y0);
         const uint32_t s = ws->tile_start[t], e = ws->tile_start[t + 1];
-        for (uint32_t k = e; k > s && live > 0; --k) {
+        uint32_t since_check = 0;
+        for (uint32_t k = e; k > s; --k) {
             const orc_splat2d* g = &ws->splats[ws->pairs[k - 1]];
             int xa, xb, ya, yb;
             pixel_range(g->px, g->hx, x0, x1, &xa, &xb);
             pixel_range(g->py, g->hy, y0, y1, &ya, &yb);
+            if (xa > xb) continue;
+            const float dx0 = ((float)xa + 0.5f) - g->px;
             for (int y = ya; y <= yb; ++y) {
-                for (int x = xa; x <= xb; ++x) {
-                    const int p = (y - y0) * TILE + (x - x0);
-                    if (T[p] < t_eps) continue;                  /* saturated: the remaining splats add < t_eps |c| */
-                    /* splat_frag.glsl:20-41, same expression as orc_composite */
-                    float dx = ((float)x + 0.5f) - g->px;
-                    float dy = ((float)y + 0.5f) - g->py;
-                    float mx = g->inv[0] * dx + g->inv[2] * dy;
-                    float my = g->inv[1] * dx + g->inv[3] * dy;
-                    float q = dx * mx + dy * my;
-                    float sa = g->alpha * expf(-0.5f * q);
-                    if (sa <= (1.0f / 256.0f)) continue;        /* discard */
-                    const float tw = T[p] * sa;
-                    cr[p] += tw * g->rgb[0];
-                    cg[p] += tw * g->rgb[1];
-                    cb[p] += tw * g->rgb[2];
-                    T[p] -= tw;
-                    if (T[p] < t_eps) --live;
-                }
+                const int p0 = (y - y0) * TILE + (xa - x0);
+                /* splat_frag.glsl:20-41 (same expression as orc_composite); a saturated pixel (T < t_eps) takes no more */
+                blend_row(T + p0, cr + p0, cg + p0, cb + p0, xb - xa + 1, dx0, ((float)y + 0.5f) - g->py, g->inv[0], g->inv[1],
+                          g->inv[2], g->inv[3], g->alpha, g->rgb[0], g->rgb[1], g->rgb[2], t_eps);
+            }
+            if (++since_check == 16 && t_eps > 0.0f) {         /* every 16 splats: is the whole tile saturated? */
+                since_check = 0;
+                int live = 0;
+                for (int yy = 0; yy < y1 - y0; ++yy)
+                    for (int xx = 0; xx < x1 - x0; ++xx) live += T[yy * TILE + xx] >= t_eps;
+                if (!live) break;
             }
         }
         for (int y = y0; y < y1; ++y) {

@@ -307,8 +307,7 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
                         atomicAdd(&s_bin[j * 256u + row], 1u);
                     } else {
                         atomicAdd(&s_hist[row], 1u);
-                        (void)__hip_atomic_fetch_add(&bincnt[row * (uint32_t)fp.tiles_x + cw], 1u, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
+                        (void)__hip_atomic_fetch_add(&bincnt[cw * 256u + row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
@@ -346,9 +345,10 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
             for (int j = 0; j < kPairCols; ++j) {
                 const uint32_t v = s_bin[j * 256 + threadIdx.x];
                 c += v;
+                // bincnt is [column][row] (256 rows per column): the rows of one column are consecutive words, so a wave's
+                // adds touch one or two cache lines (with [row][column] every lane hit its own line: 15 us instead of 7)
                 if (v != 0u)
-                    (void)__hip_atomic_fetch_add(&bincnt[threadIdx.x * (uint32_t)fp.tiles_x + c0 + j], v, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
+                    (void)__hip_atomic_fetch_add(&bincnt[(c0 + j) * 256u + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         hist[(size_t)chunk * 256 + threadIdx.x] = c;
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(kThreads) void radix_scan_small(uint32_t* __restric
 // counts -- no search in the partitioned array -- and the counting sort of the bins by list length (heaviest first,
 // what tile_order_kernel did in its own launch) reads the same numbers.  Clears the counts for the next frame and
 // resets the compositors' queue heads.  tile_start gets ceil((ntiles + 1) / 1024) * 1024 entries (the tail = D).
-__device__ __forceinline__ void tile_table_role(uint32_t* __restrict__ bincnt, int ntiles,
+__device__ __forceinline__ void tile_table_role(uint32_t* __restrict__ bincnt, int ntiles, int tiles_x,
                                                 uint32_t* __restrict__ tile_start, uint32_t* __restrict__ order,
                                                 uint32_t* __restrict__ queue, int do_order,
                                                 uint32_t* s_cnt256, uint32_t* s_off256, uint32_t* s_tmp4)
@@ -517,17 +517,22 @@ __device__ __forceinline__ void tile_table_role(uint32_t* __restrict__ bincnt, i
     const uint32_t nblk = ((uint32_t)ntiles + 1u + 1023u) / 1024u;
     uint32_t running = 0;
     for (uint32_t b = 0; b < nblk; ++b) {
-        const uint32_t i0 = b * 1024u + threadIdx.x * 4u;
-        uint4 v = *reinterpret_cast<const uint4*>(bincnt + i0);
-        if (i0 + 0u >= (uint32_t)ntiles) v.x = 0u;           // (entries past the last bin are zero anyway)
-        if (i0 + 1u >= (uint32_t)ntiles) v.y = 0u;
-        if (i0 + 2u >= (uint32_t)ntiles) v.z = 0u;
-        if (i0 + 3u >= (uint32_t)ntiles) v.w = 0u;
-        const uint32_t local = v.x + v.y + v.z + v.w;
+        const uint32_t i0 = b * 1024u + threadIdx.x * 4u;      // bins i0 .. i0 + 3 (bin = row * tiles_x + column)
+        uint32_t c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t bin = i0 + (uint32_t)k;
+            c[k] = 0u;
+            if (bin < (uint32_t)ntiles) {
+                const uint32_t row = bin / (uint32_t)tiles_x, col = bin - row * (uint32_t)tiles_x;
+                c[k] = bincnt[col * 256u + row];                  // the counts are stored [column][row]
+                bincnt[col * 256u + row] = 0u;
+            }
+        }
+        const uint32_t local = c[0] + c[1] + c[2] + c[3];
         uint32_t total;
         const uint32_t e = running + block_incl_scan(local, s_tmp4, total) - local;
-        *reinterpret_cast<uint4*>(tile_start + i0) = make_uint4(e, e + v.x, e + v.x + v.y, e + v.x + v.y + v.z);
-        *reinterpret_cast<uint4*>(bincnt + i0) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(tile_start + i0) = make_uint4(e, e + c[0], e + c[0] + c[1], e + c[0] + c[1] + c[2]);
         running += total;
     }
     if (!do_order) return;
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
     uint32_t nworkers = gridDim.x, wb = blockIdx.x;      // worker count / this workgroup's worker index
     if (MODE == MODE_PAIR && bincnt != nullptr) {
         if (blockIdx.x == 0u) {                  // workgroup-uniform; dispatched first
-            tile_table_role(bincnt, ntiles, tile_start, tile_order, queue, do_order, s_cnt[0], s_base, s_tmp);
+            tile_table_role(bincnt, ntiles, fp.tiles_x, tile_start, tile_order, queue, do_order, s_cnt[0], s_base, s_tmp);
             return;
         }
         nworkers = gridDim.x - 1u;
@@ -1547,7 +1552,6 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
     // one LDS read per item instead of a 10-step dependent search, twice per item
     constexpr uint32_t kOwnerCap = 8u * BIN_CHUNK;       // 8192 / 16384 items: 16 / 32 KB
     __shared__ __attribute__((aligned(16))) uint16_t s_owner[kOwnerCap];
-    __shared__ uint32_t s_emit[4][3][64];              // per wave: {first word, destination, base word} of a batch's items
     uint4* s_part = reinterpret_cast<uint4*>(s_owner);      // 16 KB, not live while the row sums run
     const uint32_t V = *d_V;
     const uint32_t nchunks = (V + BIN_CHUNK - 1) / BIN_CHUNK;
@@ -1684,38 +1688,22 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
                 __builtin_amdgcn_wave_barrier();
                 pos = prev + pre;
             }
-            // emit: item j writes `rows` consecutive words.  With small footprints (rows <= 2 everywhere in the batch) every
-            // lane writes its own; otherwise one screen-high splat would keep its lane busy for up to 256 iterations while
-            // the other 63 idle (scene-like clouds, r3: this kernel was 330 us of a 765 us frame), so the wave expands the
-            // batch cooperatively: word x of the batch's concatenated output belongs to the item whose exclusive row prefix
-            // covers x (6-step search in a wave-private LDS table), and consecutive lanes write consecutive words.
+            // emit: item j writes `rows` consecutive words.  Light items (at most 8 rows: all of them in a cloud of small
+            // splats) are written by their own lane; an item with more rows -- a splat a quarter of the screen high would
+            // keep its lane busy for dozens of iterations while the other 63 idle (scene-like clouds, r3: this kernel was
+            // 330 us of a 765 us frame) -- is written by the whole wave, one store instruction per 64 rows.
             const uint32_t nrows = valid ? rows : 0u;
-            if (__ballot(nrows > 2u) == 0ull) {
+            const uint32_t wbase = (ty0 << 24) | rank;
+            unsigned long long heavy = __ballot(nrows > 8u);
+            if (nrows <= 8u)
                 for (uint32_t q = 0; q < nrows; ++q)
-                    if (pos + q < cap) pairs_out[pos + q] = ((ty0 + q) << 24) | rank;
-            } else {
-                uint32_t incl = nrows;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t t = __shfl_up(incl, d, 64);
-                    if (lane >= d) incl += t;
-                }
-                const uint32_t total = __shfl(incl, 63, 64);
-                s_emit[w][0][lane] = incl - nrows;                  // first word of the item inside the batch
-                s_emit[w][1][lane] = pos;
-                s_emit[w][2][lane] = (ty0 << 24) | rank;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (uint32_t x = lane; x < total; x += 64u) {
-                    uint32_t lo = 0;                                 // last item j with excl[j] <= x
-#pragma unroll
-                    for (int st = 32; st >= 1; st >>= 1)
-                        if (s_emit[w][0][lo + st] <= x) lo += st;
-                    const uint32_t q = x - s_emit[w][0][lo], p = s_emit[w][1][lo] + q;
-                    if (p < cap) pairs_out[p] = s_emit[w][2][lo] + (q << 24);
-                }
-                __builtin_amdgcn_wave_barrier();                     // the table is rewritten by the next batch
+                    if (pos + q < cap) pairs_out[pos + q] = wbase + (q << 24);
+            while (heavy != 0ull) {                                  // wave-uniform
+                const int j = __ffsll((long long)heavy) - 1;
+                heavy &= heavy - 1ull;
+                const uint32_t r = __shfl(nrows, j, 64), p = __shfl(pos, j, 64), wb = __shfl(wbase, j, 64);
+                for (uint32_t q = lane; q < r; q += 64u)
+                    if (p + q < cap) pairs_out[p + q] = wb + (q << 24);
             }
         }
         __syncthreads();

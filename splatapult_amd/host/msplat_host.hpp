@@ -141,9 +141,10 @@ public:
         if (ctxs.empty()) return;
         cur = (cur + 1) % (int)ctxs.size();
         ctx = ctxs[cur];
-        if (msplat_sort(ctx, reinterpret_cast<const float*>(&cameraMat), reinterpret_cast<const float*>(&projMat),
-                        reinterpret_cast<const float*>(&viewport), reinterpret_cast<const float*>(&nearFar)) != MSPLAT_OK)
-            std::fprintf(stderr, "[msplat][E] Sort: %s\n", msplat_last_error(ctx));     // void, like the reference
+        const int rc = msplat_sort(ctx, reinterpret_cast<const float*>(&cameraMat), reinterpret_cast<const float*>(&projMat),
+                                   reinterpret_cast<const float*>(&viewport), reinterpret_cast<const float*>(&nearFar));
+        if (rc != MSPLAT_OK)         // void, like the reference; MSPLAT_ERR_PAIR_OVERFLOW_EARLIER is about a PAST frame
+            std::fprintf(stderr, "[msplat][%c] Sort: %s\n", rc == MSPLAT_ERR_PAIR_OVERFLOW_EARLIER ? 'W' : 'E', msplat_last_error(ctx));
     }
 
     // splatrenderer.cpp:315-343 (+ the GL pipeline behind glDrawElements)
@@ -162,10 +163,11 @@ public:
                 std::fprintf(stderr, "[msplat][E] Render: %s\n", msplat_group_last_error(group));
             return;
         }
-        if (msplat_render(ctx, reinterpret_cast<const float*>(&cameraMat), reinterpret_cast<const float*>(&projMat),
-                          reinterpret_cast<const float*>(&viewport), reinterpret_cast<const float*>(&nearFar), target,
-                          targetPitch, targetIsDevice ? 1 : 0) != MSPLAT_OK)
-            std::fprintf(stderr, "[msplat][E] Render: %s\n", msplat_last_error(ctx));
+        const int rc = msplat_render(ctx, reinterpret_cast<const float*>(&cameraMat), reinterpret_cast<const float*>(&projMat),
+                                     reinterpret_cast<const float*>(&viewport), reinterpret_cast<const float*>(&nearFar), target,
+                                     targetPitch, targetIsDevice ? 1 : 0);
+        if (rc != MSPLAT_OK)
+            std::fprintf(stderr, "[msplat][%c] Render: %s\n", rc == MSPLAT_ERR_PAIR_OVERFLOW_EARLIER ? 'W' : 'E', msplat_last_error(ctx));
     }
 
     // replaces "the currently bound GL framebuffer" (app.cpp:1000-1035)

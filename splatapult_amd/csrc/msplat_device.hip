@@ -87,6 +87,9 @@ struct msplat_ctx {
     bool bin_counts = true;     // MSPLAT_TILE_TABLE=search: tile_start_kernel / tile_order_kernel as in r2
     int xcd_map = 1;            // MSPLAT_XCD_MAP bit 0: sort downsweeps (default on: 6 M splats 196 -> 185 us, no change at 1 M), bit 1: the
                                 // column pass's downsweep (off: 6 M / 4096^2 453 -> 509 us) take XCD-contiguous chunk ranges
+    Buf heavy, heavy_flag;      // column pass: chunks with far more pairs than the others are split over several workgroups
+    uint32_t render_parity = 0;
+    bool heavy_split = true;    // MSPLAT_HEAVY_SPLIT=0: no helper workgroups (A/B)
     uint32_t bin_chunk = 1024;  // ranks per chunk of the column pass (kBinChunk / kBinChunkLarge by cloud size)
     bool scan_free = true;  // MSPLAT_SCAN_KERNELS=1 forces the 3-kernel (upsweep, scan, downsweep) passes
     uint32_t fused_max_chunks = kFusedMaxChunks;   // MSPLAT_FUSED_MAX_CHUNKS: scan-free passes up to this many chunk rows
@@ -325,6 +328,7 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         if (!ctx->atomic_rank) ctx->wide_sort = false;       // the wide kernels rank with lane-ordered LDS atomics only
         if (const char* tk = getenv("MSPLAT_TILE_TABLE")) ctx->bin_counts = std::string(tk) != "search";
         if (getenv("MSPLAT_XCD_MAP")) ctx->xcd_map = atoi(getenv("MSPLAT_XCD_MAP"));
+        if (getenv("MSPLAT_HEAVY_SPLIT")) ctx->heavy_split = atoi(getenv("MSPLAT_HEAVY_SPLIT")) != 0;
         if (ctx->wide_sort) {
             // ws_downsweep needs 72 / 104 KB of dynamic LDS: above the 64 KB a kernel gets without asking
             static const bool lds_ok = [] {
@@ -370,7 +374,7 @@ void msplat_destroy(msplat_ctx* ctx)
     Buf* all[] = {&ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist, &ctx->gsumS[0], &ctx->gsumS[1], &ctx->gsumB1, &ctx->gsumB2,
                   &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->totals1, &ctx->tile_start, &ctx->tile_order,
                   &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe, &ctx->zq, &ctx->sprite, &ctx->queue,
-                  &ctx->wsHist, &ctx->wsGsum[0], &ctx->wsGsum[1], &ctx->wsGsum[2], &ctx->vmask, &ctx->bincnt};
+                  &ctx->wsHist, &ctx->wsGsum[0], &ctx->wsGsum[1], &ctx->wsGsum[2], &ctx->vmask, &ctx->bincnt, &ctx->heavy, &ctx->heavy_flag};
     for (Buf* b : all) buf_free(ctx, *b);
     if (ctx->ev_ok)
         for (auto& set : ctx->ev)
@@ -615,6 +619,10 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
     if (ctx->depth_bits != 0 && (rc = buf_alloc(ctx, ctx->zq, alloc_n * 4))) return rc;
     ctx->bin_chunk = (uint32_t)kBinChunk;      // r3: 2048-rank chunks measured at 6 M: binning 183 -> 191 us (1080p), 459 -> 453 us (4096^2)
     if (const char* bc = getenv("MSPLAT_BIN_CHUNK")) ctx->bin_chunk = atoi(bc) == kBinChunkLarge ? (uint32_t)kBinChunkLarge : (uint32_t)kBinChunk;
+    if ((rc = buf_alloc(ctx, ctx->heavy, (size_t)2 * (1 + kHeavyCap) * 4))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->heavy.p, 0, ctx->heavy.bytes, ctx->stream));
+    if ((rc = buf_alloc(ctx, ctx->heavy_flag, (size_t)div_up(alloc_n, kBinChunk) + 64))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->heavy_flag.p, 0, ctx->heavy_flag.bytes, ctx->stream));
     ctx->hist1_stride = std::max(1u, div_up(n, kBinChunk));
     if ((rc = buf_alloc(ctx, ctx->hist1, (size_t)256 * ctx->hist1_stride * 4))) return rc;
     if ((rc = alloc_group_table(ctx, ctx->gsumB1, ctx->gsumB1_rows, ctx->hist1_stride))) return rc;
@@ -1026,6 +1034,7 @@ static int clear_frame_tables(msplat_ctx* ctx)
         if (b->p) HIP_TRY(ctx, hipMemsetAsync(b->p, 0, b->bytes, s));
     HIP_TRY(ctx, hipMemsetAsync((uint32_t*)ctx->counters.p + 10, 0xFF, 2 * sizeof(uint32_t), s));
     HIP_TRY(ctx, hipMemsetAsync(ctx->queue.p, 0, ctx->queue.bytes, s));
+    if (ctx->heavy.p) HIP_TRY(ctx, hipMemsetAsync(ctx->heavy.p, 0, ctx->heavy.bytes, s));
     ctx->tables_dirty = false;
     return MSPLAT_OK;
 }
@@ -1197,6 +1206,11 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     uint32_t* totals2 = (uint32_t*)ctx->totals.p;
     const uint32_t bchunk = ctx->bin_chunk;
     const int g1 = grid_for(div_up(N, bchunk));
+    // heavy chunks of the column pass (bin1_upsweep): list per frame parity, helper workgroups in front of the downsweep's grid
+    uint32_t* hv_cur = (uint32_t*)ctx->heavy.p + (ctx->render_parity & 1u) * (1u + kHeavyCap);
+    uint32_t* hv_next = (uint32_t*)ctx->heavy.p + ((ctx->render_parity ^ 1u) & 1u) * (1u + kHeavyCap);
+    ctx->render_parity ^= 1u;
+    const int nhelp = ctx->heavy_split ? (int)(kHeavyCap * (kHeavyParts - 1u)) : 0;
     // scan-free variants while the chunk tables are small; the row pass's size (D) is only known on the device, so
     // its choice uses the D of an EARLIER frame that the binning kernel left in host-mapped memory (0 = none yet);
     // either variant is correct at any size, the choice only matters for speed
@@ -1211,19 +1225,24 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
 #define MSPLAT_BIN1(CH)                                                                                                       \
     do {                                                                                                                      \
         hipLaunchKernelGGL(bin1_upsweep<CH>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,               \
-                           (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_overflow, fused1 ? gB1 : nullptr, gB2, ctx->gsumB2_rows); \
+                           (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_overflow, fused1 ? gB1 : nullptr, gB2,               \
+                           ctx->gsumB2_rows, hv_cur, hv_next, (uint8_t*)ctx->heavy_flag.p);                                   \
         if (!fused1)                                                                                                          \
             launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V, 0u, N, bchunk, totals1);     \
         if (ctx->atomic_rank)                                                                                                 \
-            hipLaunchKernelGGL((bin1_downsweep<true, CH>), dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V, \
-                               (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,                    \
-                               (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags, async_overflow_flag ? 1 : 0,      \
-                               fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, (ctx->xcd_map & 2) ? 1 : 0); \
+            hipLaunchKernelGGL((bin1_downsweep<true, CH>), dim3(g1 + nhelp), dim3(kThreads), 0, s,                            \
+                               (const uint32_t*)ctx->rect.p, d_V, (const uint32_t*)ctx->hist1.p, ctx->hist1_stride,           \
+                               (const uint32_t*)totals1, (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags,        \
+                               async_overflow_flag ? 1 : 0, fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, \
+                               (ctx->xcd_map & 2) ? 1 : 0, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,         \
+                               (uint32_t)nhelp, fp.tiles_x);                                                                  \
         else                                                                                                                  \
-            hipLaunchKernelGGL((bin1_downsweep<false, CH>), dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V, \
-                               (const uint32_t*)ctx->hist1.p, ctx->hist1_stride, (const uint32_t*)totals1,                    \
-                               (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags, async_overflow_flag ? 1 : 0,      \
-                               fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, (ctx->xcd_map & 2) ? 1 : 0); \
+            hipLaunchKernelGGL((bin1_downsweep<false, CH>), dim3(g1 + nhelp), dim3(kThreads), 0, s,                           \
+                               (const uint32_t*)ctx->rect.p, d_V, (const uint32_t*)ctx->hist1.p, ctx->hist1_stride,           \
+                               (const uint32_t*)totals1, (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags,        \
+                               async_overflow_flag ? 1 : 0, fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, \
+                               (ctx->xcd_map & 2) ? 1 : 0, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,         \
+                               (uint32_t)nhelp, fp.tiles_x);                                                                  \
     } while (0)
     // (bin1_upsweep also clears the row pass's group table: its consumer, the previous frame's row downsweep, is long done)
     if (bchunk == (uint32_t)kBinChunkLarge) MSPLAT_BIN1(kBinChunkLarge); else MSPLAT_BIN1(kBinChunk);

@@ -29,6 +29,9 @@ constexpr int kPairItems = 16;           // binning pass 2 moves 7x more words: 
 constexpr int kPairChunk = kThreads * kPairItems;   // 4096 words per chunk
 template <int MODE, int SORT_ITEMS> struct RadixCfg { static constexpr int ITEMS = (MODE == 2) ? kPairItems : SORT_ITEMS; static constexpr int CHUNK = kThreads * ITEMS; };
 constexpr int kBinChunk = 1024;          // draw-order ranks per chunk in the tile-column partition (512 / 2048 measured at 1 M: binning 64 -> 70 us)
+constexpr uint32_t kHeavyPairs = 49152;  // a column-pass chunk with more pairs than this is split over kHeavyParts workgroups
+constexpr uint32_t kHeavyCap = 128;      // at most this many split chunks per frame (the rest run unsplit: correct, slower)
+constexpr uint32_t kHeavyParts = 8;      // column blocks per split chunk
 constexpr int kBinChunkLarge = 2048;     // MSPLAT_BIN_CHUNK=2048: a (chunk, column) run of pair words twice as long; measured r3 at 6 M splats: no gain
 constexpr int kTile = 16;                // one compositor wave owns a 16x16 pixel tile ...
 constexpr int kBin = 32;                 // ... binning works on 32x32 bins (4 tiles share one list, each
@@ -1480,10 +1483,18 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
                                                          uint32_t* __restrict__ hist, uint32_t hist_stride,
                                                          uint32_t* __restrict__ d_overflow,
                                                          uint32_t* __restrict__ gsum_acc,
-                                                         uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_rows)
+                                                         uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_rows,
+                                                         uint32_t* __restrict__ heavy, uint32_t* __restrict__ heavy_next,
+                                                         uint8_t* __restrict__ heavy_flag)
 {
+    // Heavy chunks (r3).  The ranks are in depth order, so the huge far-away splats of a real scene (sky, background) are the
+    // FIRST ranks: a few chunks hold half of all the pairs (scene-like 6 M cloud: 25 of 2344 chunks, 500 k pairs each against
+    // 11 k), and the column pass lasted as long as the slowest of them.  A chunk with more than kHeavyPairs pairs is put on a
+    // list (heavy[0] = count, heavy[1..] = chunk numbers, order irrelevant) and bin1_downsweep gives it kHeavyParts workgroups,
+    // one per block of columns: columns are independent in that pass (a cursor per column), so the parts need no hand-off.
+    // heavy_next is the other frame parity's counter: cleared here for the next frame.
     // per-frame reset of the sticky overflow flag (set later in the frame by bin1_downsweep): saves a memset launch
-    if (blockIdx.x == 0 && threadIdx.x == 0) *d_overflow = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *d_overflow = 0u; heavy_next[0] = 0u; }
     if (gsum_zero != nullptr)      // scan-free path, see radix_upsweep
         for (uint32_t row = blockIdx.x; row < gsum_zero_rows; row += gridDim.x) gsum_zero[(size_t)row * 256 + threadIdx.x] = 0u;
     __shared__ uint32_t s_diff[kThreads + 1];
@@ -1518,6 +1529,19 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
         if (gsum_acc != nullptr && incl != 0u)
             (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(chunk >> kGroupShift) * 256 + threadIdx.x], incl, __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t psum = incl;                                  // pairs of this chunk = sum of its column counts
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) psum += __shfl_xor(psum, d, 64);
+        if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = psum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint8_t flag = 0;
+            if (s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3] > kHeavyPairs) {
+                const uint32_t slot = atomicAdd(&heavy[0], 1u);
+                if (slot < kHeavyCap) { heavy[1u + slot] = chunk; flag = 1; }
+            }
+            heavy_flag[chunk] = flag;
+        }
         __syncthreads();
     }
 }
@@ -1536,8 +1560,14 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
                                                            uint32_t* __restrict__ d_overflow,
                                                            uint32_t* __restrict__ host_words, int report_overflow,
                                                            const uint32_t* __restrict__ gsum,
-                                                           uint32_t* __restrict__ totals_out, int xcd_map)
+                                                           uint32_t* __restrict__ totals_out, int xcd_map,
+                                                           const uint32_t* __restrict__ heavy,
+                                                           const uint8_t* __restrict__ heavy_flag, uint32_t nhelp, int tiles_x)
 {
+    // The first nhelp workgroups are helpers for the heavy chunks (bin1_upsweep; first, so that they start with the launch):
+    // helper h takes column block 1 + h % (kHeavyParts - 1) of chunk heavy[1 + h / (kHeavyParts - 1)] and exits at once when
+    // there is no such chunk; the other nmain workgroups walk the chunks (grid-stride), a heavy chunk's main workgroup keeps
+    // block 0.  A part sees every rectangle of the chunk clipped to its columns.
     // gsum != nullptr: scan-free path (hist = raw per-chunk column counts, see radix_upsweep); workgroup 0 then also
     // publishes the column totals in totals_out for the row pass.  host_words (host-mapped): [0] pairs needed by an
     // overflowed device-output frame, [1] V and [2] D of the latest frame (read by the host without synchronising,
@@ -1555,6 +1585,8 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
     uint4* s_part = reinterpret_cast<uint4*>(s_owner);      // 16 KB, not live while the row sums run
     const uint32_t V = *d_V;
     const uint32_t nchunks = (V + BIN_CHUNK - 1) / BIN_CHUNK;
+    const bool helper = blockIdx.x < nhelp;
+    const uint32_t nmain = gridDim.x - nhelp, mb = blockIdx.x - nhelp;       // main workgroups / this one's index among them
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -1564,8 +1596,8 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
         uint32_t tot;
         const uint32_t incl = block_incl_scan(t, s_tmp, tot);
         s_base[threadIdx.x] = incl - t;
-        if (totals_out != nullptr && blockIdx.x == 0) totals_out[threadIdx.x] = t;
-        if (blockIdx.x == 0 && threadIdx.x == 255) {
+        if (totals_out != nullptr && !helper && mb == 0u) totals_out[threadIdx.x] = t;
+        if (!helper && mb == 0u && threadIdx.x == 255) {
             *d_D = incl;
             if (host_words != nullptr) {
                 __hip_atomic_store(host_words + 1, V, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1582,16 +1614,35 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
     }
     __syncthreads();
 
-    for (uint32_t cidx = blockIdx.x; cidx < nchunks; cidx += gridDim.x) {
+    uint32_t hchunk = 0, hpart = 0;
+    if (helper) {
+        const uint32_t h = blockIdx.x, slot = h / (kHeavyParts - 1u);
+        if (slot >= min(heavy[0], kHeavyCap)) return;            // workgroup-uniform: no such heavy chunk this frame
+        hchunk = heavy[1u + slot];
+        hpart = 1u + h % (kHeavyParts - 1u);
+    }
+    const uint32_t cpp = ((uint32_t)tiles_x + kHeavyParts - 1u) / kHeavyParts;      // columns per part
+    for (uint32_t cidx = helper ? hchunk : mb; cidx < nchunks; cidx += nmain) {
         // (xcd_map: see ws_downsweep -- the (chunk, column) runs of neighbouring chunks are adjacent in memory)
-        const uint32_t chunk = (xcd_map && (gridDim.x >= nchunks || (gridDim.x & 7u) == 0u)) ? xcd_contiguous(cidx, nchunks) : cidx;
+        const uint32_t chunk = (!helper && xcd_map && (nmain >= nchunks || (nmain & 7u) == 0u)) ? xcd_contiguous(cidx, nchunks) : cidx;
+        // this workgroup's columns of the chunk: all of them, or one block of a heavy chunk
+        uint32_t c_lo = 0u, c_hi = 255u;
+        if (helper || heavy_flag[chunk]) {
+            c_lo = hpart * cpp;
+            c_hi = c_lo + cpp - 1u;
+        }
         const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk, s_part) : hist[(size_t)chunk * 256 + threadIdx.x];
         const uint32_t rbase = chunk * BIN_CHUNK;
         uint32_t rc[PER], woff[PER], wsum = 0;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const uint32_t r = rbase + threadIdx.x * PER + k;
-            rc[k] = (r < V) ? rect[r] : kRectEmpty;
+            uint32_t x = (r < V) ? rect[r] : kRectEmpty;
+            {   // clip to [c_lo, c_hi] (a no-op for 0 .. 255)
+                const uint32_t a = max(x & 255u, c_lo), b = min((x >> 16) & 255u, c_hi);
+                x = (a <= b && (x & 255u) <= ((x >> 16) & 255u)) ? ((x & 0xFF00FF00u) | a | (b << 16)) : kRectEmpty;
+            }
+            rc[k] = x;
             woff[k] = wsum;
             wsum += rect_width(rc[k]);
         }
@@ -1692,21 +1743,25 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
             // splats) are written by their own lane; an item with more rows -- a splat a quarter of the screen high would
             // keep its lane busy for dozens of iterations while the other 63 idle (scene-like clouds, r3: this kernel was
             // 330 us of a 765 us frame) -- is written by the whole wave, one store instruction per 64 rows.
+            // Only where tall items are RARE in the batch: a batch full of them (the first ranks of a scene: background)
+            // is better served by every lane writing its own rows.
             const uint32_t nrows = valid ? rows : 0u;
             const uint32_t wbase = (ty0 << 24) | rank;
-            unsigned long long heavy = __ballot(nrows > 8u);
-            if (nrows <= 8u)
+            unsigned long long hv = __ballot(nrows > 8u);
+            if (__popcll(hv) > 6) hv = 0ull;
+            if (nrows <= 8u || hv == 0ull)
                 for (uint32_t q = 0; q < nrows; ++q)
                     if (pos + q < cap) pairs_out[pos + q] = wbase + (q << 24);
-            while (heavy != 0ull) {                                  // wave-uniform
-                const int j = __ffsll((long long)heavy) - 1;
-                heavy &= heavy - 1ull;
+            while (hv != 0ull) {                                     // wave-uniform
+                const int j = __ffsll((long long)hv) - 1;
+                hv &= hv - 1ull;
                 const uint32_t r = __shfl(nrows, j, 64), p = __shfl(pos, j, 64), wb = __shfl(wbase, j, 64);
                 for (uint32_t q = lane; q < r; q += 64u)
                     if (p + q < cap) pairs_out[p + q] = wb + (q << 24);
             }
         }
         __syncthreads();
+        if (helper) break;           // a helper serves one (chunk, column block)
     }
 }
 

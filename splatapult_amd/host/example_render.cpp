@@ -3,9 +3,10 @@
 // Sort + Render into an explicit RGBA32F framebuffer, dumped as a binary PPM-like float file.
 //
 //   g++ -std=c++17 -I. splatapult_amd/host/example_render.cpp -Lsplatapult_amd/lib -lmsplat -o example_render
-//   ./example_render scene.ply out.f32 [width height] [--nosh] [--frames-in-flight N]
+//   ./example_render scene.ply out.f32 [width height] [--nosh] [--frames-in-flight N] [--devices 0,1,2,...]
 // With --frames-in-flight N the same frame is issued N + 1 times round-robin over N contexts that share the cloud
-// (SplatRenderer::SetFramesInFlight); the last one is written.
+// (SplatRenderer::SetFramesInFlight); the last one is written.  With --devices the frame's bin rows are dealt to the
+// listed GPUs (SplatRenderer::ConfigureDevices, msplat_group_*): same pixels.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -25,9 +26,16 @@ int main(int argc, char** argv)
     bool nosh = false;
     if (argc >= 5 && argv[3][0] != '-') { W = std::atoi(argv[3]); H = std::atoi(argv[4]); }
     int inFlight = 1;
+    std::vector<int> devices;
     for (int i = 3; i < argc; ++i) {
         nosh = nosh || !std::strcmp(argv[i], "--nosh");
         if (!std::strcmp(argv[i], "--frames-in-flight") && i + 1 < argc) inFlight = std::atoi(argv[i + 1]);
+        if (!std::strcmp(argv[i], "--devices") && i + 1 < argc)
+            for (const char* p = argv[i + 1]; *p;) {
+                devices.push_back(std::atoi(p));
+                while (*p && *p != ',') ++p;
+                if (*p == ',') ++p;
+            }
     }
 
     auto cloud = std::make_shared<GaussianCloud>(GaussianCloud::Options{!nosh, false});
@@ -35,6 +43,7 @@ int main(int argc, char** argv)
 
     SplatRenderer renderer;
     renderer.SetFramesInFlight(inFlight);
+    if (devices.size() > 1) renderer.ConfigureDevices(devices, MSPLAT_BANDS_BLOCK_INTERLEAVED, 2);
     if (!renderer.Init(cloud, /*isFramebufferSRGBEnabled=*/false, /*useRgcSortOverride=*/false)) return 1;
 
     // app.cpp:73-75,1039-1042: camera at the identity pose pulled back along +Z, 45 degree fovy

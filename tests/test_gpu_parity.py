@@ -1075,6 +1075,9 @@ def test_cpp_shim_renders_like_the_python_mirror(tmp_path, golden_dir):
     img = np.fromfile(out, np.float32).reshape(H, W, 4)
     subprocess.run([exe, ply, out + "3", str(W), str(H), "--frames-in-flight", "3"], check=True)
     np.testing.assert_array_equal(np.fromfile(out + "3", np.float32).reshape(H, W, 4), img)
+    # SplatRenderer::ConfigureDevices: the same frame from a device group (three contexts on this box's one GPU)
+    subprocess.run([exe, ply, out + "g", str(W), str(H), "--devices", "0,0,0"], check=True)
+    np.testing.assert_array_equal(np.fromfile(out + "g", np.float32).reshape(H, W, 4), img)
     gc = GaussianCloud()
     assert gc.ImportPly(ply)
     cam = camera.pose((0.0, 0.0, 5.0))
@@ -1315,3 +1318,31 @@ def test_scene_like_6m_file_replay_matches_the_oracle(tmp_path):
         assert st["pairs"] > 5 * st["drawn"]                      # big footprints: many bins per splat
         assert np.isfinite(img).all() and (img[..., 3] == 1).all()
         _check_window(img, aos, W, H, cam, proj, nf, y0, y1)
+
+
+def test_heavy_chunks_of_the_column_pass_are_split_without_changing_anything(monkeypatch):
+    """depth order puts a scene's huge far splats first: a few chunks of the column pass hold most of the pairs and are given
+    eight workgroups (one per block of columns).  Same bin lists and pixels as without the helpers, and the oracle's image."""
+    a = scenes.synthetic.generate(9000, seed=404, pos_sigma=1.2, log_scale_mean=-3.4, log_scale_sigma=0.8)
+    a["xyz"][:3500, 2] -= 14.0                      # a far layer ...
+    a["log_scale"][:3500] = -0.2 + 0.3 * a["log_scale"][:3500] / 3.4      # ... of screen-sized splats: ~200 bins each
+    a["opacity"][:3500] = 1.5
+    cloud = scenes.cloud_from_attrs(a)
+    W, H = 800, 450
+    cam, proj, vp, nf = scenes.default_view(W, H, z=6.0, yaw=0.1)
+    res = []
+    for split in ("1", "0"):
+        monkeypatch.setenv("MSPLAT_HEAVY_SPLIT", split)
+        r = make_renderer(cloud)
+        for _ in range(2):                           # two frames: the per-parity heavy lists alternate
+            r.Sort(cam, proj, vp, nf)
+            img = r.Render(cam, proj, vp, nf)
+        st = _check_tile_lists_ascending(r)
+        ts, pairs = r.debug_tile_lists()
+        res.append((ts, pairs, img))
+    monkeypatch.delenv("MSPLAT_HEAVY_SPLIT")
+    assert st["pairs"] > 600_000                     # several chunks of 1024 ranks are far above the 49 152-pair threshold
+    for x, y in zip(res[0], res[1]):
+        np.testing.assert_array_equal(x, y)
+    ref = oracle_frame(cloud.as_array(), True, cam, proj, vp, nf)
+    check_image(res[0][2], ref["image"], budget=ref["budget"])

@@ -134,11 +134,12 @@ def measure(E, args, key, ply=None, primary=True):
     TILE = _capi.lib().msplat_tile_size()
     tiles_y = (H + TILE - 1) // TILE
     # bin-row layout over the ranks (msplat_band_plan): "contiguous" | "interleaved" | "block:k"; auto = blocks of
-    # ~rows / (4 ranks) rows dealt round-robin -- four blocks per rank balance the load of a centred scene while the
-    # band-restricted cull still drops most of the splats of the other ranks' rows (profiles/r03_cfg4_bands.json)
+    # ~rows / (2 ranks) rows dealt round-robin -- two blocks per rank balance the load of a centred scene while the
+    # band-restricted cull still drops most of the splats of the other ranks' rows (measured on the 6 M / 4096^2 workload, 8
+    # ranks: blocks of 8 rows 0.387 ms per rank, contiguous bands 0.417, interleaved rows 0.528: profiles/r03_cfg4_bands.json)
     lay = args.layout
     if lay == "auto":
-        lay = "block:%d" % max(1, tiles_y // (4 * world))
+        lay = "block:%d" % max(1, tiles_y // (2 * world))
     lay_kind, lay_k = (lay.split(":")[0], int(lay.split(":")[1])) if ":" in lay else (lay, 1)
     if lay_kind == "block" and lay_k == 1:
         lay_kind = "interleaved"
@@ -495,13 +496,22 @@ def cpu_baseline(cloud, wl, cams_for, projs, vp, nf, frames):
                 stages.append(r["stages_ms"])
         return time.perf_counter() - t
 
-    # thread count: the fastest of a few candidates on one frame each (more threads than the scheduler really grants --
-    # cgroup quotas, SMT siblings -- make every OpenMP barrier slower, so "all the CPUs the OS lists" is not always best)
-    cores = avail
-    one(0, nt=min(avail, 16))                         # first touch of the work buffers
+    # thread count: the fastest of a few candidates (more threads than the scheduler really grants -- a cgroup CPU quota, SMT
+    # siblings -- make every OpenMP barrier slower, so "all the CPUs the OS lists" is not always best: on the r3 GPU box the
+    # container sees 256 CPUs and owns a quota of 16, and 256 threads were 50x slower than 32)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    eff = int(min(avail, math.ceil(quota))) if quota else avail
+    cores = eff
+    one(0, nt=min(eff, 16))                           # first touch of the work buffers
     trial = {}
-    for nt in sorted({max(1, avail // 8), max(1, avail // 4), max(1, avail // 2), avail}):
-        trial[nt] = min(one(0, nt=nt), one(1, nt=nt))
+    for nt in sorted({max(1, eff // 2), eff, min(avail, 2 * eff), min(avail, 4 * eff)} | ({avail} if not quota else set())):
+        trial[nt] = float(np.median([one(k, nt=nt) for k in range(3)]))
     cores = min(trial, key=trial.get)
     t_first = trial[cores]
     if frames <= 0:
@@ -515,7 +525,7 @@ def cpu_baseline(cloud, wl, cams_for, projs, vp, nf, frames):
                      "oracle/msplat_cpu_tiled.c: tile-binned, front-to-back, early termination at T < 2^-14"
                      % (len(times), len(times) - 1, cores),
            "sec_per_frame": sec, "gsplats_per_sec": wl["n"] / sec / 1e9, "stages_ms": st,
-           "cpus_available": avail, "thread_count_trials_sec": {str(k): v for k, v in trial.items()}}
+           "cpus_available": avail, "cgroup_cpu_quota": quota, "thread_count_trials_sec": {str(k): v for k, v in trial.items()}}
     # the literal restatement of the reference shaders (what cpu_baseline was in rounds 1-2): one frame
     cams = cams_for(0)
     t = time.perf_counter()

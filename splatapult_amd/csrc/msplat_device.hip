@@ -1210,7 +1210,11 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     uint32_t* hv_cur = (uint32_t*)ctx->heavy.p + (ctx->render_parity & 1u) * (1u + kHeavyCap);
     uint32_t* hv_next = (uint32_t*)ctx->heavy.p + ((ctx->render_parity ^ 1u) & 1u) * (1u + kHeavyCap);
     ctx->render_parity ^= 1u;
-    const int nhelp = ctx->heavy_split ? (int)(kHeavyCap * (kHeavyParts - 1u)) : 0;
+    // helper workgroups for as many split chunks as an EARLIER frame asked for (host-mapped word, read without synchronising),
+    // with headroom; a frame that needs more runs its extra heavy chunks unsplit and the next launch adapts
+    const uint32_t last_heavy = ctx->h_flags ? __atomic_load_n(ctx->h_flags + 3, __ATOMIC_RELAXED) : 0u;
+    const uint32_t heavy_slots = ctx->heavy_split ? std::min<uint32_t>(kHeavyCap, 2u * last_heavy + 8u) : 0u;
+    const int nhelp = (int)(heavy_slots * (kHeavyParts - 1u));
     // scan-free variants while the chunk tables are small; the row pass's size (D) is only known on the device, so
     // its choice uses the D of an EARLIER frame that the binning kernel left in host-mapped memory (0 = none yet);
     // either variant is correct at any size, the choice only matters for speed
@@ -1226,7 +1230,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     do {                                                                                                                      \
         hipLaunchKernelGGL(bin1_upsweep<CH>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,               \
                            (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_overflow, fused1 ? gB1 : nullptr, gB2,               \
-                           ctx->gsumB2_rows, hv_cur, hv_next, (uint8_t*)ctx->heavy_flag.p);                                   \
+                           ctx->gsumB2_rows, hv_cur, hv_next, (uint8_t*)ctx->heavy_flag.p, heavy_slots);                      \
         if (!fused1)                                                                                                          \
             launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V, 0u, N, bchunk, totals1);     \
         if (ctx->atomic_rank)                                                                                                 \

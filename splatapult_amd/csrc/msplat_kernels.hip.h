@@ -1485,14 +1485,16 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
                                                          uint32_t* __restrict__ gsum_acc,
                                                          uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_rows,
                                                          uint32_t* __restrict__ heavy, uint32_t* __restrict__ heavy_next,
-                                                         uint8_t* __restrict__ heavy_flag)
+                                                         uint8_t* __restrict__ heavy_flag, uint32_t heavy_slots)
 {
     // Heavy chunks (r3).  The ranks are in depth order, so the huge far-away splats of a real scene (sky, background) are the
     // FIRST ranks: a few chunks hold half of all the pairs (scene-like 6 M cloud: 25 of 2344 chunks, 500 k pairs each against
     // 11 k), and the column pass lasted as long as the slowest of them.  A chunk with more than kHeavyPairs pairs is put on a
     // list (heavy[0] = count, heavy[1..] = chunk numbers, order irrelevant) and bin1_downsweep gives it kHeavyParts workgroups,
     // one per block of columns: columns are independent in that pass (a cursor per column), so the parts need no hand-off.
-    // heavy_next is the other frame parity's counter: cleared here for the next frame.
+    // heavy_next is the other frame parity's counter: cleared here for the next frame.  heavy_slots <= kHeavyCap = the split
+    // chunks the downsweep's grid has helper workgroups for (the host sizes it from an earlier frame's count; a chunk that
+    // gets no slot is processed unsplit -- slower, never wrong).
     // per-frame reset of the sticky overflow flag (set later in the frame by bin1_downsweep): saves a memset launch
     if (blockIdx.x == 0 && threadIdx.x == 0) { *d_overflow = 0u; heavy_next[0] = 0u; }
     if (gsum_zero != nullptr)      // scan-free path, see radix_upsweep
@@ -1538,7 +1540,7 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
             uint8_t flag = 0;
             if (s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3] > kHeavyPairs) {
                 const uint32_t slot = atomicAdd(&heavy[0], 1u);
-                if (slot < kHeavyCap) { heavy[1u + slot] = chunk; flag = 1; }
+                if (slot < heavy_slots) { heavy[1u + slot] = chunk; flag = 1; }
             }
             heavy_flag[chunk] = flag;
         }
@@ -1602,6 +1604,7 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
             if (host_words != nullptr) {
                 __hip_atomic_store(host_words + 1, V, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(host_words + 2, incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(host_words + 3, heavy[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // heavy chunks wanted
             }
             if (incl > cap) {
                 *d_overflow = incl;
@@ -1617,7 +1620,7 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
     uint32_t hchunk = 0, hpart = 0;
     if (helper) {
         const uint32_t h = blockIdx.x, slot = h / (kHeavyParts - 1u);
-        if (slot >= min(heavy[0], kHeavyCap)) return;            // workgroup-uniform: no such heavy chunk this frame
+        if (slot >= min(heavy[0], nhelp / (kHeavyParts - 1u))) return;      // workgroup-uniform: no such heavy chunk this frame
         hchunk = heavy[1u + slot];
         hpart = 1u + h % (kHeavyParts - 1u);
     }

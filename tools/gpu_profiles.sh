@@ -1,12 +1,12 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/gpu_profiles.sh <round tag, e.g. r02>
+# usage (GPU box, repo root): tools/gpu_profiles.sh <round tag, e.g. r03>
 # The evidence set of a round: GPU tests, the bench lines (default = 4 frames in flight, and serial), rocprofv3 kernel
 # summaries of the same commands for every BASELINE workload, and the PMC traffic of the serial run.  Everything lands
 # in gpurun_out/<tag>_*; copy what is to be judged into profiles/.
 cd ${GRAFT_REPO_ROOT:-.}
 R=$(pwd)
 export TMPDIR=/tmp
-T=${1:-r02}
+T=${1:-r03}
 mkdir -p gpurun_out
 ( time timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -rsP ) > gpurun_out/${T}_gpu_tests.log 2>&1
 grep -E "passed|failed|SKIPPED|check_image:" gpurun_out/${T}_gpu_tests.log | head -20
@@ -19,6 +19,7 @@ prof() {  # name, bench args
   f=$(find gpurun_out/${T}_prof_$name -name run_kernel_stats.csv | head -1)
   cp $f gpurun_out/${T}_${name}_kernel_stats.csv
   grep -h "^{" gpurun_out/${T}_prof_$name.log > gpurun_out/${T}_${name}_bench_under_rocprof.json
+  rm -rf gpurun_out/${T}_prof_$name          # the per-dispatch trace: only the summary is kept
   python - <<PY
 import csv
 print("== $name")
@@ -28,10 +29,12 @@ PY
 }
 prof cfg2_serial --frames-in-flight 1 --steps 600 --warmup 100
 prof cfg2_fif4 --steps 600 --warmup 100
-for wl in cfg3 cfg4 cfg5; do
+for wl in cfg3 cfg4 cfg5 cfg3s; do
   prof ${wl}_serial --workload $wl --frames-in-flight 1 --steps 100 --warmup 20 --prewarm 50
   timeout 600 python bench.py --workload $wl --no-cpu-baseline --steps 200 --warmup 30 > gpurun_out/${T}_${wl}_bench.json 2> gpurun_out/${T}_${wl}_bench.err
 done
+timeout 600 python tools/band_table.py --workload cfg4 --world 8 --out gpurun_out/${T}_cfg4_bands.json > gpurun_out/${T}_cfg4_bands.log 2>&1
+grep -v "    rank" gpurun_out/${T}_cfg4_bands.log | tail -8
 bash tools/pmc_traffic.sh ${T}_cfg2 cfg2
 cp gpurun_out/pmc_${T}_cfg2/traffic.json gpurun_out/${T}_pmc_traffic_cfg2.json
 for C in FETCH_SIZE WRITE_SIZE; do cp $(find gpurun_out/pmc_${T}_cfg2/$C -name run_counter_collection.csv | head -1) gpurun_out/${T}_pmc_${C}_cfg2.csv; done

@@ -73,7 +73,21 @@ typedef struct msplat_config {
     int32_t rank_mode;         /* MSPLAT_RANK_*: how the stable radix / binning passes rank the    */
                                /* keys of one wave.  Added after the first release of the struct:  */
                                /* a struct_size that ends before this field selects MSPLAT_RANK_AUTO */
+    int32_t sort_mode;         /* MSPLAT_SORT_*: which Sort kernels run.  Occupies what was padding after  */
+                               /* rank_mode: any value other than MSPLAT_SORT_WIDE3 / _LSD8 means AUTO      */
 } msplat_config;
+
+/* msplat_config.sort_mode.  Both sorts give the identical stable order.  WIDE3 (three passes of 10 + 8..11 + 8..11 key
+ * bits, 6 launches) is the shortest for one frame at a time: 58 us instead of 73 at 1 M splats, 162 instead of 204 at
+ * 6 M.  Its downsweeps are workgroups of 8 waves holding 72 KB of LDS, which find a free CU less easily while other
+ * frames' kernels occupy the GPU: with FOUR FRAMES IN FLIGHT the four 8-bit passes of LSD8 (4-wave workgroups, 24 KB)
+ * give 2 % more frames/s (6.05 k vs 5.94 k at config 2, r3), so the SplatRenderer shims select LSD8 for their in-flight
+ * contexts.  AUTO = WIDE3.  MSPLAT_SORT=lsd8|wide3 in the environment overrides the field. */
+enum {
+    MSPLAT_SORT_AUTO = 0,
+    MSPLAT_SORT_WIDE3 = 1,
+    MSPLAT_SORT_LSD8 = 2
+};
 
 /* msplat_config.rank_mode */
 enum {

@@ -48,8 +48,9 @@ struct CloudStore {
 
 }  // namespace
 
-constexpr uint32_t kFusedMaxChunks = 8192;     // scan-free passes up to this many chunk rows (r2 sweep on the 6 M workloads: 2048 -> 8192 takes
-                                               // 40 us off the sort, beyond that nothing; past it the prefix sums grow with nchunks^2)
+constexpr uint32_t kFusedMaxChunks = kSuperRows << kSuperShift;     // scan-free passes up to this many chunk rows: with the two-level
+                                               // group tables (r3) a prefix is <= nchunks / 1024 + 62 rows, so every realistic table qualifies
+                                               // (r2, one level: 8192 rows, beyond that the radix_scan kernels)
 
 struct msplat_ctx {
     msplat_config cfg{};
@@ -324,6 +325,7 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
             rc = fail(ctx, MSPLAT_ERR_HIP, "LDS atomic order probe failed to run");
         ctx->atomic_rank = (hbad == 0) && c.rank_mode != MSPLAT_RANK_BALLOT && getenv("MSPLAT_BALLOT_RANK") == nullptr;
         ctx->scan_free = getenv("MSPLAT_SCAN_KERNELS") == nullptr;
+        ctx->wide_sort = c.sort_mode != MSPLAT_SORT_LSD8;           // AUTO (and any stale padding value) = the three-pass sort
         if (const char* sk = getenv("MSPLAT_SORT")) ctx->wide_sort = std::string(sk) != "lsd8";
         if (!ctx->atomic_rank) ctx->wide_sort = false;       // the wide kernels rank with lane-ordered LDS atomics only
         if (const char* tk = getenv("MSPLAT_TILE_TABLE")) ctx->bin_counts = std::string(tk) != "search";
@@ -521,7 +523,7 @@ int msplat_wait_event(msplat_ctx* ctx, void* event)
 // group table for `nchunks` chunk rows, zero-filled (the stream is idle whenever buffers are (re)allocated)
 static int alloc_group_table(msplat_ctx* ctx, Buf& b, uint32_t& rows, uint64_t nchunks)
 {
-    rows = (uint32_t)((nchunks >> kGroupShift) + 2);
+    rows = (uint32_t)(kSuperRows + (nchunks >> kGroupShift) + 2);        // supergroup rows first, then the group rows
     int rc = buf_alloc(ctx, b, (size_t)rows * 256 * sizeof(uint32_t));
     if (rc) return rc;
     rows = (uint32_t)(b.bytes / (256 * sizeof(uint32_t)));
@@ -1218,11 +1220,12 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     // scan-free variants while the chunk tables are small; the row pass's size (D) is only known on the device, so
     // its choice uses the D of an EARLIER frame that the binning kernel left in host-mapped memory (0 = none yet);
     // either variant is correct at any size, the choice only matters for speed
-    // (the column pass's chunks are half the size of the sort's: its table is scanned by a kernel from 4096 rows on --
-    //  measured at 6 M splats: 5860 rows cost the scan-free downsweep +28 us, the scan kernel 20 us)
-    const bool fused1 = ctx->scan_free && div_up(N, bchunk) <= ctx->fused_max_chunks / 2;
+    // (r2, one-level group tables: the column pass's table was scanned by a kernel from 4096 rows on; with two levels every
+    //  table that fits the supergroup rows is scan-free)
+    const bool fused1 = ctx->scan_free && div_up(N, bchunk) <= ctx->fused_max_chunks;
     const uint32_t last_D = ctx->h_flags ? __atomic_load_n(ctx->h_flags + 2, __ATOMIC_RELAXED) : 0u;
-    const bool fused2 = ctx->scan_free && last_D != 0u && div_up((uint64_t)last_D + (last_D >> 2), kPairChunk) <= ctx->fused_max_chunks;
+    const bool fused2 = ctx->scan_free && last_D != 0u && div_up((uint64_t)last_D + (last_D >> 2), kPairChunk) <= ctx->fused_max_chunks &&
+                        div_up(cap, kPairChunk) <= (kSuperRows << kSuperShift);        // (the tables hold every chunk the capacity allows)
     uint32_t* gB1 = (uint32_t*)ctx->gsumB1.p;
     uint32_t* gB2 = (uint32_t*)ctx->gsumB2.p;
     // (bin1_upsweep also clears the row pass's group table: its consumer, the previous frame's row downsweep, is long done)

@@ -233,6 +233,14 @@ __global__ __launch_bounds__(kThreads) void lds_atomic_order_probe(uint32_t* __r
 // The prefix work grows with nchunks^2/32, so beyond a few thousand chunks the host picks the 3-kernel path
 // (radix_scan*) instead; both are correct at any size.
 constexpr int kGroupShift = 5;
+// r3: a second level.  With one level a downsweep summed nchunks / 32 + 31 rows, which grows past a few thousand chunks (6 M
+// splats: the column pass's 5860 rows and the row pass's 10 k rows fell back to a radix_scan launch of 30-50 us each).  Every
+// table now starts with kSuperRows rows of SUPERGROUP sums (1024 chunks each), the group rows follow: an exclusive prefix is
+//   sum(supergroup rows before the chunk's supergroup) + sum(group rows inside it before the chunk's group) + sum(chunk rows
+//   inside the group before the chunk)   <=  nchunks / 1024 + 31 + 31 rows,
+// and the digit totals are the sum of the supergroup rows alone.  Costs the upsweep one more row of no-return atomics.
+constexpr int kSuperShift = 10;
+constexpr uint32_t kSuperRows = 128;          // supports 131072 chunk rows; beyond that the host falls back to the scan kernels
 
 template <int MODE, int SORT_ITEMS = kSortItems>
 __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __restrict__ keys,
@@ -355,9 +363,12 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
             }
         }
         hist[(size_t)chunk * 256 + threadIdx.x] = c;
-        if (gsum_acc != nullptr && c != 0u)
-            (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(chunk >> kGroupShift) * 256 + threadIdx.x], c, __ATOMIC_RELAXED,
+        if (gsum_acc != nullptr && c != 0u) {
+            (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(kSuperRows + (chunk >> kGroupShift)) * 256 + threadIdx.x], c,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(chunk >> kSuperShift) * 256 + threadIdx.x], c, __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
     }
 }
@@ -368,7 +379,8 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
 // thread-per-digit loop would (that loop cost 3-5 us per downsweep: r2 measurement); partial sums meet in `s_part`
 // (256 uint4 of scratch LDS).  Contains two barriers: every thread of the workgroup must call it.
 __device__ __forceinline__ uint32_t coop_row_sum(const uint32_t* __restrict__ rows0, uint32_t n0,
-                                                 const uint32_t* __restrict__ rows1, uint32_t n1, uint4* s_part)
+                                                 const uint32_t* __restrict__ rows1, uint32_t n1, uint4* s_part,
+                                                 const uint32_t* __restrict__ rows2 = nullptr, uint32_t n2 = 0u)
 {
     const uint32_t q = threadIdx.x & 63u, rg = threadIdx.x >> 6;
     uint4 acc = make_uint4(0u, 0u, 0u, 0u);
@@ -399,6 +411,7 @@ __device__ __forceinline__ uint32_t coop_row_sum(const uint32_t* __restrict__ ro
     };
     sum_rows(rows0, n0);
     sum_rows(rows1, n1);
+    if (n2 != 0u) sum_rows(rows2, n2);
     s_part[rg * 64u + q] = acc;
     __syncthreads();
     const uint32_t* sp = reinterpret_cast<const uint32_t*>(s_part);
@@ -413,15 +426,16 @@ __device__ __forceinline__ uint32_t coop_row_sum(const uint32_t* __restrict__ ro
 __device__ __forceinline__ uint32_t group_prefix(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ gsum,
                                                  uint32_t chunk, uint4* s_part)
 {
-    const uint32_t g = chunk >> kGroupShift;
-    return coop_row_sum(gsum, g, hist + (size_t)(g << kGroupShift) * 256, chunk - (g << kGroupShift), s_part);
+    const uint32_t g = chunk >> kGroupShift, sg = chunk >> kSuperShift, g0 = sg << (kSuperShift - kGroupShift);
+    return coop_row_sum(gsum, sg, gsum + (size_t)(kSuperRows + g0) * 256, g - g0, s_part,
+                        hist + (size_t)(g << kGroupShift) * 256, chunk - (g << kGroupShift));
 }
 
 // digit totals = sum of all group rows
 __device__ __forceinline__ uint32_t group_total(const uint32_t* __restrict__ gsum, uint32_t nchunks, uint4* s_part)
 {
-    const uint32_t ng = (nchunks + (1u << kGroupShift) - 1u) >> kGroupShift;
-    return coop_row_sum(gsum, ng, gsum, 0u, s_part);
+    const uint32_t ns = (nchunks + (1u << kSuperShift) - 1u) >> kSuperShift;       // the supergroup rows alone
+    return coop_row_sum(gsum, ns, gsum, 0u, s_part);
 }
 
 // one workgroup per digit: exclusive scan of that digit's row over the active chunks; row total -> totals
@@ -1528,9 +1542,12 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
         uint32_t total;
         const uint32_t incl = block_incl_scan(s_diff[threadIdx.x], s_tmp, total);   // wraps mod 2^32: exact
         hist[(size_t)chunk * 256 + threadIdx.x] = incl;
-        if (gsum_acc != nullptr && incl != 0u)
-            (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(chunk >> kGroupShift) * 256 + threadIdx.x], incl, __ATOMIC_RELAXED,
+        if (gsum_acc != nullptr && incl != 0u) {
+            (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(kSuperRows + (chunk >> kGroupShift)) * 256 + threadIdx.x], incl,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(chunk >> kSuperShift) * 256 + threadIdx.x], incl, __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_AGENT);
+        }
         uint32_t psum = incl;                                  // pairs of this chunk = sum of its column counts
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) psum += __shfl_xor(psum, d, 64);

@@ -48,9 +48,9 @@ struct CloudStore {
 
 }  // namespace
 
-constexpr uint32_t kFusedMaxChunks = kSuperRows << kSuperShift;     // scan-free passes up to this many chunk rows: with the two-level
-                                               // group tables (r3) a prefix is <= nchunks / 1024 + 62 rows, so every realistic table qualifies
-                                               // (r2, one level: 8192 rows, beyond that the radix_scan kernels)
+constexpr uint32_t kFusedMaxChunks = 1u << 20;     // scan-free passes up to this many chunk rows: with the two-level group tables (r3) a
+                                               // prefix is <= nchunks / 128 + 34 rows, so every table qualifies (r2, one level: 8192 rows,
+                                               // beyond that the radix_scan kernels); MSPLAT_FUSED_MAX_CHUNKS lowers it for comparison
 
 struct msplat_ctx {
     msplat_config cfg{};
@@ -76,6 +76,7 @@ struct msplat_ctx {
     Buf gsumS[2];   // sort passes alternate between the two
     Buf gsumB1, gsumB2;     // binning: column pass / row pass
     uint32_t gsumS_rows = 0, gsumB1_rows = 0, gsumB2_rows = 0;
+    uint32_t gsupS = 0, gsupB1 = 0, gsupB2 = 0;     // supergroup rows at the head of each table (the group rows follow)
     // wide-digit 3-pass sort (r3, msplat_kernels.hip.h ws_*): histogram rows of up to 2048 digits per chunk, one group
     // table per pass, one visibility bit per splat, the visible set's minimum key per frame parity (counters[10..11])
     Buf wsHist, wsGsum[3], vmask;
@@ -521,9 +522,10 @@ int msplat_wait_event(msplat_ctx* ctx, void* event)
 }
 
 // group table for `nchunks` chunk rows, zero-filled (the stream is idle whenever buffers are (re)allocated)
-static int alloc_group_table(msplat_ctx* ctx, Buf& b, uint32_t& rows, uint64_t nchunks)
+static int alloc_group_table(msplat_ctx* ctx, Buf& b, uint32_t& rows, uint64_t nchunks, uint32_t& sup)
 {
-    rows = (uint32_t)(kSuperRows + (nchunks >> kGroupShift) + 2);        // supergroup rows first, then the group rows
+    sup = (uint32_t)((nchunks >> kSuperShift) + 2);                      // supergroup rows first, then the group rows
+    rows = (uint32_t)(sup + (nchunks >> kGroupShift) + 2);
     int rc = buf_alloc(ctx, b, (size_t)rows * 256 * sizeof(uint32_t));
     if (rc) return rc;
     rows = (uint32_t)(b.bytes / (256 * sizeof(uint32_t)));
@@ -542,7 +544,7 @@ static int ensure_pair_capacity(msplat_ctx* ctx, uint64_t cap)
     ctx->hist2_stride = div_up(cap, kPairChunk);
     rc = buf_alloc(ctx, ctx->hist2, (size_t)256 * ctx->hist2_stride * sizeof(uint32_t));
     if (rc) return rc;
-    rc = alloc_group_table(ctx, ctx->gsumB2, ctx->gsumB2_rows, ctx->hist2_stride);
+    rc = alloc_group_table(ctx, ctx->gsumB2, ctx->gsumB2_rows, ctx->hist2_stride, ctx->gsupB2);
     if (rc) return rc;
     ctx->pair_cap = cap;
     return MSPLAT_OK;
@@ -597,8 +599,8 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
     ctx->hist_stride = std::max(1u, div_up(n, kSortChunk));
     if ((rc = buf_alloc(ctx, ctx->hist, (size_t)256 * ctx->hist_stride * 4))) return rc;
     uint32_t rows_s0 = 0;
-    if ((rc = alloc_group_table(ctx, ctx->gsumS[0], rows_s0, ctx->hist_stride))) return rc;
-    if ((rc = alloc_group_table(ctx, ctx->gsumS[1], ctx->gsumS_rows, ctx->hist_stride))) return rc;
+    if ((rc = alloc_group_table(ctx, ctx->gsumS[0], rows_s0, ctx->hist_stride, ctx->gsupS))) return rc;
+    if ((rc = alloc_group_table(ctx, ctx->gsumS[1], ctx->gsumS_rows, ctx->hist_stride, ctx->gsupS))) return rc;
     ctx->gsumS_rows = std::min(ctx->gsumS_rows, rows_s0);
     if (ctx->wide_sort) {
         // 4096-key chunks up to 2 M splats, 8192 beyond (MSPLAT_WS_ITEMS = 8 | 16 overrides); groups of 16 chunk rows while
@@ -627,7 +629,7 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
     HIP_TRY(ctx, hipMemsetAsync(ctx->heavy_flag.p, 0, ctx->heavy_flag.bytes, ctx->stream));
     ctx->hist1_stride = std::max(1u, div_up(n, kBinChunk));
     if ((rc = buf_alloc(ctx, ctx->hist1, (size_t)256 * ctx->hist1_stride * 4))) return rc;
-    if ((rc = alloc_group_table(ctx, ctx->gsumB1, ctx->gsumB1_rows, ctx->hist1_stride))) return rc;
+    if ((rc = alloc_group_table(ctx, ctx->gsumB1, ctx->gsumB1_rows, ctx->hist1_stride, ctx->gsupB1))) return rc;
     uint64_t cap = ctx->cfg.pair_capacity ? ctx->cfg.pair_capacity
                                           : std::max<uint64_t>(1ull << 22, std::min<uint64_t>(32 * n, 1ull << 30));
     return ensure_pair_capacity(ctx, cap);
@@ -1143,11 +1145,12 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
     } while (0)
     // pass 0: cull + key fused into the first radix pass (presort_compute.glsl + byte 0 of the sort)
     MSPLAT_UPSWEEP(MODE_CULL, (const uint32_t*)nullptr, pos, (const uint32_t*)nullptr, N, N, 0, hist, ctx->hist_stride, gacc(0),
-                   gzero(0), ctx->gsumS_rows, fp);
+                   gzero(0), ctx->gsumS_rows, fp, (const uint32_t*)nullptr, (uint32_t*)nullptr, ctx->gsupS);
     if (!fused) launch_scan(s, ctx->N <= (2u << 20), hist, ctx->hist_stride, nullptr, N, N, chunk, totals);
     MSPLAT_DOWNSWEEP(MODE_CULL, (const uint32_t*)nullptr, (const uint32_t*)nullptr, pos, (const uint32_t*)nullptr, N, N, 0,
                      (const uint32_t*)hist, ctx->hist_stride, (const uint32_t*)totals, kB, vB, d_V, (const uint32_t*)nullptr,
-                     (const uint32_t*)gacc(0), (uint32_t*)nullptr, fp);
+                     (const uint32_t*)gacc(0), (uint32_t*)nullptr, fp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                     (uint32_t*)nullptr, 0, 0, ctx->gsupS);
     // passes 1..3 on the V survivors (V stays on the device; splatrenderer.cpp:195-204's readback is gone)
     for (int pass = 1; pass < 4; ++pass) {
         uint32_t* kin = (pass & 1) ? kB : kA;
@@ -1155,11 +1158,13 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
         uint32_t* kout = (pass & 1) ? kA : kB;
         uint32_t* vout = (pass & 1) ? vA : vB;
         MSPLAT_UPSWEEP(MODE_KEYS, (const uint32_t*)kin, (const float4*)nullptr, (const uint32_t*)d_V, 0u, N, pass * 8, hist,
-                       ctx->hist_stride, gacc(pass), gzero(pass), ctx->gsumS_rows, fp);
+                       ctx->hist_stride, gacc(pass), gzero(pass), ctx->gsumS_rows, fp, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                       ctx->gsupS);
         if (!fused) launch_scan(s, ctx->N <= (2u << 20), hist, ctx->hist_stride, d_V, 0u, N, chunk, totals);
         MSPLAT_DOWNSWEEP(MODE_KEYS, (const uint32_t*)kin, (const uint32_t*)vin, (const float4*)nullptr, (const uint32_t*)d_V, 0u, N,
                          pass * 8, (const uint32_t*)hist, ctx->hist_stride, (const uint32_t*)totals, kout, vout, (uint32_t*)nullptr,
-                         (const uint32_t*)nullptr, (const uint32_t*)gacc(pass), (uint32_t*)nullptr, fp);
+                         (const uint32_t*)nullptr, (const uint32_t*)gacc(pass), (uint32_t*)nullptr, fp, (uint32_t*)nullptr,
+                         (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0, 0, ctx->gsupS);
     }
 #undef MSPLAT_UPSWEEP
 #undef MSPLAT_DOWNSWEEP
@@ -1225,7 +1230,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const bool fused1 = ctx->scan_free && div_up(N, bchunk) <= ctx->fused_max_chunks;
     const uint32_t last_D = ctx->h_flags ? __atomic_load_n(ctx->h_flags + 2, __ATOMIC_RELAXED) : 0u;
     const bool fused2 = ctx->scan_free && last_D != 0u && div_up((uint64_t)last_D + (last_D >> 2), kPairChunk) <= ctx->fused_max_chunks &&
-                        div_up(cap, kPairChunk) <= (kSuperRows << kSuperShift);        // (the tables hold every chunk the capacity allows)
+                        div_up(cap, kPairChunk) <= ctx->hist2_stride;                  // (the tables hold every chunk the capacity allows)
     uint32_t* gB1 = (uint32_t*)ctx->gsumB1.p;
     uint32_t* gB2 = (uint32_t*)ctx->gsumB2.p;
     // (bin1_upsweep also clears the row pass's group table: its consumer, the previous frame's row downsweep, is long done)
@@ -1233,7 +1238,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     do {                                                                                                                      \
         hipLaunchKernelGGL(bin1_upsweep<CH>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,               \
                            (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_overflow, fused1 ? gB1 : nullptr, gB2,               \
-                           ctx->gsumB2_rows, hv_cur, hv_next, (uint8_t*)ctx->heavy_flag.p, heavy_slots);                      \
+                           ctx->gsumB2_rows, hv_cur, hv_next, (uint8_t*)ctx->heavy_flag.p, heavy_slots, ctx->gsupB1);         \
         if (!fused1)                                                                                                          \
             launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V, 0u, N, bchunk, totals1);     \
         if (ctx->atomic_rank)                                                                                                 \
@@ -1242,14 +1247,14 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                                (const uint32_t*)totals1, (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags,        \
                                async_overflow_flag ? 1 : 0, fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, \
                                (ctx->xcd_map & 2) ? 1 : 0, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,         \
-                               (uint32_t)nhelp, fp.tiles_x);                                                                  \
+                               (uint32_t)nhelp, fp.tiles_x, ctx->gsupB1);                                                     \
         else                                                                                                                  \
             hipLaunchKernelGGL((bin1_downsweep<false, CH>), dim3(g1 + nhelp), dim3(kThreads), 0, s,                           \
                                (const uint32_t*)ctx->rect.p, d_V, (const uint32_t*)ctx->hist1.p, ctx->hist1_stride,           \
                                (const uint32_t*)totals1, (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags,        \
                                async_overflow_flag ? 1 : 0, fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, \
                                (ctx->xcd_map & 2) ? 1 : 0, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,         \
-                               (uint32_t)nhelp, fp.tiles_x);                                                                  \
+                               (uint32_t)nhelp, fp.tiles_x, ctx->gsupB1);                                                     \
     } while (0)
     // (bin1_upsweep also clears the row pass's group table: its consumer, the previous frame's row downsweep, is long done)
     if (bchunk == (uint32_t)kBinChunkLarge) MSPLAT_BIN1(kBinChunkLarge); else MSPLAT_BIN1(kBinChunk);
@@ -1269,7 +1274,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const int g2 = grid_for(div_up(cap, kPairChunk));
     hipLaunchKernelGGL(radix_upsweep<MODE_PAIR>, dim3(g2), dim3(kThreads), 0, s, (const uint32_t*)ctx->pairsA.p,
                        nullptr, d_D, 0u, cap, 24, (uint32_t*)ctx->hist2.p, ctx->hist2_stride, fused2 ? gB2 : nullptr, gB1,
-                       ctx->gsumB1_rows, fp, (const uint32_t*)totals1, bincnt);
+                       ctx->gsumB1_rows, fp, (const uint32_t*)totals1, bincnt, ctx->gsupB2);
     if (!fused2)
         launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist2.p, ctx->hist2_stride, d_D, 0u, cap, (uint32_t)kPairChunk, totals2);
     const int g2d = g2 + (bincnt ? 1 : 0);
@@ -1279,14 +1284,14 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                            (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
                            (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1,
                            fused2 ? (const uint32_t*)gB2 : nullptr, fused2 ? totals2 : nullptr, fp, bincnt,
-                           (uint32_t*)ctx->tile_start.p, (uint32_t*)ctx->tile_order.p, d_queue, ntiles, ordered ? 1 : 0);
+                           (uint32_t*)ctx->tile_start.p, (uint32_t*)ctx->tile_order.p, d_queue, ntiles, ordered ? 1 : 0, ctx->gsupB2);
     else
         hipLaunchKernelGGL((radix_downsweep<MODE_PAIR, false, false>), dim3(g2d), dim3(kThreads), 0, s,
                            (const uint32_t*)ctx->pairsA.p, nullptr, nullptr, d_D, 0u, cap, 24,
                            (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
                            (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1,
                            fused2 ? (const uint32_t*)gB2 : nullptr, fused2 ? totals2 : nullptr, fp, bincnt,
-                           (uint32_t*)ctx->tile_start.p, (uint32_t*)ctx->tile_order.p, d_queue, ntiles, ordered ? 1 : 0);
+                           (uint32_t*)ctx->tile_start.p, (uint32_t*)ctx->tile_order.p, d_queue, ntiles, ordered ? 1 : 0, ctx->gsupB2);
     if (!bincnt) {
         hipLaunchKernelGGL(tile_start_kernel, dim3(std::max(1, (ntiles + kTileStartBins - 1) / kTileStartBins)), dim3(kThreads), 0, s,
                            (const uint32_t*)ctx->pairsB.p, (const uint32_t*)totals2, d_D, cap, fp.tiles_x, ntiles,

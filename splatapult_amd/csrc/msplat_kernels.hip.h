@@ -235,12 +235,14 @@ __global__ __launch_bounds__(kThreads) void lds_atomic_order_probe(uint32_t* __r
 constexpr int kGroupShift = 5;
 // r3: a second level.  With one level a downsweep summed nchunks / 32 + 31 rows, which grows past a few thousand chunks (6 M
 // splats: the column pass's 5860 rows and the row pass's 10 k rows fell back to a radix_scan launch of 30-50 us each).  Every
-// table now starts with kSuperRows rows of SUPERGROUP sums (1024 chunks each), the group rows follow: an exclusive prefix is
+// table now starts with `gsup` rows of SUPERGROUP sums (128 chunks = 4 groups each), the group rows follow: an exclusive
+// prefix is
 //   sum(supergroup rows before the chunk's supergroup) + sum(group rows inside it before the chunk's group) + sum(chunk rows
-//   inside the group before the chunk)   <=  nchunks / 1024 + 31 + 31 rows,
-// and the digit totals are the sum of the supergroup rows alone.  Costs the upsweep one more row of no-return atomics.
-constexpr int kSuperShift = 10;
-constexpr uint32_t kSuperRows = 128;          // supports 131072 chunk rows; beyond that the host falls back to the scan kernels
+//   inside the group before the chunk)   <=  nchunks / 128 + 3 + 31 rows,
+// and the digit totals are the sum of the supergroup rows alone.  Costs the upsweep one more row of no-return atomics.  The
+// supergroup must stay small: every chunk of it adds to the same row, and same-address atomics are served one per ~10 ns --
+// supergroups of 1024 chunks (first attempt) put a 10 us chain on every address and cost the two binning upsweeps 30 us.
+constexpr int kSuperShift = 7;
 
 template <int MODE, int SORT_ITEMS = kSortItems>
 __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __restrict__ keys,
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
                                                           uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_rows,
                                                           FrameParams fp,
                                                           const uint32_t* __restrict__ col_totals = nullptr,
-                                                          uint32_t* __restrict__ bincnt = nullptr)
+                                                          uint32_t* __restrict__ bincnt = nullptr, uint32_t gsup = 0u)
 {
     // MODE_PAIR with bincnt != nullptr (r3): the input is ordered by (column, rank) and carries the row in its top byte, so
     // counting the words per (row, column) here gives every bin's list length before the partition has run: the
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
         }
         hist[(size_t)chunk * 256 + threadIdx.x] = c;
         if (gsum_acc != nullptr && c != 0u) {
-            (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(kSuperRows + (chunk >> kGroupShift)) * 256 + threadIdx.x], c,
+            (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(gsup + (chunk >> kGroupShift)) * 256 + threadIdx.x], c,
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(chunk >> kSuperShift) * 256 + threadIdx.x], c, __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_AGENT);
@@ -424,10 +426,10 @@ __device__ __forceinline__ uint32_t coop_row_sum(const uint32_t* __restrict__ ro
 // exclusive prefix of chunk `chunk`'s histogram row over the earlier chunks (scan-free path): the group rows before
 // its group plus the chunk rows before it inside the group
 __device__ __forceinline__ uint32_t group_prefix(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ gsum,
-                                                 uint32_t chunk, uint4* s_part)
+                                                 uint32_t chunk, uint4* s_part, uint32_t gsup)
 {
     const uint32_t g = chunk >> kGroupShift, sg = chunk >> kSuperShift, g0 = sg << (kSuperShift - kGroupShift);
-    return coop_row_sum(gsum, sg, gsum + (size_t)(kSuperRows + g0) * 256, g - g0, s_part,
+    return coop_row_sum(gsum, sg, gsum + (size_t)(gsup + g0) * 256, g - g0, s_part,
                         hist + (size_t)(g << kGroupShift) * 256, chunk - (g << kGroupShift));
 }
 
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
                                                             uint32_t* __restrict__ tile_start = nullptr,
                                                             uint32_t* __restrict__ tile_order = nullptr,
                                                             uint32_t* __restrict__ queue = nullptr,
-                                                            int ntiles = 0, int do_order = 0)
+                                                            int ntiles = 0, int do_order = 0, uint32_t gsup = 0u)
 {
     // gsum != nullptr: scan-free path -- hist holds raw per-chunk counts, prefixes come from the group tables;
     // otherwise hist holds exclusive prefixes and totals the digit totals (radix_scan*).
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
 
     for (uint32_t chunk = wb; chunk < nchunks; chunk += nworkers) {
         // this chunk's exclusive prefix per digit (thread = digit): issued first, consumed after the local ranking
-        const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk, reinterpret_cast<uint4*>(s_keys))
+        const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk, reinterpret_cast<uint4*>(s_keys), gsup)
                                                      : hist[(size_t)chunk * 256 + threadIdx.x];
 #pragma unroll
         for (int k = 0; k < 4; ++k) s_cnt[k][threadIdx.x] = 0;
@@ -1499,7 +1501,7 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
                                                          uint32_t* __restrict__ gsum_acc,
                                                          uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_rows,
                                                          uint32_t* __restrict__ heavy, uint32_t* __restrict__ heavy_next,
-                                                         uint8_t* __restrict__ heavy_flag, uint32_t heavy_slots)
+                                                         uint8_t* __restrict__ heavy_flag, uint32_t heavy_slots, uint32_t gsup)
 {
     // Heavy chunks (r3).  The ranks are in depth order, so the huge far-away splats of a real scene (sky, background) are the
     // FIRST ranks: a few chunks hold half of all the pairs (scene-like 6 M cloud: 25 of 2344 chunks, 500 k pairs each against
@@ -1543,7 +1545,7 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
         const uint32_t incl = block_incl_scan(s_diff[threadIdx.x], s_tmp, total);   // wraps mod 2^32: exact
         hist[(size_t)chunk * 256 + threadIdx.x] = incl;
         if (gsum_acc != nullptr && incl != 0u) {
-            (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(kSuperRows + (chunk >> kGroupShift)) * 256 + threadIdx.x], incl,
+            (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(gsup + (chunk >> kGroupShift)) * 256 + threadIdx.x], incl,
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(chunk >> kSuperShift) * 256 + threadIdx.x], incl, __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_AGENT);
@@ -1581,7 +1583,8 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
                                                            const uint32_t* __restrict__ gsum,
                                                            uint32_t* __restrict__ totals_out, int xcd_map,
                                                            const uint32_t* __restrict__ heavy,
-                                                           const uint8_t* __restrict__ heavy_flag, uint32_t nhelp, int tiles_x)
+                                                           const uint8_t* __restrict__ heavy_flag, uint32_t nhelp, int tiles_x,
+                                                           uint32_t gsup)
 {
     // The first nhelp workgroups are helpers for the heavy chunks (bin1_upsweep; first, so that they start with the launch):
     // helper h takes column block 1 + h % (kHeavyParts - 1) of chunk heavy[1 + h / (kHeavyParts - 1)] and exits at once when
@@ -1651,7 +1654,7 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
             c_lo = hpart * cpp;
             c_hi = c_lo + cpp - 1u;
         }
-        const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk, s_part) : hist[(size_t)chunk * 256 + threadIdx.x];
+        const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk, s_part, gsup) : hist[(size_t)chunk * 256 + threadIdx.x];
         const uint32_t rbase = chunk * BIN_CHUNK;
         uint32_t rc[PER], woff[PER], wsum = 0;
 #pragma unroll

@@ -328,11 +328,14 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
             // straight-line form: every load of the chunk is in flight before the first LDS atomic (one_col: the counts land
             // in s_bin[0][row], i.e. column c0)
             if (MODE == MODE_CULL) {
+                float4 pp[MODE == MODE_CULL ? ITEMS : 1];          // clamped loads, all in flight together (see below)
+#pragma unroll
+                for (int r = 0; r < ITEMS; ++r) pp[r] = pos[min(base + r * kThreads + threadIdx.x, n - 1u)];
 #pragma unroll
                 for (int r = 0; r < ITEMS; ++r) {
                     const uint32_t i = base + r * kThreads + threadIdx.x;
                     uint32_t key;
-                    if (i < n && cull_key(pos[i], fp, key)) atomicAdd(&s_hist[digit_of<MODE>(key, shift)], 1u);
+                    if (i < n && cull_key(pp[r], fp, key)) atomicAdd(&s_hist[digit_of<MODE>(key, shift)], 1u);
                 }
             } else {
                 // unconditional (clamped) loads first: under `if (i < n)` the compiler waits for every load before it
@@ -660,6 +663,11 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
         bool valid[ITEMS];
         // wave w owns the contiguous sub-chunk [w*64*ITEMS, (w+1)*64*ITEMS): keeps the sort stable
         const uint32_t base = chunk * CHUNK + (uint32_t)w * (64 * ITEMS);
+        float4 pp[MODE == MODE_CULL ? ITEMS : 1];          // clamped loads, all in flight together (n >= 1 here)
+        if (MODE == MODE_CULL) {
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) pp[r] = pos[min(base + r * 64 + lane, n - 1u)];
+        }
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const uint32_t i = base + r * 64 + lane;
@@ -668,7 +676,7 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
             val[r] = 0;
             if (valid[r]) {
                 if (MODE == MODE_CULL) {
-                    valid[r] = cull_key(pos[i], fp, key[r]);
+                    valid[r] = cull_key(pp[r], fp, key[r]);
                     val[r] = i;
                 } else {
                     key[r] = keys_in[i];

@@ -73,20 +73,28 @@ typedef struct msplat_config {
     int32_t rank_mode;         /* MSPLAT_RANK_*: how the stable radix / binning passes rank the    */
                                /* keys of one wave.  Added after the first release of the struct:  */
                                /* a struct_size that ends before this field selects MSPLAT_RANK_AUTO */
-    int32_t sort_mode;         /* MSPLAT_SORT_*: which Sort kernels run.  Occupies what was padding after  */
-                               /* rank_mode: any value other than MSPLAT_SORT_WIDE3 / _LSD8 means AUTO      */
+    int32_t frame_mode;        /* MSPLAT_FRAMES_*: is this context the only one working on the GPU, or one of */
+                               /* several frames in flight?  Occupies what was padding after rank_mode: any   */
+                               /* value other than the two named ones means AUTO                               */
 } msplat_config;
 
-/* msplat_config.sort_mode.  Both sorts give the identical stable order.  WIDE3 (three passes of 10 + 8..11 + 8..11 key
- * bits, 6 launches) is the shortest for one frame at a time: 58 us instead of 73 at 1 M splats, 162 instead of 204 at
- * 6 M.  Its downsweeps are workgroups of 8 waves holding 72 KB of LDS, which find a free CU less easily while other
- * frames' kernels occupy the GPU: with FOUR FRAMES IN FLIGHT the four 8-bit passes of LSD8 (4-wave workgroups, 24 KB)
- * give 2 % more frames/s (6.05 k vs 5.94 k at config 2, r3), so the SplatRenderer shims select LSD8 for their in-flight
- * contexts.  AUTO = WIDE3.  MSPLAT_SORT=lsd8|wide3 in the environment overrides the field. */
+/* msplat_config.frame_mode.  Pixels, keys and lists are identical in both modes; what changes is which kernels run.
+ * MSPLAT_FRAMES_SERIAL (= AUTO): one frame at a time -- the shortest single frame: the three-pass wide-digit sort
+ *   (58 us instead of 73 at 1 M splats, 162 instead of 204 at 6 M) and the bins' list offsets from the row pass's pair
+ *   counts (two launches fewer); 12 launches per frame.
+ * MSPLAT_FRAMES_IN_FLIGHT: the context shares the GPU with other contexts' frames (SetFramesInFlight, bench.py's default
+ *   mode).  Launch latency is hidden by the other frames there and what counts is total work and how easily a workgroup
+ *   finds a free CU: the three-pass sort runs in its 4-wave form (256 threads, 40 KB of LDS, against 8 waves and 72 KB)
+ *   up to 2 M splats and the four 8-bit passes take over beyond (4 waves, 24 KB; at 6 M they measure 8 % more frames/s
+ *   than three 4-wave passes), and the list offsets come from the search kernels (the persistent compositor needs no
+ *   bin order).  Measured r3 at config 2, 4 frames in flight, same box: 6045 frames/s against 5800 with the SERIAL
+ *   kernels.  The SplatRenderer shims select it for their in-flight contexts.
+ * In the environment MSPLAT_SORT=lsd8|wide, MSPLAT_WS_THREADS=256|512 and MSPLAT_TILE_TABLE=search|count override the
+ * choices one by one. */
 enum {
-    MSPLAT_SORT_AUTO = 0,
-    MSPLAT_SORT_WIDE3 = 1,
-    MSPLAT_SORT_LSD8 = 2
+    MSPLAT_FRAMES_AUTO = 0,
+    MSPLAT_FRAMES_SERIAL = 1,
+    MSPLAT_FRAMES_IN_FLIGHT = 2
 };
 
 /* msplat_config.rank_mode */

@@ -14,7 +14,7 @@ ERR_PAIR_OVERFLOW_EARLIER = -9      # the call did its work; an EARLIER device-o
 FB_RGBA32F, FB_RGBA16F = 0, 1
 ROP_NONE, ROP_RGBA8, ROP_RGBA16F = 0, 1, 2
 RANK_AUTO, RANK_BALLOT = 0, 1
-SORT_AUTO, SORT_WIDE3, SORT_LSD8 = 0, 1, 2
+FRAMES_AUTO, FRAMES_SERIAL, FRAMES_IN_FLIGHT = 0, 1, 2
 BANDS_CONTIGUOUS, BANDS_INTERLEAVED, BANDS_BLOCK_INTERLEAVED = 0, 1, 2
 BAND_KINDS = {"contiguous": BANDS_CONTIGUOUS, "interleaved": BANDS_INTERLEAVED, "block": BANDS_BLOCK_INTERLEAVED}
 
@@ -29,7 +29,7 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("fb_format", C.c_int32),
                 ("srgb", C.c_int32), ("t_epsilon", C.c_float), ("pair_capacity", C.c_uint64),
                 ("stream", C.c_void_p), ("enable_timing", C.c_int32), ("compositor_waves", C.c_int32),
-                ("rank_mode", C.c_int32), ("sort_mode", C.c_int32)]
+                ("rank_mode", C.c_int32), ("frame_mode", C.c_int32)]
 
 
 class AttrOffsets(C.Structure):

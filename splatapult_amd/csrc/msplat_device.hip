@@ -81,7 +81,10 @@ struct msplat_ctx {
     // table per pass, one visibility bit per splat, the visible set's minimum key per frame parity (counters[10..11])
     Buf wsHist, wsGsum[3], vmask;
     uint32_t ws_items = 8, ws_gshift = 4, ws_gsum_words = 0;
+    uint32_t ws_threads = 512;  // 256 (4 waves, 40 / 56 KB of LDS) for contexts that share the GPU with other frames
     bool wide_sort = true;      // MSPLAT_SORT=lsd8 (or no lane-ordered LDS atomics): the four 8-bit passes
+    bool wide_sort_cfg = true;  // what the context asked for; wide_sort = what the uploaded cloud gets (alloc_cloud_buffers)
+    bool ws_forced = false;     // MSPLAT_SORT=wide: no size rule
     uint32_t sort_parity = 0;
     bool tables_dirty = false;  // a launch failed: clear every self-cleaning table before the next frame
     // per-bin pair counts taken by the row pass's upsweep (r3): list offsets + work order without tile_start_kernel
@@ -326,24 +329,35 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
             rc = fail(ctx, MSPLAT_ERR_HIP, "LDS atomic order probe failed to run");
         ctx->atomic_rank = (hbad == 0) && c.rank_mode != MSPLAT_RANK_BALLOT && getenv("MSPLAT_BALLOT_RANK") == nullptr;
         ctx->scan_free = getenv("MSPLAT_SCAN_KERNELS") == nullptr;
-        ctx->wide_sort = c.sort_mode != MSPLAT_SORT_LSD8;           // AUTO (and any stale padding value) = the three-pass sort
+        // frames in flight: kernels that co-schedule well (msplat.h); AUTO and any stale padding value = one frame at a time
+        ctx->wide_sort = true;
+        ctx->ws_threads = c.frame_mode == MSPLAT_FRAMES_IN_FLIGHT ? (uint32_t)kWsThreadsSmall : (uint32_t)kWsThreads;
+        ctx->bin_counts = c.frame_mode != MSPLAT_FRAMES_IN_FLIGHT;
         if (const char* sk = getenv("MSPLAT_SORT")) ctx->wide_sort = std::string(sk) != "lsd8";
+        if (const char* wt = getenv("MSPLAT_WS_THREADS")) ctx->ws_threads = atoi(wt) == kWsThreadsSmall ? (uint32_t)kWsThreadsSmall : (uint32_t)kWsThreads;
         if (!ctx->atomic_rank) ctx->wide_sort = false;       // the wide kernels rank with lane-ordered LDS atomics only
         if (const char* tk = getenv("MSPLAT_TILE_TABLE")) ctx->bin_counts = std::string(tk) != "search";
         if (getenv("MSPLAT_XCD_MAP")) ctx->xcd_map = atoi(getenv("MSPLAT_XCD_MAP"));
         if (getenv("MSPLAT_HEAVY_SPLIT")) ctx->heavy_split = atoi(getenv("MSPLAT_HEAVY_SPLIT")) != 0;
         if (ctx->wide_sort) {
-            // ws_downsweep needs 72 / 104 KB of dynamic LDS: above the 64 KB a kernel gets without asking
+            // ws_downsweep needs 72 / 104 KB of dynamic LDS with 512 threads (40 / 56 KB with 256): ask for it once
             static const bool lds_ok = [] {
                 bool ok = true;
-                ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&ws_downsweep<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_downsweep_lds(8)) == hipSuccess;
-                ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&ws_downsweep<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_downsweep_lds(8)) == hipSuccess;
-                ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&ws_downsweep<true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_downsweep_lds(16)) == hipSuccess;
-                ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&ws_downsweep<false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_downsweep_lds(16)) == hipSuccess;
+                auto want = [&](const void* f, size_t bytes) { ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess; };
+                want(reinterpret_cast<const void*>(&ws_downsweep<true, 8, kWsThreads>), ws_downsweep_lds(8, kWsThreads));
+                want(reinterpret_cast<const void*>(&ws_downsweep<false, 8, kWsThreads>), ws_downsweep_lds(8, kWsThreads));
+                want(reinterpret_cast<const void*>(&ws_downsweep<true, 16, kWsThreads>), ws_downsweep_lds(16, kWsThreads));
+                want(reinterpret_cast<const void*>(&ws_downsweep<false, 16, kWsThreads>), ws_downsweep_lds(16, kWsThreads));
+                want(reinterpret_cast<const void*>(&ws_downsweep<true, 8, kWsThreadsSmall>), ws_downsweep_lds(8, kWsThreadsSmall));
+                want(reinterpret_cast<const void*>(&ws_downsweep<false, 8, kWsThreadsSmall>), ws_downsweep_lds(8, kWsThreadsSmall));
+                want(reinterpret_cast<const void*>(&ws_downsweep<true, 16, kWsThreadsSmall>), ws_downsweep_lds(16, kWsThreadsSmall));
+                want(reinterpret_cast<const void*>(&ws_downsweep<false, 16, kWsThreadsSmall>), ws_downsweep_lds(16, kWsThreadsSmall));
                 return ok;
             }();
             if (!lds_ok) { (void)hipGetLastError(); ctx->wide_sort = false; }
         }
+        ctx->wide_sort_cfg = ctx->wide_sort;
+        if (const char* sk = getenv("MSPLAT_SORT")) ctx->ws_forced = std::string(sk) == "wide";
         if (getenv("MSPLAT_FUSED_MAX_CHUNKS")) ctx->fused_max_chunks = (uint32_t)atoi(getenv("MSPLAT_FUSED_MAX_CHUNKS"));
         if (const char* ck = getenv("MSPLAT_COMPOSITOR")) {
             const std::string k = ck;
@@ -602,12 +616,15 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
     if ((rc = alloc_group_table(ctx, ctx->gsumS[0], rows_s0, ctx->hist_stride, ctx->gsupS))) return rc;
     if ((rc = alloc_group_table(ctx, ctx->gsumS[1], ctx->gsumS_rows, ctx->hist_stride, ctx->gsupS))) return rc;
     ctx->gsumS_rows = std::min(ctx->gsumS_rows, rows_s0);
+    // frames in flight (256-thread form): three passes up to 2 M splats, the four 8-bit passes beyond -- measured r3 with 4
+    // frames in flight: 1 M 6045 vs 5880 frames/s, 6 M 1497 vs 1616 (tools/gpu_round3_ab5.sh)
+    ctx->wide_sort = ctx->wide_sort_cfg && (ctx->ws_threads == (uint32_t)kWsThreads || n <= (2u << 20) || ctx->ws_forced);
     if (ctx->wide_sort) {
         // 4096-key chunks up to 2 M splats, 8192 beyond (MSPLAT_WS_ITEMS = 8 | 16 overrides); groups of 16 chunk rows while
         // there are at most 512 rows, else of 32 (a downsweep sums <= nchunks / G + G - 1 rows)
         ctx->ws_items = n > (2u << 20) ? 16u : 8u;
         if (const char* wi = getenv("MSPLAT_WS_ITEMS")) ctx->ws_items = atoi(wi) == 16 ? 16u : 8u;
-        const uint32_t nch = std::max(1u, div_up(n, (uint64_t)kWsThreads * ctx->ws_items));
+        const uint32_t nch = std::max(1u, div_up(n, (uint64_t)ctx->ws_threads * ctx->ws_items));
         ctx->ws_gshift = nch <= 512u ? 4u : 5u;
         if ((rc = buf_alloc(ctx, ctx->wsHist, (size_t)nch * kWsMaxBins * 4))) return rc;
         const size_t gwords = (size_t)((nch >> ctx->ws_gshift) + 2) * kWsMaxBins;
@@ -1087,16 +1104,21 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
         const int gsh = (int)ctx->ws_gshift;
         const uint32_t gw = ctx->ws_gsum_words;
         auto gt = [&](int pass) { return (uint32_t*)ctx->wsGsum[(pass + 3) % 3].p; };
-        const uint32_t wchunk = (uint32_t)kWsThreads * ctx->ws_items;
+        const uint32_t wchunk = ctx->ws_threads * ctx->ws_items;
         const int wgrid = grid_for(div_up(N, wchunk));
         const uint32_t* dV = d_V;
         const int wsx = (ctx->xcd_map & 1) ? 1 : 0;
+#define MSPLAT_WS_T(KERNEL, CULLF, LDS, T, ...)                                                                          \
+    do {                                                                                                                \
+        if (ctx->ws_items == 16) hipLaunchKernelGGL((KERNEL<CULLF, 16, T>), dim3(wgrid), dim3(T), LDS(16, T), s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<CULLF, 8, T>), dim3(wgrid), dim3(T), LDS(8, T), s, __VA_ARGS__);                       \
+    } while (0)
 #define MSPLAT_WS(KERNEL, CULLF, LDS, ...)                                                                              \
     do {                                                                                                                \
-        if (ctx->ws_items == 16) hipLaunchKernelGGL((KERNEL<CULLF, 16>), dim3(wgrid), dim3(kWsThreads), LDS(16), s, __VA_ARGS__); \
-        else hipLaunchKernelGGL((KERNEL<CULLF, 8>), dim3(wgrid), dim3(kWsThreads), LDS(8), s, __VA_ARGS__);                       \
+        if (ctx->ws_threads == (uint32_t)kWsThreadsSmall) MSPLAT_WS_T(KERNEL, CULLF, LDS, kWsThreadsSmall, __VA_ARGS__); \
+        else MSPLAT_WS_T(KERNEL, CULLF, LDS, kWsThreads, __VA_ARGS__);                                                  \
     } while (0)
-#define MSPLAT_NO_LDS(I) 0
+#define MSPLAT_NO_LDS(I, T) 0
         MSPLAT_WS(ws_upsweep, true, MSPLAT_NO_LDS, (const uint32_t*)nullptr, pos, kB, vm, (const uint32_t*)nullptr, N, N, 0, mk_cur,
                   mk_next, whist, gt(0), gsh, gt(-1), gw, fp);
         MSPLAT_WS(ws_downsweep, true, ws_downsweep_lds, (const uint32_t*)kB, (const uint32_t*)nullptr, (const unsigned long long*)vm,
@@ -1112,6 +1134,7 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
                   0u, N, 2, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(2), gsh, kA, vA, (uint32_t*)nullptr, wsx);
 #undef MSPLAT_NO_LDS
 #undef MSPLAT_WS
+#undef MSPLAT_WS_T
         if (timed) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][1], s));
             ctx->sort_sets++;
@@ -1220,7 +1243,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     // helper workgroups for as many split chunks as an EARLIER frame asked for (host-mapped word, read without synchronising),
     // with headroom; a frame that needs more runs its extra heavy chunks unsplit and the next launch adapts
     const uint32_t last_heavy = ctx->h_flags ? __atomic_load_n(ctx->h_flags + 3, __ATOMIC_RELAXED) : 0u;
-    const uint32_t heavy_slots = ctx->heavy_split ? std::min<uint32_t>(kHeavyCap, 2u * last_heavy + 8u) : 0u;
+    const uint32_t heavy_slots = (ctx->heavy_split && last_heavy != 0u) ? std::min<uint32_t>(kHeavyCap, 2u * last_heavy + 8u) : 0u;
     const int nhelp = (int)(heavy_slots * (kHeavyParts - 1u));
     // scan-free variants while the chunk tables are small; the row pass's size (D) is only known on the device, so
     // its choice uses the D of an EARLIER frame that the binning kernel left in host-mapped memory (0 = none yet);

@@ -580,7 +580,7 @@ __device__ __forceinline__ void tile_table_role(uint32_t* __restrict__ bincnt, i
 }
 
 template <int MODE, bool HAS_VALUES, bool ATOMIC_RANK, int SORT_ITEMS = kSortItems>
-__global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __restrict__ keys_in,
+__global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE != MODE_PAIR && SORT_ITEMS == kSortItems) ? 5 : 2) void radix_downsweep(const uint32_t* __restrict__ keys_in,
                                                             const uint32_t* __restrict__ vals_in,
                                                             const float4* __restrict__ pos,
                                                             const uint32_t* __restrict__ d_n, uint32_t n_static,
@@ -663,20 +663,24 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
         bool valid[ITEMS];
         // wave w owns the contiguous sub-chunk [w*64*ITEMS, (w+1)*64*ITEMS): keeps the sort stable
         const uint32_t base = chunk * CHUNK + (uint32_t)w * (64 * ITEMS);
-        float4 pp[MODE == MODE_CULL ? ITEMS : 1];          // clamped loads, all in flight together (n >= 1 here)
-        if (MODE == MODE_CULL) {
-#pragma unroll
-            for (int r = 0; r < ITEMS; ++r) pp[r] = pos[min(base + r * 64 + lane, n - 1u)];
-        }
+        // MODE_CULL: clamped position loads, four in flight together (n >= 1 here; all ITEMS at once would cost the kernel its
+        // fifth wave per SIMD: 16-byte loads)
+        constexpr int kPosBatch = 4;
+        float4 pp[MODE == MODE_CULL ? kPosBatch : 1];
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
+            if (MODE == MODE_CULL && (r % kPosBatch) == 0) {
+#pragma unroll
+                for (int k = 0; k < kPosBatch; ++k)
+                    if (r + k < ITEMS) pp[k] = pos[min(base + (r + k) * 64 + lane, n - 1u)];
+            }
             const uint32_t i = base + r * 64 + lane;
             valid[r] = i < n;
             key[r] = 0;
             val[r] = 0;
             if (valid[r]) {
                 if (MODE == MODE_CULL) {
-                    valid[r] = cull_key(pp[r], fp, key[r]);
+                    valid[r] = cull_key(pp[r % kPosBatch], fp, key[r]);
                     val[r] = i;
                 } else {
                     key[r] = keys_in[i];
@@ -798,8 +802,8 @@ __global__ __launch_bounds__(kThreads) void radix_downsweep(const uint32_t* __re
 //     splat instead of re-reading the 16-byte position and recomputing the cull (r2: 1.48x traffic in pass 0).
 // Needs the lane-ordered LDS atomics (probed at msplat_create); without them the 8-bit ballot kernels are used.
 // ------------------------------------------------------------------------------------------
-constexpr int kWsThreads = 512;
-constexpr int kWsWaves = kWsThreads / 64;
+constexpr int kWsThreads = 512;              // workgroup size for one frame at a time (8 waves, 72 / 104 KB of LDS)
+constexpr int kWsThreadsSmall = 256;         // 4 waves, 40 KB: the form for contexts that share the GPU with other frames
 constexpr int kWsBits0 = 10;                 // digit of pass 0: key bits [0, 10)
 constexpr int kWsMinBits = 8, kWsMaxBits = 11;
 constexpr int kWsMaxBins = 1 << kWsMaxBits;
@@ -817,7 +821,8 @@ __device__ __forceinline__ void ws_digit_range(int pass, uint32_t minkey, int& s
     else { shift = kWsBits0 + b1; bits = rem - b1; }
 }
 
-// inclusive scan of one uint32 per thread across a 512-thread workgroup (s_tmp: 8 words); ends with a barrier
+// inclusive scan of one uint32 per thread across a workgroup of WAVES waves (s_tmp: WAVES words); ends with a barrier
+template <int WAVES>
 __device__ __forceinline__ uint32_t ws_block_incl_scan(uint32_t v, uint32_t* s_tmp, uint32_t& total)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -831,7 +836,7 @@ __device__ __forceinline__ uint32_t ws_block_incl_scan(uint32_t v, uint32_t* s_t
     uint32_t off = 0;
     total = 0;
 #pragma unroll
-    for (int k = 0; k < kWsWaves; ++k) {
+    for (int k = 0; k < WAVES; ++k) {
         const uint32_t s = s_tmp[k];
         if (k < w) off += s;
         total += s;
@@ -840,44 +845,62 @@ __device__ __forceinline__ uint32_t ws_block_incl_scan(uint32_t v, uint32_t* s_t
     return v + off;
 }
 
-// Sum of n0 rows at rows0 plus n1 rows at rows1 (rows of `nbins` uint32, nbins = 256..2048), as quads: thread t < nbins / 4
-// receives the sums of digits 4t .. 4t+3.  A row is nbins / 4 16-byte quads; thread t loads quad t % Q of the rows
-// t / Q, t / Q + 512 / Q, ... (coalesced), partial sums meet in s_part (512 uint4).  Two barriers: call from all threads.
-__device__ __forceinline__ uint4 ws_row_sum(const uint32_t* __restrict__ rows0, uint32_t n0,
-                                            const uint32_t* __restrict__ rows1, uint32_t n1, uint32_t nbins, int bits,
-                                            uint4* s_part)
+// Sum of n0 rows at rows0 plus n1 rows at rows1 (rows of `nbins` uint32, nbins = 256..2048), as quads: thread t receives in
+// out[k] the sums of digits 4 (t + k THREADS) .. + 3 for every quad t + k THREADS < nbins / 4 (QPT = 1 quad per thread with 512
+// threads, up to 2 with 256).  A row is nbins / 4 16-byte quads; with fewer quads than threads, thread t loads quad t % Q of
+// the rows t / Q, t / Q + THREADS / Q, ... (coalesced) and the partial sums meet in s_part (THREADS x QPT uint4).  Two barriers.
+template <int THREADS>
+__device__ __forceinline__ void ws_row_sum(const uint32_t* __restrict__ rows0, uint32_t n0,
+                                           const uint32_t* __restrict__ rows1, uint32_t n1, uint32_t nbins, int bits,
+                                           uint4* s_part, uint4 (&out)[kWsMaxBins / 4 / THREADS])
 {
-    const uint32_t Q = nbins >> 2, RL = (uint32_t)kWsThreads >> (bits - 2);
-    const uint32_t q = threadIdx.x & (Q - 1u), rl = threadIdx.x >> (bits - 2);
-    uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+    constexpr int QPT = kWsMaxBins / 4 / THREADS;
+    const uint32_t Q = nbins >> 2;
+    const bool wide = Q >= (uint32_t)THREADS;                               // workgroup-uniform
+    const uint32_t RL = wide ? 1u : ((uint32_t)THREADS >> (bits - 2));      // row lanes
+    const uint32_t q = wide ? threadIdx.x : (threadIdx.x & (Q - 1u)), rl = wide ? 0u : (threadIdx.x >> (bits - 2));
+    uint4 acc[QPT];
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) acc[k] = make_uint4(0u, 0u, 0u, 0u);
     // four rows per step, their loads issued together (a plain `for (r += RL)` loop compiles to load, wait, add, load, ...:
     // one memory latency per row on the critical path of every downsweep)
-    auto sum_rows = [&](const uint32_t* __restrict__ rows, uint32_t n) {
-        const uint32_t* p = rows + q * 4u;
+    auto sum_rows = [&](const uint32_t* __restrict__ rows, uint32_t n, int k) {
+        const uint32_t* p = rows + (q + (uint32_t)k * THREADS) * 4u;
+        uint4& a = acc[k];
         uint32_t r = rl;
         for (; r + 3u * RL < n; r += 4u * RL) {
             const uint4 x0 = *reinterpret_cast<const uint4*>(p + (size_t)r * nbins);
             const uint4 x1 = *reinterpret_cast<const uint4*>(p + (size_t)(r + RL) * nbins);
             const uint4 x2 = *reinterpret_cast<const uint4*>(p + (size_t)(r + 2u * RL) * nbins);
             const uint4 x3 = *reinterpret_cast<const uint4*>(p + (size_t)(r + 3u * RL) * nbins);
-            acc.x += (x0.x + x1.x) + (x2.x + x3.x); acc.y += (x0.y + x1.y) + (x2.y + x3.y);
-            acc.z += (x0.z + x1.z) + (x2.z + x3.z); acc.w += (x0.w + x1.w) + (x2.w + x3.w);
+            a.x += (x0.x + x1.x) + (x2.x + x3.x); a.y += (x0.y + x1.y) + (x2.y + x3.y);
+            a.z += (x0.z + x1.z) + (x2.z + x3.z); a.w += (x0.w + x1.w) + (x2.w + x3.w);
         }
         // tail: up to three rows, loaded together (the clamped row is added with weight 0)
         const uint32_t r1 = r + RL, r2 = r + 2u * RL;
-        const bool h0 = r < n, h1 = r1 < n, h2 = r2 < n;
-        if (h0) {
+        const bool h1 = r1 < n, h2 = r2 < n;
+        if (r < n) {
             const uint4 x0 = *reinterpret_cast<const uint4*>(p + (size_t)r * nbins);
             const uint4 x1 = *reinterpret_cast<const uint4*>(p + (size_t)(h1 ? r1 : r) * nbins);
             const uint4 x2 = *reinterpret_cast<const uint4*>(p + (size_t)(h2 ? r2 : r) * nbins);
             const uint32_t m1 = h1 ? 0xFFFFFFFFu : 0u, m2 = h2 ? 0xFFFFFFFFu : 0u;
-            acc.x += x0.x + (x1.x & m1) + (x2.x & m2); acc.y += x0.y + (x1.y & m1) + (x2.y & m2);
-            acc.z += x0.z + (x1.z & m1) + (x2.z & m2); acc.w += x0.w + (x1.w & m1) + (x2.w & m2);
+            a.x += x0.x + (x1.x & m1) + (x2.x & m2); a.y += x0.y + (x1.y & m1) + (x2.y & m2);
+            a.z += x0.z + (x1.z & m1) + (x2.z & m2); a.w += x0.w + (x1.w & m1) + (x2.w & m2);
         }
     };
-    sum_rows(rows0, n0);
-    sum_rows(rows1, n1);
-    s_part[threadIdx.x] = acc;                 // == s_part[rl * Q + q]
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+        if (k == 0 || q + (uint32_t)k * THREADS < Q) {
+            sum_rows(rows0, n0, k);
+            sum_rows(rows1, n1, k);
+        }
+    }
+    if (wide) {               // every thread already holds the complete sums of its own quads
+#pragma unroll
+        for (int k = 0; k < QPT; ++k) out[k] = acc[k];
+        return;
+    }
+    s_part[threadIdx.x] = acc[0];              // == s_part[rl * Q + q]
     __syncthreads();
     uint4 sum = make_uint4(0u, 0u, 0u, 0u);
     if (threadIdx.x < Q)
@@ -886,30 +909,33 @@ __device__ __forceinline__ uint4 ws_row_sum(const uint32_t* __restrict__ rows0, 
             sum.x += x.x; sum.y += x.y; sum.z += x.z; sum.w += x.w;
         }
     __syncthreads();
-    return sum;
+    out[0] = sum;
+#pragma unroll
+    for (int k = 1; k < QPT; ++k) out[k] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // CULL: pass 0.  keys are computed from the positions (presort_compute.glsl:38-55 via cull_key), written to raw_keys
 // together with one visibility bit per splat (vmask: one uint64 per 64 splats), and their minimum goes to *minkey_cur.
-template <bool CULL, int ITEMS>
-__global__ __launch_bounds__(kWsThreads) void ws_upsweep(const uint32_t* __restrict__ keys_in,
-                                                         const float4* __restrict__ pos,
-                                                         uint32_t* __restrict__ raw_keys,
-                                                         unsigned long long* __restrict__ vmask,
-                                                         const uint32_t* __restrict__ d_n, uint32_t n_static, uint32_t n_cap,
-                                                         int pass, uint32_t* __restrict__ minkey_cur,
-                                                         uint32_t* __restrict__ minkey_next,
-                                                         uint32_t* __restrict__ hist,
-                                                         uint32_t* __restrict__ gsum_acc, int gshift,
-                                                         uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_words,
-                                                         FrameParams fp)
+template <bool CULL, int ITEMS, int THREADS = kWsThreads>
+__global__ __launch_bounds__(THREADS) void ws_upsweep(const uint32_t* __restrict__ keys_in,
+                                                      const float4* __restrict__ pos,
+                                                      uint32_t* __restrict__ raw_keys,
+                                                      unsigned long long* __restrict__ vmask,
+                                                      const uint32_t* __restrict__ d_n, uint32_t n_static, uint32_t n_cap,
+                                                      int pass, uint32_t* __restrict__ minkey_cur,
+                                                      uint32_t* __restrict__ minkey_next,
+                                                      uint32_t* __restrict__ hist,
+                                                      uint32_t* __restrict__ gsum_acc, int gshift,
+                                                      uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_words,
+                                                      FrameParams fp)
 {
-    constexpr int CHUNK = kWsThreads * ITEMS;
+    constexpr int CHUNK = THREADS * ITEMS;
+    constexpr int WAVES = THREADS / 64;
     __shared__ uint32_t s_hist[kWsMaxBins];
-    __shared__ uint32_t s_min[kWsWaves];
+    __shared__ uint32_t s_min[WAVES];
     // the group table of the pass before this one (its consumer finished one launch ago) is cleared for the next frame
     if (gsum_zero != nullptr)
-        for (uint32_t i = blockIdx.x * kWsThreads + threadIdx.x; i < gsum_zero_words; i += gridDim.x * kWsThreads) gsum_zero[i] = 0u;
+        for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < gsum_zero_words; i += gridDim.x * THREADS) gsum_zero[i] = 0u;
     if (CULL && blockIdx.x == 0 && threadIdx.x == 0) *minkey_next = 0xFFFFFFFFu;      // the other frame parity's word
     uint32_t n = d_n ? *d_n : n_static;
     if (n > n_cap) n = n_cap;
@@ -919,7 +945,7 @@ __global__ __launch_bounds__(kWsThreads) void ws_upsweep(const uint32_t* __restr
     const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
     uint32_t mk = 0xFFFFFFFFu;
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        for (uint32_t d = threadIdx.x; d < nbins; d += kWsThreads) s_hist[d] = 0u;
+        for (uint32_t d = threadIdx.x; d < nbins; d += THREADS) s_hist[d] = 0u;
         __syncthreads();
         const uint32_t base = chunk * CHUNK;
         // unconditional (clamped) loads first, so that all of them are in flight together: under `if (i < n)` the
@@ -928,13 +954,13 @@ __global__ __launch_bounds__(kWsThreads) void ws_upsweep(const uint32_t* __restr
         uint32_t kk[CULL ? 1 : ITEMS];
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
-            const uint32_t ic = min(base + r * kWsThreads + threadIdx.x, n - 1u);          // n >= 1 inside this loop
+            const uint32_t ic = min(base + r * THREADS + threadIdx.x, n - 1u);          // n >= 1 inside this loop
             if (CULL) pp[r] = pos[ic];
             else kk[r] = keys_in[ic];
         }
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
-            const uint32_t i = base + r * kWsThreads + threadIdx.x;
+            const uint32_t i = base + r * THREADS + threadIdx.x;
             uint32_t key = 0u;
             bool ok = false;
             if (i < n) {
@@ -952,7 +978,7 @@ __global__ __launch_bounds__(kWsThreads) void ws_upsweep(const uint32_t* __restr
             if (ok) atomicAdd(&s_hist[(key >> shift) & dmask], 1u);
         }
         __syncthreads();
-        for (uint32_t d = threadIdx.x; d < nbins; d += kWsThreads) {
+        for (uint32_t d = threadIdx.x; d < nbins; d += THREADS) {
             const uint32_t c = s_hist[d];
             hist[(size_t)chunk * nbins + d] = c;
             if (c != 0u)
@@ -969,41 +995,39 @@ __global__ __launch_bounds__(kWsThreads) void ws_upsweep(const uint32_t* __restr
         if (threadIdx.x == 0) {
             uint32_t m = s_min[0];
 #pragma unroll
-            for (int k = 1; k < kWsWaves; ++k) m = min(m, s_min[k]);
+            for (int k = 1; k < WAVES; ++k) m = min(m, s_min[k]);
             if (m != 0xFFFFFFFFu) (void)atomicMin(minkey_cur, m);
         }
     }
 }
 
-// dynamic LDS of ws_downsweep<., ITEMS>: keys + values of the chunk, packed per-wave counters, per-digit deltas, scan scratch
-constexpr size_t ws_downsweep_lds(int items)
+// dynamic LDS of ws_downsweep<., ITEMS, THREADS>: keys + values of the chunk, packed per-wave counters, per-digit deltas,
+// scan scratch
+constexpr size_t ws_downsweep_lds(int items, int threads = kWsThreads)
 {
-    return (size_t)kWsThreads * items * 8 + (size_t)kWsWaves * (kWsMaxBins / 2) * 4 + (size_t)kWsMaxBins * 4 + 64;
+    return (size_t)threads * items * 8 + (size_t)(threads / 64) * (kWsMaxBins / 2) * 4 + (size_t)kWsMaxBins * 4 + 64;
 }
 
-template <bool CULL, int ITEMS>
-__global__ __launch_bounds__(kWsThreads, ITEMS == 8 ? 4 : 2) void ws_downsweep(const uint32_t* __restrict__ keys_in,
-                                                           const uint32_t* __restrict__ vals_in,
-                                                           const unsigned long long* __restrict__ vmask,
-                                                           const uint32_t* __restrict__ d_n, uint32_t n_static, uint32_t n_cap,
-                                                           int pass, const uint32_t* __restrict__ minkey_cur,
-                                                           const uint32_t* __restrict__ hist,
-                                                           const uint32_t* __restrict__ gsum, int gshift,
-                                                           uint32_t* __restrict__ keys_out,
-                                                           uint32_t* __restrict__ vals_out,
-                                                           uint32_t* __restrict__ d_count_out, int xcd_map)
+template <bool CULL, int ITEMS, int THREADS = kWsThreads>
+__global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, const unsigned long long* __restrict__ vmask,
+    const uint32_t* __restrict__ d_n, uint32_t n_static, uint32_t n_cap, int pass, const uint32_t* __restrict__ minkey_cur,
+    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ gsum, int gshift, uint32_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, uint32_t* __restrict__ d_count_out, int xcd_map)
 {
     // xcd_map: workgroup b runs on XCD b % 8; chunk = xcd_contiguous(b) gives every XCD a contiguous range of chunks, so
     // the digit runs that neighbouring chunks write next to each other meet in ONE L2 instead of being written to HBM
     // as partial lines by several (the per-XCD L2s are not coherent; every one writes back its own bytes of a shared line)
-    constexpr int CHUNK = kWsThreads * ITEMS;
+    constexpr int CHUNK = THREADS * ITEMS;
+    constexpr int WAVES = THREADS / 64;
+    constexpr int QPT = kWsMaxBins / 4 / THREADS;               // quads (4 digits) per thread in the per-digit steps: 1 or 2
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     uint32_t* s_keys = s_dyn;                                   // CHUNK
     uint32_t* s_vals = s_keys + CHUNK;                          // CHUNK
-    uint32_t* s_cnt = s_vals + CHUNK;                           // kWsWaves x (nbins / 2) packed 16-bit counters, then bases
-    uint32_t* s_gd = s_cnt + kWsWaves * (kWsMaxBins / 2);       // nbins: global position minus chunk-local position
-    uint32_t* s_tmp = s_gd + kWsMaxBins;                        // 8 words
-    uint4* s_part = reinterpret_cast<uint4*>(s_keys);           // 8 KB scratch of the row sums (s_keys not live yet)
+    uint32_t* s_cnt = s_vals + CHUNK;                           // WAVES x (nbins / 2) packed 16-bit counters, then bases
+    uint32_t* s_gd = s_cnt + WAVES * (kWsMaxBins / 2);          // nbins: global position minus chunk-local position
+    uint32_t* s_tmp = s_gd + kWsMaxBins;                        // WAVES words
+    uint4* s_part = reinterpret_cast<uint4*>(s_keys);           // THREADS uint4 of row-sum scratch (s_keys not live yet)
 
     uint32_t n = d_n ? *d_n : n_static;
     if (n > n_cap) n = n_cap;
@@ -1013,24 +1037,35 @@ __global__ __launch_bounds__(kWsThreads, ITEMS == 8 ? 4 : 2) void ws_downsweep(c
     const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
 
-    // digit totals = sum of all group rows; their exclusive scan = where each digit's run starts (kept in registers)
-    uint32_t gbase[4];
+    // digit totals = sum of all group rows; their exclusive scan = where each digit's run starts (kept in registers).
+    // Thread t owns the quads t + k THREADS (k < QPT) that exist; the scan runs over the quads in (k, t) order, i.e. the
+    // digits in ascending order: first all k = 0 quads, then -- offset by their total -- the k = 1 quads.
+    uint32_t gbase[QPT][4];
     {
         const uint32_t ng = (nchunks + (1u << gshift) - 1u) >> gshift;
-        const uint4 tot = ws_row_sum(gsum, ng, gsum, 0u, nbins, bits, s_part);
-        const uint32_t tsum = tot.x + tot.y + tot.z + tot.w;          // 0 for t >= Q
-        uint32_t total;
-        const uint32_t e = ws_block_incl_scan(tsum, s_tmp, total) - tsum;
-        gbase[0] = e; gbase[1] = e + tot.x; gbase[2] = gbase[1] + tot.y; gbase[3] = gbase[2] + tot.z;
-        if (d_count_out != nullptr && blockIdx.x == 0 && t == 0) *d_count_out = total;
+        uint4 tot[QPT];
+        ws_row_sum<THREADS>(gsum, ng, gsum, 0u, nbins, bits, s_part, tot);
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < QPT; ++k) {
+            const bool own = (uint32_t)t + (uint32_t)k * THREADS < Q;
+            const uint32_t tsum = own ? tot[k].x + tot[k].y + tot[k].z + tot[k].w : 0u;
+            uint32_t total;
+            const uint32_t e = run + ws_block_incl_scan<WAVES>(tsum, s_tmp, total) - tsum;
+            gbase[k][0] = e; gbase[k][1] = e + tot[k].x; gbase[k][2] = gbase[k][1] + tot[k].y; gbase[k][3] = gbase[k][2] + tot[k].z;
+            run += total;
+        }
+        if (d_count_out != nullptr && blockIdx.x == 0 && t == 0) *d_count_out = run;
     }
 
     for (uint32_t cidx = blockIdx.x; cidx < nchunks; cidx += gridDim.x) {
         const uint32_t chunk = (xcd_map && (gridDim.x >= nchunks || (gridDim.x & 7u) == 0u)) ? xcd_contiguous(cidx, nchunks) : cidx;
         // this chunk's exclusive prefix per digit: the group rows before its group + the chunk rows before it in the group
         const uint32_t g = chunk >> gshift;
-        const uint4 pre = ws_row_sum(gsum, g, hist + (size_t)(g << gshift) * nbins, chunk - (g << gshift), nbins, bits, s_part);
-        for (uint32_t i = t; i < nbins; i += kWsThreads) reinterpret_cast<uint4*>(s_cnt)[i] = make_uint4(0u, 0u, 0u, 0u);
+        uint4 pre[QPT];
+        ws_row_sum<THREADS>(gsum, g, hist + (size_t)(g << gshift) * nbins, chunk - (g << gshift), nbins, bits, s_part, pre);
+        __syncthreads();            // (the wide form of ws_row_sum has no barrier: s_cnt below is not the scratch, but keep the phases apart)
+        for (uint32_t i = t; i < (uint32_t)WAVES * (nbins >> 3); i += THREADS) reinterpret_cast<uint4*>(s_cnt)[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
 
         uint32_t key[ITEMS], val[ITEMS], lrank[ITEMS];
@@ -1065,33 +1100,38 @@ __global__ __launch_bounds__(kWsThreads, ITEMS == 8 ? 4 : 2) void ws_downsweep(c
             if (valid[r]) lrank[r] = (atomicAdd(&wcnt[d >> 1], 1u << sh) >> sh) & 0xFFFFu;
         }
         __syncthreads();
-        // per digit: counts of the 8 waves -> chunk-local exclusive positions -> per-wave bases (16 bit: < CHUNK <= 8192)
-        uint32_t chunk_count;
-        {
-            uint32_t c[kWsWaves][4];
-            uint32_t tot[4] = {0u, 0u, 0u, 0u};
-            if ((uint32_t)t < Q) {
+        // per digit: counts of the waves -> chunk-local exclusive positions -> per-wave bases (16 bit: < CHUNK <= 8192)
+        uint32_t chunk_count = 0;
 #pragma unroll
-                for (int k = 0; k < kWsWaves; ++k) {
-                    const uint2 x = *reinterpret_cast<const uint2*>(s_cnt + (uint32_t)k * half + 2u * t);
+        for (int kq = 0; kq < QPT; ++kq) {
+            const uint32_t qd = (uint32_t)t + (uint32_t)kq * THREADS;            // this thread's quad (digits 4 qd .. 4 qd + 3)
+            const bool own = qd < Q;
+            uint32_t c[WAVES][4];
+            uint32_t tot[4] = {0u, 0u, 0u, 0u};
+            if (own) {
+#pragma unroll
+                for (int k = 0; k < WAVES; ++k) {
+                    const uint2 x = *reinterpret_cast<const uint2*>(s_cnt + (uint32_t)k * half + 2u * qd);
                     c[k][0] = x.x & 0xFFFFu; c[k][1] = x.x >> 16; c[k][2] = x.y & 0xFFFFu; c[k][3] = x.y >> 16;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) tot[j] += c[k][j];
                 }
             }
             const uint32_t tsum = tot[0] + tot[1] + tot[2] + tot[3];
-            const uint32_t e = ws_block_incl_scan(tsum, s_tmp, chunk_count) - tsum;
-            if ((uint32_t)t < Q) {
+            uint32_t part_total;
+            const uint32_t e = chunk_count + ws_block_incl_scan<WAVES>(tsum, s_tmp, part_total) - tsum;
+            chunk_count += part_total;
+            if (own) {
                 uint32_t run[4] = {e, e + tot[0], e + tot[0] + tot[1], e + tot[0] + tot[1] + tot[2]};
-                const uint32_t pr[4] = {pre.x, pre.y, pre.z, pre.w};
+                const uint32_t pr[4] = {pre[kq].x, pre[kq].y, pre[kq].z, pre[kq].w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s_gd[4u * t + j] = gbase[j] + pr[j] - run[j];
+                for (int j = 0; j < 4; ++j) s_gd[4u * qd + j] = gbase[kq][j] + pr[j] - run[j];
 #pragma unroll
-                for (int k = 0; k < kWsWaves; ++k) {
+                for (int k = 0; k < WAVES; ++k) {
                     uint2 x;
                     x.x = run[0] | (run[1] << 16);
                     x.y = run[2] | (run[3] << 16);
-                    *reinterpret_cast<uint2*>(s_cnt + (uint32_t)k * half + 2u * t) = x;
+                    *reinterpret_cast<uint2*>(s_cnt + (uint32_t)k * half + 2u * qd) = x;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) run[j] += c[k][j];
                 }
@@ -1112,7 +1152,7 @@ __global__ __launch_bounds__(kWsThreads, ITEMS == 8 ? 4 : 2) void ws_downsweep(c
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
-            const uint32_t p = k * kWsThreads + t;
+            const uint32_t p = k * THREADS + t;
             if (p < chunk_count) {
                 const uint32_t kk = s_keys[p];
                 const uint32_t dst = p + s_gd[(kk >> shift) & dmask];
@@ -1569,7 +1609,7 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
                 const uint32_t slot = atomicAdd(&heavy[0], 1u);
                 if (slot < heavy_slots) { heavy[1u + slot] = chunk; flag = 1; }
             }
-            heavy_flag[chunk] = flag;
+            if (heavy_slots != 0u) heavy_flag[chunk] = flag;
         }
         __syncthreads();
     }
@@ -1579,8 +1619,10 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
 // order, weight = number of tile rows; wave w takes a contiguous quarter of the chunk's items, so
 // (wave, round, lane) order == item order.  Ranking inside a wave: ballot-match on the column byte,
 // weighted prefix from 9 ballots over the bits of the weight (rows <= 256).
+// (5 waves per SIMD = 5 workgroups per CU, as in r2: the r3 additions had pushed the kernel to 106 VGPRs = 4, which cost
+//  the frames-in-flight mode throughput)
 template <bool ATOMIC_RANK, int BIN_CHUNK>
-__global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __restrict__ rect,
+__global__ __launch_bounds__(kThreads, (ATOMIC_RANK && BIN_CHUNK == kBinChunk) ? 5 : 2) void bin1_downsweep(const uint32_t* __restrict__ rect,
                                                            const uint32_t* __restrict__ d_V,
                                                            const uint32_t* __restrict__ hist, uint32_t hist_stride,
                                                            const uint32_t* __restrict__ totals,
@@ -1658,7 +1700,7 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
         const uint32_t chunk = (!helper && xcd_map && (nmain >= nchunks || (nmain & 7u) == 0u)) ? xcd_contiguous(cidx, nchunks) : cidx;
         // this workgroup's columns of the chunk: all of them, or one block of a heavy chunk
         uint32_t c_lo = 0u, c_hi = 255u;
-        if (helper || heavy_flag[chunk]) {
+        if (helper || (nhelp != 0u && heavy_flag[chunk])) {       // (no helpers launched: no chunk is split, no flag to read)
             c_lo = hpart * cpp;
             c_hi = c_lo + cpp - 1u;
         }
@@ -1770,26 +1812,12 @@ __global__ __launch_bounds__(kThreads) void bin1_downsweep(const uint32_t* __res
                 __builtin_amdgcn_wave_barrier();
                 pos = prev + pre;
             }
-            // emit: item j writes `rows` consecutive words.  Light items (at most 8 rows: all of them in a cloud of small
-            // splats) are written by their own lane; an item with more rows -- a splat a quarter of the screen high would
-            // keep its lane busy for dozens of iterations while the other 63 idle (scene-like clouds, r3: this kernel was
-            // 330 us of a 765 us frame) -- is written by the whole wave, one store instruction per 64 rows.
-            // Only where tall items are RARE in the batch: a batch full of them (the first ranks of a scene: background)
-            // is better served by every lane writing its own rows.
-            const uint32_t nrows = valid ? rows : 0u;
-            const uint32_t wbase = (ty0 << 24) | rank;
-            unsigned long long hv = __ballot(nrows > 8u);
-            if (__popcll(hv) > 6) hv = 0ull;
-            if (nrows <= 8u || hv == 0ull)
-                for (uint32_t q = 0; q < nrows; ++q)
-                    if (pos + q < cap) pairs_out[pos + q] = wbase + (q << 24);
-            while (hv != 0ull) {                                     // wave-uniform
-                const int j = __ffsll((long long)hv) - 1;
-                hv &= hv - 1ull;
-                const uint32_t r = __shfl(nrows, j, 64), p = __shfl(pos, j, 64), wb = __shfl(wbase, j, 64);
-                for (uint32_t q = lane; q < r; q += 64u)
-                    if (p + q < cap) pairs_out[p + q] = wb + (q << 24);
-            }
+            // emit: item j writes `rows` consecutive words.  (r3: one wave-wide store loop per tall item, and a cooperative
+            // expansion of the batch's words by binary search, were both measured on the scene-like cloud and dropped -- 674 /
+            // 392 us; what fixed that workload is splitting the heavy CHUNKS over workgroups, above.)
+            if (valid)
+                for (uint32_t q = 0; q < rows; ++q)
+                    if (pos + q < cap) pairs_out[pos + q] = ((ty0 + q) << 24) | rank;
         }
         __syncthreads();
         if (helper) break;           // a helper serves one (chunk, column block)

@@ -83,7 +83,7 @@ public:
         if (framesInFlight > 1) {
             c.stream = nullptr;
             c.compositor_waves = 1024;       // frames share the CUs (measured)
-            c.sort_mode = MSPLAT_SORT_LSD8;  // 4-wave sort workgroups co-schedule better with other frames' kernels (+2 %)
+            c.frame_mode = MSPLAT_FRAMES_IN_FLIGHT;   // kernels that co-schedule well with other frames' kernels (+2-3 %)
         }
         for (int k = 0; k < framesInFlight; ++k) {
             msplat_ctx* h = nullptr;

@@ -19,7 +19,7 @@ def _m(a, n):
 
 class SplatRenderer:
     def __init__(self, device=0, fb_format="fp32", t_epsilon=-1.0, pair_capacity=0, stream=None,
-                 enable_timing=False, frames_in_flight=1, rank_mode=_capi.RANK_AUTO, sort_mode=None):
+                 enable_timing=False, frames_in_flight=1, rank_mode=_capi.RANK_AUTO, frame_mode=None):
         """frames_in_flight > 1: every Sort moves on to the next of that many contexts (own stream and
         per-frame buffers, ONE shared cloud -- msplat_attach_cloud), so successive frames overlap on the
         GPU; Render and the getters use the context of the latest Sort.  `stream` is only used with depth 1;
@@ -37,9 +37,9 @@ class SplatRenderer:
         self._stream = stream
         self._timing = enable_timing
         self._rank_mode = int(rank_mode)       # msplat_config.rank_mode (RANK_AUTO / RANK_BALLOT)
-        # msplat_config.sort_mode: the three wide passes for one frame at a time, the four 8-bit passes (smaller workgroups)
-        # for contexts that share the GPU with other frames in flight (msplat.h, MSPLAT_SORT_*)
-        self._sort_mode = int(sort_mode) if sort_mode is not None else (_capi.SORT_LSD8 if self._depth > 1 else _capi.SORT_AUTO)
+        # msplat_config.frame_mode: kernels for one frame at a time, or for contexts that share the GPU with other frames in
+        # flight (msplat.h, MSPLAT_FRAMES_*)
+        self._frame_mode = int(frame_mode) if frame_mode is not None else (_capi.FRAMES_IN_FLIGHT if self._depth > 1 else _capi.FRAMES_AUTO)
         self._n = 0
 
     def __del__(self):
@@ -85,7 +85,7 @@ class SplatRenderer:
         cfg.enable_timing = int(self._timing)
         cfg.compositor_waves = 0 if self._depth == 1 else 1024     # measured: bench sweep, DESIGN.md 5
         cfg.rank_mode = self._rank_mode
-        cfg.sort_mode = self._sort_mode
+        cfg.frame_mode = self._frame_mode
         for k in range(self._depth):
             if isinstance(self._stream, (list, tuple)):       # one caller-owned stream per frame in flight
                 cfg.stream = self._stream[k]

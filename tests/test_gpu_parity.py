@@ -1178,7 +1178,9 @@ def test_gpu_ingest_test_ply_and_errors(golden_dir, tmp_path):
                                     (1.0e6, 7.0, 30000),      # tiny q (B < 26): the minimum widths 10 + 8 + 8
                                     (1000.0, 7.0, 5000),      # the reference's far plane
                                     (64.0, 30.0, 200000)])    # many chunks, B = 31
-def test_sort_exact_for_every_key_range(zf, z, n):
+@pytest.mark.parametrize("ws_threads", ["512", "256"])       # one frame at a time / the form for frames in flight
+def test_sort_exact_for_every_key_range(zf, z, n, ws_threads, monkeypatch):
+    monkeypatch.setenv("MSPLAT_WS_THREADS", ws_threads)
     cloud = scenes.synth_cloud(n, 1234 + int(zf))
     cam, proj, vp, _ = scenes.default_view(640, 480, z=z, yaw=0.4)
     nf = [0.1, zf]
@@ -1200,14 +1202,35 @@ def test_wide_sort_and_legacy_sort_and_tile_tables_agree(monkeypatch):
     cloud = scenes.synth_cloud(150000, 77, log_scale_mean=-3.6)
     cam, proj, vp, nf = scenes.default_view(800, 450, yaw=-0.3)
     res = []
-    for env in ({}, {"MSPLAT_SORT": "lsd8"}, {"MSPLAT_TILE_TABLE": "search"}, {"MSPLAT_WS_ITEMS": "16"}):
-        for k in ("MSPLAT_SORT", "MSPLAT_TILE_TABLE", "MSPLAT_WS_ITEMS"):
+    for env in ({}, {"MSPLAT_SORT": "lsd8"}, {"MSPLAT_TILE_TABLE": "search"}, {"MSPLAT_WS_ITEMS": "16"}, {"MSPLAT_WS_THREADS": "256"},
+                {"MSPLAT_WS_THREADS": "256", "MSPLAT_WS_ITEMS": "16"}):
+        for k in ("MSPLAT_SORT", "MSPLAT_TILE_TABLE", "MSPLAT_WS_ITEMS", "MSPLAT_WS_THREADS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         r = make_renderer(cloud)
         r.Sort(cam, proj, vp, nf)
         img = r.Render(cam, proj, vp, nf)
+        ts, pairs = r.debug_tile_lists()
+        res.append((r.sorted_keys(), r.sorted_indices(), ts, pairs, img))
+        assert r.verify_order() == (0, 0)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_frame_modes_give_identical_frames():
+    """msplat_config.frame_mode only chooses kernels (msplat.h): a context configured for frames in flight returns the keys,
+    permutation, bin lists and pixels of one configured for a single frame at a time"""
+    from splatapult_amd import _capi
+    cloud = scenes.synth_cloud(120000, 91, log_scale_mean=-3.5)
+    cam, proj, vp, nf = scenes.default_view(800, 450, yaw=0.5)
+    res = []
+    for mode in (_capi.FRAMES_AUTO, _capi.FRAMES_SERIAL, _capi.FRAMES_IN_FLIGHT, 77):       # 77: stale padding = AUTO
+        r = make_renderer(cloud, frame_mode=mode)
+        for _ in range(2):
+            r.Sort(cam, proj, vp, nf)
+            img = r.Render(cam, proj, vp, nf)
         ts, pairs = r.debug_tile_lists()
         res.append((r.sorted_keys(), r.sorted_indices(), ts, pairs, img))
         assert r.verify_order() == (0, 0)

@@ -90,8 +90,10 @@ struct msplat_ctx {
     // per-bin pair counts taken by the row pass's upsweep (r3): list offsets + work order without tile_start_kernel
     Buf bincnt;
     bool bin_counts = true;     // MSPLAT_TILE_TABLE=search: tile_start_kernel / tile_order_kernel as in r2
-    int xcd_map = 1;            // MSPLAT_XCD_MAP bit 0: sort downsweeps (default on: 6 M splats 196 -> 185 us, no change at 1 M), bit 1: the
-                                // column pass's downsweep (off: 6 M / 4096^2 453 -> 509 us) take XCD-contiguous chunk ranges
+    int xcd_map = 5;            // MSPLAT_XCD_MAP: which scatter kernels take XCD-contiguous chunk ranges.  bit 0: the sort's downsweeps
+                                // (on: 6 M splats 196 -> 185 us, no change at 1 M); bit 1: the column pass's downsweep (off: 6 M / 4096^2
+                                // binning 453 -> 509 us); bit 2: the row pass's downsweep (on: 6 M / 4096^2 binning 347 -> 327 us, 1080p
+                                // 141 -> 136, 1 M 59 -> 57: a column's chunks write adjacent runs of every row)
     Buf heavy, heavy_flag;      // column pass: chunks with far more pairs than the others are split over several workgroups
     uint32_t render_parity = 0;
     bool heavy_split = true;    // MSPLAT_HEAVY_SPLIT=0: no helper workgroups (A/B)
@@ -1307,14 +1309,14 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                            (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
                            (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1,
                            fused2 ? (const uint32_t*)gB2 : nullptr, fused2 ? totals2 : nullptr, fp, bincnt,
-                           (uint32_t*)ctx->tile_start.p, (uint32_t*)ctx->tile_order.p, d_queue, ntiles, ordered ? 1 : 0, ctx->gsupB2);
+                           (uint32_t*)ctx->tile_start.p, (uint32_t*)ctx->tile_order.p, d_queue, ntiles, (ordered ? 1 : 0) | ((ctx->xcd_map & 4) ? 2 : 0), ctx->gsupB2);
     else
         hipLaunchKernelGGL((radix_downsweep<MODE_PAIR, false, false>), dim3(g2d), dim3(kThreads), 0, s,
                            (const uint32_t*)ctx->pairsA.p, nullptr, nullptr, d_D, 0u, cap, 24,
                            (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
                            (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1,
                            fused2 ? (const uint32_t*)gB2 : nullptr, fused2 ? totals2 : nullptr, fp, bincnt,
-                           (uint32_t*)ctx->tile_start.p, (uint32_t*)ctx->tile_order.p, d_queue, ntiles, ordered ? 1 : 0, ctx->gsupB2);
+                           (uint32_t*)ctx->tile_start.p, (uint32_t*)ctx->tile_order.p, d_queue, ntiles, (ordered ? 1 : 0) | ((ctx->xcd_map & 4) ? 2 : 0), ctx->gsupB2);
     if (!bincnt) {
         hipLaunchKernelGGL(tile_start_kernel, dim3(std::max(1, (ntiles + kTileStartBins - 1) / kTileStartBins)), dim3(kThreads), 0, s,
                            (const uint32_t*)ctx->pairsB.p, (const uint32_t*)totals2, d_D, cap, fp.tiles_x, ntiles,

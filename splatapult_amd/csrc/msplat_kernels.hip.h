@@ -619,7 +619,7 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE != MODE_PAIR && SORT
     uint32_t nworkers = gridDim.x, wb = blockIdx.x;      // worker count / this workgroup's worker index
     if (MODE == MODE_PAIR && bincnt != nullptr) {
         if (blockIdx.x == 0u) {                  // workgroup-uniform; dispatched first
-            tile_table_role(bincnt, ntiles, fp.tiles_x, tile_start, tile_order, queue, do_order, s_cnt[0], s_base, s_tmp);
+            tile_table_role(bincnt, ntiles, fp.tiles_x, tile_start, tile_order, queue, do_order & 1, s_cnt[0], s_base, s_tmp);
             return;
         }
         nworkers = gridDim.x - 1u;
@@ -649,7 +649,10 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE != MODE_PAIR && SORT
     }
     __syncthreads();
 
-    for (uint32_t chunk = wb; chunk < nchunks; chunk += nworkers) {
+    // do_order bit 1 (MODE_PAIR): XCD-contiguous chunk ranges, see ws_downsweep -- a column's chunks write adjacent runs
+    const bool xmap = MODE == MODE_PAIR && (do_order & 2) && (nworkers >= nchunks || (nworkers & 7u) == 0u);
+    for (uint32_t cidx = wb; cidx < nchunks; cidx += nworkers) {
+        const uint32_t chunk = xmap ? xcd_contiguous(cidx, nchunks) : cidx;
         // this chunk's exclusive prefix per digit (thread = digit): issued first, consumed after the local ranking
         const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk, reinterpret_cast<uint4*>(s_keys), gsup)
                                                      : hist[(size_t)chunk * 256 + threadIdx.x];
@@ -1815,9 +1818,30 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && BIN_CHUNK == kBinChunk) ?
             // emit: item j writes `rows` consecutive words.  (r3: one wave-wide store loop per tall item, and a cooperative
             // expansion of the batch's words by binary search, were both measured on the scene-like cloud and dropped -- 674 /
             // 392 us; what fixed that workload is splitting the heavy CHUNKS over workgroups, above.)
-            if (valid)
-                for (uint32_t q = 0; q < rows; ++q)
-                    if (pos + q < cap) pairs_out[pos + q] = ((ty0 + q) << 24) | rank;
+            // The pass is bound by the NUMBER of store requests (every lane of a store instruction hits its own line): an
+            // item's words are consecutive, so they go out as 8- and 16-byte stores once pos is aligned.
+            if (valid) {
+                const uint32_t w0 = (ty0 << 24) | rank;
+                if (pos + rows <= cap) {
+                    uint32_t q = 0;
+                    if ((pos & 1u) && rows != 0u) { pairs_out[pos] = w0; q = 1u; }
+                    if (((pos + q) & 2u) && q + 2u <= rows) {
+                        *reinterpret_cast<uint2*>(pairs_out + pos + q) = make_uint2(w0 + (q << 24), w0 + ((q + 1u) << 24));
+                        q += 2u;
+                    }
+                    for (; q + 4u <= rows; q += 4u)
+                        *reinterpret_cast<uint4*>(pairs_out + pos + q) =
+                            make_uint4(w0 + (q << 24), w0 + ((q + 1u) << 24), w0 + ((q + 2u) << 24), w0 + ((q + 3u) << 24));
+                    if (q + 2u <= rows) {
+                        *reinterpret_cast<uint2*>(pairs_out + pos + q) = make_uint2(w0 + (q << 24), w0 + ((q + 1u) << 24));
+                        q += 2u;
+                    }
+                    if (q < rows) pairs_out[pos + q] = w0 + (q << 24);
+                } else {
+                    for (uint32_t q = 0; q < rows; ++q)
+                        if (pos + q < cap) pairs_out[pos + q] = w0 + (q << 24);
+                }
+            }
         }
         __syncthreads();
         if (helper) break;           // a helper serves one (chunk, column block)

@@ -158,14 +158,16 @@ def measure(E, args, key, ply=None, primary=True):
     else:   # BASELINE config 5: asymmetric XR frusta (util.cpp:420-480)
         projs = [camera.create_projection(-1.0, 0.8, 0.95, -0.95), camera.create_projection(-0.8, 1.0, 0.95, -0.95)]
 
+    pose_cache = {}      # the orbit has 64 poses: built once (a pose costs the host 8 us, a frame's launches ~40)
+
     def cams_for(step):
-        if scene_cams:
-            c = scene_cams[step % len(scene_cams)]
-        else:
-            c = camera.orbit(wl["cam_z"], 2.0 * math.pi * (step % 64) / 64.0)
-        if views == 1:
-            return [c]
-        return [camera.translate_local(c, dx=-0.032), camera.translate_local(c, dx=+0.032)]
+        k = step % (len(scene_cams) if scene_cams else 64)
+        cs = pose_cache.get(k)
+        if cs is None:
+            c = scene_cams[k] if scene_cams else camera.orbit(wl["cam_z"], 2.0 * math.pi * k / 64.0)
+            cs = [c] if views == 1 else [camera.translate_local(c, dx=-0.032), camera.translate_local(c, dx=+0.032)]
+            pose_cache[k] = cs
+        return cs
 
     # the only exchange step: every rank's bin rows go straight into rank 0's framebuffer (splatapult_amd/dist.py)
     gathers = None

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from .renderer import SplatRenderer, _m
+from .renderer import SplatRenderer
 
 
 class PointCloud:

@@ -11,10 +11,35 @@ from . import _capi
 from .scene import GaussianCloud
 
 
-def _m(a, n):
-    a = np.ascontiguousarray(np.asarray(a, np.float32).reshape(-1))
-    assert a.shape[0] == n, "expected %d floats" % n
-    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+class _FrameArgs:
+    """cameraMat, projMat, viewport, nearFar of one Sort / Render call, marshalled into ONE preallocated float buffer whose
+    four pointers are made once: building four ctypes pointers per call cost 20 us, a third of the time it takes the host
+    to issue a frame's launches (r3, bench.py's host_enqueue_ms_per_frame).  The library copies what it needs
+    during the call, so the buffer is free again when the call returns."""
+    __slots__ = ("buf", "cam", "proj", "vp", "nf", "p_cam", "p_proj", "p_vp", "p_nf")
+
+    def __init__(self):
+        self.buf = np.zeros(38, np.float32)
+        self.cam, self.proj, self.vp, self.nf = self.buf[0:16], self.buf[16:32], self.buf[32:36], self.buf[36:38]
+        base = self.buf.ctypes.data
+        fp = C.POINTER(C.c_float)
+        self.p_cam, self.p_proj = C.cast(base, fp), C.cast(base + 64, fp)
+        self.p_vp, self.p_nf = C.cast(base + 128, fp), C.cast(base + 144, fp)
+
+    @staticmethod
+    def _flat(a, n):
+        a = np.asarray(a, np.float32).reshape(-1)
+        if a.shape[0] != n:
+            raise AssertionError("expected %d floats" % n)
+        return a
+
+    def load(self, cameraMat, projMat, viewport, nearFar):
+        f = self._flat
+        self.cam[:] = f(cameraMat, 16)
+        self.proj[:] = f(projMat, 16)
+        self.vp[:] = f(viewport, 4)
+        self.nf[:] = f(nearFar, 2)
+        return self.p_cam, self.p_proj, self.p_vp, self.p_nf
 
 
 class SplatRenderer:
@@ -30,6 +55,7 @@ class SplatRenderer:
         self._ctxs = []
         self._cur = 0
         self._depth = max(1, int(frames_in_flight))
+        self._args = _FrameArgs()
         self._device = device
         self._fb_format = {"fp32": _capi.FB_RGBA32F, "fp16": _capi.FB_RGBA16F}[fb_format]
         self._t_eps = t_epsilon
@@ -134,7 +160,7 @@ class SplatRenderer:
 
     def Sort(self, cameraMat, projMat, viewport, nearFar):
         """splatrenderer.cpp:153-312"""
-        _, c = _m(cameraMat, 16); _, p = _m(projMat, 16); _, v = _m(viewport, 4); _, nf = _m(nearFar, 2)
+        c, p, v, nf = self._args.load(cameraMat, projMat, viewport, nearFar)
         self._cur = (self._cur + 1) % len(self._ctxs)
         self._ctx = self._ctxs[self._cur]
         _capi.check(self._ctx, self._lib.msplat_sort(self._ctx, c, p, v, nf))
@@ -144,7 +170,8 @@ class SplatRenderer:
         out=None      -> returns a new (H, W, 4) numpy array (float32 or float16), row 0 = GL bottom row
         out=ndarray   -> filled in place
         out_ptr=int   -> device pointer (e.g. torch tensor .data_ptr()); asynchronous on the stream"""
-        _, c = _m(cameraMat, 16); _, p = _m(projMat, 16); vp, v = _m(viewport, 4); _, nf = _m(nearFar, 2)
+        c, p, v, nf = self._args.load(cameraMat, projMat, viewport, nearFar)
+        vp = self._args.vp
         if out_ptr is not None:
             _capi.check(self._ctx, self._lib.msplat_render(self._ctx, c, p, v, nf, C.c_void_p(out_ptr),
                                                            pitch_bytes, 1))
@@ -310,6 +337,7 @@ class SplatRendererGroup:
                  enable_timing=False):
         self._lib = _capi.lib()
         self._g = None
+        self._args = _FrameArgs()
         self._devices = [int(d) for d in devices]
         self._fb_format = {"fp32": _capi.FB_RGBA32F, "fp16": _capi.FB_RGBA16F}[fb_format]
         self._t_eps = t_epsilon
@@ -385,13 +413,14 @@ class SplatRendererGroup:
         return v.value
 
     def Sort(self, cameraMat, projMat, viewport, nearFar):
-        _, c = _m(cameraMat, 16); _, p = _m(projMat, 16); _, v = _m(viewport, 4); _, nf = _m(nearFar, 2)
+        c, p, v, nf = self._args.load(cameraMat, projMat, viewport, nearFar)
         self._check(self._lib.msplat_group_sort(self._g, c, p, v, nf))
 
     def Render(self, cameraMat, projMat, viewport, nearFar, out=None, out_ptr=None, pitch_bytes=0):
         """out_ptr: device pointer ON devices[0] (asynchronous; synchronize() or wait on context 0's stream);
         otherwise a host array is filled / returned"""
-        _, c = _m(cameraMat, 16); _, p = _m(projMat, 16); vp, v = _m(viewport, 4); _, nf = _m(nearFar, 2)
+        c, p, v, nf = self._args.load(cameraMat, projMat, viewport, nearFar)
+        vp = self._args.vp
         if out_ptr is not None:
             self._check(self._lib.msplat_group_render(self._g, c, p, v, nf, C.c_void_p(out_ptr), pitch_bytes, 1))
             return None

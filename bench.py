@@ -7,13 +7,14 @@
 
 One "step" = one frame = SplatRenderer::Sort + SplatRenderer::Render of the resident cloud from a
 camera on a 64-step orbit (stereo workloads: one Sort + two Renders).  With N > 1 the frame's bin
-rows are sharded across the ranks (interleaved, row % N == rank) and gathered to rank 0 over RCCL:
-total work is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
+rows are sharded across the ranks (--layout: contiguous | interleaved | block:k | auto = blocks of
+rows / (2 N), the best of profiles/r03_cfg4_bands.json) and gathered to rank 0 over RCCL: total work
+is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
 
 What is measured:
   value / ms_per_step ... EXACTLY `--steps` frames between barrier + synchronize on both sides, `--frames-in-flight`
                           frames overlapped on the GPU (default 4).  The block is repeated until >= 0.25 s of frames
-                          have been timed and the MEDIAN block is reported (a 20-frame block lasts 4 ms).
+                          have been timed and the MEDIAN block is reported (a 20-frame block lasts 3.5 ms).
   serial ................ the same frames strictly one after the other on ONE stream (a second renderer, 8192 compositor
                           waves): single-frame latency, and every kernel has the GPU to itself, so its launch duration
                           is a clean per-kernel number.  `roofline` is computed from THIS phase; the rocprofv3 summary
@@ -24,8 +25,11 @@ What is measured:
                           8 TB/s; beside it the SURVEY 8d formula bytes (52 D + W H bpp), the PMC traffic, and the
                           VALU view -- (pixel, splat) evaluations/s and their share of the 157.3 TFLOP/s fp32 vector
                           peak at SURVEY's 20 flop per evaluation -- because VALU, not HBM, bounds this kernel.
-  cpu_baseline .......... the oracle (C restatement of the reference shaders, OpenMP row bands) on the host cores, on a
-                          bounded sample of the same workload; rank 0, N = 1 only.
+  cpu_baseline .......... the tiled CPU renderer of SURVEY 8d(ii) (oracle/msplat_cpu_tiled.c, kind "port-tiled": parallel
+                          radix sort, tile binning, front-to-back with early termination; thread count from the cgroup
+                          CPU quota) on a bounded sample of the same workload; rank 0, N = 1 only.
+  cpu_baseline_literal .. the literal oracle (C restatement of the reference shaders, every OpenMP row band walks all
+                          visible splats back to front), one frame.
 
 PyTorch is plumbing only (device selection, the framebuffer tensor, torch.distributed); all compute
 is libmsplat.so's HIP kernels.

@@ -82,7 +82,7 @@ public:
         msplat_config c = cfg;
         if (framesInFlight > 1) {
             c.stream = nullptr;
-            c.compositor_waves = 1024;       // frames share the CUs (measured)
+            c.compositor_waves = 1280;       // frames share the CUs (measured r3: 768 .. 2048)
             c.frame_mode = MSPLAT_FRAMES_IN_FLIGHT;   // kernels that co-schedule well with other frames' kernels (+2-3 %)
         }
         for (int k = 0; k < framesInFlight; ++k) {

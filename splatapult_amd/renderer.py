@@ -109,7 +109,7 @@ class SplatRenderer:
         cfg.t_epsilon = self._t_eps
         cfg.pair_capacity = self._pair_cap
         cfg.enable_timing = int(self._timing)
-        cfg.compositor_waves = 0 if self._depth == 1 else 1024     # measured: bench sweep, DESIGN.md 5
+        cfg.compositor_waves = 0 if self._depth == 1 else 1280     # measured r3: pool sweep 768 .. 2048, DESIGN.md 5
         cfg.rank_mode = self._rank_mode
         cfg.frame_mode = self._frame_mode
         for k in range(self._depth):

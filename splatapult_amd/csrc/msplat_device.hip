@@ -90,12 +90,6 @@ struct msplat_ctx {
     // per-bin pair counts taken by the row pass's upsweep (r3): list offsets + work order without tile_start_kernel
     Buf bincnt;
     bool bin_counts = true;     // MSPLAT_TILE_TABLE=search: tile_start_kernel / tile_order_kernel as in r2
-    // one-partition binning (bw_*, frames with at most 2048 bins): per-chunk histogram rows, group rows per frame parity
-    Buf bwHist, bwGsum[2];
-    bool bw_cfg = true;         // MSPLAT_BINNING=twopass: never; =onepass: also beyond the size rule
-    bool bw_forced = false;
-    bool bw_ok = false;         // the uploaded cloud has the tables (alloc_cloud_buffers)
-    uint32_t bw_gshift = 4, bw_gsum_words = 0, bw_parity = 0;
     int xcd_map = 5;            // MSPLAT_XCD_MAP: which scatter kernels take XCD-contiguous chunk ranges.  bit 0: the sort's downsweeps
                                 // (on: 6 M splats 196 -> 185 us, no change at 1 M); bit 1: the column pass's downsweep (off: 6 M / 4096^2
                                 // binning 453 -> 509 us); bit 2: the row pass's downsweep (on: 6 M / 4096^2 binning 347 -> 327 us, 1080p
@@ -345,15 +339,6 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         if (const char* wt = getenv("MSPLAT_WS_THREADS")) ctx->ws_threads = atoi(wt) == kWsThreadsSmall ? (uint32_t)kWsThreadsSmall : (uint32_t)kWsThreads;
         if (!ctx->atomic_rank) ctx->wide_sort = false;       // the wide kernels rank with lane-ordered LDS atomics only
         if (const char* tk = getenv("MSPLAT_TILE_TABLE")) ctx->bin_counts = std::string(tk) != "search";
-        ctx->bw_cfg = ctx->atomic_rank && c.frame_mode != MSPLAT_FRAMES_IN_FLIGHT;
-        if (const char* bk = getenv("MSPLAT_BINNING")) {
-            ctx->bw_cfg = ctx->atomic_rank && std::string(bk) != "twopass";
-            ctx->bw_forced = std::string(bk) == "onepass";
-        }
-        if (ctx->bw_cfg) {
-            static const bool bw_lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&bw_downsweep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwDownLds) == hipSuccess;
-            if (!bw_lds_ok) { (void)hipGetLastError(); ctx->bw_cfg = false; }
-        }
         if (getenv("MSPLAT_XCD_MAP")) ctx->xcd_map = atoi(getenv("MSPLAT_XCD_MAP"));
         if (getenv("MSPLAT_HEAVY_SPLIT")) ctx->heavy_split = atoi(getenv("MSPLAT_HEAVY_SPLIT")) != 0;
         if (ctx->wide_sort) {
@@ -651,19 +636,6 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
         }
         ctx->ws_gsum_words = (uint32_t)gwords;
         if ((rc = buf_alloc(ctx, ctx->vmask, (size_t)div_up(alloc_n, 64) * 8 + 64))) return rc;
-    }
-    // one-partition binning: 4096-rank chunks, rows of 2048 bins; up to 2 M splats (beyond, a prefix sums too many 8 KB rows)
-    ctx->bw_ok = ctx->bw_cfg && (n <= (2u << 20) || ctx->bw_forced);
-    if (ctx->bw_ok) {
-        const uint32_t nch = std::max(1u, div_up(n, (uint64_t)kBwChunk));
-        ctx->bw_gshift = nch <= 512u ? 4u : 5u;
-        if ((rc = buf_alloc(ctx, ctx->bwHist, (size_t)nch * kBwBins * 4))) return rc;
-        const size_t gwords = (size_t)((nch >> ctx->bw_gshift) + 2) * kBwBins;
-        for (auto& g : ctx->bwGsum) {
-            if ((rc = buf_alloc(ctx, g, gwords * 4))) return rc;
-            HIP_TRY(ctx, hipMemsetAsync(g.p, 0, g.bytes, ctx->stream));
-        }
-        ctx->bw_gsum_words = (uint32_t)gwords;
     }
     if ((rc = buf_alloc(ctx, ctx->rec2d, alloc_n * 48))) return rc;
     if ((rc = buf_alloc(ctx, ctx->rect, alloc_n * 4))) return rc;
@@ -1080,7 +1052,7 @@ static int clear_frame_tables(msplat_ctx* ctx)
 {
     hipStream_t s = ctx->stream;
     Buf* zero[] = {&ctx->gsumS[0], &ctx->gsumS[1], &ctx->gsumB1, &ctx->gsumB2, &ctx->wsGsum[0], &ctx->wsGsum[1], &ctx->wsGsum[2],
-                   &ctx->bincnt, &ctx->bwGsum[0], &ctx->bwGsum[1]};
+                   &ctx->bincnt};
     for (Buf* b : zero)
         if (b->p) HIP_TRY(ctx, hipMemsetAsync(b->p, 0, b->bytes, s));
     HIP_TRY(ctx, hipMemsetAsync((uint32_t*)ctx->counters.p + 10, 0xFF, 2 * sizeof(uint32_t), s));
@@ -1261,11 +1233,6 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                            ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][3], s));
 
-    // (what the binning must leave behind for the compositor: see the comment at pass 2)
-    const bool wave_comp = !ctx->point_mode && ctx->depth_bits == 0 && ctx->rop == 0 && ctx->comp_kind != 2;
-    const uint32_t comp_items = (uint32_t)ntiles * (ctx->comp_kind == 1 ? 8u : 4u);
-    const uint32_t comp_pool = (ctx->comp_waves_auto && comp_items <= 20480u) ? comp_items : (uint32_t)ctx->comp_waves;
-    const bool ordered = !(wave_comp && comp_pool < comp_items) || ctx->comp_always_order;
     // pass 1: stable partition by tile column, enumerated from the rank-ordered rectangles
     uint32_t* totals1 = (uint32_t*)ctx->totals1.p;
     uint32_t* totals2 = (uint32_t*)ctx->totals.p;
@@ -1289,24 +1256,6 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const uint32_t last_D = ctx->h_flags ? __atomic_load_n(ctx->h_flags + 2, __ATOMIC_RELAXED) : 0u;
     const bool fused2 = ctx->scan_free && last_D != 0u && div_up((uint64_t)last_D + (last_D >> 2), kPairChunk) <= ctx->fused_max_chunks &&
                         div_up(cap, kPairChunk) <= ctx->hist2_stride;                  // (the tables hold every chunk the capacity allows)
-    // r3: frames with at most 2048 bins are binned by ONE stable partition by bin number (bw_upsweep / bw_downsweep: two
-    // launches instead of four, no intermediate pair array).  Not while an earlier frame reported heavy chunks: the two-pass
-    // path can split those over workgroups.
-    const bool onepass = ctx->bw_ok && ntiles <= kBwBins && (last_heavy == 0u || ctx->bw_forced);
-    if (onepass) {
-        uint32_t* bg_cur = (uint32_t*)ctx->bwGsum[ctx->bw_parity & 1u].p;
-        uint32_t* bg_next = (uint32_t*)ctx->bwGsum[(ctx->bw_parity ^ 1u) & 1u].p;
-        ctx->bw_parity ^= 1u;
-        const int gw = grid_for(div_up(N, (uint64_t)kBwChunk));
-        hipLaunchKernelGGL(bw_upsweep, dim3(gw), dim3(kBwThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V, N, (uint32_t)fp.tiles_x,
-                           (uint32_t*)ctx->bwHist.p, bg_cur, (int)ctx->bw_gshift, bg_next, ctx->bw_gsum_words, d_overflow, hv_cur,
-                           hv_next);
-        hipLaunchKernelGGL(bw_downsweep, dim3(gw + 1), dim3(kBwThreads), kBwDownLds, s, (const uint32_t*)ctx->rect.p, d_V, N,
-                           (uint32_t)fp.tiles_x, ntiles, (const uint32_t*)ctx->bwHist.p, (const uint32_t*)bg_cur, (int)ctx->bw_gshift,
-                           (uint32_t*)ctx->pairsB.p, cap, d_D, d_overflow, ctx->d_flags, async_overflow_flag ? 1 : 0,
-                           (uint32_t*)ctx->tile_start.p, (uint32_t*)ctx->tile_order.p, d_queue, ordered ? 1 : 0,
-                           (const uint32_t*)hv_cur, (ctx->xcd_map & 4) ? 1 : 0);
-    } else {
     uint32_t* gB1 = (uint32_t*)ctx->gsumB1.p;
     uint32_t* gB2 = (uint32_t*)ctx->gsumB2.p;
     // (bin1_upsweep also clears the row pass's group table: its consumer, the previous frame's row downsweep, is long done)
@@ -1339,6 +1288,10 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     // The heaviest-first order of the bins only pays when every work item has its own wave (the hardware then starts the
     // waves in item order: 83 -> 97 us without it at config 2); persistent waves that pull items from the queue balance
     // themselves: they walk the bins in storage order (`tile_order` + 65536 holds 0, 1, 2, ...).
+    const bool wave_comp = !ctx->point_mode && ctx->depth_bits == 0 && ctx->rop == 0 && ctx->comp_kind != 2;
+    const uint32_t comp_items = (uint32_t)ntiles * (ctx->comp_kind == 1 ? 8u : 4u);
+    const uint32_t comp_pool = (ctx->comp_waves_auto && comp_items <= 20480u) ? comp_items : (uint32_t)ctx->comp_waves;
+    const bool ordered = !(wave_comp && comp_pool < comp_items) || ctx->comp_always_order;
     // r3: the upsweep of the row pass also counts the pairs per bin, and one extra workgroup of its downsweep turns the
     // counts into the list offsets (+ the heaviest-first order when it is wanted): tile_start_kernel / tile_order_kernel
     // are not launched (MSPLAT_TILE_TABLE=search brings them back for comparison)
@@ -1371,7 +1324,6 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         if (ordered)
             hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)ctx->tile_start.p, ntiles,
                                (uint32_t*)ctx->tile_order.p, d_queue);
-    }
     }
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][4], s));
 

@@ -1848,297 +1848,6 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && BIN_CHUNK == kBinChunk) ?
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// One-partition binning (r3): frames with at most kBwBins bins (1920x1080 has 60 x 34 = 2040).
-// The two stable partitions above (column, then row) are four launches; with so few bins the (splat, bin) pairs can be
-// partitioned by BIN NUMBER in one upsweep + downsweep, exactly like a pass of the three-pass sort (ws_*): per-chunk
-// histogram rows of kBwBins entries + group rows, the prefix of a chunk = a sum of rows, per-wave packed 16-bit counters,
-// stable rank = return value of one lane-ordered LDS atomic.  What differs from a sort pass: the items (pairs) are
-// enumerated on the fly from the rank-ordered rectangles, and their number per rank varies.
-//   * a chunk is kBwChunk = 4096 ranks (a row is 8 KB, so rows must be rare), a wave owns 512 consecutive ranks of it and
-//     walks them in batches of 64 (lane = rank);
-//   * counting (the upsweep, and the per-wave counts of the downsweep) needs no order: a lane adds its own bins when its
-//     rectangle has at most kBwSmall of them, larger rectangles are added by the whole wave, 64 bins per step;
-//   * ranking needs the pairs in (rank) order: per batch the pairs are expanded 64 at a time, lane j of a window takes pair
-//     base + j; its owner (the rank it belongs to) is found by announcing every rank's first pair in a 64-entry LDS
-//     table and a running maximum over the lanes.  A bin receives at most one pair per rank, so all pairs that go to one
-//     bin inside a window come from ascending ranks in ascending lanes, and the LDS atomic hands them their places in
-//     that order; windows, batches, waves and chunks follow each other in rank order by construction.
-// Output = the final pair array (word = (tx << 24) | rank, bins in row-major order) and the bins' list offsets, which are
-// the exclusive scan of the bin totals every workgroup computes anyway.  No pairsA, no column / row tables.
-// A chunk of 1024 ranks with more than kHeavyPairs pairs is reported exactly as bin1_upsweep reports it: the host then
-// goes back to the two-pass path, which can split such chunks (bw_downsweep would walk them with one wave).
-// ------------------------------------------------------------------------------------------
-constexpr int kBwThreads = 512;
-constexpr int kBwWaves = kBwThreads / 64;
-constexpr int kBwChunk = 4096;                       // ranks per chunk
-constexpr int kBwWaveRanks = kBwChunk / kBwWaves;    // 512: consecutive ranks owned by one wave
-constexpr int kBwBatches = kBwWaveRanks / 64;        // 8 batches of 64 ranks
-constexpr int kBwBins = 2048;                        // histogram row width = most bins a frame may have on this path
-constexpr uint32_t kBwSmall = 16;                    // rectangles with at most this many bins are counted by their own lane
-
-// quotient of small integers (k < w * 256, 1 <= w < 256) through the float reciprocal, corrected: exact
-__device__ __forceinline__ uint32_t bw_div(uint32_t k, uint32_t w)
-{
-    uint32_t q = (uint32_t)(((float)k + 0.5f) * __frcp_rn((float)w));
-    if (q * w > k) --q;
-    if ((q + 1u) * w <= k) ++q;
-    return q;
-}
-
-// counting: add(bin) once for every bin of the wave's 64 rectangles (rc per lane), in no particular order
-template <class F>
-__device__ __forceinline__ void bw_count_batch(uint32_t rc, uint32_t tiles_x, F&& add)
-{
-    const int lane = threadIdx.x & 63;
-    const uint32_t tx0 = rc & 255u, ty0 = (rc >> 8) & 255u, tx1 = (rc >> 16) & 255u, ty1 = rc >> 24;
-    const bool ok = tx0 <= tx1 && ty0 <= ty1;
-    const uint32_t w = ok ? tx1 - tx0 + 1u : 0u, n = ok ? w * (ty1 - ty0 + 1u) : 0u;
-    if (n != 0u && n <= kBwSmall) {
-        uint32_t x = 0u, b = ty0 * tiles_x + tx0;
-        for (uint32_t k = 0; k < n; ++k) {
-            add(b + x);
-            if (++x == w) { x = 0u; b += tiles_x; }
-        }
-    }
-    unsigned long long big = __ballot(n > kBwSmall);
-    while (big) {                                        // wave-uniform
-        const int l = __builtin_ctzll(big);
-        big &= big - 1ull;
-        const uint32_t rb = (uint32_t)__shfl((int)rc, l, 64);
-        const uint32_t bx0 = rb & 255u, by0 = (rb >> 8) & 255u, bw = ((rb >> 16) & 255u) - bx0 + 1u, bh = (rb >> 24) - by0 + 1u;
-        const uint32_t nb = bw * bh;
-        for (uint32_t p = (uint32_t)lane; p < nb; p += 64u) {
-            const uint32_t dy = bw_div(p, bw);
-            add((by0 + dy) * tiles_x + bx0 + (p - dy * bw));
-        }
-    }
-}
-
-__global__ __launch_bounds__(kBwThreads) void bw_upsweep(const uint32_t* __restrict__ rect, const uint32_t* __restrict__ d_V,
-                                                         uint32_t n_cap, uint32_t tiles_x,
-                                                         uint32_t* __restrict__ hist, uint32_t* __restrict__ gsum_acc, int gshift,
-                                                         uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_words,
-                                                         uint32_t* __restrict__ d_overflow,
-                                                         uint32_t* __restrict__ heavy, uint32_t* __restrict__ heavy_next)
-{
-    __shared__ uint32_t s_hist[kBwBins];
-    __shared__ uint32_t s_pairs[kBwWaves];
-    // per-frame resets (see bin1_upsweep); the other frame parity's group table is cleared for the next frame
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *d_overflow = 0u; heavy_next[0] = 0u; }
-    for (uint32_t i = blockIdx.x * kBwThreads + threadIdx.x; i < gsum_zero_words; i += gridDim.x * kBwThreads) gsum_zero[i] = 0u;
-    uint32_t V = *d_V;
-    if (V > n_cap) V = n_cap;
-    const uint32_t nchunks = (V + kBwChunk - 1) / kBwChunk;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        for (uint32_t d = threadIdx.x; d < (uint32_t)kBwBins; d += kBwThreads) s_hist[d] = 0u;
-        __syncthreads();
-        const uint32_t base = chunk * kBwChunk + (uint32_t)w * kBwWaveRanks;
-        uint32_t rcs[kBwBatches];
-#pragma unroll
-        for (int k = 0; k < kBwBatches; ++k) rcs[k] = rect[min(base + k * 64 + lane, V - 1u)];       // V >= 1 here
-        uint32_t mine = 0;                               // pairs of this lane's ranks
-#pragma unroll
-        for (int k = 0; k < kBwBatches; ++k) {
-            const uint32_t rc = (base + k * 64 + lane < V) ? rcs[k] : kRectEmpty;
-            const uint32_t tx0 = rc & 255u, ty0 = (rc >> 8) & 255u, tx1 = (rc >> 16) & 255u, ty1 = rc >> 24;
-            if (tx0 <= tx1 && ty0 <= ty1) mine += (tx1 - tx0 + 1u) * (ty1 - ty0 + 1u);
-            bw_count_batch(rc, tiles_x, [&](uint32_t bin) { atomicAdd(&s_hist[bin], 1u); });
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
-        if (lane == 0) s_pairs[w] = mine;
-        __syncthreads();
-        for (uint32_t d = threadIdx.x; d < (uint32_t)kBwBins; d += kBwThreads) {
-            const uint32_t c = s_hist[d];
-            hist[(size_t)chunk * kBwBins + d] = c;
-            if (c != 0u)
-                (void)__hip_atomic_fetch_add(&gsum_acc[(size_t)(chunk >> gshift) * kBwBins + d], c, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // the same criterion, on the same 1024-rank boundaries, as bin1_upsweep: two waves = one of its chunks
-        if (threadIdx.x < kBwWaves / 2 && s_pairs[2 * threadIdx.x] + s_pairs[2 * threadIdx.x + 1] > kHeavyPairs) atomicAdd(&heavy[0], 1u);
-        __syncthreads();
-    }
-}
-
-// dynamic LDS of bw_downsweep: packed per-wave counters, per-bin global positions, expansion tables, scan scratch
-constexpr size_t kBwDownLds = (size_t)kBwWaves * (kBwBins / 2) * 4 + (size_t)kBwBins * 4 + (size_t)kBwWaves * 64 * 4 + 64;
-
-__global__ __launch_bounds__(kBwThreads, 4) void bw_downsweep(
-    const uint32_t* __restrict__ rect, const uint32_t* __restrict__ d_V, uint32_t n_cap, uint32_t tiles_x, int ntiles,
-    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ gsum, int gshift, uint32_t* __restrict__ pairs_out,
-    uint32_t cap, uint32_t* __restrict__ d_D, uint32_t* __restrict__ d_overflow, uint32_t* __restrict__ host_words,
-    int report_overflow, uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_order, uint32_t* __restrict__ queue,
-    int do_order, const uint32_t* __restrict__ heavy, int xcd_map)
-{
-    // workgroup 0 is the table role (list offsets, D, overflow flag, host words, queue heads, heaviest-first order): it
-    // moves no pairs; workgroups 1 .. are the workers.
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-    uint32_t* s_cnt = s_dyn;                                   // kBwWaves x (kBwBins / 2) packed 16-bit counters, then bases
-    uint32_t* s_gd = s_cnt + kBwWaves * (kBwBins / 2);         // kBwBins: first global position of this chunk's run, per bin
-    uint32_t* s_mark = s_gd + kBwBins;                         // kBwWaves x 64: first-pair announcements of the expansion
-    uint32_t* s_tmp = s_mark + kBwWaves * 64;                  // kBwWaves words
-    uint4* s_part = reinterpret_cast<uint4*>(s_cnt);           // row-sum scratch (the counters are not live then)
-
-    uint32_t V = *d_V;
-    if (V > n_cap) V = n_cap;
-    const uint32_t nchunks = (V + kBwChunk - 1) / kBwChunk;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    constexpr uint32_t half = kBwBins / 2;
-
-    // bin totals = sum of all group rows; exclusive scan = the bins' list offsets (thread t owns bins 4 t .. 4 t + 3)
-    uint32_t gbase[4], len[4];
-    uint32_t D;
-    {
-        const uint32_t ng = (nchunks + (1u << gshift) - 1u) >> gshift;
-        uint4 tot[1];
-        ws_row_sum<kBwThreads>(gsum, ng, gsum, 0u, (uint32_t)kBwBins, 11, s_part, tot);
-        len[0] = tot[0].x; len[1] = tot[0].y; len[2] = tot[0].z; len[3] = tot[0].w;
-        const uint32_t tsum = len[0] + len[1] + len[2] + len[3];
-        const uint32_t e = ws_block_incl_scan<kBwWaves>(tsum, s_tmp, D) - tsum;
-        gbase[0] = e; gbase[1] = e + len[0]; gbase[2] = gbase[1] + len[1]; gbase[3] = gbase[2] + len[2];
-    }
-    if (blockIdx.x == 0u) {
-        // ---- table role ----
-        if (t < (int)kQueueShards) queue[t * kQueueStride] = 0u;
-        // tile_start has ceil((ntiles + 1) / 1024) * 1024 entries; entries from ntiles on = D (bins >= ntiles are empty)
-        *reinterpret_cast<uint4*>(tile_start + 4 * t) = make_uint4(gbase[0], gbase[1], gbase[2], gbase[3]);
-        const uint32_t pad = (((uint32_t)ntiles + 1u + 1023u) / 1024u) * 1024u;
-        for (uint32_t i = (uint32_t)kBwBins + t; i < pad; i += kBwThreads) tile_start[i] = D;
-        if (t == 0) {
-            *d_D = D;
-            if (host_words != nullptr) {
-                __hip_atomic_store(host_words + 1, V, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(host_words + 2, D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(host_words + 3, heavy[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            if (D > cap) {
-                *d_overflow = D;
-                if (host_words != nullptr && report_overflow) __hip_atomic_store(host_words, D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-        if (!do_order) return;
-        // bins by descending list length (counting sort on len / 16), as tile_table_role
-        uint32_t* s_c = s_gd;                  // 256 bucket counters
-        uint32_t* s_o = s_gd + 256;            // 256 bucket offsets
-        if (t < 256) s_c[t] = 0u;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (4 * t + k < ntiles) atomicAdd(&s_c[255u - min(len[k] >> 4, 255u)], 1u);
-        __syncthreads();
-        {
-            const uint32_t c = t < 256 ? s_c[t] : 0u;
-            uint32_t total;
-            const uint32_t incl = ws_block_incl_scan<kBwWaves>(c, s_tmp, total);
-            if (t < 256) s_o[t] = incl - c;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (4 * t + k < ntiles) {
-                const uint32_t pos = atomicAdd(&s_o[255u - min(len[k] >> 4, 255u)], 1u);
-                tile_order[pos] = (uint32_t)(4 * t + k);      // order inside a bucket is irrelevant (tiles are independent)
-            }
-        return;
-    }
-
-    // ---- workers ----
-    s_mark[t] = 0u;                                            // stamps start at 1: everything in the table is older
-    const uint32_t nworkers = gridDim.x - 1u, wb = blockIdx.x - 1u;
-    const bool xmap = xcd_map && (nworkers >= nchunks || (nworkers & 7u) == 0u);
-    uint32_t* wcnt = s_cnt + (uint32_t)w * half;
-    uint32_t* wmark = s_mark + (uint32_t)w * 64u;
-    uint32_t stamp = 0;                                        // wave-uniform window counter (24 bits)
-    for (uint32_t cidx = wb; cidx < nchunks; cidx += nworkers) {
-        const uint32_t chunk = xmap ? xcd_contiguous(cidx, nchunks) : cidx;
-        const uint32_t g = chunk >> gshift;
-        uint4 pre[1];
-        ws_row_sum<kBwThreads>(gsum, g, hist + (size_t)(g << gshift) * kBwBins, chunk - (g << gshift), (uint32_t)kBwBins, 11, s_part, pre);
-        __syncthreads();
-        for (uint32_t i = t; i < (uint32_t)kBwWaves * (half >> 2); i += kBwThreads) reinterpret_cast<uint4*>(s_cnt)[i] = make_uint4(0u, 0u, 0u, 0u);
-        __syncthreads();
-
-        const uint32_t base = chunk * kBwChunk + (uint32_t)w * kBwWaveRanks;
-        uint32_t rcs[kBwBatches];
-#pragma unroll
-        for (int k = 0; k < kBwBatches; ++k) rcs[k] = rect[min(base + k * 64 + lane, V - 1u)];
-#pragma unroll
-        for (int k = 0; k < kBwBatches; ++k)
-            if (base + k * 64 + lane >= V) rcs[k] = kRectEmpty;
-        // pass A: this wave's pairs per bin
-#pragma unroll
-        for (int k = 0; k < kBwBatches; ++k)
-            bw_count_batch(rcs[k], tiles_x, [&](uint32_t bin) { atomicAdd(&wcnt[bin >> 1], 1u << ((bin & 1u) << 4)); });
-        __syncthreads();
-        // per bin: counts of the waves -> chunk-local exclusive positions of the waves' runs (< 4096: 16 bits)
-        {
-            uint32_t run[4] = {0u, 0u, 0u, 0u};
-            const uint32_t pr[4] = {pre[0].x, pre[0].y, pre[0].z, pre[0].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s_gd[4 * t + j] = gbase[j] + pr[j];
-#pragma unroll
-            for (int k = 0; k < kBwWaves; ++k) {
-                const uint2 x = *reinterpret_cast<const uint2*>(s_cnt + (uint32_t)k * half + 2u * t);
-                uint2 y;
-                y.x = run[0] | (run[1] << 16);
-                y.y = run[2] | (run[3] << 16);
-                *reinterpret_cast<uint2*>(s_cnt + (uint32_t)k * half + 2u * t) = y;
-                run[0] += x.x & 0xFFFFu; run[1] += x.x >> 16; run[2] += x.y & 0xFFFFu; run[3] += x.y >> 16;
-            }
-        }
-        __syncthreads();
-        // pass B: the pairs in rank order, 64 per window
-#pragma unroll 1
-        for (int k = 0; k < kBwBatches; ++k) {
-            const uint32_t rc = rcs[k];
-            const uint32_t tx0 = rc & 255u, ty0 = (rc >> 8) & 255u, tx1 = (rc >> 16) & 255u, ty1 = rc >> 24;
-            const bool ok = tx0 <= tx1 && ty0 <= ty1;
-            const uint32_t n = ok ? (tx1 - tx0 + 1u) * (ty1 - ty0 + 1u) : 0u;
-            uint32_t inc = n;                                  // inclusive scan of the pair counts over the lanes
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t u = __shfl_up(inc, d, 64);
-                if (lane >= d) inc += u;
-            }
-            const uint32_t e = inc - n;
-            const uint32_t T = (uint32_t)__shfl((int)inc, 63, 64);
-            const uint32_t rank0 = base + (uint32_t)k * 64u;
-            uint32_t carry = 0;                                // (stamp, lane + 1) of the owner of the pair before the window
-            for (uint32_t wbase = 0; wbase < T; wbase += 64u) {    // wave-uniform
-                ++stamp;
-                __builtin_amdgcn_wave_barrier();
-                if (n != 0u && e >= wbase && e < wbase + 64u) wmark[e - wbase] = (stamp << 8) | (uint32_t)(lane + 1);
-                __builtin_amdgcn_wave_barrier();
-                uint32_t own = wmark[lane];
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t u = __shfl_up(own, d, 64);
-                    if (lane >= d) own = max(own, u);
-                }
-                own = max(own, carry);
-                carry = (uint32_t)__shfl((int)own, 63, 64);
-                const uint32_t p = wbase + (uint32_t)lane;
-                // (the shuffles are executed by all lanes: an owner lane need not hold a pair of this window itself)
-                const int o = max((int)(own & 255u) - 1, 0);
-                const uint32_t ro = (uint32_t)__shfl((int)rc, o, 64), eo = (uint32_t)__shfl((int)e, o, 64);
-                if (p < T) {
-                    const uint32_t ox0 = ro & 255u, oy0 = (ro >> 8) & 255u, ow = ((ro >> 16) & 255u) - ox0 + 1u;
-                    const uint32_t q = p - eo, dy = bw_div(q, ow), tx = ox0 + (q - dy * ow);
-                    const uint32_t bin = (oy0 + dy) * tiles_x + tx, sh = (bin & 1u) << 4;
-                    const uint32_t local = (atomicAdd(&wcnt[bin >> 1], 1u << sh) >> sh) & 0xFFFFu;
-                    const uint32_t pos = s_gd[bin] + local;
-                    if (pos < cap) pairs_out[pos] = (tx << 24) | (rank0 + (uint32_t)o);
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // per bin: first position of its list in the final pair array.  The array is sorted by (row, word)
 // with word = (tx << 24) | rank, so inside row vty the words are ascending: lower_bound(tx << 24).
 // One WAVE per bin and a 64-ary search: every step probes 64 evenly spaced words of the remaining range with

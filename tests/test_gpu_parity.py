@@ -1203,9 +1203,8 @@ def test_wide_sort_and_legacy_sort_and_tile_tables_agree(monkeypatch):
     cam, proj, vp, nf = scenes.default_view(800, 450, yaw=-0.3)
     res = []
     for env in ({}, {"MSPLAT_SORT": "lsd8"}, {"MSPLAT_TILE_TABLE": "search"}, {"MSPLAT_WS_ITEMS": "16"}, {"MSPLAT_WS_THREADS": "256"},
-                {"MSPLAT_WS_THREADS": "256", "MSPLAT_WS_ITEMS": "16"}, {"MSPLAT_BINNING": "twopass"},
-                {"MSPLAT_BINNING": "twopass", "MSPLAT_TILE_TABLE": "search"}):
-        for k in ("MSPLAT_SORT", "MSPLAT_TILE_TABLE", "MSPLAT_WS_ITEMS", "MSPLAT_WS_THREADS", "MSPLAT_BINNING"):
+                {"MSPLAT_WS_THREADS": "256", "MSPLAT_WS_ITEMS": "16"}):
+        for k in ("MSPLAT_SORT", "MSPLAT_TILE_TABLE", "MSPLAT_WS_ITEMS", "MSPLAT_WS_THREADS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1218,48 +1217,6 @@ def test_wide_sort_and_legacy_sort_and_tile_tables_agree(monkeypatch):
     for other in res[1:]:
         for a, b in zip(res[0], other):
             np.testing.assert_array_equal(a, b)
-
-
-@pytest.mark.parametrize("case", ["big_splats", "few_splats", "exactly_2048_bins", "row_bands"])
-def test_one_partition_binning_equals_the_two_pass_binning(case, monkeypatch):
-    """frames with at most 2048 bins are binned by one stable partition by bin number (bw_upsweep / bw_downsweep); the lists,
-    offsets and pixels are those of the column + row passes, for rectangles of every size (own-lane and wave-wide counting,
-    windows that start inside a rectangle), partial batches, the largest bin count, virtual rows and an overflowing pair buffer"""
-    W, H, kw, n = 800, 450, {}, 60000
-    if case == "big_splats":
-        a = scenes.synthetic.generate(20000, seed=31, pos_sigma=1.2, log_scale_mean=-3.4, log_scale_sigma=0.9)
-        a["log_scale"][::7] = -0.6 + 0.1 * a["log_scale"][::7]            # every 7th splat covers tens to hundreds of bins
-        cloud = scenes.cloud_from_attrs(a)
-    elif case == "few_splats":
-        cloud = scenes.synth_cloud(37, 5, log_scale_mean=-2.0)
-    elif case == "exactly_2048_bins":
-        W, H = 2048, 1024                                                  # 64 x 32 bins
-        cloud = scenes.synth_cloud(n, 17, log_scale_mean=-3.4)
-    elif case == "small_capacity":
-        cloud = scenes.synth_cloud(n, 23, log_scale_mean=-3.0)
-        kw = dict(pair_capacity=4096)                                      # grows on the synchronous path: both frames overflow first
-    else:
-        cloud = scenes.synth_cloud(n, 11, log_scale_mean=-3.2)
-    cam, proj, vp, nf = scenes.default_view(W, H, yaw=0.3)
-    res = []
-    for mode in ("onepass", "twopass"):
-        monkeypatch.setenv("MSPLAT_BINNING", mode)
-        r = make_renderer(cloud, **kw)
-        if case == "row_bands":
-            r.set_band_layout(1, 7, 2, 4, band_cull=True)                  # blocks of 2 rows: 1-2, 5-6, 9-10, 13
-        for _ in range(2):                                                 # the second frame runs on the other parity's tables
-            r.Sort(cam, proj, vp, nf)
-            img = r.Render(cam, proj, vp, nf)
-        ts, pairs = r.debug_tile_lists()
-        res.append((ts, pairs, img, np.uint64(r.stats()["pairs"])))
-        assert r.verify_order() == (0, 0)
-    monkeypatch.delenv("MSPLAT_BINNING")
-    assert len(res[0][1]) > 0
-    for x, y in zip(res[0], res[1]):
-        np.testing.assert_array_equal(x, y)
-    if case in ("big_splats", "few_splats"):
-        ref = oracle_frame(cloud.as_array(), True, cam, proj, vp, nf)
-        check_image(res[0][2], ref["image"], budget=ref["budget"])
 
 
 def test_frame_modes_give_identical_frames():

@@ -626,7 +626,8 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
         // there are at most 512 rows, else of 32 (a downsweep sums <= nchunks / G + G - 1 rows)
         ctx->ws_items = n > (2u << 20) ? 16u : 8u;
         if (const char* wi = getenv("MSPLAT_WS_ITEMS")) ctx->ws_items = atoi(wi) == 16 ? 16u : 8u;
-        const uint32_t nch = std::max(1u, div_up(n, (uint64_t)ctx->ws_threads * ctx->ws_items));
+        // (the tables are sized for 8 keys per thread: passes 1 and 2 drop to that when few splats survive the cull, below)
+        const uint32_t nch = std::max(1u, div_up(n, (uint64_t)ctx->ws_threads * 8u));
         ctx->ws_gshift = nch <= 512u ? 4u : 5u;
         if ((rc = buf_alloc(ctx, ctx->wsHist, (size_t)nch * kWsMaxBins * 4))) return rc;
         const size_t gwords = (size_t)((nch >> ctx->ws_gshift) + 2) * kWsMaxBins;
@@ -1106,13 +1107,19 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
         const int gsh = (int)ctx->ws_gshift;
         const uint32_t gw = ctx->ws_gsum_words;
         auto gt = [&](int pass) { return (uint32_t*)ctx->wsGsum[(pass + 3) % 3].p; };
-        const uint32_t wchunk = ctx->ws_threads * ctx->ws_items;
-        const int wgrid = grid_for(div_up(N, wchunk));
+        // Passes 1 and 2 see only the V splats that survived the cull.  With 8192-key chunks and V << N (a band-culled rank of a
+        // multi-GPU frame keeps 17 %, a camera inside a scene 40 %) they would run on ~100 workgroups: they take 4096-key chunks
+        // when an EARLIER frame's V (host-mapped word, read without synchronising) was below 2 M.  Any choice is correct at any V.
+        const uint32_t last_V = ctx->h_flags ? __atomic_load_n(ctx->h_flags + 1, __ATOMIC_RELAXED) : 0u;
+        const uint32_t items0 = ctx->ws_items;
+        const uint32_t items12 = (items0 == 16u && last_V != 0u && (uint64_t)last_V + (last_V >> 2) <= (2u << 20)) ? 8u : items0;
+        uint32_t items = items0;
+        int wgrid = grid_for(div_up(N, ctx->ws_threads * items));
         const uint32_t* dV = d_V;
         const int wsx = (ctx->xcd_map & 1) ? 1 : 0;
 #define MSPLAT_WS_T(KERNEL, CULLF, LDS, T, ...)                                                                          \
     do {                                                                                                                \
-        if (ctx->ws_items == 16) hipLaunchKernelGGL((KERNEL<CULLF, 16, T>), dim3(wgrid), dim3(T), LDS(16, T), s, __VA_ARGS__); \
+        if (items == 16u) hipLaunchKernelGGL((KERNEL<CULLF, 16, T>), dim3(wgrid), dim3(T), LDS(16, T), s, __VA_ARGS__); \
         else hipLaunchKernelGGL((KERNEL<CULLF, 8, T>), dim3(wgrid), dim3(T), LDS(8, T), s, __VA_ARGS__);                       \
     } while (0)
 #define MSPLAT_WS(KERNEL, CULLF, LDS, ...)                                                                              \
@@ -1126,6 +1133,8 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
         MSPLAT_WS(ws_downsweep, true, ws_downsweep_lds, (const uint32_t*)kB, (const uint32_t*)nullptr, (const unsigned long long*)vm,
                   (const uint32_t*)nullptr, N, N, 0, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(0), gsh, kA, vA,
                   d_V, wsx);
+        items = items12;
+        wgrid = grid_for(div_up(N, ctx->ws_threads * items));
         MSPLAT_WS(ws_upsweep, false, MSPLAT_NO_LDS, (const uint32_t*)kA, (const float4*)nullptr, (uint32_t*)nullptr,
                   (unsigned long long*)nullptr, dV, 0u, N, 1, mk_cur, mk_next, whist, gt(1), gsh, gt(0), gw, fp);
         MSPLAT_WS(ws_downsweep, false, ws_downsweep_lds, (const uint32_t*)kA, (const uint32_t*)vA, (const unsigned long long*)nullptr, dV,

@@ -950,19 +950,25 @@ __global__ __launch_bounds__(THREADS) void ws_upsweep(const uint32_t* __restrict
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         for (uint32_t d = threadIdx.x; d < nbins; d += THREADS) s_hist[d] = 0u;
         __syncthreads();
-        const uint32_t base = chunk * CHUNK;
         // unconditional (clamped) loads first, so that all of them are in flight together: under `if (i < n)` the
-        // compiler waits for each load before it issues the next (r3, seen in the ISA)
-        float4 pp[CULL ? ITEMS : 1];
-        uint32_t kk[CULL ? 1 : ITEMS];
+        // compiler waits for each load before it issues the next (r3, seen in the ISA).  The cull pass over 8192-key chunks
+        // takes its chunk in two halves: 16 positions in flight cost 126 VGPRs = 2 workgroups per CU = 512 slots for the 733
+        // chunks of 6 M splats (a second, half-empty round); 8 in flight fit 3 per CU.
+        constexpr int SUB = (CULL && ITEMS == 16) ? 2 : 1;
+        constexpr int IPS = ITEMS / SUB;
+#pragma unroll 1
+        for (int sub = 0; sub < SUB; ++sub) {
+        const uint32_t base = chunk * CHUNK + (uint32_t)sub * (IPS * THREADS);
+        float4 pp[CULL ? IPS : 1];
+        uint32_t kk[CULL ? 1 : IPS];
 #pragma unroll
-        for (int r = 0; r < ITEMS; ++r) {
+        for (int r = 0; r < IPS; ++r) {
             const uint32_t ic = min(base + r * THREADS + threadIdx.x, n - 1u);          // n >= 1 inside this loop
             if (CULL) pp[r] = pos[ic];
             else kk[r] = keys_in[ic];
         }
 #pragma unroll
-        for (int r = 0; r < ITEMS; ++r) {
+        for (int r = 0; r < IPS; ++r) {
             const uint32_t i = base + r * THREADS + threadIdx.x;
             uint32_t key = 0u;
             bool ok = false;
@@ -979,6 +985,7 @@ __global__ __launch_bounds__(THREADS) void ws_upsweep(const uint32_t* __restrict
                 }
             }
             if (ok) atomicAdd(&s_hist[(key >> shift) & dmask], 1u);
+        }
         }
         __syncthreads();
         for (uint32_t d = threadIdx.x; d < nbins; d += THREADS) {

@@ -1056,6 +1056,30 @@ def test_large_cloud_uses_the_wide_scan_path():
         ranks = pairs[ts[b]:ts[b + 1]] & 0xFFFFFF
         assert (np.diff(ranks.astype(np.int64)) > 0).all()
     check_image(img, ref["image"], budget=ref["budget"])
+    # a view that culls most of the cloud: from the second such frame on, passes 1 and 2 of the sort take 4096-key chunks
+    # (the V an earlier frame left in host-mapped memory is below 2 M) while pass 0 keeps 8192-key chunks: same exact order
+    cam_in = camera.orbit(0.5, 1.3)
+    mvp = orc.mat4_mul(proj, orc.mat4_inverse(cam_in))
+    keys_in, idx_in = orc.sort(*orc.presort(cloud.as_array(), mvp, nf[1]))
+    assert 1000 < keys_in.shape[0] < 1_500_000
+    for _ in range(3):
+        r.Sort(cam_in, proj, vp, nf)
+        r.Render(cam_in, proj, vp, nf)
+        assert r.sort_count() == keys_in.shape[0]
+        np.testing.assert_array_equal(r.sorted_keys(), keys_in)
+        np.testing.assert_array_equal(r.sorted_indices(), idx_in)
+    assert r.verify_order() == (0, 0)
+    # a context configured for frames in flight takes the four 8-bit passes beyond 2 M splats (msplat.h, frame_mode): same frame
+    from splatapult_amd import _capi
+    r2 = make_renderer(cloud, frame_mode=_capi.FRAMES_IN_FLIGHT)
+    r2.Sort(cam, proj, vp, nf)
+    img2 = r2.Render(cam, proj, vp, nf)
+    np.testing.assert_array_equal(r2.sorted_keys(), ref["sorted_keys"])
+    np.testing.assert_array_equal(r2.sorted_indices(), ref["sorted_idx"])
+    ts2, pairs2 = r2.debug_tile_lists()
+    np.testing.assert_array_equal(ts2, ts)
+    np.testing.assert_array_equal(pairs2, pairs)
+    np.testing.assert_array_equal(img2, img)
 
 
 def test_cpp_shim_renders_like_the_python_mirror(tmp_path, golden_dir):

@@ -4,7 +4,7 @@ cd ${GRAFT_REPO_ROOT:-.}
 R=$(pwd)
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r03m2_prof -o run --output-format csv -- python $R/bench.py --no-cpu-baseline --frames-in-flight 1 --steps 300 --warmup 50 --prewarm 100 --serial-frames 16 --profile-frames 1 "$@" > $R/gpurun_out/r03m2_prof.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r03m2_prof -o run --output-format csv -- python $R/bench.py --no-cpu-baseline --frames-in-flight 1 --steps 100 --warmup 20 --prewarm 40 --serial-frames 16 --profile-frames 1 "$@" > $R/gpurun_out/r03m2_prof.log 2>&1)
 f=$(find gpurun_out/r03m2_prof -name run_kernel_stats.csv | head -1)
 python - <<PY
 import csv

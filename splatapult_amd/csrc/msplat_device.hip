@@ -81,6 +81,7 @@ struct msplat_ctx {
     // table per pass, one visibility bit per splat, the visible set's minimum key per frame parity (counters[10..11])
     Buf wsHist, wsGsum[3], vmask;
     uint32_t ws_items = 8, ws_gshift = 4, ws_gsum_words = 0;
+    bool ws_up2 = true;         // upsweeps of the three-pass sort with twice the threads per chunk (512-thread form, 4096-key chunks)
     uint32_t ws_threads = 512;  // 256 (4 waves, 40 / 56 KB of LDS) for contexts that share the GPU with other frames
     bool wide_sort = true;      // MSPLAT_SORT=lsd8 (or no lane-ordered LDS atomics): the four 8-bit passes
     bool wide_sort_cfg = true;  // what the context asked for; wide_sort = what the uploaded cloud gets (alloc_cloud_buffers)
@@ -336,6 +337,7 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         ctx->ws_threads = c.frame_mode == MSPLAT_FRAMES_IN_FLIGHT ? (uint32_t)kWsThreadsSmall : (uint32_t)kWsThreads;
         ctx->bin_counts = c.frame_mode != MSPLAT_FRAMES_IN_FLIGHT;
         if (const char* sk = getenv("MSPLAT_SORT")) ctx->wide_sort = std::string(sk) != "lsd8";
+        if (const char* u2 = getenv("MSPLAT_WS_UP2")) ctx->ws_up2 = atoi(u2) != 0;
         if (const char* wt = getenv("MSPLAT_WS_THREADS")) ctx->ws_threads = atoi(wt) == kWsThreadsSmall ? (uint32_t)kWsThreadsSmall : (uint32_t)kWsThreads;
         if (!ctx->atomic_rank) ctx->wide_sort = false;       // the wide kernels rank with lane-ordered LDS atomics only
         if (const char* tk = getenv("MSPLAT_TILE_TABLE")) ctx->bin_counts = std::string(tk) != "search";
@@ -1128,24 +1130,34 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
         else MSPLAT_WS_T(KERNEL, CULLF, LDS, kWsThreads, __VA_ARGS__);                                                  \
     } while (0)
 #define MSPLAT_NO_LDS(I, T) 0
-        MSPLAT_WS(ws_upsweep, true, MSPLAT_NO_LDS, (const uint32_t*)nullptr, pos, kB, vm, (const uint32_t*)nullptr, N, N, 0, mk_cur,
+        // The upsweeps have no order to keep.  One frame at a time and 4096-key chunks (up to 2 M splats): twice the threads per
+        // chunk, half the keys per thread -- 241 workgroups of 16 waves instead of 8 at 1 M: sort 57.4 -> 55.7 us.  Not at 6 M
+        // (158 -> 166 us) and not for frames in flight (-0.5 %): `tools/gpu_round3_q2.sh`; MSPLAT_WS_UP2=0|1 overrides.
+#define MSPLAT_WS_UP(CULLF, ...)                                                                                        \
+    do {                                                                                                                \
+        if (ctx->ws_up2 && items == 8u && ctx->ws_threads == (uint32_t)kWsThreads)                                      \
+            hipLaunchKernelGGL((ws_upsweep<CULLF, 4, 2 * kWsThreads>), dim3(wgrid), dim3(2 * kWsThreads), 0, s, __VA_ARGS__); \
+        else MSPLAT_WS(ws_upsweep, CULLF, MSPLAT_NO_LDS, __VA_ARGS__);                                                    \
+    } while (0)
+        MSPLAT_WS_UP(true, (const uint32_t*)nullptr, pos, kB, vm, (const uint32_t*)nullptr, N, N, 0, mk_cur,
                   mk_next, whist, gt(0), gsh, gt(-1), gw, fp);
         MSPLAT_WS(ws_downsweep, true, ws_downsweep_lds, (const uint32_t*)kB, (const uint32_t*)nullptr, (const unsigned long long*)vm,
                   (const uint32_t*)nullptr, N, N, 0, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(0), gsh, kA, vA,
                   d_V, wsx);
         items = items12;
         wgrid = grid_for(div_up(N, ctx->ws_threads * items));
-        MSPLAT_WS(ws_upsweep, false, MSPLAT_NO_LDS, (const uint32_t*)kA, (const float4*)nullptr, (uint32_t*)nullptr,
+        MSPLAT_WS_UP(false, (const uint32_t*)kA, (const float4*)nullptr, (uint32_t*)nullptr,
                   (unsigned long long*)nullptr, dV, 0u, N, 1, mk_cur, mk_next, whist, gt(1), gsh, gt(0), gw, fp);
         MSPLAT_WS(ws_downsweep, false, ws_downsweep_lds, (const uint32_t*)kA, (const uint32_t*)vA, (const unsigned long long*)nullptr, dV,
                   0u, N, 1, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(1), gsh, kB, vB, (uint32_t*)nullptr, wsx);
-        MSPLAT_WS(ws_upsweep, false, MSPLAT_NO_LDS, (const uint32_t*)kB, (const float4*)nullptr, (uint32_t*)nullptr,
+        MSPLAT_WS_UP(false, (const uint32_t*)kB, (const float4*)nullptr, (uint32_t*)nullptr,
                   (unsigned long long*)nullptr, dV, 0u, N, 2, mk_cur, mk_next, whist, gt(2), gsh, gt(1), gw, fp);
         MSPLAT_WS(ws_downsweep, false, ws_downsweep_lds, (const uint32_t*)kB, (const uint32_t*)vB, (const unsigned long long*)nullptr, dV,
                   0u, N, 2, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(2), gsh, kA, vA, (uint32_t*)nullptr, wsx);
 #undef MSPLAT_NO_LDS
 #undef MSPLAT_WS
 #undef MSPLAT_WS_T
+#undef MSPLAT_WS_UP
         if (timed) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][1], s));
             ctx->sort_sets++;

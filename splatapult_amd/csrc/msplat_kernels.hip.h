@@ -810,6 +810,7 @@ constexpr int kWsThreadsSmall = 256;         // 4 waves, 40 KB: the form for con
 constexpr int kWsBits0 = 10;                 // digit of pass 0: key bits [0, 10)
 constexpr int kWsMinBits = 8, kWsMaxBits = 11;
 constexpr int kWsMaxBins = 1 << kWsMaxBits;
+constexpr int ws_qpt(int threads) { return kWsMaxBins / 4 / threads > 0 ? kWsMaxBins / 4 / threads : 1; }   // quads of digits per thread
 
 // digit of pass `pass`: bits [shift, shift + bits) of the key.  minkey = smallest key of the visible set (pass >= 1)
 __device__ __forceinline__ void ws_digit_range(int pass, uint32_t minkey, int& shift, int& bits)
@@ -855,9 +856,9 @@ __device__ __forceinline__ uint32_t ws_block_incl_scan(uint32_t v, uint32_t* s_t
 template <int THREADS>
 __device__ __forceinline__ void ws_row_sum(const uint32_t* __restrict__ rows0, uint32_t n0,
                                            const uint32_t* __restrict__ rows1, uint32_t n1, uint32_t nbins, int bits,
-                                           uint4* s_part, uint4 (&out)[kWsMaxBins / 4 / THREADS])
+                                           uint4* s_part, uint4 (&out)[ws_qpt(THREADS)])
 {
-    constexpr int QPT = kWsMaxBins / 4 / THREADS;
+    constexpr int QPT = ws_qpt(THREADS);
     const uint32_t Q = nbins >> 2;
     const bool wide = Q >= (uint32_t)THREADS;                               // workgroup-uniform
     const uint32_t RL = wide ? 1u : ((uint32_t)THREADS >> (bits - 2));      // row lanes
@@ -1030,7 +1031,7 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
     // as partial lines by several (the per-XCD L2s are not coherent; every one writes back its own bytes of a shared line)
     constexpr int CHUNK = THREADS * ITEMS;
     constexpr int WAVES = THREADS / 64;
-    constexpr int QPT = kWsMaxBins / 4 / THREADS;               // quads (4 digits) per thread in the per-digit steps: 1 or 2
+    constexpr int QPT = ws_qpt(THREADS);                        // quads (4 digits) per thread in the per-digit steps: 1 or 2
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     uint32_t* s_keys = s_dyn;                                   // CHUNK
     uint32_t* s_vals = s_keys + CHUNK;                          // CHUNK
@@ -1116,15 +1117,14 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
         for (int kq = 0; kq < QPT; ++kq) {
             const uint32_t qd = (uint32_t)t + (uint32_t)kq * THREADS;            // this thread's quad (digits 4 qd .. 4 qd + 3)
             const bool own = qd < Q;
-            uint32_t c[WAVES][4];
+            // (the waves' counts are read twice -- once for the totals, once for the bases -- instead of being kept: 16 waves
+            //  x 4 digits would be 64 registers)
             uint32_t tot[4] = {0u, 0u, 0u, 0u};
             if (own) {
 #pragma unroll
                 for (int k = 0; k < WAVES; ++k) {
                     const uint2 x = *reinterpret_cast<const uint2*>(s_cnt + (uint32_t)k * half + 2u * qd);
-                    c[k][0] = x.x & 0xFFFFu; c[k][1] = x.x >> 16; c[k][2] = x.y & 0xFFFFu; c[k][3] = x.y >> 16;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) tot[j] += c[k][j];
+                    tot[0] += x.x & 0xFFFFu; tot[1] += x.x >> 16; tot[2] += x.y & 0xFFFFu; tot[3] += x.y >> 16;
                 }
             }
             const uint32_t tsum = tot[0] + tot[1] + tot[2] + tot[3];
@@ -1138,12 +1138,13 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
                 for (int j = 0; j < 4; ++j) s_gd[4u * qd + j] = gbase[kq][j] + pr[j] - run[j];
 #pragma unroll
                 for (int k = 0; k < WAVES; ++k) {
+                    uint2* slot = reinterpret_cast<uint2*>(s_cnt + (uint32_t)k * half + 2u * qd);
+                    const uint2 c = *slot;
                     uint2 x;
                     x.x = run[0] | (run[1] << 16);
                     x.y = run[2] | (run[3] << 16);
-                    *reinterpret_cast<uint2*>(s_cnt + (uint32_t)k * half + 2u * qd) = x;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) run[j] += c[k][j];
+                    *slot = x;
+                    run[0] += c.x & 0xFFFFu; run[1] += c.x >> 16; run[2] += c.y & 0xFFFFu; run[3] += c.y >> 16;
                 }
             }
         }

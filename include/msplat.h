@@ -69,7 +69,7 @@ typedef struct msplat_config {
                                /* (msplat_get_timings averages them); 0 = never             */
     int32_t compositor_waves;  /* persistent compositor waves per render; 0 = default (8192, the  */
                                /* measured best for one frame at a time; the SplatRenderer shims   */
-                               /* use 1024 with frames in flight so that frames share the CUs)     */
+                               /* use 1280 with frames in flight so that frames share the CUs)     */
     int32_t rank_mode;         /* MSPLAT_RANK_*: how the stable radix / binning passes rank the    */
                                /* keys of one wave.  Added after the first release of the struct:  */
                                /* a struct_size that ends before this field selects MSPLAT_RANK_AUTO */

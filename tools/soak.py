@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """tools/soak.py -- a few thousand frames over poses that make the frame change its kernel selection from frame to frame
 (visible count above / below 2 M: chunk size of sort passes 1 and 2; heavy chunks of the column pass present / absent:
-helper workgroups; pair counts above / below the scan-free limit), one frame at a time and with four frames in flight.
+helper workgroups; pair counts above / below the scan-free limit), one frame at a time, with four frames in flight, and as one
+rank of a row-sharded frame (block layout, band-culled sort).
 
 Every stateful shortcut of the frame is exercised across those switches: the self-cleaning group tables, the per-parity
 minimum-key and heavy-chunk words, the host-mapped hints of an earlier frame.  Checked: every render of a pose is
@@ -48,9 +49,12 @@ def main(argv=None):
     rng = np.random.default_rng(7)
     order = rng.integers(0, len(poses), size=args.frames)
     failures = 0
-    for depth in (1, 4):
+    for kind in ("serial", "in flight", "band"):
+        depth = 4 if kind == "in flight" else 1
         r = SplatRenderer(device=0, frames_in_flight=depth)
         assert r.Init(gc, False, False), r.last_error()
+        if kind == "band":        # rank 1 of 4 under the block layout, band-culled sort: virtual rows, V a fraction of the cloud's
+            r.set_band_plan("block", (H + 31) // 32, 4, 1, block_rows=2, band_cull=True)
         Hpad = (H + 31) // 32 * 32           # the compositor writes whole bins
         fbs = [torch.zeros((Hpad, W, 4), dtype=torch.float32, device=dev) for _ in range(depth)]
         first, counts = {}, {}
@@ -66,7 +70,7 @@ def main(argv=None):
                         first[pp] = img.clone()
                     elif not torch.equal(first[pp], img):
                         failures += 1
-                        print("MISMATCH depth %d frame %d pose %d: %d pixels differ" % (depth, f, pp, int((first[pp] != img).any(-1).sum())))
+                        print("MISMATCH %s frame %d pose %d: %d pixels differ" % (kind, f, pp, int((first[pp] != img).any(-1).sum())))
                 pending = []
             r.Sort(poses[p], proj, vp, nf)
             r.Render(poses[p], proj, vp, nf, out_ptr=fbs[slot].data_ptr(), pitch_bytes=W * 16)
@@ -78,14 +82,14 @@ def main(argv=None):
                 key = (st["sort_count"], st["pairs"])
                 if vo != (0, 0):
                     failures += 1
-                    print("ORDER depth %d frame %d pose %d: %s" % (depth, f, p, vo))
+                    print("ORDER %s frame %d pose %d: %s" % (kind, f, p, vo))
                 if counts.setdefault(int(p), key) != key:
                     failures += 1
-                    print("COUNTS depth %d frame %d pose %d: %s != %s" % (depth, f, p, key, counts[int(p)]))
+                    print("COUNTS %s frame %d pose %d: %s != %s" % (kind, f, p, key, counts[int(p)]))
         r.synchronize()
         el = time.time() - t0
-        print("depth %d: %d frames in %.1f s (%.0f frames/s incl. checks), poses seen %d, V/pairs per pose: %s"
-              % (depth, args.frames, el, args.frames / el, len(first), {k: v for k, v in sorted(counts.items())}), flush=True)
+        print("%s: %d frames in %.1f s (%.0f frames/s incl. checks), poses seen %d, V/pairs per pose: %s"
+              % (kind, args.frames, el, args.frames / el, len(first), {k: v for k, v in sorted(counts.items())}), flush=True)
     print("soak: %s" % ("OK" if failures == 0 else "%d FAILURES" % failures))
     return 1 if failures else 0
 

@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
 import pytest
 
 from splatapult_amd import SplatRenderer, _capi
@@ -110,3 +111,27 @@ def test_cpp_shim_compiles_with_plain_gxx(tmp_path):
         p = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "test.ply"), str(tmp_path / "o.f32"), "64", "48"],
                            capture_output=True, text=True)
         assert p.returncode == 1 and "no CPU fallback" in p.stderr
+
+
+def test_frame_arguments_are_marshalled_through_one_buffer():
+    """renderer._FrameArgs (r3): the four per-call arrays go through one preallocated float buffer whose pointers are made
+    once; sizes are still checked, lists and (4, 4) arrays are accepted, values arrive unchanged"""
+    import ctypes as C
+    from splatapult_amd.renderer import _FrameArgs
+    a = _FrameArgs()
+    cam = np.arange(16, dtype=np.float32).reshape(4, 4)
+    proj = [float(v) for v in range(100, 116)]
+    pc, pp, pv, pn = a.load(cam, proj, [0, 0, 640, 480], (0.1, 1000.0))
+    assert [pc[i] for i in range(16)] == list(range(16))
+    assert [pp[i] for i in range(16)] == list(range(100, 116))
+    assert [pv[i] for i in range(4)] == [0.0, 0.0, 640.0, 480.0]
+    assert abs(pn[0] - 0.1) < 1e-7 and pn[1] == 1000.0
+    base = C.addressof(pc.contents)
+    for p, off in ((pp, 64), (pv, 128), (pn, 144)):
+        assert C.addressof(p.contents) == base + off
+    again = a.load(cam.T.copy(), proj, [0, 0, 8, 8], (1.0, 2.0))
+    assert C.addressof(again[0].contents) == base and again[0][1] == 4.0       # same buffer, new values
+    for bad in ((cam[:3], proj, [0, 0, 1, 1], (0.1, 1.0)), (cam, proj[:15], [0, 0, 1, 1], (0.1, 1.0)),
+                (cam, proj, [0, 0, 1], (0.1, 1.0)), (cam, proj, [0, 0, 1, 1], (0.1,)), (cam, proj, [0, 0, 1, 1], 3.0)):
+        with pytest.raises(AssertionError):
+            a.load(*bad)

@@ -1010,6 +1010,7 @@ static int make_frame_params(msplat_ctx* ctx, const float cameraMat[16], const f
     fp.band_first = ctx->band_first;
     fp.band_block = ctx->band_block;
     fp.band_stride = ctx->band_stride;
+    fp.band_inv_stride = 1.0f / (float)std::max(1, ctx->band_stride);
     fp.tiles_y = rows_full;
     if (ctx->banded) {           // owned rows below rows_full, at most band_count of them
         int owned = 0;

@@ -103,10 +103,10 @@ def measure(E, args, key, ply=None, primary=True):
         import tempfile
         scene_dir = tempfile.mkdtemp(prefix="msplat_scene_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
         ply = os.path.join(scene_dir, "point_cloud", "iteration_30000", "point_cloud.ply")
-        if rank == 0 or world == 1 or True:       # every rank writes its own copy (ranks do not share the scratch directory)
-            os.makedirs(os.path.dirname(ply))
-            synthetic.write_ply(ply, synthetic.generate_scene(wl["n"], seed=wl["seed"]))
-            synthetic.write_cameras_json(os.path.join(scene_dir, "cameras.json"), synthetic.scene_cameras(64), W, H, camera.FOVY)
+        # every rank writes its own copy (ranks do not share the scratch directory)
+        os.makedirs(os.path.dirname(ply))
+        synthetic.write_ply(ply, synthetic.generate_scene(wl["n"], seed=wl["seed"]))
+        synthetic.write_cameras_json(os.path.join(scene_dir, "cameras.json"), synthetic.scene_cameras(64), W, H, camera.FOVY)
     from_file = ply is not None
     if ply:
         from splatapult_amd import GaussianCloud
@@ -278,11 +278,14 @@ def measure(E, args, key, ply=None, primary=True):
     Vs, Ds, drawn, Dbin, works = [], [], [], [], []
     rs.set_tile_probe(True)
     for s in range(max(1, args.profile_frames)):
-        frame(args.warmup + s * 7, rs, rs_sets)
+        # (no gather here: only the compositor's own counters are wanted; every view's launch is probed)
+        cams = cams_for(args.warmup + s * 7)
+        rs.Sort(cams[0], projs[0], vp, nf)
+        for v in range(views):
+            rs.Render(cams[v], projs[v], vp, nf, out_ptr=rs_sets[0][v].data_ptr(), pitch_bytes=W * bpp)
+            works.append(rs.composite_work())
         st = rs.stats()
         Vs.append(st["sort_count"]); Ds.append(st["pairs_tile16"]); drawn.append(st["drawn"]); Dbin.append(st["pairs"])
-        if views == 1:
-            works.append(rs.composite_work())
     rs.set_tile_probe(False)
     ts_last, _ = rs.debug_tile_lists(want_pairs=False)
     longest_list = int(np.diff(ts_last.astype(np.int64)).max()) if ts_last.shape[0] > 1 else 0
@@ -296,11 +299,16 @@ def measure(E, args, key, ply=None, primary=True):
     else:
         D_total = D
 
+    # ---- N > 1: is rank 0's gathered frame THE frame?  (outside every timed region) ----
+    gcheck = gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf, cloud, lay_kind, lay_k, primary) \
+        if (world > 1 and gathers is not None) else None
+
     fps = args.steps / elapsed
     ms = 1e3 * elapsed / args.steps
     # algorithmic bytes of the whole frame:  B = 16 N + (8+68+S+48) V + views (52 D + W H bpp)
     S = 244
     B_frame = 16.0 * n + (8 + 68 + S + 48) * V + (52.0 * D_total + W * H * bpp) * views
+    Dbin_mean = float(np.mean(Dbin))
     # dominant kernel: composite_kernel, one launch per view, measured with the GPU to itself (serial phase)
     fb_bytes = (W * H * bpp) / world
     B_formula = 52.0 * D + fb_bytes                         # every (splat, 16x16 tile) pair fetched
@@ -329,6 +337,21 @@ def measure(E, args, key, ply=None, primary=True):
                 break
             except (KeyError, ValueError, IndexError):
                 traffic = None
+    # per-stage view of the serial frame (every kernel alone on the GPU): bytes the stage has to move by its own design --
+    # SURVEY 8d's terms for sort (16 N + 8 V + 68 V) and projection ((S + 48) V), 4 V + 16 D32 for the two binning partitions
+    # (rectangle read; every (splat, 32-px bin) pair word written, read, written, read), and for the compositor what its
+    # front-to-back walk really fetched (probe) + the framebuffer -- over the stage's time; none of them can exceed 1
+    stages = None
+    if prof_serial and prof_serial.get("sort_total", 0) > 0:
+        # (stereo: projection, binning and the compositor run once per view; their stage times and bytes are per Render call)
+        sb = {"sort": 16.0 * n + 76.0 * V, "project": (S + 48.0) * V, "binning": 4.0 * V + 16.0 * Dbin_mean, "composite": B_used}
+        st_ms = {"sort": prof_serial["sort_total"], "project": prof_serial["project"], "binning": prof_serial["binning"],
+                 "composite": comp_serial_ms}
+        stages = {k: {"bytes": sb[k], "us": 1e3 * st_ms[k], "frac": min(1.0, sb[k] / max(st_ms[k] * 1e-3, 1e-12) / HBM_PEAK)}
+                  for k in sb}
+        stages["bytes_definition"] = ("sort 16 N + 76 V; project 292 V; binning 4 V + 16 D32 (D32 = (splat, 32-px bin) pairs); composite = bytes "
+                                      "fetched (probe) + framebuffer; us = stage time of a serial frame (per Render call for stereo)")
+    B_moved = (16.0 * n + 76.0 * V) + views * ((S + 48.0) * V + 4.0 * V + 16.0 * Dbin_mean + B_used)
     roof = {
         "kernel": "composite_kernel", "bound": "hbm", "limiter": "valu (exp + blend per pixel-splat); the HBM fraction is honest-but-low",
         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
@@ -337,9 +360,8 @@ def measure(E, args, key, ply=None, primary=True):
         "bytes_definition": ("fetched under early termination: 4 B x %.0f list entries + 48 B x %.0f records (of %.0f list entries "
                              "in the bins) + %.0f B framebuffer" % (work["pair_words_fetched"], work["records_fetched"],
                                                                    work["list_entries"], fb_bytes)) if work
-                            else "SURVEY 8d formula 52 D + W H bpp (stereo workload: no probe)",
-        "formula_bytes_per_launch": B_formula,
-        "formula_frac": (B_formula / comp_s / HBM_PEAK) if comp_s > 0 else None,
+                            else "SURVEY 8d formula 52 D + W H bpp (no probe data)",
+        "stages": stages,
         "avg_launch_ms": comp_serial_ms,
         "avg_launch_source": "hipExtLaunchKernelGGL begin/end events on the launch stream, %d serial frames (kernel alone on the GPU)"
                              % (prof_serial or {}).get("frames_averaged", 0),
@@ -360,7 +382,8 @@ def measure(E, args, key, ply=None, primary=True):
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not ply else "file",
         "gsplats_per_sec": n * fps / 1e9,
-        "rccl_ranks": world if (world > 1 and not E.one_dev) else (0 if world > 1 else 1),
+        "rccl_ranks": (E.pg["world_size"] if E.pg["backend"] == "nccl" else 0) if world > 1 else 1,
+        "process_group": E.pg if world > 1 else None,
         "config": {"workload": wl["desc"], "key": key, "splats": n, "width": W, "height": H,
                    "views": views, "framebuffer": wl["fb"],
                    "sharding": ("bin rows of %d px over %d ranks, layout %s" % (TILE, world, lay)) if world > 1 else "none (one GPU)",
@@ -374,11 +397,16 @@ def measure(E, args, key, ply=None, primary=True):
                    "single_frame_latency_ms_host_to_host": latency_ms, "stages_ms": prof_serial},
         "stages_ms": prof,
         "host_enqueue_ms_per_frame": 1e3 * enqueue / args.steps,
-        "frame_algorithmic_GB": B_frame / 1e9,
-        "frame_hbm_frac": (B_frame / (elapsed / args.steps)) / HBM_PEAK / world,
-        "frame_hbm_frac_serial": (B_frame / (serial_ms * 1e-3)) / HBM_PEAK / world,
+        # bytes a frame moves by the stages' own design (sum of roofline.stages, compositor = fetched bytes) against the peak;
+        # (r1-r3 printed SURVEY 8d's 52 D formula here, which credits bytes an early-terminating compositor never moves)
+        "frame_moved_GB": B_moved / 1e9,
+        "frame_moved_frac": min(1.0, (B_moved / (elapsed / args.steps)) / HBM_PEAK),
+        "frame_moved_frac_serial": min(1.0, (B_moved / (serial_ms * 1e-3)) / HBM_PEAK),
+        "survey_8d_formula_GB": B_frame / 1e9,
         "roofline": roof,
     }
+    if gcheck is not None:
+        out["gather_check"] = gcheck
     if world > 1 and gathers is not None:
         out["gather"] = {"p2p_ops_per_frame_rank0": (len(gathers[0].plan) * views) if rank == 0 else None,
                          "bytes_into_rank0_per_frame": None}
@@ -447,12 +475,16 @@ def main():
         E.local_rank = 0
     torch.cuda.set_device(E.local_rank)
     E.dev = torch.device("cuda", E.local_rank)
+    E.pg, E.cpu_group = {"backend": None, "world_size": 1}, None
     if E.world > 1:
         if E.one_dev:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=E.dev)
         dist.barrier()
+        # host-side barriers (while one rank works alone, the others must not spin in a collective kernel on their GPUs)
+        E.cpu_group = dist.new_group(backend="gloo")
+        E.pg = process_group_report(E, torch, dist)
     # a dedicated (non-null) torch stream: libmsplat launches on it, so torch copies, RCCL's stream
     # hand-off and torch.cuda.synchronize all order correctly with the HIP kernels
     E.stream = torch.cuda.Stream(device=E.dev)
@@ -466,15 +498,125 @@ def main():
             raise SystemExit("unknown workload in --also: " + key)
         sub = measure(E, args, key, primary=False)
         extra[key] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "gsplats_per_sec", "n_gpus", "rccl_ranks", "config",
-                                          "timed_blocks", "serial", "stages_ms", "frame_hbm_frac", "roofline", "gather")
+                                          "timed_blocks", "serial", "stages_ms", "frame_moved_frac", "roofline", "gather",
+                                          "gather_check")
                       if k in sub}
     if extra:
         out["also"] = extra
+    # N > 1: a gathered frame that is not bit-identical to the single-context frame voids the number
+    bad = [k for k, d in [(args.workload, out)] + list(extra.items())
+           if d.get("gather_check") is not None and not d["gather_check"]["bit_exact"]]
+    if bad:
+        out["value"] = None
+        out["error"] = "gather_check failed for %s: rank 0's gathered frame differs from the unbanded render" % ", ".join(bad)
     if E.rank == 0:
         print(json.dumps(out))
     if E.world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if bad:
+        sys.exit(3)
+
+
+def process_group_report(E, torch, dist):
+    """what the LIVE process group says: backend, world size, and every rank's device (ordinal, PCI bus id, name), so that a
+    run on N distinct GPUs can be told from N ranks on one"""
+    import ctypes
+    bus = None
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, ctypes.c_int(E.local_rank)) == 0:
+            bus = buf.value.decode()
+    except OSError:
+        pass
+    props = torch.cuda.get_device_properties(E.dev)
+    mine = {"rank": E.rank, "local_rank": E.local_rank, "device": int(E.dev.index), "pci_bus_id": bus, "name": props.name,
+            "host": os.uname().nodename, "pid": os.getpid()}
+    allr = [None] * dist.get_world_size()
+    dist.all_gather_object(allr, mine, group=E.cpu_group)
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": allr,
+            "distinct_devices": len({(r["host"], r["pci_bus_id"] or r["device"]) for r in allr})}
+
+
+def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf, cloud, lay_kind, lay_k, primary):
+    """Rank 0 renders two orbit poses UNBANDED on a plain single context and compares them bit for bit with the frame the ranks
+    rendered in bands and gathered into its framebuffer (the bench's own exchange: grouped send / receive over RCCL, or gloo in
+    the one-device debug mode).  On the primary workload, when rank 0's process can see one device per rank, the single-process
+    device group (msplat_group_*: the other devices' compositors store their rows into device 0's framebuffer over the peer
+    mapping) renders the same poses too.  Outside every timed region."""
+    import torch
+    import torch.distributed as dist
+    from splatapult_amd import SplatRenderer, SplatRendererGroup
+    rank, world, dev, stream = E.rank, E.world, E.dev, E.stream
+    W, H, views = wl["W"], wl["H"], wl["views"]
+    bpp = 8 if wl["fb"] == "fp16" else 16
+    poses = [5, 37]
+    bits = torch.int16 if wl["fb"] == "fp16" else torch.int32
+
+    def host_barrier():
+        torch.cuda.synchronize(dev)
+        dist.barrier(group=E.cpu_group)
+
+    res = {"bit_exact": True, "poses": poses, "exchange": dist.get_backend(), "values_compared": 0, "values_different": 0,
+           "max_abs_diff": 0.0, "peer_store": None}
+    ref, ref_fbs, keep = None, None, {}
+    if rank == 0:
+        ref = SplatRenderer(device=E.local_rank, fb_format=wl["fb"], stream=stream.cuda_stream, frames_in_flight=1)
+        init(ref)
+        ref_fbs = [torch.zeros_like(rs_sets[0][v]) for v in range(views)]
+    for k in poses:
+        for t in rs_sets[0]:
+            t.zero_()                               # rows left by an earlier frame must not pass for gathered ones
+        host_barrier()
+        frame(k, rs, rs_sets)                       # every rank: its bands + the gather into rank 0's framebuffer
+        host_barrier()
+        if rank == 0:
+            cams = cams_for(k)
+            ref.Sort(cams[0], projs[0], vp, nf)
+            for v in range(views):
+                ref.Render(cams[v], projs[v], vp, nf, out_ptr=ref_fbs[v].data_ptr(), pitch_bytes=W * bpp)
+            torch.cuda.synchronize(dev)
+            keep[k] = [t.clone() for t in ref_fbs]
+            for v in range(views):
+                a, b = rs_sets[0][v][:H], ref_fbs[v][:H]
+                ne = int((a.view(bits) != b.view(bits)).sum().item())
+                res["values_compared"] += a.numel()
+                res["values_different"] += ne
+                if ne:
+                    res["max_abs_diff"] = max(res["max_abs_diff"], float((a.float() - b.float()).abs().max().item()))
+    # the other exchange form: one process, one context per device, peer stores into device 0's framebuffer
+    if rank == 0 and primary and not E.one_dev and torch.cuda.device_count() >= world:
+        ps = {"devices": list(range(world)), "bit_exact": None, "peer_store_ranks": None, "error": None}
+        try:
+            g = SplatRendererGroup(list(range(world)), fb_format=wl["fb"], layout=lay_kind, block_rows=lay_k, band_cull=(views == 1))
+            if not g.Init(cloud, False, False):
+                raise RuntimeError(g.last_error())
+            ps["peer_store_ranks"] = [i for i in range(g.size) if g.peer_store(i)]
+            gfb = torch.zeros_like(rs_sets[0][0])
+            ok = True
+            for k in poses:
+                cams = cams_for(k)
+                gfb.zero_()
+                torch.cuda.synchronize(dev)
+                g.Sort(cams[0], projs[0], vp, nf)
+                for v in range(views):
+                    g.Render(cams[v], projs[v], vp, nf, out_ptr=gfb.data_ptr(), pitch_bytes=W * bpp)
+                    g.synchronize()
+                    ok = ok and bool((gfb[:H].view(bits) == keep[k][v][:H].view(bits)).all().item())
+            ps["bit_exact"] = ok
+            g.close()
+        except Exception as e:                      # reported, not fatal: the bench's own exchange is the gather above
+            ps["error"] = "%s: %s" % (type(e).__name__, e)
+        res["peer_store"] = ps
+    if ref is not None:
+        ref.close()
+    host_barrier()
+    flag = torch.tensor([res["values_different"]], dtype=torch.int64)
+    dist.broadcast(flag, src=0, group=E.cpu_group)
+    res["values_different"] = int(flag.item())
+    res["bit_exact"] = res["values_different"] == 0
+    return res
 
 
 def cpu_baseline(cloud, wl, cams_for, projs, vp, nf, frames):
@@ -526,7 +668,7 @@ def cpu_baseline(cloud, wl, cams_for, projs, vp, nf, frames):
     times = [one(s, stages) for s in range(frames)]
     sec = float(np.median(times))
     st = {k: float(np.median([s[k] for s in stages])) for k in stages[0]}
-    out = {"value": 1.0 / sec, "unit": "frames/s", "cores": cores, "kind": "port-tiled",
+    out = {"value": 1.0 / sec, "unit": "frames/s", "cores": int(min(cores, eff)), "threads": cores, "kind": "port-tiled",
            "sample": "%d frame(s) of the same workload (orbit steps 0..%d), median, %d host threads (OpenMP), "
                      "oracle/msplat_cpu_tiled.c: tile-binned, front-to-back, early termination at T < 2^-14"
                      % (len(times), len(times) - 1, cores),
@@ -539,7 +681,7 @@ def cpu_baseline(cloud, wl, cams_for, projs, vp, nf, frames):
         orc.render_frame(aos, True, cams[0], projs[0], vp, nf, render_cam=cams[v], render_proj=projs[v], nthreads=avail)
     lit = time.perf_counter() - t
     cores = avail
-    return out, {"value": 1.0 / lit, "unit": "frames/s", "cores": cores, "kind": "port",
+    return out, {"value": 1.0 / lit, "unit": "frames/s", "cores": int(min(avail, eff)), "threads": avail, "kind": "port",
                  "sample": "1 frame (orbit step 0), %d host threads, oracle/msplat_oracle.c via OpenMP row bands (every band "
                            "walks all visible splats back to front; single-threaded sort)" % cores,
                  "sec_per_frame": lit}

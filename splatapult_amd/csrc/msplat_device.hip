@@ -16,6 +16,7 @@
 #include <cstring>
 #include <exception>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -50,7 +51,7 @@ struct CloudStore {
 
 constexpr uint32_t kFusedMaxChunks = 1u << 20;     // scan-free passes up to this many chunk rows: with the two-level group tables (r3) a
                                                // prefix is <= nchunks / 128 + 34 rows, so every table qualifies (r2, one level: 8192 rows,
-                                               // beyond that the radix_scan kernels); MSPLAT_FUSED_MAX_CHUNKS lowers it for comparison
+                                               // beyond that the radix_scan kernels)
 
 struct msplat_ctx {
     msplat_config cfg{};
@@ -81,7 +82,6 @@ struct msplat_ctx {
     // table per pass, one visibility bit per splat, the visible set's minimum key per frame parity (counters[10..11])
     Buf wsHist, wsGsum[3], vmask;
     uint32_t ws_items = 8, ws_gshift = 4, ws_gsum_words = 0;
-    bool ws_up2 = true;         // upsweeps of the three-pass sort with twice the threads per chunk (512-thread form, 4096-key chunks)
     uint32_t ws_threads = 512;  // 256 (4 waves, 40 / 56 KB of LDS) for contexts that share the GPU with other frames
     bool wide_sort = true;      // MSPLAT_SORT=lsd8 (or no lane-ordered LDS atomics): the four 8-bit passes
     bool wide_sort_cfg = true;  // what the context asked for; wide_sort = what the uploaded cloud gets (alloc_cloud_buffers)
@@ -90,24 +90,13 @@ struct msplat_ctx {
     bool tables_dirty = false;  // a launch failed: clear every self-cleaning table before the next frame
     // per-bin pair counts taken by the row pass's upsweep (r3): list offsets + work order without tile_start_kernel
     Buf bincnt;
-    bool bin_counts = true;     // MSPLAT_TILE_TABLE=search: tile_start_kernel / tile_order_kernel as in r2
-    int xcd_map = 5;            // MSPLAT_XCD_MAP: which scatter kernels take XCD-contiguous chunk ranges.  bit 0: the sort's downsweeps
-                                // (on: 6 M splats 196 -> 185 us, no change at 1 M); bit 1: the column pass's downsweep (off: 6 M / 4096^2
-                                // binning 453 -> 509 us); bit 2: the row pass's downsweep (on: 6 M / 4096^2 binning 347 -> 327 us, 1080p
-                                // 141 -> 136, 1 M 59 -> 57: a column's chunks write adjacent runs of every row)
+    bool bin_counts = true;     // MSPLAT_TILE_TABLE=search (and contexts with frames in flight): tile_start_kernel / tile_order_kernel
+    // (XCD-contiguous chunk ranges: on for the sort's downsweeps -- 6 M splats 196 -> 185 us, no change at 1 M -- and the row
+    //  pass's downsweep -- 6 M / 4096^2 binning 347 -> 327 us: a column's chunks write adjacent runs of every row --, off for the
+    //  column pass's downsweep, where they were measured slower: 453 -> 509 us.  Fixed since r4.)
     Buf heavy, heavy_flag;      // column pass: chunks with far more pairs than the others are split over several workgroups
     uint32_t render_parity = 0;
-    bool heavy_split = true;    // MSPLAT_HEAVY_SPLIT=0: no helper workgroups (A/B)
-    uint32_t bin_chunk = 1024;  // ranks per chunk of the column pass (kBinChunk / kBinChunkLarge by cloud size)
     bool scan_free = true;  // MSPLAT_SCAN_KERNELS=1 forces the 3-kernel (upsweep, scan, downsweep) passes
-    uint32_t fused_max_chunks = kFusedMaxChunks;   // MSPLAT_FUSED_MAX_CHUNKS: scan-free passes up to this many chunk rows
-    // compositor formulation: 0 = one wave per 16x16 tile (default), 1 = one wave per 16x8 half tile, 2 = four waves per
-    // tile (composite_quad_kernel, LDS-bound, kept for comparison); MSPLAT_COMPOSITOR=wave|half|quad
-    int comp_kind = 0;
-    bool comp_ftz = true;   // discard by underflow in the compositor (MSPLAT_COMP_FTZ=0: compare + select)
-    int comp_xcd = 1;       // the four quadrants of a bin run on one XCD (MSPLAT_COMP_XCD=0: plain item order)
-    bool comp_always_order = false;   // MSPLAT_COMP_ORDER=1: heaviest-first order for persistent waves too (A/B)
-    int comp_prio = -1;     // wave issue priority follows the work item's weight: -1 auto, 0 off, 1 by item number, 2 by list length
     Buf totals;     // uint32[256]  digit totals of the current radix pass (rows in binning pass 2)
     Buf totals1;    // uint32[256]  column totals of binning pass 1
     Buf counters;   // uint32[16]: 0=V, 1=D, 2=overflow, 4=drawn, 6..7=pairs16 (u64), 8=probe
@@ -337,15 +326,17 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         ctx->ws_threads = c.frame_mode == MSPLAT_FRAMES_IN_FLIGHT ? (uint32_t)kWsThreadsSmall : (uint32_t)kWsThreads;
         ctx->bin_counts = c.frame_mode != MSPLAT_FRAMES_IN_FLIGHT;
         if (const char* sk = getenv("MSPLAT_SORT")) ctx->wide_sort = std::string(sk) != "lsd8";
-        if (const char* u2 = getenv("MSPLAT_WS_UP2")) ctx->ws_up2 = atoi(u2) != 0;
-        if (const char* wt = getenv("MSPLAT_WS_THREADS")) ctx->ws_threads = atoi(wt) == kWsThreadsSmall ? (uint32_t)kWsThreadsSmall : (uint32_t)kWsThreads;
         if (!ctx->atomic_rank) ctx->wide_sort = false;       // the wide kernels rank with lane-ordered LDS atomics only
         if (const char* tk = getenv("MSPLAT_TILE_TABLE")) ctx->bin_counts = std::string(tk) != "search";
-        if (getenv("MSPLAT_XCD_MAP")) ctx->xcd_map = atoi(getenv("MSPLAT_XCD_MAP"));
-        if (getenv("MSPLAT_HEAVY_SPLIT")) ctx->heavy_split = atoi(getenv("MSPLAT_HEAVY_SPLIT")) != 0;
         if (ctx->wide_sort) {
-            // ws_downsweep needs 72 / 104 KB of dynamic LDS with 512 threads (40 / 56 KB with 256): ask for it once
-            static const bool lds_ok = [] {
+            // ws_downsweep needs 72 / 104 KB of dynamic LDS with 512 threads (40 / 56 KB with 256).  The attribute belongs to
+            // the function ON A DEVICE (a kernel object per device): it is requested once per device, with that device current
+            // (a process-wide flag left devices 1.. of a msplat_group without it)
+            static std::mutex lds_mu;
+            static int lds_state[64];          // per device ordinal: 0 = not asked yet, 1 = granted, -1 = refused
+            const int dslot = ctx->device & 63;
+            std::lock_guard<std::mutex> lk(lds_mu);
+            if (lds_state[dslot] == 0) lds_state[dslot] = [] {
                 bool ok = true;
                 auto want = [&](const void* f, size_t bytes) { ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess; };
                 want(reinterpret_cast<const void*>(&ws_downsweep<true, 8, kWsThreads>), ws_downsweep_lds(8, kWsThreads));
@@ -356,21 +347,12 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
                 want(reinterpret_cast<const void*>(&ws_downsweep<false, 8, kWsThreadsSmall>), ws_downsweep_lds(8, kWsThreadsSmall));
                 want(reinterpret_cast<const void*>(&ws_downsweep<true, 16, kWsThreadsSmall>), ws_downsweep_lds(16, kWsThreadsSmall));
                 want(reinterpret_cast<const void*>(&ws_downsweep<false, 16, kWsThreadsSmall>), ws_downsweep_lds(16, kWsThreadsSmall));
-                return ok;
+                return ok ? 1 : -1;
             }();
-            if (!lds_ok) { (void)hipGetLastError(); ctx->wide_sort = false; }
+            if (lds_state[dslot] < 0) { (void)hipGetLastError(); ctx->wide_sort = false; }
         }
         ctx->wide_sort_cfg = ctx->wide_sort;
         if (const char* sk = getenv("MSPLAT_SORT")) ctx->ws_forced = std::string(sk) == "wide";
-        if (getenv("MSPLAT_FUSED_MAX_CHUNKS")) ctx->fused_max_chunks = (uint32_t)atoi(getenv("MSPLAT_FUSED_MAX_CHUNKS"));
-        if (const char* ck = getenv("MSPLAT_COMPOSITOR")) {
-            const std::string k = ck;
-            ctx->comp_kind = k == "half" ? 1 : k == "quad" ? 2 : 0;
-        }
-        if (getenv("MSPLAT_COMP_FTZ")) ctx->comp_ftz = atoi(getenv("MSPLAT_COMP_FTZ")) != 0;
-        if (getenv("MSPLAT_COMP_PRIO")) ctx->comp_prio = atoi(getenv("MSPLAT_COMP_PRIO"));
-        if (getenv("MSPLAT_COMP_ORDER")) ctx->comp_always_order = atoi(getenv("MSPLAT_COMP_ORDER")) != 0;
-        if (getenv("MSPLAT_COMP_XCD")) ctx->comp_xcd = atoi(getenv("MSPLAT_COMP_XCD"));
     }
     if (rc != MSPLAT_OK) {
         std::string msg = ctx->err;
@@ -621,13 +603,12 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
     if ((rc = alloc_group_table(ctx, ctx->gsumS[1], ctx->gsumS_rows, ctx->hist_stride, ctx->gsupS))) return rc;
     ctx->gsumS_rows = std::min(ctx->gsumS_rows, rows_s0);
     // frames in flight (256-thread form): three passes up to 2 M splats, the four 8-bit passes beyond -- measured r3 with 4
-    // frames in flight: 1 M 6045 vs 5880 frames/s, 6 M 1497 vs 1616 (tools/gpu_round3_ab5.sh)
+    // frames in flight: 1 M 6045 vs 5880 frames/s, 6 M 1497 vs 1616 (tools/archive/gpu_round3_ab5.sh)
     ctx->wide_sort = ctx->wide_sort_cfg && (ctx->ws_threads == (uint32_t)kWsThreads || n <= (2u << 20) || ctx->ws_forced);
     if (ctx->wide_sort) {
-        // 4096-key chunks up to 2 M splats, 8192 beyond (MSPLAT_WS_ITEMS = 8 | 16 overrides); groups of 16 chunk rows while
+        // 4096-key chunks up to 2 M splats, 8192 beyond; groups of 16 chunk rows while
         // there are at most 512 rows, else of 32 (a downsweep sums <= nchunks / G + G - 1 rows)
         ctx->ws_items = n > (2u << 20) ? 16u : 8u;
-        if (const char* wi = getenv("MSPLAT_WS_ITEMS")) ctx->ws_items = atoi(wi) == 16 ? 16u : 8u;
         // (the tables are sized for 8 keys per thread: passes 1 and 2 drop to that when few splats survive the cull, below)
         const uint32_t nch = std::max(1u, div_up(n, (uint64_t)ctx->ws_threads * 8u));
         ctx->ws_gshift = nch <= 512u ? 4u : 5u;
@@ -643,8 +624,7 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
     if ((rc = buf_alloc(ctx, ctx->rec2d, alloc_n * 48))) return rc;
     if ((rc = buf_alloc(ctx, ctx->rect, alloc_n * 4))) return rc;
     if (ctx->depth_bits != 0 && (rc = buf_alloc(ctx, ctx->zq, alloc_n * 4))) return rc;
-    ctx->bin_chunk = (uint32_t)kBinChunk;      // r3: 2048-rank chunks measured at 6 M: binning 183 -> 191 us (1080p), 459 -> 453 us (4096^2)
-    if (const char* bc = getenv("MSPLAT_BIN_CHUNK")) ctx->bin_chunk = atoi(bc) == kBinChunkLarge ? (uint32_t)kBinChunkLarge : (uint32_t)kBinChunk;
+    // (column pass: 1024-rank chunks; 2048 measured r3 at 6 M: binning 183 -> 191 us at 1080p, 459 -> 453 us at 4096^2)
     if ((rc = buf_alloc(ctx, ctx->heavy, (size_t)2 * (1 + kHeavyCap) * 4))) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->heavy.p, 0, ctx->heavy.bytes, ctx->stream));
     if ((rc = buf_alloc(ctx, ctx->heavy_flag, (size_t)div_up(alloc_n, kBinChunk) + 64))) return rc;
@@ -1119,7 +1099,7 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
         uint32_t items = items0;
         int wgrid = grid_for(div_up(N, ctx->ws_threads * items));
         const uint32_t* dV = d_V;
-        const int wsx = (ctx->xcd_map & 1) ? 1 : 0;
+        const int wsx = 1;          // XCD-contiguous chunk ranges in the downsweeps
 #define MSPLAT_WS_T(KERNEL, CULLF, LDS, T, ...)                                                                          \
     do {                                                                                                                \
         if (items == 16u) hipLaunchKernelGGL((KERNEL<CULLF, 16, T>), dim3(wgrid), dim3(T), LDS(16, T), s, __VA_ARGS__); \
@@ -1133,10 +1113,10 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
 #define MSPLAT_NO_LDS(I, T) 0
         // The upsweeps have no order to keep.  One frame at a time and 4096-key chunks (up to 2 M splats): twice the threads per
         // chunk, half the keys per thread -- 241 workgroups of 16 waves instead of 8 at 1 M: sort 57.4 -> 55.7 us.  Not at 6 M
-        // (158 -> 166 us) and not for frames in flight (-0.5 %): `tools/gpu_round3_q2.sh`; MSPLAT_WS_UP2=0|1 overrides.
+        // (158 -> 166 us) and not for frames in flight (-0.5 %): `tools/archive/gpu_round3_q2.sh`.
 #define MSPLAT_WS_UP(CULLF, ...)                                                                                        \
     do {                                                                                                                \
-        if (ctx->ws_up2 && items == 8u && ctx->ws_threads == (uint32_t)kWsThreads)                                      \
+        if (items == 8u && ctx->ws_threads == (uint32_t)kWsThreads)                                                     \
             hipLaunchKernelGGL((ws_upsweep<CULLF, 4, 2 * kWsThreads>), dim3(wgrid), dim3(2 * kWsThreads), 0, s, __VA_ARGS__); \
         else MSPLAT_WS(ws_upsweep, CULLF, MSPLAT_NO_LDS, __VA_ARGS__);                                                    \
     } while (0)
@@ -1163,16 +1143,21 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
             HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][1], s));
             ctx->sort_sets++;
         }
-        if (hipGetLastError() != hipSuccess) {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            // e.g. the dynamic-LDS request was not honoured on this device: later frames take the four 8-bit passes, which
+            // need no opt-in (this frame is lost; the tables are restored before the next one)
             ctx->tables_dirty = true;
-            return fail(ctx, MSPLAT_ERR_HIP, "msplat_sort: a kernel launch failed");
+            ctx->wide_sort = ctx->wide_sort_cfg = false;
+            return fail(ctx, MSPLAT_ERR_HIP, "msplat_sort: a kernel launch of the three-pass sort failed (%s); the context falls back "
+                        "to the 8-bit passes from the next frame on", hipGetErrorString(le));
         }
         ctx->has_sort = true;
         if (pending) return fail(ctx, MSPLAT_ERR_PAIR_OVERFLOW_EARLIER, "%s", pending_msg.c_str());
         return MSPLAT_OK;
     }
     // scan-free passes (2 launches each) while the chunk table is small, else upsweep + scan + downsweep
-    const bool fused = ctx->scan_free && div_up(N, chunk) <= ctx->fused_max_chunks;
+    const bool fused = ctx->scan_free && div_up(N, chunk) <= kFusedMaxChunks;
     auto gacc = [&](int pass) { return fused ? (uint32_t*)ctx->gsumS[pass & 1].p : nullptr; };
     auto gzero = [&](int pass) { return (uint32_t*)ctx->gsumS[(pass + 1) & 1].p; };      // always: keeps both tables clean
 #define MSPLAT_UPSWEEP(MODE, ...)                                                                                       \
@@ -1258,7 +1243,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     // pass 1: stable partition by tile column, enumerated from the rank-ordered rectangles
     uint32_t* totals1 = (uint32_t*)ctx->totals1.p;
     uint32_t* totals2 = (uint32_t*)ctx->totals.p;
-    const uint32_t bchunk = ctx->bin_chunk;
+    const uint32_t bchunk = (uint32_t)kBinChunk;
     const int g1 = grid_for(div_up(N, bchunk));
     // heavy chunks of the column pass (bin1_upsweep): list per frame parity, helper workgroups in front of the downsweep's grid
     uint32_t* hv_cur = (uint32_t*)ctx->heavy.p + (ctx->render_parity & 1u) * (1u + kHeavyCap);
@@ -1267,16 +1252,16 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     // helper workgroups for as many split chunks as an EARLIER frame asked for (host-mapped word, read without synchronising),
     // with headroom; a frame that needs more runs its extra heavy chunks unsplit and the next launch adapts
     const uint32_t last_heavy = ctx->h_flags ? __atomic_load_n(ctx->h_flags + 3, __ATOMIC_RELAXED) : 0u;
-    const uint32_t heavy_slots = (ctx->heavy_split && last_heavy != 0u) ? std::min<uint32_t>(kHeavyCap, 2u * last_heavy + 8u) : 0u;
+    const uint32_t heavy_slots = last_heavy != 0u ? std::min<uint32_t>(kHeavyCap, 2u * last_heavy + 8u) : 0u;
     const int nhelp = (int)(heavy_slots * (kHeavyParts - 1u));
     // scan-free variants while the chunk tables are small; the row pass's size (D) is only known on the device, so
     // its choice uses the D of an EARLIER frame that the binning kernel left in host-mapped memory (0 = none yet);
     // either variant is correct at any size, the choice only matters for speed
     // (r2, one-level group tables: the column pass's table was scanned by a kernel from 4096 rows on; with two levels every
     //  table that fits the supergroup rows is scan-free)
-    const bool fused1 = ctx->scan_free && div_up(N, bchunk) <= ctx->fused_max_chunks;
+    const bool fused1 = ctx->scan_free && div_up(N, bchunk) <= kFusedMaxChunks;
     const uint32_t last_D = ctx->h_flags ? __atomic_load_n(ctx->h_flags + 2, __ATOMIC_RELAXED) : 0u;
-    const bool fused2 = ctx->scan_free && last_D != 0u && div_up((uint64_t)last_D + (last_D >> 2), kPairChunk) <= ctx->fused_max_chunks &&
+    const bool fused2 = ctx->scan_free && last_D != 0u && div_up((uint64_t)last_D + (last_D >> 2), kPairChunk) <= kFusedMaxChunks &&
                         div_up(cap, kPairChunk) <= ctx->hist2_stride;                  // (the tables hold every chunk the capacity allows)
     uint32_t* gB1 = (uint32_t*)ctx->gsumB1.p;
     uint32_t* gB2 = (uint32_t*)ctx->gsumB2.p;
@@ -1293,27 +1278,27 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                                (const uint32_t*)ctx->rect.p, d_V, (const uint32_t*)ctx->hist1.p, ctx->hist1_stride,           \
                                (const uint32_t*)totals1, (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags,        \
                                async_overflow_flag ? 1 : 0, fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, \
-                               (ctx->xcd_map & 2) ? 1 : 0, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,         \
+                               0, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,                                  \
                                (uint32_t)nhelp, fp.tiles_x, ctx->gsupB1);                                                     \
         else                                                                                                                  \
             hipLaunchKernelGGL((bin1_downsweep<false, CH>), dim3(g1 + nhelp), dim3(kThreads), 0, s,                           \
                                (const uint32_t*)ctx->rect.p, d_V, (const uint32_t*)ctx->hist1.p, ctx->hist1_stride,           \
                                (const uint32_t*)totals1, (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags,        \
                                async_overflow_flag ? 1 : 0, fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, \
-                               (ctx->xcd_map & 2) ? 1 : 0, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,         \
+                               0, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,                                  \
                                (uint32_t)nhelp, fp.tiles_x, ctx->gsupB1);                                                     \
     } while (0)
     // (bin1_upsweep also clears the row pass's group table: its consumer, the previous frame's row downsweep, is long done)
-    if (bchunk == (uint32_t)kBinChunkLarge) MSPLAT_BIN1(kBinChunkLarge); else MSPLAT_BIN1(kBinChunk);
+    MSPLAT_BIN1(kBinChunk);
 #undef MSPLAT_BIN1
     // pass 2: stable partition by tile row (one generic radix pass on the top byte); words become (tx<<24)|rank
     // The heaviest-first order of the bins only pays when every work item has its own wave (the hardware then starts the
     // waves in item order: 83 -> 97 us without it at config 2); persistent waves that pull items from the queue balance
     // themselves: they walk the bins in storage order (`tile_order` + 65536 holds 0, 1, 2, ...).
-    const bool wave_comp = !ctx->point_mode && ctx->depth_bits == 0 && ctx->rop == 0 && ctx->comp_kind != 2;
-    const uint32_t comp_items = (uint32_t)ntiles * (ctx->comp_kind == 1 ? 8u : 4u);
+    const bool wave_comp = !ctx->point_mode && ctx->depth_bits == 0 && ctx->rop == 0;
+    const uint32_t comp_items = (uint32_t)ntiles * 4u;
     const uint32_t comp_pool = (ctx->comp_waves_auto && comp_items <= 20480u) ? comp_items : (uint32_t)ctx->comp_waves;
-    const bool ordered = !(wave_comp && comp_pool < comp_items) || ctx->comp_always_order;
+    const bool ordered = !(wave_comp && comp_pool < comp_items);
     // r3: the upsweep of the row pass also counts the pairs per bin, and one extra workgroup of its downsweep turns the
     // counts into the list offsets (+ the heaviest-first order when it is wanted): tile_start_kernel / tile_order_kernel
     // are not launched (MSPLAT_TILE_TABLE=search brings them back for comparison)
@@ -1331,14 +1316,14 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                            (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
                            (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1,
                            fused2 ? (const uint32_t*)gB2 : nullptr, fused2 ? totals2 : nullptr, fp, bincnt,
-                           (uint32_t*)ctx->tile_start.p, (uint32_t*)ctx->tile_order.p, d_queue, ntiles, (ordered ? 1 : 0) | ((ctx->xcd_map & 4) ? 2 : 0), ctx->gsupB2);
+                           (uint32_t*)ctx->tile_start.p, (uint32_t*)ctx->tile_order.p, d_queue, ntiles, (ordered ? 1 : 0) | 2, ctx->gsupB2);
     else
         hipLaunchKernelGGL((radix_downsweep<MODE_PAIR, false, false>), dim3(g2d), dim3(kThreads), 0, s,
                            (const uint32_t*)ctx->pairsA.p, nullptr, nullptr, d_D, 0u, cap, 24,
                            (const uint32_t*)ctx->hist2.p, ctx->hist2_stride, (const uint32_t*)totals2,
                            (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1,
                            fused2 ? (const uint32_t*)gB2 : nullptr, fused2 ? totals2 : nullptr, fp, bincnt,
-                           (uint32_t*)ctx->tile_start.p, (uint32_t*)ctx->tile_order.p, d_queue, ntiles, (ordered ? 1 : 0) | ((ctx->xcd_map & 4) ? 2 : 0), ctx->gsupB2);
+                           (uint32_t*)ctx->tile_start.p, (uint32_t*)ctx->tile_order.p, d_queue, ntiles, (ordered ? 1 : 0) | 2, ctx->gsupB2);
     if (!bincnt) {
         hipLaunchKernelGGL(tile_start_kernel, dim3(std::max(1, (ntiles + kTileStartBins - 1) / kTileStartBins)), dim3(kThreads), 0, s,
                            (const uint32_t*)ctx->pairsB.p, (const uint32_t*)totals2, d_D, cap, fp.tiles_x, ntiles,
@@ -1394,39 +1379,17 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         const float4* r2 = (const float4*)ctx->rec2d.p;
         const uint32_t* ord = (const uint32_t*)ctx->tile_order.p + (ordered ? 0 : 65536);
         const bool f16 = ctx->cfg.fb_format == MSPLAT_FB_RGBA16F;
-        if (ctx->comp_kind == 2) {
-            // four waves per tile: the pool is counted in workgroups of four waves
-            const int qgrid = std::min(ntiles * 4, std::max(64, ctx->comp_waves / 4));
-            if (f16)
-                hipExtLaunchKernelGGL(composite_quad_kernel<true>, dim3(qgrid), dim3(kQuadThreads), 0, s, e0, e1, 0, ts, pb, r2,
-                                      d_out, pitch, fp, cap, ord, d_queue, (uint32_t)ntiles * 4u, probe);
-            else
-                hipExtLaunchKernelGGL(composite_quad_kernel<false>, dim3(qgrid), dim3(kQuadThreads), 0, s, e0, e1, 0, ts, pb, r2,
-                                      d_out, pitch, fp, cap, ord, d_queue, (uint32_t)ntiles * 4u, probe);
-        } else {
-            // one wave per 16x8 half tile (twice the work items) or per 16x16 tile
-            const bool half = ctx->comp_kind == 1;
-            const uint32_t nitems = comp_items, pool = comp_pool;
-            // wave issue priority: by item number where the items are numbered heaviest-first, by the bin's list length where
-            // persistent waves walk the bins in storage order (the item number says nothing there);
-            // MSPLAT_COMP_PRIO = 0 none, 1 item number, 2 list length; unset: by item number for ordered items, none for
-            // persistent waves (r3, 4 frames in flight at config 2: 0 / 1 / 2 -> 5.82 / 5.76 / 5.79 k frames/s, i.e. no effect)
-            const int prio_mode = ctx->comp_prio < 0 ? (ordered ? 1 : 0) : ctx->comp_prio;
-            const int grid = (int)std::min<uint32_t>(nitems, pool);
-#define MSPLAT_LAUNCH_COMP(F16, NP, OCC, FZ)                                                                          \
-    hipExtLaunchKernelGGL((composite_kernel<F16, NP, OCC, FZ>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, \
-                          d_out, pitch, fp, cap, ord, d_queue, nitems, probe, prio_mode, ctx->comp_xcd)
-#define MSPLAT_LAUNCH_COMP_F(NP, OCC, FZ) do { if (f16) MSPLAT_LAUNCH_COMP(true, NP, OCC, FZ); else MSPLAT_LAUNCH_COMP(false, NP, OCC, FZ); } while (0)
-            if (half) {                          // experiment: one wave per 16x8 half tile
-                MSPLAT_LAUNCH_COMP_F(1, 6, false);
-            } else if (ctx->comp_ftz) {
-                MSPLAT_LAUNCH_COMP_F(2, 5, true);
-            } else {
-                MSPLAT_LAUNCH_COMP_F(2, 5, false);
-            }
-#undef MSPLAT_LAUNCH_COMP_F
-#undef MSPLAT_LAUNCH_COMP
-        }
+        // wave issue priority by item number where the items are numbered heaviest-first (every item on its own wave); none for
+        // persistent waves that walk the bins in storage order (r3, 4 frames in flight: none / by item number / by list length
+        // = 5.82 / 5.76 / 5.79 k frames/s, i.e. no effect there)
+        const int prio_mode = ordered ? 1 : 0;
+        const int grid = (int)std::min<uint32_t>(comp_items, comp_pool);
+        if (f16)
+            hipExtLaunchKernelGGL(composite_kernel<true>, dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
+                                  cap, ord, d_queue, comp_items, probe, prio_mode);
+        else
+            hipExtLaunchKernelGGL(composite_kernel<false>, dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
+                                  cap, ord, d_queue, comp_items, probe, prio_mode);
         ctx->comp_kernel_timed = timed;
     } else {
         ctx->comp_kernel_timed = false;
@@ -1663,8 +1626,8 @@ int msplat_debug_get_tile_probe8(msplat_ctx* ctx, uint32_t* dst, uint32_t tile_c
     if (!ctx->has_render) return fail(ctx, MSPLAT_ERR_NO_SORT, "no render yet");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t ntiles = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y) * (ctx->comp_kind == 1 ? 8u : 4u);   // work items
-    if (tile_cap < ntiles) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile capacity too small (work items = bins x %u)", ctx->comp_kind == 1 ? 8u : 4u);
+    const uint32_t ntiles = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y) * 4u;   // work items = (bin, quadrant)
+    if (tile_cap < ntiles) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile capacity too small (work items = bins x 4)");
     HIP_TRY(ctx, hipMemcpy(dst, ctx->probe.p, (size_t)ntiles * kProbeWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return MSPLAT_OK;
 }
@@ -1679,7 +1642,7 @@ int msplat_get_composite_work(msplat_ctx* ctx, msplat_composite_work* out)
     if (!ctx->probe.p || !ctx->probe_on)
         return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile probe not enabled (msplat_set_tile_probe)");
     if (!ctx->has_render) return fail(ctx, MSPLAT_ERR_NO_SORT, "no render yet");
-    const uint32_t items = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y) * (ctx->comp_kind == 1 ? 8u : 4u);
+    const uint32_t items = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y) * 4u;
     std::vector<uint32_t> h;
     try {
         h.resize((size_t)items * kProbeWords);
@@ -1694,8 +1657,8 @@ int msplat_get_composite_work(msplat_ctx* ctx, msplat_composite_work* out)
         out->work_items += 1;
         out->clocks_sum += p[0];
         out->clocks_max = std::max<uint64_t>(out->clocks_max, p[0]);
-        out->records_composited += p[1];        // one wave per tile: records; four waves per tile: (record, sub-block) pairs
-        out->pixel_evals += (uint64_t)p[1] * (p[7] == 2u ? 64u : p[7] == 3u ? 128u : (uint64_t)(kTile * kTile));
+        out->records_composited += p[1];
+        out->pixel_evals += (uint64_t)p[1] * (uint64_t)(kTile * kTile);
         out->batches += p[2];
         out->inner_clocks_sum += p[3];
         out->pair_words_fetched += p[4];

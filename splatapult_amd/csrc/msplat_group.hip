@@ -88,7 +88,10 @@ struct msplat_group {
     int kind = MSPLAT_BANDS_CONTIGUOUS, block_rows = 1;
     bool band_cull = false;
     int planned_rows = -1;                             // rows_full the contexts' layouts were set for
+    hipEvent_t order_ev = nullptr;                     // "everything queued on context 0's stream so far" (msplat_group_render)
     std::string err;
+    std::vector<std::string> rank_err;                 // [i]: text of a failure on rank i's worker thread that is not the
+                                                       // context's own (HIP calls of the staged exchange); merged by for_all
 };
 
 namespace {
@@ -107,11 +110,25 @@ int gfail(msplat_group* g, int code, const char* fmt, ...)
     return code;
 }
 
+// failure inside rank i's part of a for_all (possibly on a worker thread): the text goes to the rank's own slot -- several
+// ranks may fail at once (they raced on g->err) -- and for_all reports it from the caller's thread
+int rfail(msplat_group* g, uint32_t i, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g->rank_err[i] = buf;
+    return code;
+}
+
 // runs f(i) for every rank: ranks >= 1 on their worker threads, rank 0 on the caller's; returns the first real error
 // (MSPLAT_ERR_PAIR_OVERFLOW[_EARLIER] -- a deferred report about an EARLIER frame -- only if nothing worse happened)
 int for_all(msplat_group* g, const std::function<int(uint32_t)>& f)
 {
     const uint32_t n = (uint32_t)g->ctx.size();
+    for (auto& e : g->rank_err) e.clear();
     for (uint32_t i = 1; i < n; ++i) g->workers[i - 1]->post([&f, i] { return f(i); });
     std::vector<int> rc(n, MSPLAT_OK);
     rc[0] = f(0);
@@ -123,7 +140,8 @@ int for_all(msplat_group* g, const std::function<int(uint32_t)>& f)
             if (!soft) { soft = rc[i]; g->err = msplat_last_error(g->ctx[i]); }
             continue;
         }
-        g->err = std::string("device ") + std::to_string(g->devices[i]) + ": " + msplat_last_error(g->ctx[i]);
+        g->err = std::string("device ") + std::to_string(g->devices[i]) + ": " +
+                 (g->rank_err[i].empty() ? std::string(msplat_last_error(g->ctx[i])) : g->rank_err[i]);
         g_group_error = g->err;
         return rc[i];
     }
@@ -196,6 +214,12 @@ int msplat_group_create(msplat_group** out, const int32_t* devices, uint32_t n, 
     g->peer_store.assign(n, true);
     g->stage.assign(n, nullptr);
     g->stage_bytes.assign(n, 0);
+    g->rank_err.assign(n, std::string());
+    if (n > 1 && (hipSetDevice(devices[0]) != hipSuccess || hipEventCreateWithFlags(&g->order_ev, hipEventDisableTiming) != hipSuccess)) {
+        gfail(nullptr, MSPLAT_ERR_HIP, "msplat_group_create: cannot create the ordering event on device %d", devices[0]);
+        msplat_group_destroy(g);
+        return MSPLAT_ERR_HIP;
+    }
     // peer mapping towards device 0: the other devices' compositors then write their rows into its framebuffer directly
     for (uint32_t i = 1; i < n; ++i) {
         if (devices[i] == devices[0]) continue;            // same device (tests): plain device memory
@@ -231,6 +255,7 @@ void msplat_group_destroy(msplat_group* g)
         if (i < g->stage.size() && g->stage[i]) { (void)hipSetDevice(g->devices[i]); (void)hipFree(g->stage[i]); }
         msplat_destroy(g->ctx[i]);
     }
+    if (g->order_ev) { (void)hipSetDevice(g->devices[0]); (void)hipEventDestroy(g->order_ev); }
     delete g;
 }
 
@@ -301,12 +326,23 @@ int msplat_group_render(msplat_group* g, const float cameraMat[16], const float 
     const size_t bpp = g->fb_format == MSPLAT_FB_RGBA16F ? 8 : 16;
     const size_t tight = (size_t)W * bpp;
     if (pitch_bytes == 0) pitch_bytes = tight;
+    if (W < 1 || H < 1 || pitch_bytes < tight || pitch_bytes % bpp != 0)
+        return gfail(g, MSPLAT_ERR_INVALID_ARG, "msplat_group_render: pitch %llu too small / misaligned for a %dx%d target of %zu bytes per pixel",
+                     (unsigned long long)pitch_bytes, W, H, bpp);
     if (!out_is_device)         // host image: every context copies its own rows into it (msplat_render's band rule)
         return for_all(g, [&](uint32_t i) { return msplat_render(g->ctx[i], cameraMat, projMat, viewport, nearFar, rgba, pitch_bytes, 0); });
 
+    // The frame inherits context 0's stream order on EVERY rank: whatever the caller queued on that stream before
+    // this call -- typically the consumer of the previous frame in the same framebuffer -- is finished before any rank's
+    // compositor or row copy writes into `rgba`, exactly as with a single context.  One event record + n - 1 stream waits.
     void* stream0 = msplat_get_stream(g->ctx[0]);
+    if (n > 1) {
+        if (hipSetDevice(g->devices[0]) != hipSuccess || hipEventRecord(g->order_ev, (hipStream_t)stream0) != hipSuccess)
+            return gfail(g, MSPLAT_ERR_HIP, "msplat_group_render: cannot record the ordering event on device %d", g->devices[0]);
+    }
     rc = for_all(g, [&](uint32_t i) -> int {
         msplat_ctx* c = g->ctx[i];
+        if (i != 0) { const int j = msplat_wait_event(c, g->order_ev); if (j) return j; }
         if (i == 0 || g->peer_store[i]) {
             // zero-copy: this device's compositor writes its rows where they belong in device 0's framebuffer
             int r = msplat_render(c, cameraMat, projMat, viewport, nearFar, rgba, pitch_bytes, 1);
@@ -315,14 +351,14 @@ int msplat_group_render(msplat_group* g, const float cameraMat[16], const float 
             return r;
         }
         // no peer mapping: render into a local image, then one copy per run of consecutive owned rows
-        if (hipSetDevice(g->devices[i]) != hipSuccess) return gfail(g, MSPLAT_ERR_HIP, "hipSetDevice(%d) failed", g->devices[i]);
+        if (hipSetDevice(g->devices[i]) != hipSuccess) return rfail(g, i, MSPLAT_ERR_HIP, "hipSetDevice(%d) failed", g->devices[i]);
         const size_t need = tight * (size_t)H;
         if (g->stage_bytes[i] < need) {
             (void)msplat_synchronize(c);
             if (g->stage[i]) (void)hipFree(g->stage[i]);
             g->stage[i] = nullptr;
             g->stage_bytes[i] = 0;
-            if (hipMalloc(&g->stage[i], need) != hipSuccess) return gfail(g, MSPLAT_ERR_HIP, "staging framebuffer: out of device memory");
+            if (hipMalloc(&g->stage[i], need) != hipSuccess) return rfail(g, i, MSPLAT_ERR_HIP, "staging framebuffer: out of device memory");
             g->stage_bytes[i] = need;
         }
         int r = msplat_render(c, cameraMat, projMat, viewport, nearFar, g->stage[i], tight, 1);
@@ -330,7 +366,7 @@ int msplat_group_render(msplat_group* g, const float cameraMat[16], const float 
         int32_t first, count, block, stride;
         const int rows_full = (H + T - 1) / T;
         int pr = msplat_band_plan(g->kind, rows_full, (int32_t)n, (int32_t)i, g->block_rows, &first, &count, &block, &stride);
-        if (pr) return pr;
+        if (pr) return rfail(g, i, pr, "%s", msplat_last_error(nullptr));
         hipStream_t s = (hipStream_t)msplat_get_stream(c);
         for (int v = 0; v < count;) {
             const int k = v / block, row = first + k * stride + (v - k * block);
@@ -340,7 +376,7 @@ int msplat_group_render(msplat_group* g, const float cameraMat[16], const float 
             if (nrows <= 0) break;
             if (hipMemcpy2DAsync((char*)rgba + (size_t)y0 * pitch_bytes, pitch_bytes, (const char*)g->stage[i] + (size_t)y0 * tight,
                                  tight, tight, (size_t)nrows, hipMemcpyDeviceToDevice, s) != hipSuccess)
-                return gfail(g, MSPLAT_ERR_HIP, "hipMemcpy2DAsync (device %d -> %d) failed", g->devices[i], g->devices[0]);
+                return rfail(g, i, MSPLAT_ERR_HIP, "hipMemcpy2DAsync (device %d -> %d) failed", g->devices[i], g->devices[0]);
         }
         const int j = msplat_stream_wait(c, stream0);
         return j ? j : r;

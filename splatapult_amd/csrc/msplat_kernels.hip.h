@@ -32,7 +32,6 @@ constexpr int kBinChunk = 1024;          // draw-order ranks per chunk in the ti
 constexpr uint32_t kHeavyPairs = 49152;  // a column-pass chunk with more pairs than this is split over kHeavyParts workgroups
 constexpr uint32_t kHeavyCap = 128;      // at most this many split chunks per frame (the rest run unsplit: correct, slower)
 constexpr uint32_t kHeavyParts = 8;      // column blocks per split chunk
-constexpr int kBinChunkLarge = 2048;     // MSPLAT_BIN_CHUNK=2048: a (chunk, column) run of pair words twice as long; measured r3 at 6 M splats: no gain
 constexpr int kTile = 16;                // one compositor wave owns a 16x16 pixel tile ...
 constexpr int kBin = 32;                 // ... binning works on 32x32 bins (4 tiles share one list, each
                                          // wave filters it for its own quadrant): 2.2-2.9x fewer pairs
@@ -1953,7 +1952,7 @@ __global__ __launch_bounds__(kThreads) void verify_order_kernel(const uint32_t* 
 // half-tile launch pulling 8 k items from one head spent ~90 us queueing), so the head is sharded: item i lives
 // in shard i % 32, a workgroup pulls from the shard of its index and, when that one is drained, from up to two
 // neighbours (checked with a plain load first, so drained shards are not hammered by the exiting waves).
-// Where the items are numbered heaviest-first (every item on its own wave, or MSPLAT_COMP_ORDER=1) every shard hands out its
+// Where the items are numbered heaviest-first (every item on its own wave) every shard hands out its
 // share heaviest-first too; persistent waves otherwise walk the bins in storage order (`tile_order` + 65536).  The first item
 // of every workgroup is static (its own index): queue[s] counts only the items of shard s taken dynamically.
 __device__ __forceinline__ uint32_t queue_next(uint32_t* __restrict__ queue, uint32_t nitems)
@@ -2027,38 +2026,28 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
 // ------------------------------------------------------------------------------------------
 
 constexpr int kCompThreads = 64;   // one wave per 16x16 tile, 4 pixels (one per 16x4 strip) per lane
+constexpr int kCompOcc = 5;        // waves per SIMD the register allocation leaves room for (76 VGPRs; 6+ measured slower)
 
-// NP = strip pairs per work item: 2 = the whole 16x16 tile (work item = (bin, quadrant)), 1 = one 16x8 HALF tile
-// (work item = (bin, quadrant, half)).  Round-2 measurements behind the half-tile form: the launch
-// lasts exactly as long as its heaviest work item (the heaviest tile needs 2.4x the mean and finishes alone on its
-// SIMD, where one wave issues VALU at a quarter of the SIMD's rate); a half tile sees 79 % of its tile's
-// records, so two halves cost 0.84 of the tile, with half the dependent chain and twice the work items for the queue.
-// 64 pixels per wave (four waves per tile, composite_quad_kernel below) is NOT the next step: every record costs
-// ~10 LDS-pipe cycles per wave however few pixels the wave owns, and at 64 pixels the four SIMDs of a CU ask for
-// more broadcast reads than its one LDS pipe delivers.
-// OCC = waves per SIMD the register allocation must leave room for (__launch_bounds__).  The kernel is VALU bound:
-// 21.5 VALU instructions per record in the inner loop (12 packed, 4 v_exp_f32, 3 scalar FMAs: ~147 pipe cycles) and
-// ~70 per staged batch; it takes 76 VGPRs (six waves per SIMD).  Measured: more resident waves do not help.
-// FTZ: the fragment shader's discard (w <= 1/256, splat_frag.glsl:37-40) costs a compare and a select per pixel in
-// a loop that then had ~9 instructions per (pixel, record).  Here it is free: the exponent is biased by -118, so that
-// w' = exp2(e - 118) is a NORMAL float exactly when e >= -8 and underflows otherwise, and the wave runs with fp32
-// denormals flushed (MODE.FP_DENORM, set below): the underflowing weights come out of v_exp_f32 as exact zeros.
-// The transmittance is carried scaled by 2^118 (Ts = 2^118 T), so tw = Ts w' = T w exactly as before (powers of
-// two), colours accumulate unchanged and Ts -= 2^118 tw.  The bias costs 4 bits of the exponent's absolute
-// precision (|e - 118| ~ 2^7 instead of <= 2^3): a relative error of 3e-6 in w.  Only e == -8 exactly (w == 1/256,
-// which the reference discards) is kept: a measure-zero threshold flip.
-// (r3, measured and removed: a per-record mask of the strip PAIRS its y reach touches, with a scalar branch over the other
-//  pair's packed instructions -- 80 -> 105 us at config 2, 404 -> 530 us at config 4: the two pairs are independent
-//  dependency chains inside one basic block that the in-order wave overlaps; a branch per pair serialises them.  DESIGN.md 4.)
-template <bool HALF, int NP, int OCC, bool FTZ>
-__global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint32_t* __restrict__ tile_start,
+// Work item = (bin, quadrant): one wave composites one 16x16 tile of a 32x32 bin.  The kernel is VALU bound: 21.5 VALU
+// instructions per record in the inner loop (12 packed, 4 v_exp_f32, 3 scalar FMAs: ~147 pipe cycles) and ~70 per staged
+// batch.  Formulations that were built, measured and removed (numbers in DESIGN.md 4): four waves per tile with 8x8 sub-block
+// queues (LDS-pipe bound), one wave per 16x8 half tile, per-strip-pair masks, 6-8 waves per SIMD.
+// Discard by underflow: the fragment shader's discard (w <= 1/256, splat_frag.glsl:37-40) would cost a compare and a select
+// per pixel.  Here it is free: the exponent is biased by -118, so that w' = exp2(e - 118) is a NORMAL float exactly when
+// e >= -8 and underflows otherwise, and the wave runs with fp32 denormals flushed (MODE.FP_DENORM, set below): the
+// underflowing weights come out of v_exp_f32 as exact zeros.  The transmittance is carried scaled by 2^118 (Ts = 2^118 T), so
+// tw = Ts w' = T w exactly as before (powers of two), colours accumulate unchanged and Ts -= 2^118 tw.  The bias costs 4 bits
+// of the exponent's absolute precision (|e - 118| ~ 2^7 instead of <= 2^3): a relative error of 3e-6 in w.  Only e == -8
+// exactly (w == 1/256, which the reference discards) is kept: a measure-zero threshold flip.
+template <bool F16>
+__global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const uint32_t* __restrict__ tile_start,
                                                                  const uint32_t* __restrict__ pairs,
                                                                  const float4* __restrict__ rec,
                                                                  void* __restrict__ out, size_t pitch_bytes,
                                                                  FrameParams fp, uint32_t cap,
                                                                  const uint32_t* __restrict__ order,
                                                                  uint32_t* __restrict__ queue, uint32_t ntiles,
-                                                                 uint32_t* __restrict__ probe, int prio_levels, int xcd_affinity)
+                                                                 uint32_t* __restrict__ probe, int prio_levels)
 {
     // Lane (lx, ly) owns pixels (x0+lx, y0 + 4k + ly), k = 0..3: strip k is the 16x4 pixel block of
     // rows 4k..4k+3.  Per splat the exponent is split into a part shared by the four strips and a
@@ -2071,21 +2060,21 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
     // The first tile of every wave is static (its workgroup index): same-address atomics are served
     // at only ~8 ns each, so thousands of waves pulling at launch would queue up for tens of us.
     // Work item = (bin, quadrant): the four 16x16 tiles of a 32x32 bin share the bin's list.
-    constexpr float kBias = FTZ ? 118.0f : 0.0f;
-    constexpr float kScale = FTZ ? 0x1p118f : 1.0f;
-    if (FTZ) __builtin_amdgcn_s_setreg(1 | (4 << 6) | ((2 - 1) << 11), 0);      // MODE[5:4] = 0: flush fp32 denormals
+    constexpr float kBias = 118.0f;
+    constexpr float kScale = 0x1p118f;
+    __builtin_amdgcn_s_setreg(1 | (4 << 6) | ((2 - 1) << 11), 0);      // MODE[5:4] = 0: flush fp32 denormals
+    constexpr int NP = 2;                            // strip pairs per work item (the whole 16x16 tile)
     constexpr int NS = 2 * NP;                       // 16x4 strips per work item
     constexpr int ROWS = 4 * NS;                     // pixel rows per work item
     for (uint32_t qpos = blockIdx.x; qpos < ntiles;) {
     const int tile = (int)qpos;                       // probe slot
-    const uint32_t tpos = (NP == 2) ? qpos : (qpos >> 1);          // (bin, quadrant) index
-    const int half = (NP == 2) ? 0 : (int)(qpos & 1u);            // which 16x8 half of the tile
+    const uint32_t tpos = qpos;                       // (bin, quadrant) index
     // The four tiles of a bin walk the SAME list, and workgroup b runs on XCD b % 8 (each XCD has its own L2): inside every
     // group of 32 items the quadrants of one bin are the items r, r + 8, r + 16, r + 24, i.e. on one XCD, as the first
     // (static) item of a wave and -- shard = item % 32, home shard = workgroup % 32 -- as a pulled one.  Three of the four
     // waves then find the list words and records in their XCD's L2 instead of fetching them from HBM again.
     uint32_t slot = tpos >> 2, quadrant = tpos & 3u;
-    if (xcd_affinity && tpos < (((NP == 2) ? ntiles : (ntiles >> 1)) & ~31u)) {
+    if (tpos < (ntiles & ~31u)) {
         slot = (tpos >> 5) * 8u + (tpos & 7u);
         quadrant = (tpos >> 3) & 3u;
     }
@@ -2094,7 +2083,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
     const int bvy = bin / fp.tiles_x;
     const int tx = (bin - bvy * fp.tiles_x) * 2 + (quad & 1);
     const int ty = band_real_row(fp, bvy) * 2 + (quad >> 1);
-    if (tx * kTile >= fp.width || ty * kTile + half * ROWS >= fp.height) {      // work item entirely outside the image
+    if (tx * kTile >= fp.width || ty * kTile >= fp.height) {      // work item entirely outside the image
         if (gridDim.x >= ntiles) break;
         uint32_t nq = 0;
         if (threadIdx.x == 0) nq = queue_next(queue, ntiles);
@@ -2116,23 +2105,14 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
     }
     const int lane = threadIdx.x;
     const int lx = lane & 15, ly = lane >> 4;
-    const int x = tx * kTile + lx, ybase = ty * kTile + half * ROWS + ly;
+    const int x = tx * kTile + lx, ybase = ty * kTile + ly;
     const float fx = (float)x + 0.5f;
     const float fy0 = (float)ybase + 0.5f;
-    const float tile_y0 = (float)(ty * kTile + half * ROWS);
+    const float tile_y0 = (float)(ty * kTile);
 
     uint32_t start = tile_start[bin], end = tile_start[bin + 1];
     if (start > cap) start = cap;
     if (end > cap) end = cap;
-    if (prio_levels == 2) {
-        // items in storage order (persistent waves): the weight is the bin's list length against the mean list length
-        const uint32_t nbins = (uint32_t)(fp.tiles_x * fp.tiles_y);
-        const uint32_t mean = tile_start[nbins] / max(nbins, 1u), len = end - start;
-        if (len >= 2u * mean) __builtin_amdgcn_s_setprio(3);
-        else if (4u * len >= 5u * mean) __builtin_amdgcn_s_setprio(2);
-        else if (4u * len >= 3u * mean) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-    }
 
     // Accumulators are kept as strip PAIRS (0,1) and (2,3): gfx950 executes a plain wave64 fp32 VALU
     // op in ~4 cycles but a packed v_pk_{fma,mul,add}_f32 does two per lane in the same slot (measured:
@@ -2142,7 +2122,7 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
     bool inside[NS];
 #pragma unroll
     for (int h = 0; h < NP; ++h) {
-        T[h] = (v2f){kScale, kScale};                // FTZ: the transmittance scaled by 2^118
+        T[h] = (v2f){kScale, kScale};                // the transmittance scaled by 2^118
         cr[h] = (v2f){0.0f, 0.0f}; cg[h] = (v2f){0.0f, 0.0f}; cb[h] = (v2f){0.0f, 0.0f};
     }
 #pragma unroll
@@ -2282,20 +2262,14 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
                 for (int h = 0; h < NP; ++h) {
                     const v2f e = __builtin_elementwise_fma(vp[h], __builtin_elementwise_fma(vC, vp[h], vlin), vbase);
                     // splat_frag.glsl:37-40 discard: w = exp2(e) > 1/256  <=>  e > -8
-                    v2f w;
-                    if (FTZ) {       // discard by underflow (see the kernel's header)
-                        w.x = __builtin_amdgcn_exp2f(e.x);
-                        w.y = __builtin_amdgcn_exp2f(e.y);
-                    } else {
-                        w.x = (e.x > -8.0f) ? __builtin_amdgcn_exp2f(e.x) : 0.0f;
-                        w.y = (e.y > -8.0f) ? __builtin_amdgcn_exp2f(e.y) : 0.0f;
-                    }
+                    v2f w;           // discard by underflow (see the kernel's header)
+                    w.x = __builtin_amdgcn_exp2f(e.x);
+                    w.y = __builtin_amdgcn_exp2f(e.y);
                     const v2f tw = T[h] * w;
                     cr[h] = __builtin_elementwise_fma(tw, vr, cr[h]);
                     cg[h] = __builtin_elementwise_fma(tw, vg, cg[h]);
                     cb[h] = __builtin_elementwise_fma(tw, vb, cb[h]);
-                    if (FTZ) T[h] = __builtin_elementwise_fma(tw, (v2f){-kScale, -kScale}, T[h]);
-                    else T[h] = T[h] - tw;
+                    T[h] = __builtin_elementwise_fma(tw, (v2f){-kScale, -kScale}, T[h]);
                 }
                 a = na; b = nb; c4 = nc4;
             }
@@ -2318,13 +2292,13 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
         probe[tile * 8 + 4] = probe_words;      // 4-byte pair words loaded
         probe[tile * 8 + 5] = probe_recs;       // 48-byte projected records loaded
         probe[tile * 8 + 6] = end - start;      // length of the bin list
-        probe[tile * 8 + 7] = (NP == 2) ? 1u : 3u;      // work item ran; 1 = 256, 3 = 128 evaluations per composited record
+        probe[tile * 8 + 7] = 1u;               // work item ran
     }
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         if (inside[k]) {
             char* row = (char*)out + (size_t)(ybase + 4 * k) * pitch_bytes;
-            if (HALF) {
+            if (F16) {
                 union { _Float16 h[4]; uint2 u; } pk;
                 pk.h[0] = (_Float16)cr[k >> 1][k & 1]; pk.h[1] = (_Float16)cg[k >> 1][k & 1]; pk.h[2] = (_Float16)cb[k >> 1][k & 1]; pk.h[3] = (_Float16)1.0f;
                 ((uint2*)row)[x] = pk.u;
@@ -2339,248 +2313,6 @@ __global__ __launch_bounds__(kCompThreads, OCC) void composite_kernel(const uint
     if (threadIdx.x == 0) nq = queue_next(queue, ntiles);
     qpos = __builtin_amdgcn_readfirstlane(nq);
     }   // persistent tile loop
-}
-
-// ------------------------------------------------------------------------------------------
-// composite, second formulation (round 2): ONE WORKGROUP OF FOUR WAVES per 16x16 tile, wave w owns the
-// 8x8 sub-block (w & 1, w >> 1) with ONE pixel per lane.
-//
-// Why (measured on the one-wave-per-tile kernel above, config 2):
-//  * its launch lasts exactly as long as its heaviest tile -- 8 k tiles on 8 k resident waves, the
-//    heaviest needs 2.4x the mean and ends alone on its SIMD, where a single wave issues VALU at a quarter
-//    of the SIMD's rate (tools/ubench_valu: 5.2 vs 1.4 clocks per instruction at 1 vs 8 waves): wave slots are
-//    41 % occupied on average.  Four waves per tile cut every tile's dependent chain by four and
-//    leave 4x more work items than workgroup slots for the dynamic queue to balance;
-//  * only 36 % of the (pixel, record) evaluations of a 16x16 tile lie inside the record's footprint; an 8x8
-//    sub-block sees 62 % of its tile's records (exact test), so the sub-block queues drop 38 % of the
-//    evaluations, and packing two pixels per lane buys only 7 % on gfx950 (v_pk_fma_f32 takes 1.87x a
-//    v_fma_f32), so one pixel per lane costs little.
-//
-// Per batch of 128 list entries (nearest first): threads 0..127 turn their prefetched record into the
-// coefficients of  e(u, v) = c0 + c1 u + c2 v + c3 u^2 + c4 u v + c5 v^2  in TILE-CENTRED pixel coordinates
-// (|u|, |v| <= 7.5: no cancellation trouble) and put them in LDS; every wave then tests the 128 records
-// exactly against its own sub-block (maximum of the concave quadratic over the box of pixel centres) and
-// keeps the survivors' slot numbers in a wave-private queue, in list order; the inner loop walks that queue.
-// Nothing crosses waves except the record array and one "still alive" flag per sub-block: two barriers
-// per batch.  Per pixel the records are blended in exactly the list order, whatever the scheduling.
-// ------------------------------------------------------------------------------------------
-constexpr int kQuadThreads = 256;
-constexpr int kQuadBatch = 128;
-
-template <bool HALF>
-__global__ __launch_bounds__(kQuadThreads) void composite_quad_kernel(const uint32_t* __restrict__ tile_start,
-                                                                      const uint32_t* __restrict__ pairs,
-                                                                      const float4* __restrict__ rec,
-                                                                      void* __restrict__ out, size_t pitch_bytes,
-                                                                      FrameParams fp, uint32_t cap,
-                                                                      const uint32_t* __restrict__ order,
-                                                                      uint32_t* __restrict__ queue, uint32_t nitems,
-                                                                      uint32_t* __restrict__ probe)
-{
-    // per entry of the batch: {c0, c1, c2, c3} {c4, c5, r, g} {b, a, b, -}   (a, b = splat centre, tile coordinates)
-    __shared__ float4 s_rec[kQuadBatch * 3];
-    // wave-private queues of the records that reach the wave's sub-block (64 entries are tested at a time)
-    __shared__ float4 s_q0[4][64 + 1];       // c0 c1 c2 c3
-    __shared__ float4 s_q1[4][64 + 1];       // c4 c5 r g
-    __shared__ float s_qb[4][64 + 4];        // b
-    __shared__ uint32_t s_alive[4];
-    __shared__ uint32_t s_next;
-    __shared__ uint32_t s_probe[4];
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int lx = lane & 7, ly = lane >> 3;
-    const int sbx = w & 1, sby = w >> 1;
-    // this lane's pixel and this wave's sub-block, in tile-centred coordinates (pixel centres at -7.5 ... 7.5)
-    const float u = (float)(sbx * 8 + lx) - 7.5f, v = (float)(sby * 8 + ly) - 7.5f;
-    const float u0 = (float)(sbx * 8) - 7.5f, u1 = u0 + 7.0f, v0 = (float)(sby * 8) - 7.5f, v1 = v0 + 7.0f;
-    __syncthreads();
-
-    for (uint32_t qpos = blockIdx.x; qpos < nitems;) {
-        const int bin = (int)order[qpos >> 2];
-        const int quad = (int)(qpos & 3u);
-        const int bvy = bin / fp.tiles_x;
-        const int tx = (bin - bvy * fp.tiles_x) * 2 + (quad & 1);
-        const int ty = band_real_row(fp, bvy) * 2 + (quad >> 1);
-        const bool tile_in_image = tx * kTile < fp.width && ty * kTile < fp.height;
-        if (tile_in_image) {
-            const int x = tx * kTile + sbx * 8 + lx, y = ty * kTile + sby * 8 + ly;
-            const bool inside = x < fp.width && y < fp.height;
-            const float xc = (float)(tx * kTile + 8), yc = (float)(ty * kTile + 8);
-            float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-            bool alive = __ballot(inside) != 0ull;              // wave-uniform: this sub-block still has a live pixel
-            uint32_t start = tile_start[bin], end = tile_start[bin + 1];
-            if (start > cap) start = cap;
-            if (end > cap) end = cap;
-
-            // three-stage pipeline over batches of 128 entries (threads 0..127 load): pair words two batches ahead,
-            // projected records one batch ahead of the batch being composited
-            const bool loader = tid < kQuadBatch;
-            uint32_t hiA = end;
-            uint32_t cntA = min((uint32_t)kQuadBatch, hiA - start);
-            uint32_t rankA = 0;
-            if (loader && tid < (int)cntA) rankA = pairs[hiA - 1u - tid];      // entry 0 of a batch is the nearest splat
-            hiA -= cntA;
-            uint32_t cnt = cntA;
-            float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
-            if (loader && tid < (int)cnt) {
-                uint32_t rk = rankA & kRankMask;
-                asm volatile("" : "+v"(rk));          // keep the mask out of the address arithmetic (see composite_depth_kernel)
-                const float4* src = rec + (size_t)rk * 3;
-                p0 = src[0]; p1 = src[1]; p2 = src[2];
-            }
-            cntA = min((uint32_t)kQuadBatch, hiA - start);
-            if (loader && tid < (int)cntA) rankA = pairs[hiA - 1u - tid];
-            hiA -= cntA;
-            const uint64_t probe_t0 = probe ? clock64() : 0ull;
-            uint32_t probe_n = 0, probe_batches = 0, probe_words = min(end - start, 2u * (uint32_t)kQuadBatch), probe_recs = cnt;
-            uint64_t probe_inner = 0;
-
-            while (cnt != 0u) {
-                // (a) records -> tile-centred polynomial coefficients, one LDS slot per list entry of the batch
-                if (loader && tid < (int)cnt) {
-                    const float a = p0.x - xc, b = p0.y - yc;
-                    const float A = p0.z, B = p0.w, C = p1.x, L = p1.y;
-                    const float c1 = -(2.0f * A * a + B * b);
-                    const float c2 = -(2.0f * C * b + B * a);
-                    const float c0 = (A * a + B * b) * a + (C * b * b + L);
-                    s_rec[tid * 3 + 0] = make_float4(c0, c1, c2, A);
-                    s_rec[tid * 3 + 1] = make_float4(B, C, p1.z, p1.w);
-                    s_rec[tid * 3 + 2] = make_float4(p2.x, a, b, 0.0f);
-                }
-                __syncthreads();
-                const uint32_t cur = cnt;
-                // next batch's records and the batch after's pair words go out now: in flight during the tests
-                // and the inner loop
-                cnt = cntA;
-                if (loader && tid < (int)cnt) {
-                    uint32_t rk = rankA & kRankMask;
-                    asm volatile("" : "+v"(rk));
-                    const float4* src = rec + (size_t)rk * 3;
-                    p0 = src[0]; p1 = src[1]; p2 = src[2];
-                }
-                cntA = min((uint32_t)kQuadBatch, hiA - start);
-                if (loader && tid < (int)cntA) rankA = pairs[hiA - 1u - tid];
-                hiA -= cntA;
-                probe_words += cntA;
-                probe_recs += cnt;
-                ++probe_batches;
-
-                // (b) + (c), 64 entries at a time: this wave's exact footprint-vs-sub-block test of the records; the
-                //     survivors are copied, in list order, into the wave-private queue (affine addresses: the inner loop
-                //     can prefetch), which is then blended front to back
-                //     (splat_frag.glsl:18-42, reversed: C += T w c, T -= T w)
-                const uint64_t probe_t1 = probe ? clock64() : 0ull;
-                if (alive) {
-                    for (int r = 0; r * 64 < (int)cur; ++r) {
-                        const int e = r * 64 + lane;
-                        bool pass = false;
-                        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
-                        if (e < (int)cur) {
-                            q0 = s_rec[e * 3 + 0];       // c0 c1 c2 c3
-                            q1 = s_rec[e * 3 + 1];       // c4 c5 r g
-                            q2 = s_rec[e * 3 + 2];       // blue a b .
-                            const float c0 = q0.x, c1 = q0.y, c2 = q0.z, c3 = q0.w, c4 = q1.x, c5 = q1.y;
-                            const float a = q2.y, b = q2.z;
-                            if (a >= u0 && a <= u1 && b >= v0 && b <= v1) {
-                                pass = true;      // centre inside the box of pixel centres: e_max = log2(alpha) > -8
-                            } else {
-                                // e is a concave quadratic: with the centre outside, its maximum over the box lies on an
-                                // edge; on an edge it is a 1-D concave quadratic, maximised at the clamped vertex
-                                // (v_rcp_f32 is accurate enough for the maximiser: the test keeps 0.05 of slack)
-                                const float i2c5 = __builtin_amdgcn_rcpf(2.0f * c5), i2c3 = __builtin_amdgcn_rcpf(2.0f * c3);
-                                float emax = -1e30f;
-#pragma unroll
-                                for (int s = 0; s < 2; ++s) {
-                                    const float ue = s ? u1 : u0;                 // vertical edges
-                                    const float lin = c2 + c4 * ue;
-                                    const float cst = c0 + ue * (c1 + c3 * ue);
-                                    const float vs = fminf(fmaxf(-lin * i2c5, v0), v1);
-                                    emax = fmaxf(emax, cst + vs * (lin + c5 * vs));
-                                    const float ve = s ? v1 : v0;                 // horizontal edges
-                                    const float lin2 = c1 + c4 * ve;
-                                    const float cst2 = c0 + ve * (c2 + c5 * ve);
-                                    const float us = fminf(fmaxf(-lin2 * i2c3, u0), u1);
-                                    emax = fmaxf(emax, cst2 + us * (lin2 + c3 * us));
-                                }
-                                pass = emax > -8.05f;
-                            }
-                        }
-                        const uint64_t m = __ballot(pass);
-                        const uint32_t n = (uint32_t)__popcll(m);
-                        if (pass) {
-                            const int slot = __popcll(m & ((1ull << lane) - 1ull));
-                            s_q0[w][slot] = q0;
-                            s_q1[w][slot] = q1;
-                            s_qb[w][slot] = q2.x;
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                        probe_n += n;
-                        if (n != 0u) {
-                            float4 a0 = s_q0[w][0];          // c0 c1 c2 c3
-                            float4 a1 = s_q1[w][0];          // c4 c5 r g
-                            float ab = s_qb[w][0];
-#pragma unroll 2
-                            for (uint32_t j = 0; j < n; ++j) {
-                                // next record (slot n is a harmless over-read inside the 65-slot arrays)
-                                const float4 n0 = s_q0[w][j + 1];
-                                const float4 n1 = s_q1[w][j + 1];
-                                const float nb = s_qb[w][j + 1];
-                                const float t1 = __builtin_fmaf(a1.x, v, __builtin_fmaf(a0.w, u, a0.y));     // c1 + c3 u + c4 v
-                                const float t2 = __builtin_fmaf(a1.y, v, a0.z);                              // c2 + c5 v
-                                const float e2 = __builtin_fmaf(u, t1, __builtin_fmaf(v, t2, a0.x));
-                                // splat_frag.glsl:37-40 discard: w = exp2(e) > 1/256  <=>  e > -8
-                                const float wgt = (e2 > -8.0f) ? __builtin_amdgcn_exp2f(e2) : 0.0f;
-                                const float tw = T * wgt;
-                                cr = __builtin_fmaf(tw, a1.z, cr);
-                                cg = __builtin_fmaf(tw, a1.w, cg);
-                                cb = __builtin_fmaf(tw, ab, cb);
-                                T = T - tw;
-                                a0 = n0; a1 = n1; ab = nb;
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();      // the queue is refilled by the next 64 entries
-                    }
-                }
-                if (probe) probe_inner += clock64() - probe_t1;
-                // (d) a sub-block is finished once all its pixels are saturated (or outside the image)
-                alive = alive && (__ballot(inside && T >= fp.t_eps) != 0ull);
-                if (lane == 0) s_alive[w] = alive ? 1u : 0u;
-                __syncthreads();                      // also: every wave is done with this batch's s_rec
-                if ((s_alive[0] | s_alive[1] | s_alive[2] | s_alive[3]) == 0u) break;
-            }
-
-            if (probe != nullptr) {
-                if (lane == 0) s_probe[w] = probe_n;
-                __syncthreads();
-                if (tid == 0) {
-                    const int slot = (int)qpos;
-                    probe[slot * 8 + 0] = (uint32_t)(clock64() - probe_t0);
-                    probe[slot * 8 + 1] = s_probe[0] + s_probe[1] + s_probe[2] + s_probe[3];   // (record, sub-block) pairs blended
-                    probe[slot * 8 + 2] = probe_batches;
-                    probe[slot * 8 + 3] = (uint32_t)probe_inner;
-                    probe[slot * 8 + 4] = probe_words;
-                    probe[slot * 8 + 5] = probe_recs;
-                    probe[slot * 8 + 6] = end - start;
-                    probe[slot * 8 + 7] = 2u;             // ran; 2 = evaluations are 64 per blended pair (1 = 256 per record)
-                }
-            }
-            if (inside) {
-                char* row = (char*)out + (size_t)y * pitch_bytes;
-                if (HALF) {
-                    union { _Float16 h[4]; uint2 u2; } pk;
-                    pk.h[0] = (_Float16)cr; pk.h[1] = (_Float16)cg; pk.h[2] = (_Float16)cb; pk.h[3] = (_Float16)1.0f;
-                    ((uint2*)row)[x] = pk.u2;
-                } else {
-                    ((float4*)row)[x] = make_float4(cr, cg, cb, 1.0f);
-                }
-            }
-        }
-        // next work item: one atomic per workgroup, broadcast through LDS
-        __syncthreads();
-        if (tid == 0) s_next = queue_next(queue, nitems);
-        __syncthreads();
-        qpos = s_next;
-    }
 }
 
 // ------------------------------------------------------------------------------------------

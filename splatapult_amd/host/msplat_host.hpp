@@ -134,9 +134,9 @@ public:
     {
         static_assert(sizeof(Mat4) == 64 && sizeof(Vec4) == 16 && sizeof(Vec2) == 8, "glm-compatible layout expected");
         if (group) {
-            if (msplat_group_sort(group, reinterpret_cast<const float*>(&cameraMat), reinterpret_cast<const float*>(&projMat),
-                                  reinterpret_cast<const float*>(&viewport), reinterpret_cast<const float*>(&nearFar)) != MSPLAT_OK)
-                std::fprintf(stderr, "[msplat][E] Sort: %s\n", msplat_group_last_error(group));
+            const int grc = msplat_group_sort(group, reinterpret_cast<const float*>(&cameraMat), reinterpret_cast<const float*>(&projMat),
+                                              reinterpret_cast<const float*>(&viewport), reinterpret_cast<const float*>(&nearFar));
+            if (grc != MSPLAT_OK) std::fprintf(stderr, "[msplat][%c] Sort: %s\n", Level(grc), msplat_group_last_error(group));
             return;
         }
         if (ctxs.empty()) return;
@@ -144,8 +144,8 @@ public:
         ctx = ctxs[cur];
         const int rc = msplat_sort(ctx, reinterpret_cast<const float*>(&cameraMat), reinterpret_cast<const float*>(&projMat),
                                    reinterpret_cast<const float*>(&viewport), reinterpret_cast<const float*>(&nearFar));
-        if (rc != MSPLAT_OK)         // void, like the reference; MSPLAT_ERR_PAIR_OVERFLOW_EARLIER is about a PAST frame
-            std::fprintf(stderr, "[msplat][%c] Sort: %s\n", rc == MSPLAT_ERR_PAIR_OVERFLOW_EARLIER ? 'W' : 'E', msplat_last_error(ctx));
+        if (rc != MSPLAT_OK)         // void, like the reference
+            std::fprintf(stderr, "[msplat][%c] Sort: %s\n", Level(rc), msplat_last_error(ctx));
     }
 
     // splatrenderer.cpp:315-343 (+ the GL pipeline behind glDrawElements)
@@ -158,17 +158,16 @@ public:
             return;
         }
         if (group) {
-            if (msplat_group_render(group, reinterpret_cast<const float*>(&cameraMat), reinterpret_cast<const float*>(&projMat),
-                                    reinterpret_cast<const float*>(&viewport), reinterpret_cast<const float*>(&nearFar), target,
-                                    targetPitch, targetIsDevice ? 1 : 0) != MSPLAT_OK)
-                std::fprintf(stderr, "[msplat][E] Render: %s\n", msplat_group_last_error(group));
+            const int grc = msplat_group_render(group, reinterpret_cast<const float*>(&cameraMat), reinterpret_cast<const float*>(&projMat),
+                                                reinterpret_cast<const float*>(&viewport), reinterpret_cast<const float*>(&nearFar), target,
+                                                targetPitch, targetIsDevice ? 1 : 0);
+            if (grc != MSPLAT_OK) std::fprintf(stderr, "[msplat][%c] Render: %s\n", Level(grc), msplat_group_last_error(group));
             return;
         }
         const int rc = msplat_render(ctx, reinterpret_cast<const float*>(&cameraMat), reinterpret_cast<const float*>(&projMat),
                                      reinterpret_cast<const float*>(&viewport), reinterpret_cast<const float*>(&nearFar), target,
                                      targetPitch, targetIsDevice ? 1 : 0);
-        if (rc != MSPLAT_OK)
-            std::fprintf(stderr, "[msplat][%c] Render: %s\n", rc == MSPLAT_ERR_PAIR_OVERFLOW_EARLIER ? 'W' : 'E', msplat_last_error(ctx));
+        if (rc != MSPLAT_OK) std::fprintf(stderr, "[msplat][%c] Render: %s\n", Level(rc), msplat_last_error(ctx));
     }
 
     // replaces "the currently bound GL framebuffer" (app.cpp:1000-1035)
@@ -253,6 +252,9 @@ protected:
         }
         return true;
     }
+
+    // log level of a status code: MSPLAT_ERR_PAIR_OVERFLOW_EARLIER reports a PAST frame, the call itself did its work
+    static char Level(int rc) { return rc == MSPLAT_ERR_PAIR_OVERFLOW_EARLIER ? 'W' : 'E'; }
 
     void DestroyContexts()
     {

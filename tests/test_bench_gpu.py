@@ -33,6 +33,13 @@ def _check_contract(d, n):
     assert 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["avg_launch_ms"] > 0 and (r["traffic"] is None or r["traffic"] > 0)
     assert d["serial"]["ms_per_frame"] > 0
+    # no fraction in the line can exceed 1 (r3 printed SURVEY 8d's 52 D formula as a "fraction": 1.9 on the scene-like cloud)
+    assert set(r["stages"]) >= {"sort", "project", "binning", "composite"}
+    for k in ("sort", "project", "binning", "composite"):
+        st = r["stages"][k]
+        assert st["bytes"] > 0 and st["us"] > 0 and 0.0 < st["frac"] <= 1.0, (k, st)
+    assert 0.0 < d["frame_moved_frac"] <= 1.0 and 0.0 < d["frame_moved_frac_serial"] <= 1.0
+    assert "formula_frac" not in r and "frame_hbm_frac" not in d
 
 
 def test_bench_single_gpu_json_contract():
@@ -41,9 +48,9 @@ def test_bench_single_gpu_json_contract():
     assert p.returncode == 0, p.stderr[-2000:]
     d = _line(p.stdout)
     _check_contract(d, 1)
-    assert d["rccl_ranks"] == 1
+    assert d["rccl_ranks"] == 1 and d["process_group"] is None and "gather_check" not in d
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port-tiled" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "frames/s" and cb["sample"]
+    assert cb["kind"] == "port-tiled" and cb["value"] > 0 and 1 <= cb["cores"] <= cb["threads"] and cb["unit"] == "frames/s" and cb["sample"]
     lit = d["cpu_baseline_literal"]                        # the one-to-one restatement of the shaders, kept beside it
     assert lit["kind"] == "port" and lit["value"] > 0 and lit["cores"] >= 1
     assert d["value"] > 10 * cb["value"]                   # sanity only: the ratio says nothing about the kernels
@@ -63,5 +70,11 @@ def test_bench_two_ranks_one_device_control_flow():
     d = _line(p.stdout)
     _check_contract(d, 2)
     assert d["rccl_ranks"] == 0                            # gloo stand-in: no RCCL ranks are claimed
+    pg = d["process_group"]                                # what the live process group reports
+    assert pg["backend"] == "gloo" and pg["world_size"] == 2 and len(pg["ranks"]) == 2
+    assert sorted(x["rank"] for x in pg["ranks"]) == [0, 1] and pg["distinct_devices"] == 1      # both ranks on device 0 here
+    gc = d["gather_check"]                                 # rank 0's gathered frame == the unbanded single-context frame
+    assert gc["bit_exact"] is True and gc["values_different"] == 0 and gc["values_compared"] >= 2 * 1920 * 1080 * 4
+    assert gc["poses"] == [5, 37] and gc["exchange"] == "gloo"
     assert "over 2 ranks" in d["config"]["sharding"] and "layout" in d["config"]["sharding"]
     assert d["gather"]["bytes_into_rank0_per_frame"] > 0

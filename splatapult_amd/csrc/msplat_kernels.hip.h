@@ -178,6 +178,96 @@ __device__ __forceinline__ bool cull_key(const float4 p, const FrameParams& fp, 
     return false;
 }
 
+// ------------------------------------------------------------------------------------------
+// Chunk-level cull over a spatially ordered cloud (round 4).
+// The reference culls per splat over the whole cloud (presort_compute.glsl:31-57, dispatched over N at splatrenderer.cpp:188-189)
+// and so does pass 0 of the sort -- which is all of its work when most of the cloud cannot be seen: a rank of a row-sharded
+// frame keeps 17 % of the splats, a camera inside a scene 40 %.  Large clouds are therefore STORED in Morton order of their
+// positions (msplat_device.hip, spatial_reorder; the storage order is the library's business: sorted indices are reported in
+// upload numbering and msplat_get_storage_order exposes the permutation) and every kBoxSplats consecutive stored splats carry a
+// bounding box.  Pass 0 tests a chunk's boxes first and skips the dead ones whole: no position is loaded, no key computed.
+// box_live is CONSERVATIVE: it returns false only if cull_key returns false for every splat the box can contain, so the
+// visible set and the keys are exactly those of the per-splat test.
+// ------------------------------------------------------------------------------------------
+constexpr int kBoxSplats = 1024;         // stored splats per bounding box: 2 / 4 / 8 boxes per pass-0 chunk
+struct CullBox {                         // 32 bytes
+    float4 lo;                           // min x, y, z of the finite positions; .w = max footprint bound (pos4.w) of the box
+    float4 hi;                           // max x, y, z; .w unused.  lo.x > hi.x: no finite position in the box
+};
+
+__device__ __forceinline__ bool box_live(const CullBox& b, const FrameParams& fp)
+{
+    if (!(b.lo.x <= b.hi.x)) return false;            // nothing finite inside: cull_key rejects NaN / inf positions (comparisons false)
+    const float* m = fp.mvp;
+    const float* v = fp.view;
+    // clip coordinates are affine in the position: over the box every plane function takes its extremes at the corners
+    float w_max = -INFINITY, w_min = INFINITY, w_mag = 0.0f;
+    float xr_min = INFINITY, xl_max = -INFINITY, yt_min = INFINITY, yb_max = -INFINITY, xy_mag = 0.0f;
+    float yy_min = INFINITY, yy_max = -INFINITY, tz_max = -INFINITY, ty_abs = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float x = (c & 1) ? b.hi.x : b.lo.x, y = (c & 2) ? b.hi.y : b.lo.y, z = (c & 4) ? b.hi.z : b.lo.z;
+        const float px = m[0] * x + m[4] * y + m[8] * z + m[12];
+        const float py = m[1] * x + m[5] * y + m[9] * z + m[13];
+        const float pw = m[3] * x + m[7] * y + m[11] * z + m[15];
+        const float aw = fabsf(m[3] * x) + fabsf(m[7] * y) + fabsf(m[11] * z) + fabsf(m[15]);
+        const float ax = fabsf(m[0] * x) + fabsf(m[4] * y) + fabsf(m[8] * z) + fabsf(m[12]);
+        const float ay = fabsf(m[1] * x) + fabsf(m[5] * y) + fabsf(m[9] * z) + fabsf(m[13]);
+        w_max = fmaxf(w_max, pw); w_min = fminf(w_min, pw); w_mag = fmaxf(w_mag, aw);
+        xy_mag = fmaxf(xy_mag, fmaxf(ax, ay) + 1.5f * aw);
+        xr_min = fminf(xr_min, px - 1.5f * pw);       // visible needs px / pw <  1.5  <=>  px - 1.5 pw < 0  (pw > 0)
+        xl_max = fmaxf(xl_max, px + 1.5f * pw);       //                px / pw > -1.5  <=>  px + 1.5 pw > 0
+        yt_min = fminf(yt_min, py - 1.5f * pw);
+        yb_max = fmaxf(yb_max, py + 1.5f * pw);
+        if (fp.band_cull) {
+            yy_min = fminf(yy_min, py / pw); yy_max = fmaxf(yy_max, py / pw);       // meaningful only when w_min > 0 (below)
+            tz_max = fmaxf(tz_max, v[2] * x + v[6] * y + v[10] * z + v[14]);
+            ty_abs = fmaxf(ty_abs, fabsf(v[1] * x + v[5] * y + v[9] * z + v[13]));
+        }
+    }
+    // margins: the per-splat test evaluates the same sums in fp32 in another order (a few ulp of the sum of magnitudes)
+    const float ew = 1e-5f * w_mag, exy = 1e-5f * xy_mag;
+    if (!(w_max > -ew)) return false;                 // every splat has depth <= 0 (or the box is NaN: then nothing passes either)
+    if (xr_min > exy || xl_max < -exy || yt_min > exy || yb_max < -exy) return false;
+    if (fp.band_cull) {
+        if (!(b.lo.w > 0.0f)) return false;           // every splat has alpha <= 1/256: cull_key drops them under the band cull
+        // the band test needs the whole box in front of the camera (y / w is monotone along every edge only there)
+        if (w_min > ew && tz_max < 0.0f) {
+            const float rtz = 1.0f / -tz_max;         // largest 1 / |tz| in the box
+            const float jsy = 0.5f * fabsf(fp.proj[5]) * fp.H * rtz;
+            const float tr = ty_abs * rtz;
+            const float j2 = jsy * jsy * (1.0f + tr * tr);
+            // cull_key: ey = sqrt(j2 view_scale2 p.w + 3.4) * 1.002 + 1.5 with 1-ulp rcp / sqrt: 0.2 % + 1 px on top
+            const float ey = sqrtf(j2 * fp.view_scale2 * b.lo.w + 3.4f) * 1.004f + 2.5f;
+            const float cy0 = 0.5f * (fp.H + yy_min * fp.H) + fp.Y0, cy1 = 0.5f * (fp.H + yy_max * fp.H) + fp.Y0;
+            const float slack = 1e-4f * (fabsf(cy0) + fabsf(cy1) + fp.H);
+            const float y0 = fmaxf(cy0 - ey - slack, 0.0f), y1 = fminf(cy1 + ey + slack, fp.H - 1.0f);
+            if (!(y0 <= y1)) return false;
+            const int r0 = (int)y0 / kBin, r1 = (int)y1 / kBin;
+            const int v0 = band_first_owned_from(fp, r0), v1 = min(band_last_owned_upto(fp, r1), fp.tiles_y - 1);
+            if (v0 > v1) return false;                // no owned bin row between the box's lowest and highest reach
+        }
+    }
+    return true;
+}
+
+// live-box mask of chunk `chunk` (NB boxes per chunk, bit k = box chunk * NB + k): evaluated by the first NB lanes of the
+// workgroup's first wave, returned to every thread through s_word.  Contains one barrier.
+template <int NB>
+__device__ __forceinline__ uint32_t chunk_live_mask(const CullBox* __restrict__ boxes, uint32_t nboxes, uint32_t chunk,
+                                                    const FrameParams& fp, uint32_t* s_word)
+{
+    if (threadIdx.x < 64) {
+        bool l = false;
+        const uint32_t bi = chunk * NB + threadIdx.x;
+        if (threadIdx.x < NB && bi < nboxes) l = box_live(boxes[bi], fp);
+        const unsigned long long mk = __ballot(l);
+        if (threadIdx.x == 0) *s_word = (uint32_t)mk;
+    }
+    __syncthreads();
+    return *s_word;
+}
+
 template <int MODE>
 __device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift)
 {
@@ -1276,6 +1366,116 @@ __global__ __launch_bounds__(64) void ingest_kernel(const char* __restrict__ raw
     pos4[i] = make_float4(f[0], f[1], f[2], rho2 > 0.0f ? rho2 * (f[16] + f[20] + f[24]) : 0.0f);
 #pragma unroll
     for (int k = 0; k < F4; ++k) recs[i * F4 + k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
+}
+
+// ------------------------------------------------------------------------------------------
+// Spatial storage order (round 4; see box_live above).  Upload-time only: the moments of the positions, a 30-bit Morton code
+// per splat (10 bits per axis over mean +- 3 sigma, outliers clamped to the border cells), a stable sort of the codes with the
+// 8-bit radix passes above (ties keep upload order), a gather of the cloud into that order and one bounding box per
+// kBoxSplats stored splats.  Nothing of this changes a pixel: draw order is by depth key, ties by STORAGE order.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void cloud_moments_kernel(const float4* __restrict__ pos, uint32_t n,
+                                                                 double* __restrict__ acc /* sum xyz, sum sq xyz, count */)
+{
+    double s[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        const float4 p = pos[i];
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            s[0] += p.x; s[1] += p.y; s[2] += p.z;
+            s[3] += (double)p.x * p.x; s[4] += (double)p.y * p.y; s[5] += (double)p.z * p.z;
+            s[6] += 1.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s[k] += __shfl_xor(s[k], d, 64);
+        if ((threadIdx.x & 63) == 0 && s[6] != 0.0) atomicAdd(&acc[k], s[k]);
+    }
+}
+
+__device__ __forceinline__ uint32_t morton_spread10(uint32_t v)      // 10 bits -> every third bit
+{
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ __launch_bounds__(kThreads) void morton_kernel(const float4* __restrict__ pos, uint32_t n,
+                                                          const double* __restrict__ acc, uint32_t* __restrict__ code,
+                                                          uint32_t* __restrict__ index)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const double cnt = acc[6] > 0.0 ? acc[6] : 1.0;
+    float q[3];
+    const float4 p = pos[i];
+    const float c[3] = {p.x, p.y, p.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double mean = acc[k] / cnt;
+        const double var = acc[3 + k] / cnt - mean * mean;
+        const float sd = (float)sqrt(var > 1e-30 ? var : 1e-30);
+        const float t = (c[k] - (float)mean) / (6.0f * sd) + 0.5f;                // mean +- 3 sigma -> [0, 1]
+        q[k] = isfinite(t) ? fminf(fmaxf(t, 0.0f), 1.0f) * 1023.0f : 0.0f;
+    }
+    code[i] = morton_spread10((uint32_t)q[0]) | (morton_spread10((uint32_t)q[1]) << 1) | (morton_spread10((uint32_t)q[2]) << 2);
+    index[i] = i;
+}
+
+// stored slot j <- uploaded splat order[j]: one wave moves 64 / F4 records per step with coalesced 16-byte accesses
+__global__ __launch_bounds__(kThreads) void gather_cloud_kernel(const uint32_t* __restrict__ order, uint32_t n, int F4,
+                                                                const float4* __restrict__ pos_in,
+                                                                const float4* __restrict__ recs_in,
+                                                                float4* __restrict__ pos_out, float4* __restrict__ recs_out)
+{
+    const uint64_t total = (uint64_t)n * (uint32_t)F4;
+    for (uint64_t e = (uint64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (uint64_t)gridDim.x * kThreads) {
+        const uint32_t j = (uint32_t)(e / (uint32_t)F4), sub = (uint32_t)(e - (uint64_t)j * (uint32_t)F4);
+        const uint32_t src = order[j];
+        recs_out[e] = recs_in[(size_t)src * F4 + sub];
+        if (sub == 0u) pos_out[j] = pos_in[src];
+    }
+}
+
+// one workgroup per box of kBoxSplats stored splats
+__global__ __launch_bounds__(kThreads) void cull_boxes_kernel(const float4* __restrict__ pos, uint32_t n,
+                                                              CullBox* __restrict__ boxes)
+{
+    __shared__ float s_red[7][kThreads / 64];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, wmax = 0.0f;
+    const uint32_t base = blockIdx.x * kBoxSplats;
+    for (uint32_t k = threadIdx.x; k < (uint32_t)kBoxSplats && base + k < n; k += kThreads) {
+        const float4 p = pos[base + k];
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
+            hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+            if (p.w > wmax) wmax = p.w;                                     // (NaN never wins; inf does, and then nothing is band-culled)
+        }
+    }
+    float r[7] = {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], wmax};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float o = __shfl_xor(r[k], d, 64);
+            r[k] = k < 3 ? fminf(r[k], o) : fmaxf(r[k], o);
+        }
+        if ((threadIdx.x & 63) == 0) s_red[k][threadIdx.x >> 6] = r[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            for (int w = 1; w < kThreads / 64; ++w) r[k] = k < 3 ? fminf(r[k], s_red[k][w]) : fmaxf(r[k], s_red[k][w]);
+        CullBox b;
+        b.lo = make_float4(r[0], r[1], r[2], r[6]);
+        b.hi = make_float4(r[3], r[4], r[5], 0.0f);
+        boxes[blockIdx.x] = b;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -3,8 +3,8 @@
 Tolerances, stated once:
   keys, visible set, sorted permutation, tile lists ........ exact
   projected centre ......................................... <= 1e-3 px
-  conic / colour ........................................... relative to max(|x|, floor), bound = CONIC_RTOL / RGB_RTOL below
-                                                             (_check_projection prints the measured worst case)
+  conic / colour ........................................... rel 1e-5 relative to max(|x|, 1e-3); measured: 0
+                                                             (_check_projection prints the worst case of every call)
   fp32 framebuffer ......................................... >= 99.9 % of values within 1e-4,
                                                              mean |diff| <= 1e-4, max |diff| <= 5e-3
      A value above 5e-3 is accepted only when the oracle EXPLAINS it: orc_composite_flip reports per pixel
@@ -39,9 +39,11 @@ def make_renderer(cloud, srgb=False, **kw):
 
 
 TIGHT = 5e-3          # max abs per channel
-# SURVEY 8c states rel 1e-5 for conic and colour.  Relative to max(|x|, floor): conic entries and SH colours pass through zero.
-CONIC_RTOL, CONIC_FLOOR = 1e-4, 1e-2
-RGB_RTOL, RGB_FLOOR = 1e-4, 2e-2
+# SURVEY 8c states rel 1e-5 for conic and colour: asserted as stated, relative to max(|x|, floor) because conic entries and SH
+# colours pass through zero.  Measured on the MI355X (r4, every _check_projection call of the suite, 176 k splats): worst relative
+# error 0 -- project_kernel evaluates the oracle's operation order without contraction, so these values are bit-identical.
+CONIC_RTOL, CONIC_FLOOR = 1e-5, 1e-3
+RGB_RTOL, RGB_FLOOR = 1e-5, 1e-3
 WORST = {"conic": 0.0, "rgb": 0.0}
 
 

@@ -76,7 +76,31 @@ typedef struct msplat_config {
     int32_t frame_mode;        /* MSPLAT_FRAMES_*: is this context the only one working on the GPU, or one of */
                                /* several frames in flight?  Occupies what was padding after rank_mode: any   */
                                /* value other than the two named ones means AUTO                               */
+    int32_t spatial_order;     /* MSPLAT_SPATIAL_* (r4): may the library store the cloud in its own (Morton)  */
+                               /* order so that the cull can skip whole chunks?  A shorter struct_size = AUTO  */
+    int32_t reserved0;         /* must be 0                                                                    */
 } msplat_config;
+
+/* msplat_config.spatial_order -- the STORAGE order of the uploaded cloud and the tie rule of the sort.
+ * The reference culls per splat over the whole cloud every frame (shader/presort_compute.glsl:31-57 dispatched over N,
+ * src/splatrenderer.cpp:188-189) and so did pass 0 of this sort: 24 us of 249 when everything is visible, but most of the sort
+ * when little is -- a rank of a row-sharded frame keeps 17 % of the splats, a camera inside a scene 40 %.  With spatial order the
+ * upload stores the cloud sorted by the Morton code of the positions (ties in upload order), keeps one bounding box per 1024
+ * stored splats, and the cull tests a chunk's boxes before it touches a splat: dead chunks are skipped whole.  The box test is
+ * conservative -- the visible set, the keys and every pixel are what the per-splat test alone gives.
+ * What it changes is the TIE RULE.  Draw order = ascending 32-bit depth key (splatrenderer.cpp:165-169), and splats with EQUAL
+ * keys are drawn in ascending storage slot.  The reference's own tie order is undefined (the slots come from an atomic counter,
+ * presort_compute.glsl:50), so any rule is one of its outcomes; this one is deterministic and reproducible:
+ * msplat_get_storage_order returns the permutation (slot -> upload index), and a CPU oracle fed the cloud in that order gives the
+ * same frame bit for bit (tests/).  Without reordering the storage slot IS the upload index.  Everything the API reports about
+ * splats (msplat_get_sorted_indices, msplat_download_cloud) is in upload numbering either way.
+ * AUTO: on from 262 144 splats (below that a pass-0 chunk is a large part of the cloud and there is nothing to skip); point
+ * clouds are never reordered.  MSPLAT_SPATIAL_ORDER=0|1 in the environment overrides the field. */
+enum {
+    MSPLAT_SPATIAL_AUTO = 0,
+    MSPLAT_SPATIAL_ON = 1,
+    MSPLAT_SPATIAL_OFF = 2
+};
 
 /* msplat_config.frame_mode.  Pixels, keys and lists are identical in both modes; what changes is which kernels run.
  * MSPLAT_FRAMES_SERIAL (= AUTO): one frame at a time -- the shortest single frame: the three-pass wide-digit sort
@@ -89,8 +113,7 @@ typedef struct msplat_config {
  *   than three 4-wave passes), and the list offsets come from the search kernels (the persistent compositor needs no
  *   bin order).  Measured r3 at config 2, 4 frames in flight, same box: 6045 frames/s against 5800 with the SERIAL
  *   kernels.  The SplatRenderer shims select it for their in-flight contexts.
- * In the environment MSPLAT_SORT=lsd8|wide, MSPLAT_WS_THREADS=256|512 and MSPLAT_TILE_TABLE=search|count override the
- * choices one by one. */
+ * In the environment MSPLAT_SORT=lsd8|wide and MSPLAT_TILE_TABLE=search|count override the choices one by one. */
 enum {
     MSPLAT_FRAMES_AUTO = 0,
     MSPLAT_FRAMES_SERIAL = 1,
@@ -325,10 +348,16 @@ int msplat_group_synchronize(msplat_group* g);
 
 /* sortCount of the last Sort (splatrenderer.cpp:198-199); synchronises */
 int msplat_sort_count(msplat_ctx* ctx, uint32_t* v);
-/* the element buffer the reference fills at splatrenderer.cpp:296-311 (draw order:
- * ascending key = far to near; equal keys in ascending splat index); synchronises */
+/* the element buffer the reference fills at splatrenderer.cpp:296-311: upload indices of the visible splats in draw order
+ * (ascending key = far to near; equal keys in ascending storage slot, see msplat_config.spatial_order); synchronises */
 int msplat_get_sorted_indices(msplat_ctx* ctx, uint32_t* dst, uint32_t cap);
 int msplat_get_sorted_keys(msplat_ctx* ctx, uint32_t* dst, uint32_t cap);
+/* storage order of the uploaded cloud: dst[slot] = upload index (identity unless the cloud was reordered; *reordered, if not
+ * NULL, says which).  dst may be NULL to ask only whether.  cap = entries dst can take (>= N). */
+int msplat_get_storage_order(msplat_ctx* ctx, uint32_t* dst, uint64_t cap, int* reordered);
+/* chunk-level cull of the latest Sort: bounding boxes (of 1024 stored splats) whose splats were tested / boxes in the cloud;
+ * 0 / 0 for a cloud in upload order.  Synchronises. */
+int msplat_debug_get_cull_boxes(msplat_ctx* ctx, uint32_t* live, uint32_t* total);
 
 int msplat_get_stats(msplat_ctx* ctx, msplat_stats* out);      /* synchronises */
 int msplat_get_timings(msplat_ctx* ctx, msplat_timings* out);  /* synchronises */
@@ -342,7 +371,7 @@ int msplat_debug_get_projected(msplat_ctx* ctx, float* rec12, uint32_t* rect, ui
 int msplat_debug_get_tile_lists(msplat_ctx* ctx, uint32_t* tile_start, uint32_t tile_cap,
                                 uint32_t* pairs, uint64_t pair_cap);
 
-/* on-device self-check of the ordering contracts (sorted keys ascending, ties by ascending splat index; every bin list
+/* on-device self-check of the ordering contracts (sorted keys ascending, ties by ascending storage slot; every bin list
  * ascending in draw-order rank): counts of violations, both 0 on a healthy context.  Guards the lane-ordered LDS-atomic
  * ranking, which msplat_create probes but the hardware does not document (MSPLAT_BALLOT_RANK=1 selects the ballot path) */
 int msplat_debug_verify_order(msplat_ctx* ctx, uint32_t* key_violations, uint32_t* list_violations);

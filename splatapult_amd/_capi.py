@@ -15,6 +15,7 @@ FB_RGBA32F, FB_RGBA16F = 0, 1
 ROP_NONE, ROP_RGBA8, ROP_RGBA16F = 0, 1, 2
 RANK_AUTO, RANK_BALLOT = 0, 1
 FRAMES_AUTO, FRAMES_SERIAL, FRAMES_IN_FLIGHT = 0, 1, 2
+SPATIAL_AUTO, SPATIAL_ON, SPATIAL_OFF = 0, 1, 2
 BANDS_CONTIGUOUS, BANDS_INTERLEAVED, BANDS_BLOCK_INTERLEAVED = 0, 1, 2
 BAND_KINDS = {"contiguous": BANDS_CONTIGUOUS, "interleaved": BANDS_INTERLEAVED, "block": BANDS_BLOCK_INTERLEAVED}
 
@@ -29,7 +30,7 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("fb_format", C.c_int32),
                 ("srgb", C.c_int32), ("t_epsilon", C.c_float), ("pair_capacity", C.c_uint64),
                 ("stream", C.c_void_p), ("enable_timing", C.c_int32), ("compositor_waves", C.c_int32),
-                ("rank_mode", C.c_int32), ("frame_mode", C.c_int32)]
+                ("rank_mode", C.c_int32), ("frame_mode", C.c_int32), ("spatial_order", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class AttrOffsets(C.Structure):
@@ -117,6 +118,8 @@ SYMBOLS = [
     ("msplat_sort_count", C.c_int, [C.c_void_p, _U32P]),
     ("msplat_get_sorted_indices", C.c_int, [C.c_void_p, _U32P, C.c_uint32]),
     ("msplat_get_sorted_keys", C.c_int, [C.c_void_p, _U32P, C.c_uint32]),
+    ("msplat_get_storage_order", C.c_int, [C.c_void_p, _U32P, C.c_uint64, C.POINTER(C.c_int)]),
+    ("msplat_debug_get_cull_boxes", C.c_int, [C.c_void_p, _U32P, _U32P]),
     ("msplat_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     ("msplat_get_timings", C.c_int, [C.c_void_p, C.POINTER(Timings)]),
     ("msplat_debug_get_projected", C.c_int, [C.c_void_p, _F16, _U32P, C.c_uint32]),

@@ -39,13 +39,23 @@ struct Buf {
 struct CloudStore {
     int device = 0;
     Buf pos4, recs;
+    // spatial storage order (r4): slot j holds the splat uploaded as order_host[j]; one bounding box per kBoxSplats slots
+    bool reordered = false;
+    std::vector<uint32_t> order_host;
+    Buf boxes;
+    uint32_t nboxes = 0;
     ~CloudStore()
     {
         (void)hipSetDevice(device);
         if (pos4.p) (void)hipFree(pos4.p);
         if (recs.p) (void)hipFree(recs.p);
+        if (boxes.p) (void)hipFree(boxes.p);
     }
 };
+
+// clouds of at least this many splats are stored in Morton order (msplat_config.spatial_order = AUTO): below it a pass-0
+// chunk is a large part of the cloud and there is nothing to skip
+constexpr uint64_t kSpatialMinSplats = 1ull << 18;
 
 }  // namespace
 
@@ -81,6 +91,9 @@ struct msplat_ctx {
     // wide-digit 3-pass sort (r3, msplat_kernels.hip.h ws_*): histogram rows of up to 2048 digits per chunk, one group
     // table per pass, one visibility bit per splat, the visible set's minimum key per frame parity (counters[10..11])
     Buf wsHist, wsGsum[3], vmask;
+    Buf cmask;                  // live-box mask per pass-0 chunk of the latest Sort (chunk-level cull, spatially ordered clouds)
+    int spatial_mode = 0;       // msplat_config.spatial_order / MSPLAT_SPATIAL_ORDER: 0 auto, 1 always, 2 never
+    uint32_t sort_chunk0 = 2048;   // splats per pass-0 chunk of the latest Sort (what a cmask word covers)
     uint32_t ws_items = 8, ws_gshift = 4, ws_gsum_words = 0;
     uint32_t ws_threads = 512;  // 256 (4 waves, 40 / 56 KB of LDS) for contexts that share the GPU with other frames
     bool wide_sort = true;      // MSPLAT_SORT=lsd8 (or no lane-ordered LDS atomics): the four 8-bit passes
@@ -240,7 +253,7 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
     c.t_epsilon = -1.0f;
     if (cfg) {
         // the struct grows at its end: a caller built against an older header passes a shorter struct_size
-        constexpr size_t kMinConfig = offsetof(msplat_config, rank_mode);
+        constexpr size_t kMinConfig = offsetof(msplat_config, rank_mode);      // (spatial_order, added in r4, defaults to AUTO too)
         if (cfg->struct_size < kMinConfig || cfg->struct_size > sizeof(msplat_config))
             return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: config struct_size %u not in [%zu, %zu]",
                         cfg->struct_size, kMinConfig, sizeof(msplat_config));
@@ -251,6 +264,8 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: bad rank_mode %d", c.rank_mode);
     if (c.fb_format != MSPLAT_FB_RGBA32F && c.fb_format != MSPLAT_FB_RGBA16F)
         return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: bad fb_format %d", c.fb_format);
+    if (c.spatial_order < MSPLAT_SPATIAL_AUTO || c.spatial_order > MSPLAT_SPATIAL_OFF)
+        return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: bad spatial_order %d", c.spatial_order);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -328,6 +343,8 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         if (const char* sk = getenv("MSPLAT_SORT")) ctx->wide_sort = std::string(sk) != "lsd8";
         if (!ctx->atomic_rank) ctx->wide_sort = false;       // the wide kernels rank with lane-ordered LDS atomics only
         if (const char* tk = getenv("MSPLAT_TILE_TABLE")) ctx->bin_counts = std::string(tk) != "search";
+        ctx->spatial_mode = c.spatial_order;
+        if (const char* so = getenv("MSPLAT_SPATIAL_ORDER")) ctx->spatial_mode = atoi(so) != 0 ? MSPLAT_SPATIAL_ON : MSPLAT_SPATIAL_OFF;
         if (ctx->wide_sort) {
             // ws_downsweep needs 72 / 104 KB of dynamic LDS with 512 threads (40 / 56 KB with 256).  The attribute belongs to
             // the function ON A DEVICE (a kernel object per device): it is requested once per device, with that device current
@@ -377,7 +394,8 @@ void msplat_destroy(msplat_ctx* ctx)
     Buf* all[] = {&ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist, &ctx->gsumS[0], &ctx->gsumS[1], &ctx->gsumB1, &ctx->gsumB2,
                   &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->totals1, &ctx->tile_start, &ctx->tile_order,
                   &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe, &ctx->zq, &ctx->sprite, &ctx->queue,
-                  &ctx->wsHist, &ctx->wsGsum[0], &ctx->wsGsum[1], &ctx->wsGsum[2], &ctx->vmask, &ctx->bincnt, &ctx->heavy, &ctx->heavy_flag};
+                  &ctx->wsHist, &ctx->wsGsum[0], &ctx->wsGsum[1], &ctx->wsGsum[2], &ctx->vmask, &ctx->bincnt, &ctx->heavy, &ctx->heavy_flag,
+                  &ctx->cmask};
     for (Buf* b : all) buf_free(ctx, *b);
     if (ctx->ev_ok)
         for (auto& set : ctx->ev)
@@ -589,6 +607,11 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
             ctx->device_bytes += need_pos + need_rec;
             ctx->store = st;
         }
+        // a fresh upload starts in upload order (spatial_reorder runs once the cloud is on the device)
+        ctx->store->reordered = false;
+        ctx->store->order_host.clear();
+        if (ctx->store->boxes.p) { (void)hipFree(ctx->store->boxes.p); ctx->store->boxes = Buf{}; }
+        ctx->store->nboxes = 0;
     }
     ctx->pos4 = ctx->store->pos4;
     ctx->recs = ctx->store->recs;
@@ -621,6 +644,7 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
         ctx->ws_gsum_words = (uint32_t)gwords;
         if ((rc = buf_alloc(ctx, ctx->vmask, (size_t)div_up(alloc_n, 64) * 8 + 64))) return rc;
     }
+    if ((rc = buf_alloc(ctx, ctx->cmask, ((size_t)div_up(alloc_n, 2048) + 16) * 4))) return rc;      // pass-0 chunks are >= 2048 splats
     if ((rc = buf_alloc(ctx, ctx->rec2d, alloc_n * 48))) return rc;
     if ((rc = buf_alloc(ctx, ctx->rect, alloc_n * 4))) return rc;
     if (ctx->depth_bits != 0 && (rc = buf_alloc(ctx, ctx->zq, alloc_n * 4))) return rc;
@@ -635,6 +659,104 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
     uint64_t cap = ctx->cfg.pair_capacity ? ctx->cfg.pair_capacity
                                           : std::max<uint64_t>(1ull << 22, std::min<uint64_t>(32 * n, 1ull << 30));
     return ensure_pair_capacity(ctx, cap);
+}
+
+static void launch_scan(hipStream_t s, bool small, uint32_t* hist, uint32_t hist_stride, const uint32_t* d_n,
+                        uint32_t n_static, uint32_t n_cap, uint32_t chunk, uint32_t* totals);
+
+// Spatial storage order (r4, msplat_kernels.hip.h: box_live).  Called at the end of an upload, the cloud being on the device in
+// UPLOAD order: Morton codes of the positions, a stable sort of (code, upload index) with the library's own 8-bit radix passes,
+// the cloud gathered into that order, one bounding box per kBoxSplats slots.  From then on slot j holds upload index
+// order_host[j]; everything that reports splat numbers (msplat_get_sorted_indices, msplat_download_cloud) maps back.
+// Draw order = ascending key, ties in ascending STORAGE slot: for a cloud that is not reordered that is the upload index.
+// Out of device memory for the second copy: the cloud simply stays in upload order.
+static int spatial_reorder(msplat_ctx* ctx)
+{
+    const uint64_t n64 = ctx->N;
+    const bool want = !ctx->point_mode && n64 > 1 &&
+                      (ctx->spatial_mode == MSPLAT_SPATIAL_ON || (ctx->spatial_mode == MSPLAT_SPATIAL_AUTO && n64 >= kSpatialMinSplats));
+    if (!want) return MSPLAT_OK;
+    CloudStore& st = *ctx->store;
+    hipStream_t s = ctx->stream;
+    const uint32_t N = (uint32_t)n64;
+    const int F4 = ctx->full_sh ? 16 : 8;
+    const size_t need_pos = (size_t)N * 16, need_rec = (size_t)N * F4 * 16;
+    void *npos = nullptr, *nrec = nullptr;
+    if (hipMalloc(&npos, need_pos) != hipSuccess || hipMalloc(&nrec, need_rec) != hipSuccess) {
+        (void)hipGetLastError();
+        if (npos) (void)hipFree(npos);
+        return MSPLAT_OK;
+    }
+    double* acc = (double*)ctx->totals1.p;          // 1 KB, idle outside a render
+    uint32_t *kA = (uint32_t*)ctx->keyA.p, *kB = (uint32_t*)ctx->keyB.p, *vA = (uint32_t*)ctx->valA.p, *vB = (uint32_t*)ctx->valB.p;
+    const float4* pos = (const float4*)st.pos4.p;
+    const uint32_t mrows = std::min(div_up(N, kThreads), 1024u);
+    void* mpart = nullptr;
+    hipError_t e = hipMalloc(&mpart, (size_t)mrows * 7 * sizeof(double));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(npos); (void)hipFree(nrec);
+        return MSPLAT_OK;
+    }
+    hipLaunchKernelGGL(cloud_moments_kernel, dim3(mrows), dim3(kThreads), 0, s, pos, N, (double*)mpart);
+    hipLaunchKernelGGL(cloud_moments_finish, dim3(1), dim3(kThreads), 0, s, (const double*)mpart, mrows, acc);
+    hipLaunchKernelGGL(morton_kernel, dim3(div_up(N, kThreads)), dim3(kThreads), 0, s, pos, N, (const double*)acc, kA, vA);
+    const bool large = n64 > (2u << 20);
+    const uint32_t chunk = (uint32_t)kThreads * (large ? kSortItemsLarge : kSortItems);
+    const int grid = grid_for(div_up(N, chunk));
+    FrameParams fp0;
+    std::memset(&fp0, 0, sizeof(fp0));
+    uint32_t* hist = (uint32_t*)ctx->hist.p;
+    uint32_t* totals = (uint32_t*)ctx->totals.p;
+    for (int pass = 0; pass < 4; ++pass) {          // A -> B -> A -> B -> A
+        uint32_t *kin = (pass & 1) ? kB : kA, *vin = (pass & 1) ? vB : vA, *kout = (pass & 1) ? kA : kB, *vout = (pass & 1) ? vA : vB;
+#define MSPLAT_SP_UP(IT) hipLaunchKernelGGL((radix_upsweep<MODE_KEYS, IT>), dim3(grid), dim3(kThreads), 0, s, (const uint32_t*)kin, \
+        (const float4*)nullptr, (const uint32_t*)nullptr, N, N, pass * 8, hist, ctx->hist_stride, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, fp0)
+#define MSPLAT_SP_DOWN(AR, IT) hipLaunchKernelGGL((radix_downsweep<MODE_KEYS, true, AR, IT>), dim3(grid), dim3(kThreads), 0, s, \
+        (const uint32_t*)kin, (const uint32_t*)vin, (const float4*)nullptr, (const uint32_t*)nullptr, N, N, pass * 8, (const uint32_t*)hist, \
+        ctx->hist_stride, (const uint32_t*)totals, kout, vout, (uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr,     \
+        (uint32_t*)nullptr, fp0)
+        if (large) MSPLAT_SP_UP(kSortItemsLarge); else MSPLAT_SP_UP(kSortItems);
+        launch_scan(s, !large, hist, ctx->hist_stride, nullptr, N, N, chunk, totals);
+        if (large) { if (ctx->atomic_rank) MSPLAT_SP_DOWN(true, kSortItemsLarge); else MSPLAT_SP_DOWN(false, kSortItemsLarge); }
+        else { if (ctx->atomic_rank) MSPLAT_SP_DOWN(true, kSortItems); else MSPLAT_SP_DOWN(false, kSortItems); }
+#undef MSPLAT_SP_UP
+#undef MSPLAT_SP_DOWN
+    }
+    hipLaunchKernelGGL(gather_cloud_kernel, dim3(2048), dim3(kThreads), 0, s, (const uint32_t*)vA, N, F4, pos,
+                       (const float4*)st.recs.p, (float4*)npos, (float4*)nrec);
+    const uint32_t nboxes = div_up(N, kBoxSplats);
+    void* nbox = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&nbox, (size_t)nboxes * sizeof(CullBox));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(cull_boxes_kernel, dim3(nboxes), dim3(kThreads), 0, s, (const float4*)npos, N, (CullBox*)nbox);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        try {
+            st.order_host.resize(N);
+        } catch (const std::exception&) {
+            e = hipErrorOutOfMemory;
+        }
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(st.order_host.data(), vA, (size_t)N * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(mpart);
+    if (e != hipSuccess) {
+        (void)hipFree(npos); (void)hipFree(nrec);
+        if (nbox) (void)hipFree(nbox);
+        st.order_host.clear();
+        return fail(ctx, MSPLAT_ERR_HIP, "spatial reordering of the cloud failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(st.pos4.p); (void)hipFree(st.recs.p);
+    st.pos4.p = npos; st.pos4.bytes = need_pos;
+    st.recs.p = nrec; st.recs.bytes = need_rec;
+    st.boxes.p = nbox; st.boxes.bytes = (size_t)nboxes * sizeof(CullBox);
+    st.nboxes = nboxes;
+    st.reordered = true;
+    ctx->pos4 = st.pos4;
+    ctx->recs = st.recs;
+    return MSPLAT_OK;
 }
 
 int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t stride_bytes,
@@ -698,6 +820,7 @@ int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t s
         HIP_TRY(ctx, hipMemcpy((char*)ctx->recs.p + base * F4 * 16, stage_rec.data(), cnt * F4 * 16, hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy((char*)ctx->pos4.p + base * 16, stage_pos.data(), cnt * 16, hipMemcpyHostToDevice));
     }
+    if ((rc = spatial_reorder(ctx))) return rc;
     ctx->has_cloud = true;
     return MSPLAT_OK;
 }
@@ -747,6 +870,7 @@ int msplat_upload_ply_vertices(msplat_ctx* ctx, const void* vertices, uint64_t n
         buf_free(ctx, raw);
         if (e != hipSuccess) return fail(ctx, MSPLAT_ERR_HIP, "GPU ingest failed: %s", hipGetErrorString(e));
     }
+    if ((rc = spatial_reorder(ctx))) return rc;
     ctx->has_cloud = true;
     return MSPLAT_OK;
 }
@@ -888,11 +1012,12 @@ int msplat_download_cloud(msplat_ctx* ctx, void* aos_out, uint64_t cap_bytes)
         return fail(ctx, MSPLAT_ERR_HIP, "msplat_download_cloud: out of host memory");
     }
     float* dst = static_cast<float*>(aos_out);
+    const bool ro = ctx->store && ctx->store->reordered;       // stored slot j = upload index order_host[j]
     for (uint64_t base = 0; base < ctx->N; base += chunk) {
         const size_t cnt = (size_t)std::min<uint64_t>(chunk, ctx->N - base);
         HIP_TRY(ctx, hipMemcpy(stage.data(), (const char*)ctx->recs.p + base * F4 * 16, cnt * F4 * 16, hipMemcpyDeviceToHost));
         for (size_t j = 0; j < cnt; ++j)
-            std::memcpy(dst + (base + j) * rec_floats, stage.data() + j * F4 * 4, rec_floats * 4);
+            std::memcpy(dst + (ro ? (size_t)ctx->store->order_host[base + j] : base + j) * rec_floats, stage.data() + j * F4 * 4, rec_floats * 4);
     }
     return MSPLAT_OK;
 }
@@ -1120,11 +1245,17 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
             hipLaunchKernelGGL((ws_upsweep<CULLF, 4, 2 * kWsThreads>), dim3(wgrid), dim3(2 * kWsThreads), 0, s, __VA_ARGS__); \
         else MSPLAT_WS(ws_upsweep, CULLF, MSPLAT_NO_LDS, __VA_ARGS__);                                                    \
     } while (0)
+        // chunk-level cull over a spatially ordered cloud: pass 0 tests the chunk's bounding boxes first (box_live)
+        const bool boxed = ctx->store->reordered && ctx->store->boxes.p != nullptr;
+        const CullBox* boxes = boxed ? (const CullBox*)ctx->store->boxes.p : nullptr;
+        const uint32_t nboxes = boxed ? ctx->store->nboxes : 0u;
+        uint32_t* cmask = boxed ? (uint32_t*)ctx->cmask.p : nullptr;
+        ctx->sort_chunk0 = ctx->ws_threads * items;
         MSPLAT_WS_UP(true, (const uint32_t*)nullptr, pos, kB, vm, (const uint32_t*)nullptr, N, N, 0, mk_cur,
-                  mk_next, whist, gt(0), gsh, gt(-1), gw, fp);
+                  mk_next, whist, gt(0), gsh, gt(-1), gw, fp, boxes, nboxes, cmask);
         MSPLAT_WS(ws_downsweep, true, ws_downsweep_lds, (const uint32_t*)kB, (const uint32_t*)nullptr, (const unsigned long long*)vm,
                   (const uint32_t*)nullptr, N, N, 0, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(0), gsh, kA, vA,
-                  d_V, wsx);
+                  d_V, wsx, (const uint32_t*)cmask);
         items = items12;
         wgrid = grid_for(div_up(N, ctx->ws_threads * items));
         MSPLAT_WS_UP(false, (const uint32_t*)kA, (const float4*)nullptr, (uint32_t*)nullptr,
@@ -1176,13 +1307,18 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
         }                                                                                                                        \
     } while (0)
     // pass 0: cull + key fused into the first radix pass (presort_compute.glsl + byte 0 of the sort)
+    const bool boxed = ctx->store->reordered && ctx->store->boxes.p != nullptr;       // chunk-level cull, see the three-pass branch
+    const CullBox* boxes = boxed ? (const CullBox*)ctx->store->boxes.p : nullptr;
+    const uint32_t nboxes = boxed ? ctx->store->nboxes : 0u;
+    uint32_t* cmask = boxed ? (uint32_t*)ctx->cmask.p : nullptr;
+    ctx->sort_chunk0 = chunk;
     MSPLAT_UPSWEEP(MODE_CULL, (const uint32_t*)nullptr, pos, (const uint32_t*)nullptr, N, N, 0, hist, ctx->hist_stride, gacc(0),
-                   gzero(0), ctx->gsumS_rows, fp, (const uint32_t*)nullptr, (uint32_t*)nullptr, ctx->gsupS);
+                   gzero(0), ctx->gsumS_rows, fp, (const uint32_t*)nullptr, (uint32_t*)nullptr, ctx->gsupS, boxes, nboxes, cmask);
     if (!fused) launch_scan(s, ctx->N <= (2u << 20), hist, ctx->hist_stride, nullptr, N, N, chunk, totals);
     MSPLAT_DOWNSWEEP(MODE_CULL, (const uint32_t*)nullptr, (const uint32_t*)nullptr, pos, (const uint32_t*)nullptr, N, N, 0,
                      (const uint32_t*)hist, ctx->hist_stride, (const uint32_t*)totals, kB, vB, d_V, (const uint32_t*)nullptr,
                      (const uint32_t*)gacc(0), (uint32_t*)nullptr, fp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                     (uint32_t*)nullptr, 0, 0, ctx->gsupS);
+                     (uint32_t*)nullptr, 0, 0, ctx->gsupS, (const uint32_t*)cmask);
     // passes 1..3 on the V survivors (V stays on the device; splatrenderer.cpp:195-204's readback is gone)
     for (int pass = 1; pass < 4; ++pass) {
         uint32_t* kin = (pass & 1) ? kB : kA;
@@ -1502,7 +1638,48 @@ static int copy_sorted(msplat_ctx* ctx, const Buf& src, uint32_t* dst, uint32_t 
 int msplat_get_sorted_indices(msplat_ctx* ctx, uint32_t* dst, uint32_t cap)
 {
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
-    return copy_sorted(ctx, ctx->valA, dst, cap);
+    int rc = copy_sorted(ctx, ctx->valA, dst, cap);
+    if (rc == MSPLAT_OK && ctx->store && ctx->store->reordered) {      // storage slots -> upload indices
+        uint32_t v = 0;
+        if ((rc = msplat_sort_count(ctx, &v))) return rc;
+        const std::vector<uint32_t>& ord = ctx->store->order_host;
+        for (uint32_t i = 0; i < v; ++i) dst[i] = ord[dst[i]];
+    }
+    return rc;
+}
+
+// The storage order of the uploaded cloud: dst[j] = upload index of the splat in storage slot j (identity when the cloud
+// was not reordered; *reordered says which).  Equal depth keys are drawn in ascending storage slot.
+int msplat_get_storage_order(msplat_ctx* ctx, uint32_t* dst, uint64_t cap, int* reordered)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if (!ctx->has_cloud) return fail(ctx, MSPLAT_ERR_NO_CLOUD, "no cloud uploaded");
+    const bool ro = ctx->store && ctx->store->reordered;
+    if (reordered) *reordered = ro ? 1 : 0;
+    if (dst) {
+        if (cap < ctx->N) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "capacity %llu < %llu splats", (unsigned long long)cap, (unsigned long long)ctx->N);
+        for (uint64_t j = 0; j < ctx->N; ++j) dst[j] = ro ? ctx->store->order_host[j] : (uint32_t)j;
+    }
+    return MSPLAT_OK;
+}
+
+// chunk-level cull of the latest Sort (spatially ordered clouds): bounding boxes that were live / boxes in the cloud
+int msplat_debug_get_cull_boxes(msplat_ctx* ctx, uint32_t* live, uint32_t* total)
+{
+    if (!ctx || !live || !total) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
+    if (!ctx->has_sort) return fail(ctx, MSPLAT_ERR_NO_SORT, "no sort yet");
+    *live = *total = 0;
+    if (!(ctx->store && ctx->store->reordered)) return MSPLAT_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t per = ctx->sort_chunk0 / (uint32_t)kBoxSplats, nch = div_up(ctx->N, ctx->sort_chunk0);
+    std::vector<uint32_t> m;
+    try { m.resize(nch); } catch (const std::exception&) { return fail(ctx, MSPLAT_ERR_HIP, "out of host memory"); }
+    HIP_TRY(ctx, hipMemcpy(m.data(), ctx->cmask.p, (size_t)nch * 4, hipMemcpyDeviceToHost));
+    const uint32_t bits = per >= 32u ? 0xFFFFFFFFu : ((1u << per) - 1u);
+    for (uint32_t c = 0; c < nch; ++c) *live += (uint32_t)__builtin_popcount(m[c] & bits);
+    *total = ctx->store->nboxes;
+    return MSPLAT_OK;
 }
 
 int msplat_get_sorted_keys(msplat_ctx* ctx, uint32_t* dst, uint32_t cap)

@@ -354,8 +354,11 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
                                                           uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_rows,
                                                           FrameParams fp,
                                                           const uint32_t* __restrict__ col_totals = nullptr,
-                                                          uint32_t* __restrict__ bincnt = nullptr, uint32_t gsup = 0u)
+                                                          uint32_t* __restrict__ bincnt = nullptr, uint32_t gsup = 0u,
+                                                          const CullBox* __restrict__ boxes = nullptr, uint32_t nboxes = 0u,
+                                                          uint32_t* __restrict__ cmask = nullptr)
 {
+    // MODE_CULL with boxes != nullptr: chunk-level cull over a spatially ordered cloud, see ws_upsweep / box_live
     // MODE_PAIR with bincnt != nullptr (r3): the input is ordered by (column, rank) and carries the row in its top byte, so
     // counting the words per (row, column) here gives every bin's list length before the partition has run: the
     // downsweep's extra workgroup turns the counts into the bins' list offsets (tile_table_role) and the two launches
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
     __shared__ uint32_t s_bin[MODE == MODE_PAIR ? kPairCols * 256 : 1];
     __shared__ uint32_t s_col[MODE == MODE_PAIR ? 257 : 1];       // first input position of each column
     __shared__ uint32_t s_tmp4[4];
+    __shared__ uint32_t s_live;
     if (gsum_zero != nullptr)
         for (uint32_t row = blockIdx.x; row < gsum_zero_rows; row += gridDim.x) gsum_zero[(size_t)row * 256 + threadIdx.x] = 0u;
     uint32_t n = d_n ? *d_n : n_static;
@@ -385,6 +389,16 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
         __syncthreads();
     }
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        uint32_t live = 0xFFFFFFFFu;
+        if (MODE == MODE_CULL && boxes != nullptr) {
+            live = chunk_live_mask<(CHUNK >= kBoxSplats ? CHUNK / kBoxSplats : 1)>(boxes, nboxes, chunk, fp, &s_live);
+            if (threadIdx.x == 0) cmask[chunk] = live;
+            if (live == 0u) {                  // workgroup-uniform: a dead chunk only zeroes its histogram row
+                hist[(size_t)chunk * 256 + threadIdx.x] = 0u;
+                __syncthreads();
+                continue;
+            }
+        }
         s_hist[threadIdx.x] = 0;
         if (count_bins)
 #pragma unroll
@@ -429,10 +443,13 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
             // in s_bin[0][row], i.e. column c0)
             if (MODE == MODE_CULL) {
                 float4 pp[MODE == MODE_CULL ? ITEMS : 1];          // clamped loads, all in flight together (see below)
+                // (row r = 256 consecutive splats of box r * 256 / kBoxSplats: a dead box's rows load one hot address)
 #pragma unroll
-                for (int r = 0; r < ITEMS; ++r) pp[r] = pos[min(base + r * kThreads + threadIdx.x, n - 1u)];
+                for (int r = 0; r < ITEMS; ++r)
+                    pp[r] = pos[((live >> (r * kThreads / kBoxSplats)) & 1u) ? min(base + r * kThreads + threadIdx.x, n - 1u) : min(base, n - 1u)];
 #pragma unroll
                 for (int r = 0; r < ITEMS; ++r) {
+                    if (!((live >> (r * kThreads / kBoxSplats)) & 1u)) continue;        // workgroup-uniform
                     const uint32_t i = base + r * kThreads + threadIdx.x;
                     uint32_t key;
                     if (i < n && cull_key(pp[r], fp, key)) atomicAdd(&s_hist[digit_of<MODE>(key, shift)], 1u);
@@ -698,8 +715,10 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE != MODE_PAIR && SORT
                                                             uint32_t* __restrict__ tile_start = nullptr,
                                                             uint32_t* __restrict__ tile_order = nullptr,
                                                             uint32_t* __restrict__ queue = nullptr,
-                                                            int ntiles = 0, int do_order = 0, uint32_t gsup = 0u)
+                                                            int ntiles = 0, int do_order = 0, uint32_t gsup = 0u,
+                                                            const uint32_t* __restrict__ cmask = nullptr)
 {
+    // cmask != nullptr (MODE_CULL): live-box masks of the chunks from radix_upsweep; dead chunks / boxes are skipped
     // gsum != nullptr: scan-free path -- hist holds raw per-chunk counts, prefixes come from the group tables;
     // otherwise hist holds exclusive prefixes and totals the digit totals (radix_scan*).
     // totals_out != nullptr: workgroup 0 publishes the digit totals (the row totals tile_start_kernel needs).
@@ -753,6 +772,11 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE != MODE_PAIR && SORT
     const bool xmap = MODE == MODE_PAIR && (do_order & 2) && (nworkers >= nchunks || (nworkers & 7u) == 0u);
     for (uint32_t cidx = wb; cidx < nchunks; cidx += nworkers) {
         const uint32_t chunk = xmap ? xcd_contiguous(cidx, nchunks) : cidx;
+        uint32_t live = 0xFFFFFFFFu;
+        if (MODE == MODE_CULL && cmask != nullptr) {
+            live = cmask[chunk];                   // workgroup-uniform
+            if (live == 0u) continue;
+        }
         // this chunk's exclusive prefix per digit (thread = digit): issued first, consumed after the local ranking
         const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk, reinterpret_cast<uint4*>(s_keys), gsup)
                                                      : hist[(size_t)chunk * 256 + threadIdx.x];
@@ -770,15 +794,17 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE != MODE_PAIR && SORT
         // fifth wave per SIMD: 16-byte loads)
         constexpr int kPosBatch = 4;
         float4 pp[MODE == MODE_CULL ? kPosBatch : 1];
+        // (the wave's sub-chunk of 64 * ITEMS splats lies in one box -- 512 or 1024 splats -- or covers whole boxes)
+        const bool wave_live = MODE != MODE_CULL || ((live >> (((uint32_t)w * (64 * ITEMS)) / kBoxSplats)) & 1u) != 0u;
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             if (MODE == MODE_CULL && (r % kPosBatch) == 0) {
 #pragma unroll
                 for (int k = 0; k < kPosBatch; ++k)
-                    if (r + k < ITEMS) pp[k] = pos[min(base + (r + k) * 64 + lane, n - 1u)];
+                    if (r + k < ITEMS) pp[k] = pos[wave_live ? min(base + (r + k) * 64 + lane, n - 1u) : min(chunk * CHUNK, n - 1u)];
             }
             const uint32_t i = base + r * 64 + lane;
-            valid[r] = i < n;
+            valid[r] = (i < n) && wave_live;
             key[r] = 0;
             val[r] = 0;
             if (valid[r]) {
@@ -1031,12 +1057,18 @@ __global__ __launch_bounds__(THREADS) void ws_upsweep(const uint32_t* __restrict
                                                       uint32_t* __restrict__ hist,
                                                       uint32_t* __restrict__ gsum_acc, int gshift,
                                                       uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_words,
-                                                      FrameParams fp)
+                                                      FrameParams fp, const CullBox* __restrict__ boxes = nullptr,
+                                                      uint32_t nboxes = 0u, uint32_t* __restrict__ cmask = nullptr)
 {
+    // boxes != nullptr (CULL, spatially ordered cloud): the chunk's bounding boxes are tested first (box_live); the mask of live
+    // boxes goes to cmask[chunk] for the downsweep, dead boxes are neither loaded nor keyed, a dead chunk only zeroes its row
     constexpr int CHUNK = THREADS * ITEMS;
     constexpr int WAVES = THREADS / 64;
+    constexpr int NB = CHUNK / kBoxSplats;                     // boxes per chunk: 2, 4 or 8
+    static_assert(CHUNK % kBoxSplats == 0 && (THREADS % kBoxSplats == 0 || kBoxSplats % THREADS == 0), "rows must not straddle boxes");
     __shared__ uint32_t s_hist[kWsMaxBins];
     __shared__ uint32_t s_min[WAVES];
+    __shared__ uint32_t s_live;
     // the group table of the pass before this one (its consumer finished one launch ago) is cleared for the next frame
     if (gsum_zero != nullptr)
         for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < gsum_zero_words; i += gridDim.x * THREADS) gsum_zero[i] = 0u;
@@ -1049,6 +1081,16 @@ __global__ __launch_bounds__(THREADS) void ws_upsweep(const uint32_t* __restrict
     const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
     uint32_t mk = 0xFFFFFFFFu;
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        uint32_t live = 0xFFFFFFFFu;
+        if (CULL && boxes != nullptr) {
+            live = chunk_live_mask<NB>(boxes, nboxes, chunk, fp, &s_live);
+            if (threadIdx.x == 0) cmask[chunk] = live;
+            if (live == 0u) {                  // workgroup-uniform: nothing of this chunk can be seen
+                for (uint32_t d = threadIdx.x; d < nbins; d += THREADS) hist[(size_t)chunk * nbins + d] = 0u;
+                __syncthreads();               // (s_live is rewritten by the next chunk)
+                continue;
+            }
+        }
         for (uint32_t d = threadIdx.x; d < nbins; d += THREADS) s_hist[d] = 0u;
         __syncthreads();
         // unconditional (clamped) loads first, so that all of them are in flight together: under `if (i < n)` the
@@ -1062,14 +1104,18 @@ __global__ __launch_bounds__(THREADS) void ws_upsweep(const uint32_t* __restrict
         const uint32_t base = chunk * CHUNK + (uint32_t)sub * (IPS * THREADS);
         float4 pp[CULL ? IPS : 1];
         uint32_t kk[CULL ? 1 : IPS];
+        // row r of the chunk = THREADS consecutive splats inside box (sub * IPS + r) * THREADS / kBoxSplats: a dead box's rows
+        // load one hot address instead of their positions (the loads stay unconditional) and skip the key arithmetic
+        auto row_live = [&](int r) { return CULL ? ((live >> (((uint32_t)sub * IPS + r) * THREADS / kBoxSplats)) & 1u) != 0u : true; };
 #pragma unroll
         for (int r = 0; r < IPS; ++r) {
             const uint32_t ic = min(base + r * THREADS + threadIdx.x, n - 1u);          // n >= 1 inside this loop
-            if (CULL) pp[r] = pos[ic];
+            if (CULL) pp[r] = pos[row_live(r) ? ic : min(chunk * CHUNK, n - 1u)];
             else kk[r] = keys_in[ic];
         }
 #pragma unroll
         for (int r = 0; r < IPS; ++r) {
+            if (CULL && !row_live(r)) continue;                                         // workgroup-uniform
             const uint32_t i = base + r * THREADS + threadIdx.x;
             uint32_t key = 0u;
             bool ok = false;
@@ -1124,8 +1170,10 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, const unsigned long long* __restrict__ vmask,
     const uint32_t* __restrict__ d_n, uint32_t n_static, uint32_t n_cap, int pass, const uint32_t* __restrict__ minkey_cur,
     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ gsum, int gshift, uint32_t* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out, uint32_t* __restrict__ d_count_out, int xcd_map)
+    uint32_t* __restrict__ vals_out, uint32_t* __restrict__ d_count_out, int xcd_map, const uint32_t* __restrict__ cmask = nullptr)
 {
+    // cmask != nullptr (CULL): the live-box mask ws_upsweep left per chunk; a dead chunk is skipped whole, a dead box's wave
+    // ranks nothing (its raw keys / visibility words were never written).
     // xcd_map: workgroup b runs on XCD b % 8; chunk = xcd_contiguous(b) gives every XCD a contiguous range of chunks, so
     // the digit runs that neighbouring chunks write next to each other meet in ONE L2 instead of being written to HBM
     // as partial lines by several (the per-XCD L2s are not coherent; every one writes back its own bytes of a shared line)
@@ -1171,6 +1219,11 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
 
     for (uint32_t cidx = blockIdx.x; cidx < nchunks; cidx += gridDim.x) {
         const uint32_t chunk = (xcd_map && (gridDim.x >= nchunks || (gridDim.x & 7u) == 0u)) ? xcd_contiguous(cidx, nchunks) : cidx;
+        uint32_t live = 0xFFFFFFFFu;
+        if (CULL && cmask != nullptr) {
+            live = cmask[chunk];                   // workgroup-uniform
+            if (live == 0u) continue;
+        }
         // this chunk's exclusive prefix per digit: the group rows before its group + the chunk rows before it in the group
         const uint32_t g = chunk >> gshift;
         uint4 pre[QPT];
@@ -1197,7 +1250,8 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
             const uint32_t i = base + r * 64 + lane;
             valid[r] = i < n;
             if (CULL) {
-                valid[r] = valid[r] && ((vm[r] >> lane) & 1ull);
+                // (box of this row: 64 consecutive splats, never across a box boundary)
+                valid[r] = valid[r] && ((live >> (((uint32_t)w * (64 * ITEMS) + r * 64) / kBoxSplats)) & 1u) && ((vm[r] >> lane) & 1ull);
                 val[r] = i;
             }
         }
@@ -1374,10 +1428,13 @@ __global__ __launch_bounds__(64) void ingest_kernel(const char* __restrict__ raw
 // 8-bit radix passes above (ties keep upload order), a gather of the cloud into that order and one bounding box per
 // kBoxSplats stored splats.  Nothing of this changes a pixel: draw order is by depth key, ties by STORAGE order.
 // ------------------------------------------------------------------------------------------
+// (two stages with a fixed summation order and no atomics: every device of a group, and every run, must arrive at the same
+//  storage order bit for bit -- tie order is part of the frame)
 __global__ __launch_bounds__(kThreads) void cloud_moments_kernel(const float4* __restrict__ pos, uint32_t n,
-                                                                 double* __restrict__ acc /* sum xyz, sum sq xyz, count */)
+                                                                 double* __restrict__ part /* [gridDim.x][7] */)
 {
-    double s[7] = {0, 0, 0, 0, 0, 0, 0};
+    __shared__ double s_w[kThreads / 64][7];
+    double s[7] = {0, 0, 0, 0, 0, 0, 0};           // sum xyz, sum of squares xyz, count of finite positions
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         const float4 p = pos[i];
         if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
@@ -1390,8 +1447,34 @@ __global__ __launch_bounds__(kThreads) void cloud_moments_kernel(const float4* _
     for (int k = 0; k < 7; ++k) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) s[k] += __shfl_xor(s[k], d, 64);
-        if ((threadIdx.x & 63) == 0 && s[6] != 0.0) atomicAdd(&acc[k], s[k]);
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6][k] = s[k];
     }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        double t = 0.0;
+        for (int w = 0; w < kThreads / 64; ++w) t += s_w[w][threadIdx.x];
+        part[(size_t)blockIdx.x * 7 + threadIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void cloud_moments_finish(const double* __restrict__ part, uint32_t rows,
+                                                                 double* __restrict__ acc /* 7 */)
+{
+    __shared__ double s_t[kThreads][7];
+    double s[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t r = threadIdx.x; r < rows; r += kThreads)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s[k] += part[(size_t)r * 7 + k];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s_t[threadIdx.x][k] = s[k];
+    __syncthreads();
+    for (int half = kThreads / 2; half >= 1; half >>= 1) {
+        if ((int)threadIdx.x < half)
+#pragma unroll
+            for (int k = 0; k < 7; ++k) s_t[threadIdx.x][k] += s_t[threadIdx.x + half][k];
+        __syncthreads();
+    }
+    if (threadIdx.x < 7) acc[threadIdx.x] = s_t[0][threadIdx.x];
 }
 
 __device__ __forceinline__ uint32_t morton_spread10(uint32_t v)      // 10 bits -> every third bit

@@ -44,7 +44,8 @@ class _FrameArgs:
 
 class SplatRenderer:
     def __init__(self, device=0, fb_format="fp32", t_epsilon=-1.0, pair_capacity=0, stream=None,
-                 enable_timing=False, frames_in_flight=1, rank_mode=_capi.RANK_AUTO, frame_mode=None):
+                 enable_timing=False, frames_in_flight=1, rank_mode=_capi.RANK_AUTO, frame_mode=None,
+                 spatial_order=_capi.SPATIAL_AUTO):
         """frames_in_flight > 1: every Sort moves on to the next of that many contexts (own stream and
         per-frame buffers, ONE shared cloud -- msplat_attach_cloud), so successive frames overlap on the
         GPU; Render and the getters use the context of the latest Sort.  `stream` is only used with depth 1;
@@ -63,6 +64,7 @@ class SplatRenderer:
         self._stream = stream
         self._timing = enable_timing
         self._rank_mode = int(rank_mode)       # msplat_config.rank_mode (RANK_AUTO / RANK_BALLOT)
+        self._spatial = int(spatial_order)     # msplat_config.spatial_order (SPATIAL_AUTO / _ON / _OFF)
         # msplat_config.frame_mode: kernels for one frame at a time, or for contexts that share the GPU with other frames in
         # flight (msplat.h, MSPLAT_FRAMES_*)
         self._frame_mode = int(frame_mode) if frame_mode is not None else (_capi.FRAMES_IN_FLIGHT if self._depth > 1 else _capi.FRAMES_AUTO)
@@ -112,6 +114,7 @@ class SplatRenderer:
         cfg.compositor_waves = 0 if self._depth == 1 else 1280     # measured r3: pool sweep 768 .. 2048, DESIGN.md 5
         cfg.rank_mode = self._rank_mode
         cfg.frame_mode = self._frame_mode
+        cfg.spatial_order = self._spatial
         for k in range(self._depth):
             if isinstance(self._stream, (list, tuple)):       # one caller-owned stream per frame in flight
                 cfg.stream = self._stream[k]
@@ -251,6 +254,24 @@ class SplatRenderer:
         _capi.check(self._ctx, self._lib.msplat_get_sorted_indices(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                                    out.shape[0]))
         return out[:self.sort_count()].copy()
+
+    def storage_order(self):
+        """None when the cloud is stored in upload order, else the permutation slot -> upload index of the library's spatial
+        storage order (msplat_config.spatial_order): equal depth keys are drawn in ascending storage slot"""
+        ro = C.c_int(0)
+        _capi.check(self._ctx, self._lib.msplat_get_storage_order(self._ctx, None, 0, C.byref(ro)))
+        if not ro.value:
+            return None
+        out = np.empty(max(self._n, 1), np.uint32)
+        _capi.check(self._ctx, self._lib.msplat_get_storage_order(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                                  out.shape[0], None))
+        return out[:self._n]
+
+    def cull_boxes(self):
+        """(live, total) bounding boxes of the latest Sort's chunk-level cull; (0, 0) for a cloud in upload order"""
+        a, b = C.c_uint32(), C.c_uint32()
+        _capi.check(self._ctx, self._lib.msplat_debug_get_cull_boxes(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def sorted_keys(self):
         out = np.empty(max(self._n, 1), np.uint32)

@@ -79,11 +79,35 @@ def check_fp16_image(img, ref, budget):
     assert (img[..., 3] == 1).all()
 
 
+_STORAGE_CACHE = {}
+
+
+def storage_aos(r, aos):
+    """(the cloud in the renderer's STORAGE order, the permutation slot -> upload index or None).  Large clouds are stored in
+    Morton order (msplat_config.spatial_order) and splats with EQUAL depth keys are drawn in ascending storage slot: the
+    reference's tie order is undefined (atomic slots, presort_compute.glsl:50); ours is reproduced by feeding the oracle the
+    cloud in that order.  Everything the renderer reports is in upload numbering, so oracle indices are mapped with order[idx]."""
+    order = r.storage_order()
+    if order is None:
+        return aos, None
+    key = (aos.shape, float(aos[0, 0]), float(aos[-1, 5]), float(aos[aos.shape[0] // 2, 17]), int(order[:97].sum()), int(order[-97:].sum()))
+    hit = _STORAGE_CACHE.get("last")
+    if hit is None or hit[0] != key:
+        _STORAGE_CACHE["last"] = hit = (key, np.ascontiguousarray(aos[order]))
+    return hit[1], order
+
+
 def oracle_frame(aos, full_sh, cam, proj, vp, nf, render_cam=None, render_proj=None, srgb=False, nthreads=16,
-                 row0=0, row1=None):
-    """oracle Sort + Render with the per-pixel threshold-flip budget: dict(V, image, budget, splats, sorted_*)"""
+                 row0=0, row1=None, r=None):
+    """oracle Sort + Render with the per-pixel threshold-flip budget: dict(V, image, budget, splats, sorted_*).
+    r: the renderer whose storage order the oracle is to follow (storage_aos); sorted_idx comes back in upload numbering"""
+    order = None
+    if r is not None:
+        aos, order = storage_aos(r, aos)
     ref = orc.render_frame(aos, full_sh, cam, proj, vp, nf, render_cam=render_cam, render_proj=render_proj, srgb=srgb,
                            nthreads=nthreads, want_image=False, want_splats=True)
+    if order is not None:
+        ref["sorted_idx"] = order[ref["sorted_idx"]]
     W, H = int(vp[2]), int(vp[3])
     ref["image"], ref["budget"] = orc.composite_flip(ref["splats"], W, H, nthreads=nthreads, row0=row0, row1=row1)
     return ref
@@ -94,7 +118,7 @@ def run_frame(cloud, view, full_sh=True, srgb=False, **kw):
     r = make_renderer(cloud, srgb=srgb, **kw)
     r.Sort(cam, proj, vp, nf)
     img = r.Render(cam, proj, vp, nf)
-    ref = oracle_frame(cloud.as_array(), full_sh, cam, proj, vp, nf, srgb=srgb)
+    ref = oracle_frame(cloud.as_array(), full_sh, cam, proj, vp, nf, srgb=srgb, r=r)
     return r, img, ref
 
 
@@ -896,11 +920,14 @@ def cloud_6m():
 
 
 def _check_sort_exact(r, aos, cam, proj, nf):
+    aos_s, order = storage_aos(r, aos)
     mvp = orc.mat4_mul(proj, orc.mat4_inverse(cam))
-    keys, idx = orc.sort(*orc.presort(aos, mvp, nf[1]))
+    keys, idx = orc.sort(*orc.presort(aos_s, mvp, nf[1]))
+    if order is not None:
+        idx = order[idx]
     gk, gi = r.sorted_keys(), r.sorted_indices()
     np.testing.assert_array_equal(gk, keys)
-    np.testing.assert_array_equal(gi, idx)                        # stable: ties in ascending splat index
+    np.testing.assert_array_equal(gi, idx)                        # stable: ties in ascending storage slot (= upload index unless reordered)
     assert (np.diff(gk.astype(np.int64)) >= 0).all()              # sortedness
     assert np.unique(gi).shape[0] == gi.shape[0]                  # a permutation of the visible set
     return keys.shape[0]
@@ -920,9 +947,10 @@ def _check_tile_lists_ascending(r):
     return st
 
 
-def _check_window(img, aos, W, H, cam, proj, nf, y0, y1, render_cam=None, render_proj=None, fp16=False):
-    """bounded oracle comparison at full workload: rows [y0, y1) of the frame"""
+def _check_window(r, img, aos, W, H, cam, proj, nf, y0, y1, render_cam=None, render_proj=None, fp16=False):
+    """bounded oracle comparison at full workload: rows [y0, y1) of the frame (the oracle follows r's storage order)"""
     import os
+    aos, _ = storage_aos(r, aos)
     nt = max(32, min(128, os.cpu_count() or 32)) if y1 - y0 > 512 else 32         # whole frames: more row bands
     ref = orc.render_frame(aos, True, cam, proj, [0, 0, W, H], nf, render_cam=render_cam, render_proj=render_proj,
                            nthreads=32, want_image=False, want_splats=True)
@@ -948,7 +976,7 @@ def test_full_size_config2_sort_and_properties(cloud_1m):
     assert np.isfinite(img).all() and (img[..., 3] == 1).all()
     # idempotence: rendering again from the same sort is bit-identical
     np.testing.assert_array_equal(r.Render(cam, proj, vp, nf), img)
-    _check_window(img, aos, W, H, cam, proj, nf, 0, H)          # the WHOLE frame, incl. the ragged top bin row (33.75 bins)
+    _check_window(r, img, aos, W, H, cam, proj, nf, 0, H)          # the WHOLE frame, incl. the ragged top bin row (33.75 bins)
 
 
 @pytest.mark.parametrize("step", [17, 40])
@@ -966,7 +994,7 @@ def test_full_size_config2_whole_frame_at_rotated_orbit_poses(cloud_1m, step):
     img = r.Render(cam, proj, vp, nf)
     st = _check_tile_lists_ascending(r)
     assert st["sort_count"] == V
-    _check_window(img, aos, W, H, cam, proj, nf, 0, H)
+    _check_window(r, img, aos, W, H, cam, proj, nf, 0, H)
 
 
 def test_full_size_config3_6m_1080p(cloud_6m):
@@ -983,8 +1011,8 @@ def test_full_size_config3_6m_1080p(cloud_6m):
     st = _check_tile_lists_ascending(r)
     assert st["sort_count"] == V and st["pairs"] > st["drawn"] > 4_000_000
     assert np.isfinite(img).all() and (img[..., 3] == 1).all()
-    _check_window(img, aos, W, H, cam, proj, nf, 412, 668)
-    _check_window(img, aos, W, H, cam, proj, nf, 1056, 1080)      # the ragged top bin row (1080 = 33.75 bins)
+    _check_window(r, img, aos, W, H, cam, proj, nf, 412, 668)
+    _check_window(r, img, aos, W, H, cam, proj, nf, 1056, 1080)      # the ragged top bin row (1080 = 33.75 bins)
 
 
 def test_full_size_config4_6m_4096_and_8_bands(cloud_6m):
@@ -999,8 +1027,9 @@ def test_full_size_config4_6m_4096_and_8_bands(cloud_6m):
     st = _check_tile_lists_ascending(r)
     assert st["tiles_x"] == 128 and st["tiles_y"] == 128 and st["pairs"] > 20_000_000
     assert np.isfinite(full).all() and (full[..., 3] == 1).all()
-    _check_window(full, cloud_6m.as_array(), W, H, cam, proj, nf, 1984, 2112)
-    _check_window(full, cloud_6m.as_array(), W, H, cam, proj, nf, 4064, 4096)     # the top bin row
+    aos = cloud_6m.as_array()
+    _check_window(r, full, aos, W, H, cam, proj, nf, 1984, 2112)
+    _check_window(r, full, aos, W, H, cam, proj, nf, 4064, 4096)     # the top bin row
     from splatapult_amd import _capi
     G = 8
     part = np.zeros_like(full)
@@ -1035,8 +1064,8 @@ def test_full_size_config5_stereo_fp16(cloud_1m):
         img = r.Render(eyes[e], projs[e], vp, nf)
         assert img.dtype == np.float16 and img.shape == (H, W, 4)
         _check_tile_lists_ascending(r)
-        _check_window(img, aos, W, H, eyes[0], projs[0], nf, 992, 1248, render_cam=eyes[e], render_proj=projs[e], fp16=True)
-        _check_window(img, aos, W, H, eyes[0], projs[0], nf, 2208, 2240, render_cam=eyes[e], render_proj=projs[e], fp16=True)
+        _check_window(r, img, aos, W, H, eyes[0], projs[0], nf, 992, 1248, render_cam=eyes[e], render_proj=projs[e], fp16=True)
+        _check_window(r, img, aos, W, H, eyes[0], projs[0], nf, 2208, 2240, render_cam=eyes[e], render_proj=projs[e], fp16=True)
 
 
 def test_large_cloud_uses_the_wide_scan_path():
@@ -1048,7 +1077,8 @@ def test_large_cloud_uses_the_wide_scan_path():
     r = make_renderer(cloud)
     r.Sort(cam, proj, vp, nf)
     img = r.Render(cam, proj, vp, nf)
-    ref = oracle_frame(cloud.as_array(), False, cam, proj, vp, nf)
+    ref = oracle_frame(cloud.as_array(), False, cam, proj, vp, nf, r=r)
+    assert r.storage_order() is not None                 # 2.2 M splats: stored in Morton order (msplat_config.spatial_order = AUTO)
     assert r.sort_count() == ref["V"] and ref["V"] > 2_100_000
     np.testing.assert_array_equal(r.sorted_indices(), ref["sorted_idx"])
     np.testing.assert_array_equal(r.sorted_keys(), ref["sorted_keys"])
@@ -1061,7 +1091,9 @@ def test_large_cloud_uses_the_wide_scan_path():
     # (the V an earlier frame left in host-mapped memory is below 2 M) while pass 0 keeps 8192-key chunks: same exact order
     cam_in = camera.orbit(0.5, 1.3)
     mvp = orc.mat4_mul(proj, orc.mat4_inverse(cam_in))
-    keys_in, idx_in = orc.sort(*orc.presort(cloud.as_array(), mvp, nf[1]))
+    aos_s, order = storage_aos(r, cloud.as_array())
+    keys_in, idx_in = orc.sort(*orc.presort(aos_s, mvp, nf[1]))
+    idx_in = order[idx_in]
     assert 1000 < keys_in.shape[0] < 1_500_000
     for _ in range(3):
         r.Sort(cam_in, proj, vp, nf)
@@ -1366,7 +1398,7 @@ def test_scene_like_6m_file_replay_matches_the_oracle(tmp_path):
               % (k, V, st["drawn"], st["pairs"], st["pairs"] / n, longest, cap0, st["pair_capacity"]))
         assert st["pairs"] > 5 * st["drawn"]                      # big footprints: many bins per splat
         assert np.isfinite(img).all() and (img[..., 3] == 1).all()
-        _check_window(img, aos, W, H, cam, proj, nf, y0, y1)
+        _check_window(r, img, aos, W, H, cam, proj, nf, y0, y1)
 
 
 def test_heavy_chunks_of_the_column_pass_are_split_without_changing_anything():
@@ -1395,3 +1427,154 @@ def test_heavy_chunks_of_the_column_pass_are_split_without_changing_anything():
             np.testing.assert_array_equal(x, y)
     ref = oracle_frame(cloud.as_array(), True, cam, proj, vp, nf)
     check_image(res[0][2], ref["image"], budget=ref["budget"])
+
+
+# ------------------------------------------------------------------------------------------------
+# round 4: spatial storage order (Morton-sorted cloud, one bounding box per 1024 stored splats) and the chunk-level cull.
+# Contract (include/msplat.h, msplat_config.spatial_order): the visible set, the keys and the draw order are those of the
+# per-splat test with ties in ascending STORAGE slot; everything reported is in upload numbering.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,seed,hard", [(1, 3, False), (1023, 4, False), (5000, 5, True), (40000, 6, False)])
+def test_spatial_order_small_scenes_exact_sort_image_and_download(n, seed, hard):
+    from splatapult_amd import _capi
+    cloud = scenes.cloud_from_attrs(scenes.hard_attrs(n, seed)) if hard else scenes.synth_cloud(n, seed, log_scale_mean=-3.0)
+    aos = cloud.as_array()
+    r = make_renderer(cloud, spatial_order=_capi.SPATIAL_ON)
+    order = r.storage_order()
+    if n == 1:
+        assert order is None                                # nothing to reorder
+    else:
+        assert order is not None and np.array_equal(np.sort(order), np.arange(n))          # a permutation of the upload indices
+        assert not np.array_equal(order, np.arange(n))
+    np.testing.assert_array_equal(r.download_cloud(True), aos)      # the API speaks upload numbering
+    off = make_renderer(cloud, spatial_order=_capi.SPATIAL_OFF)
+    assert off.storage_order() is None
+    for yaw, z in ((0.0, 7.0), (0.7, 5.0), (3.0, 0.5)):               # outside looking in; oblique; inside the cloud
+        cam, proj, vp, nf = scenes.default_view(640, 360, yaw=yaw, z=z)
+        r.Sort(cam, proj, vp, nf)
+        off.Sort(cam, proj, vp, nf)
+        V = _check_sort_exact(r, aos, cam, proj, nf)                  # incl. the tie rule (hard_attrs has exact duplicates)
+        assert off.sort_count() == V                                  # the chunk-level cull never changes the visible set
+        np.testing.assert_array_equal(np.sort(r.sorted_indices()), np.sort(off.sorted_indices()))
+        np.testing.assert_array_equal(r.sorted_keys(), off.sorted_keys())
+        img = r.Render(cam, proj, vp, nf)
+        ref = oracle_frame(aos, True, cam, proj, vp, nf, r=r)
+        check_image(img, ref["image"], budget=ref["budget"])
+        assert r.verify_order() == (0, 0)
+        live, total = r.cull_boxes()
+        assert total == (n + 1023) // 1024 * (order is not None) and live <= total
+
+
+@pytest.mark.parametrize("mode", ["serial", "in_flight", "lsd8", "ballot"])
+def test_chunk_level_cull_skips_boxes_and_keeps_everything_exact(mode, monkeypatch):
+    """400 k splats (stored in Morton order by default), views that see little of the cloud: most bounding boxes are dead, and
+    V, keys, permutation, bin lists and pixels are what the per-splat cull gives -- for every pass-0 kernel (three-pass sort in
+    its 512- and 256-thread forms, the 8-bit passes, the ballot fallback)"""
+    from splatapult_amd import _capi
+    kw = {}
+    if mode == "in_flight":
+        kw["frame_mode"] = _capi.FRAMES_IN_FLIGHT
+    if mode == "lsd8":
+        monkeypatch.setenv("MSPLAT_SORT", "lsd8")
+    if mode == "ballot":
+        kw["rank_mode"] = _capi.RANK_BALLOT
+    n = 400_000
+    cloud = scenes.synth_cloud(n, 77, log_scale_mean=-4.5, pos_sigma=2.0)
+    aos = cloud.as_array()
+    r = make_renderer(cloud, **kw)
+    ref_r = make_renderer(cloud, spatial_order=_capi.SPATIAL_OFF)     # per-splat cull over the whole cloud, upload order
+    assert r.storage_order() is not None and ref_r.storage_order() is None
+    W, H = 640, 360
+    seen = []
+    for k, (pos, yaw, pitch) in enumerate((((0.0, 0.0, 7.0), 0.0, 0.0),          # everything in view
+                                           ((0.3, 0.2, 0.5), 1.3, 0.2),          # inside, looking sideways
+                                           ((4.0, 0.0, 4.0), 2.6, 0.0),          # outside, the cloud mostly behind / beside
+                                           ((0.0, 0.0, 7.0), 3.14159, 0.0))):    # looking away: nothing
+        cam = camera.pose(pos, yaw, pitch)
+        proj, vp, nf = camera.perspective(camera.FOVY, W / H), [0, 0, W, H], scenes.NF
+        for _ in range(2):                                            # twice: the second frame runs on the first one's tables
+            r.Sort(cam, proj, vp, nf)
+        ref_r.Sort(cam, proj, vp, nf)
+        V = _check_sort_exact(r, aos, cam, proj, nf)
+        assert ref_r.sort_count() == V
+        np.testing.assert_array_equal(r.sorted_keys(), ref_r.sorted_keys())
+        live, total = r.cull_boxes()
+        assert total == (n + 1023) // 1024
+        seen.append((V, live))
+        img = r.Render(cam, proj, vp, nf)
+        _check_tile_lists_ascending(r)
+        if V:
+            ref = oracle_frame(aos, True, cam, proj, vp, nf, r=r)
+            check_image(img, ref["image"], budget=ref["budget"])
+        else:
+            assert (img[..., :3] == 0).all() and live == 0
+    print("chunk-level cull (%s): (V, live boxes of %d) per view: %s" % (mode, (n + 1023) // 1024, seen))
+    assert seen[0][1] > 0.9 * total                                   # everything in view: (almost) every box is live
+    assert seen[1][1] < 0.8 * total and seen[2][1] < 0.8 * total      # partial views skip boxes
+    assert seen[1][0] > 1000
+
+
+def test_chunk_level_cull_with_row_bands_reassembles_bit_exact():
+    """the band-restricted cull at box level (box_live: the box's reach in y against the owned bin rows): every rank's Sort
+    keeps what the per-splat band test keeps, the bands reassemble the unbanded frame bit for bit, a rank tests fewer boxes"""
+    from splatapult_amd import _capi
+    n, W, H = 400_000, 800, 800
+    cloud = scenes.synth_cloud(n, 78, log_scale_mean=-4.3, pos_sigma=2.0)
+    cam, proj, vp, nf = scenes.default_view(W, H, z=6.5, yaw=0.2)
+    r = make_renderer(cloud)
+    r.Sort(cam, proj, vp, nf)
+    full = r.Render(cam, proj, vp, nf)
+    live_full, total = r.cull_boxes()
+    off = make_renderer(cloud, spatial_order=_capi.SPATIAL_OFF)
+    R = (H + bin_px() - 1) // bin_px()
+    for kind, k, G in (("contiguous", 1, 8), ("block", 2, 4), ("interleaved", 1, 3)):
+        acc = np.zeros_like(full)
+        lives = []
+        for g in range(G):
+            lay = r.set_band_plan(kind, R, G, g, block_rows=k, band_cull=True)
+            off.set_band_plan(kind, R, G, g, block_rows=k, band_cull=True)
+            r.Sort(cam, proj, vp, nf)
+            off.Sort(cam, proj, vp, nf)
+            assert r.sort_count() == off.sort_count()                 # box-level band test == per-splat band test
+            np.testing.assert_array_equal(r.sorted_keys(), off.sorted_keys())
+            lives.append(r.cull_boxes()[0])
+            part = r.Render(cam, proj, vp, nf)
+            rows = np.isin(np.arange(H) // bin_px(), _capi.band_rows(*lay, rows_full=R))
+            acc[rows] = part[rows]
+        np.testing.assert_array_equal(acc, full)
+        print("band cull at box level, %s x %d: live boxes per rank %s of %d (unbanded %d)" % (kind, G, lives, total, live_full))
+        if kind == "contiguous":
+            assert max(lives) < 0.6 * live_full
+    r.set_band(1, 0)
+
+
+def test_spatial_order_through_the_file_path_and_shared_clouds(tmp_path, monkeypatch):
+    """GPU ingest (InitFromPly) followed by the reordering: download_cloud returns the file's order; contexts that share the
+    cloud (frames in flight) see the same storage order and render identical frames"""
+    from splatapult_amd import synthetic
+    from splatapult_amd.scene import GaussianCloud
+    monkeypatch.setenv("MSPLAT_SPATIAL_ORDER", "1")
+    n = 6000
+    ply = str(tmp_path / "c.ply")
+    synthetic.write_ply(ply, synthetic.generate(n, seed=91, pos_sigma=1.5, log_scale_mean=-3.0))
+    r = SplatRenderer(device=0, frames_in_flight=3)
+    assert r.InitFromPly(ply, True, False), r.last_error()
+    host = GaussianCloud()
+    assert host.ImportPly(ply)
+    aos = host.as_array()
+    order = r.storage_order()
+    assert order is not None and np.array_equal(np.sort(order), np.arange(n))
+    dl = r.download_cloud(True)
+    np.testing.assert_array_equal(dl[:, :3], aos[:, :3])              # positions pass through the ingest untouched
+    np.testing.assert_allclose(dl, aos, rtol=2e-5, atol=2e-6)         # (device expf / sqrtf vs glibc, see test_gpu_ingest_*)
+    cam, proj, vp, nf = scenes.default_view(480, 270, z=6.0, yaw=0.4)
+    imgs = []
+    for _ in range(3):                                                # one frame on each of the three contexts
+        r.Sort(cam, proj, vp, nf)
+        assert np.array_equal(r.storage_order(), order)
+        _check_sort_exact(r, dl, cam, proj, nf)                       # (the oracle gets the DEVICE cloud: exact keys)
+        imgs.append(r.Render(cam, proj, vp, nf))
+    np.testing.assert_array_equal(imgs[0], imgs[1])
+    np.testing.assert_array_equal(imgs[0], imgs[2])
+    ref = oracle_frame(dl, True, cam, proj, vp, nf, r=r)
+    check_image(imgs[0], ref["image"], budget=ref["budget"])

@@ -85,9 +85,10 @@ typedef struct msplat_config {
  * The reference culls per splat over the whole cloud every frame (shader/presort_compute.glsl:31-57 dispatched over N,
  * src/splatrenderer.cpp:188-189) and so did pass 0 of this sort: 24 us of 249 when everything is visible, but most of the sort
  * when little is -- a rank of a row-sharded frame keeps 17 % of the splats, a camera inside a scene 40 %.  With spatial order the
- * upload stores the cloud sorted by the Morton code of the positions (ties in upload order), keeps one bounding box per 1024
- * stored splats, and the cull tests a chunk's boxes before it touches a splat: dead chunks are skipped whole.  The box test is
- * conservative -- the visible set, the keys and every pixel are what the per-splat test alone gives.
+ * upload stores the cloud sorted by the Morton code of the positions (ties in upload order), keeps one bounding box per 256
+ * stored splats, and a Sort whose predecessor saw less than 70 % of the cloud first lists the boxes that can hold a visible
+ * splat and runs its cull + first radix pass over those alone.  The box test is conservative -- the visible set, the keys and
+ * every pixel are what the per-splat test alone gives.
  * What it changes is the TIE RULE.  Draw order = ascending 32-bit depth key (splatrenderer.cpp:165-169), and splats with EQUAL
  * keys are drawn in ascending storage slot.  The reference's own tie order is undefined (the slots come from an atomic counter,
  * presort_compute.glsl:50), so any rule is one of its outcomes; this one is deterministic and reproducible:
@@ -355,9 +356,10 @@ int msplat_get_sorted_keys(msplat_ctx* ctx, uint32_t* dst, uint32_t cap);
 /* storage order of the uploaded cloud: dst[slot] = upload index (identity unless the cloud was reordered; *reordered, if not
  * NULL, says which).  dst may be NULL to ask only whether.  cap = entries dst can take (>= N). */
 int msplat_get_storage_order(msplat_ctx* ctx, uint32_t* dst, uint64_t cap, int* reordered);
-/* chunk-level cull of the latest Sort: bounding boxes (of 1024 stored splats) whose splats were tested / boxes in the cloud;
- * 0 / 0 for a cloud in upload order.  Synchronises. */
-int msplat_debug_get_cull_boxes(msplat_ctx* ctx, uint32_t* live, uint32_t* total);
+/* chunk-level cull, evaluated for the latest Sort's camera: bounding boxes (of 256 stored splats) that can hold a visible splat /
+ * boxes in the cloud (0 / 0 for a cloud in upload order); *listed (may be NULL) = 1 when that Sort's first pass walked only the
+ * listed live boxes (it does once an earlier frame saw less than 70 % of the cloud).  Synchronises. */
+int msplat_debug_get_cull_boxes(msplat_ctx* ctx, uint32_t* live, uint32_t* total, int* listed);
 
 int msplat_get_stats(msplat_ctx* ctx, msplat_stats* out);      /* synchronises */
 int msplat_get_timings(msplat_ctx* ctx, msplat_timings* out);  /* synchronises */

@@ -119,7 +119,7 @@ SYMBOLS = [
     ("msplat_get_sorted_indices", C.c_int, [C.c_void_p, _U32P, C.c_uint32]),
     ("msplat_get_sorted_keys", C.c_int, [C.c_void_p, _U32P, C.c_uint32]),
     ("msplat_get_storage_order", C.c_int, [C.c_void_p, _U32P, C.c_uint64, C.POINTER(C.c_int)]),
-    ("msplat_debug_get_cull_boxes", C.c_int, [C.c_void_p, _U32P, _U32P]),
+    ("msplat_debug_get_cull_boxes", C.c_int, [C.c_void_p, _U32P, _U32P, C.POINTER(C.c_int)]),
     ("msplat_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     ("msplat_get_timings", C.c_int, [C.c_void_p, C.POINTER(Timings)]),
     ("msplat_debug_get_projected", C.c_int, [C.c_void_p, _F16, _U32P, C.c_uint32]),

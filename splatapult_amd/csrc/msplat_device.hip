@@ -91,9 +91,10 @@ struct msplat_ctx {
     // wide-digit 3-pass sort (r3, msplat_kernels.hip.h ws_*): histogram rows of up to 2048 digits per chunk, one group
     // table per pass, one visibility bit per splat, the visible set's minimum key per frame parity (counters[10..11])
     Buf wsHist, wsGsum[3], vmask;
-    Buf cmask;                  // live-box mask per pass-0 chunk of the latest Sort (chunk-level cull, spatially ordered clouds)
+    Buf live_list, live_cnt;    // live bounding boxes of the latest Sort that ran box_cull_kernel (spatially ordered clouds)
     int spatial_mode = 0;       // msplat_config.spatial_order / MSPLAT_SPATIAL_ORDER: 0 auto, 1 always, 2 never
-    uint32_t sort_chunk0 = 2048;   // splats per pass-0 chunk of the latest Sort (what a cmask word covers)
+    bool last_sort_listed = false;   // the latest Sort's pass 0 walked the listed boxes only
+    FrameParams last_sort_fp{};
     uint32_t ws_items = 8, ws_gshift = 4, ws_gsum_words = 0;
     uint32_t ws_threads = 512;  // 256 (4 waves, 40 / 56 KB of LDS) for contexts that share the GPU with other frames
     bool wide_sort = true;      // MSPLAT_SORT=lsd8 (or no lane-ordered LDS atomics): the four 8-bit passes
@@ -395,7 +396,7 @@ void msplat_destroy(msplat_ctx* ctx)
                   &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->totals1, &ctx->tile_start, &ctx->tile_order,
                   &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe, &ctx->zq, &ctx->sprite, &ctx->queue,
                   &ctx->wsHist, &ctx->wsGsum[0], &ctx->wsGsum[1], &ctx->wsGsum[2], &ctx->vmask, &ctx->bincnt, &ctx->heavy, &ctx->heavy_flag,
-                  &ctx->cmask};
+                  &ctx->live_list, &ctx->live_cnt};
     for (Buf* b : all) buf_free(ctx, *b);
     if (ctx->ev_ok)
         for (auto& set : ctx->ev)
@@ -644,7 +645,8 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
         ctx->ws_gsum_words = (uint32_t)gwords;
         if ((rc = buf_alloc(ctx, ctx->vmask, (size_t)div_up(alloc_n, 64) * 8 + 64))) return rc;
     }
-    if ((rc = buf_alloc(ctx, ctx->cmask, ((size_t)div_up(alloc_n, 2048) + 16) * 4))) return rc;      // pass-0 chunks are >= 2048 splats
+    if ((rc = buf_alloc(ctx, ctx->live_list, ((size_t)div_up(div_up(alloc_n, kBoxSplats), kBoxGroup) * kBoxGroup + 16) * 4))) return rc;
+    if ((rc = buf_alloc(ctx, ctx->live_cnt, 256 * 4))) return rc;
     if ((rc = buf_alloc(ctx, ctx->rec2d, alloc_n * 48))) return rc;
     if ((rc = buf_alloc(ctx, ctx->rect, alloc_n * 4))) return rc;
     if (ctx->depth_bits != 0 && (rc = buf_alloc(ctx, ctx->zq, alloc_n * 4))) return rc;
@@ -1171,6 +1173,28 @@ static int clear_frame_tables(msplat_ctx* ctx)
     return MSPLAT_OK;
 }
 
+// Chunk-level cull (msplat_kernels.hip.h, box_live): for a spatially ordered cloud of which an EARLIER frame saw less than 70 %
+// (host-mapped V, read without synchronising; 0 = no frame yet) Sort starts with box_cull_kernel and pass 0 walks the listed
+// live boxes only.  Either form gives the same visible set, keys and order; the choice only matters for speed: the extra launch
+// costs ~4 us, which a view of the whole cloud (BASELINE configs[1]: V = 0.99 N) would pay for nothing.
+static LiveBoxes list_live_boxes(msplat_ctx* ctx, const FrameParams& fp, uint32_t last_V)
+{
+    LiveBoxes lb{nullptr, nullptr, 0u, (uint32_t)ctx->N};
+    ctx->last_sort_fp = fp;
+    ctx->last_sort_listed = false;
+    const CloudStore* st = ctx->store.get();
+    if (!st || !st->reordered || !st->boxes.p || ctx->point_mode) return lb;
+    if (last_V == 0u || (uint64_t)last_V * 10u >= ctx->N * 7u) return lb;
+    const uint32_t wgs = div_up(st->nboxes, kBoxGroup);
+    hipLaunchKernelGGL(box_cull_kernel, dim3(wgs), dim3(kBoxGroup), 0, ctx->stream, (const CullBox*)st->boxes.p, st->nboxes, fp,
+                       (uint32_t*)ctx->live_list.p, (uint32_t*)ctx->live_cnt.p);
+    lb.list = (const uint32_t*)ctx->live_list.p;
+    lb.cnt = (const uint32_t*)ctx->live_cnt.p;
+    lb.wgs = wgs;
+    ctx->last_sort_listed = true;
+    return lb;
+}
+
 int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[16],
                 const float viewport[4], const float nearFar[2])
 {
@@ -1245,17 +1269,12 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
             hipLaunchKernelGGL((ws_upsweep<CULLF, 4, 2 * kWsThreads>), dim3(wgrid), dim3(2 * kWsThreads), 0, s, __VA_ARGS__); \
         else MSPLAT_WS(ws_upsweep, CULLF, MSPLAT_NO_LDS, __VA_ARGS__);                                                    \
     } while (0)
-        // chunk-level cull over a spatially ordered cloud: pass 0 tests the chunk's bounding boxes first (box_live)
-        const bool boxed = ctx->store->reordered && ctx->store->boxes.p != nullptr;
-        const CullBox* boxes = boxed ? (const CullBox*)ctx->store->boxes.p : nullptr;
-        const uint32_t nboxes = boxed ? ctx->store->nboxes : 0u;
-        uint32_t* cmask = boxed ? (uint32_t*)ctx->cmask.p : nullptr;
-        ctx->sort_chunk0 = ctx->ws_threads * items;
+        const LiveBoxes lb = list_live_boxes(ctx, fp, last_V);       // (launches box_cull_kernel when the view is a partial one)
         MSPLAT_WS_UP(true, (const uint32_t*)nullptr, pos, kB, vm, (const uint32_t*)nullptr, N, N, 0, mk_cur,
-                  mk_next, whist, gt(0), gsh, gt(-1), gw, fp, boxes, nboxes, cmask);
+                  mk_next, whist, gt(0), gsh, gt(-1), gw, fp, lb);
         MSPLAT_WS(ws_downsweep, true, ws_downsweep_lds, (const uint32_t*)kB, (const uint32_t*)nullptr, (const unsigned long long*)vm,
                   (const uint32_t*)nullptr, N, N, 0, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(0), gsh, kA, vA,
-                  d_V, wsx, (const uint32_t*)cmask);
+                  d_V, wsx, lb);
         items = items12;
         wgrid = grid_for(div_up(N, ctx->ws_threads * items));
         MSPLAT_WS_UP(false, (const uint32_t*)kA, (const float4*)nullptr, (uint32_t*)nullptr,
@@ -1307,18 +1326,14 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
         }                                                                                                                        \
     } while (0)
     // pass 0: cull + key fused into the first radix pass (presort_compute.glsl + byte 0 of the sort)
-    const bool boxed = ctx->store->reordered && ctx->store->boxes.p != nullptr;       // chunk-level cull, see the three-pass branch
-    const CullBox* boxes = boxed ? (const CullBox*)ctx->store->boxes.p : nullptr;
-    const uint32_t nboxes = boxed ? ctx->store->nboxes : 0u;
-    uint32_t* cmask = boxed ? (uint32_t*)ctx->cmask.p : nullptr;
-    ctx->sort_chunk0 = chunk;
+    const LiveBoxes lb = list_live_boxes(ctx, fp, ctx->h_flags ? __atomic_load_n(ctx->h_flags + 1, __ATOMIC_RELAXED) : 0u);
     MSPLAT_UPSWEEP(MODE_CULL, (const uint32_t*)nullptr, pos, (const uint32_t*)nullptr, N, N, 0, hist, ctx->hist_stride, gacc(0),
-                   gzero(0), ctx->gsumS_rows, fp, (const uint32_t*)nullptr, (uint32_t*)nullptr, ctx->gsupS, boxes, nboxes, cmask);
+                   gzero(0), ctx->gsumS_rows, fp, (const uint32_t*)nullptr, (uint32_t*)nullptr, ctx->gsupS, lb);
     if (!fused) launch_scan(s, ctx->N <= (2u << 20), hist, ctx->hist_stride, nullptr, N, N, chunk, totals);
     MSPLAT_DOWNSWEEP(MODE_CULL, (const uint32_t*)nullptr, (const uint32_t*)nullptr, pos, (const uint32_t*)nullptr, N, N, 0,
                      (const uint32_t*)hist, ctx->hist_stride, (const uint32_t*)totals, kB, vB, d_V, (const uint32_t*)nullptr,
                      (const uint32_t*)gacc(0), (uint32_t*)nullptr, fp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                     (uint32_t*)nullptr, 0, 0, ctx->gsupS, (const uint32_t*)cmask);
+                     (uint32_t*)nullptr, 0, 0, ctx->gsupS, lb);
     // passes 1..3 on the V survivors (V stays on the device; splatrenderer.cpp:195-204's readback is gone)
     for (int pass = 1; pass < 4; ++pass) {
         uint32_t* kin = (pass & 1) ? kB : kA;
@@ -1663,23 +1678,34 @@ int msplat_get_storage_order(msplat_ctx* ctx, uint32_t* dst, uint64_t cap, int* 
     return MSPLAT_OK;
 }
 
-// chunk-level cull of the latest Sort (spatially ordered clouds): bounding boxes that were live / boxes in the cloud
-int msplat_debug_get_cull_boxes(msplat_ctx* ctx, uint32_t* live, uint32_t* total)
+// chunk-level cull, for the latest Sort's camera: bounding boxes box_live keeps / boxes in the cloud (0 / 0 for a cloud in upload
+// order); *listed = 1 when that Sort's pass 0 walked the listed boxes only.  Runs box_cull_kernel on demand; synchronises.
+int msplat_debug_get_cull_boxes(msplat_ctx* ctx, uint32_t* live, uint32_t* total, int* listed)
 {
     if (!ctx || !live || !total) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
     if (!ctx->has_sort) return fail(ctx, MSPLAT_ERR_NO_SORT, "no sort yet");
     *live = *total = 0;
-    if (!(ctx->store && ctx->store->reordered)) return MSPLAT_OK;
+    if (listed) *listed = ctx->last_sort_listed ? 1 : 0;
+    const CloudStore* st = ctx->store.get();
+    if (!(st && st->reordered && st->boxes.p)) return MSPLAT_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t per = ctx->sort_chunk0 / (uint32_t)kBoxSplats, nch = div_up(ctx->N, ctx->sort_chunk0);
-    std::vector<uint32_t> m;
-    try { m.resize(nch); } catch (const std::exception&) { return fail(ctx, MSPLAT_ERR_HIP, "out of host memory"); }
-    HIP_TRY(ctx, hipMemcpy(m.data(), ctx->cmask.p, (size_t)nch * 4, hipMemcpyDeviceToHost));
-    const uint32_t bits = per >= 32u ? 0xFFFFFFFFu : ((1u << per) - 1u);
-    for (uint32_t c = 0; c < nch; ++c) *live += (uint32_t)__builtin_popcount(m[c] & bits);
-    *total = ctx->store->nboxes;
-    return MSPLAT_OK;
+    const uint32_t wgs = div_up(st->nboxes, kBoxGroup);
+    Buf list, cnt;
+    int rc = buf_alloc(ctx, list, (size_t)wgs * kBoxGroup * 4);
+    if (!rc) rc = buf_alloc(ctx, cnt, 256 * 4);
+    if (!rc) {
+        hipLaunchKernelGGL(box_cull_kernel, dim3(wgs), dim3(kBoxGroup), 0, ctx->stream, (const CullBox*)st->boxes.p, st->nboxes,
+                           ctx->last_sort_fp, (uint32_t*)list.p, (uint32_t*)cnt.p);
+        uint32_t h[256];
+        hipError_t e = hipMemcpyAsync(h, cnt.p, (size_t)wgs * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, MSPLAT_ERR_HIP, "msplat_debug_get_cull_boxes: %s", hipGetErrorString(e));
+        else for (uint32_t g = 0; g < wgs; ++g) *live += h[g];
+    }
+    buf_free(ctx, list);
+    buf_free(ctx, cnt);
+    *total = st->nboxes;
+    return rc;
 }
 
 int msplat_get_sorted_keys(msplat_ctx* ctx, uint32_t* dst, uint32_t cap)

@@ -185,11 +185,16 @@ __device__ __forceinline__ bool cull_key(const float4 p, const FrameParams& fp, 
 // frame keeps 17 % of the splats, a camera inside a scene 40 %.  Large clouds are therefore STORED in Morton order of their
 // positions (msplat_device.hip, spatial_reorder; the storage order is the library's business: sorted indices are reported in
 // upload numbering and msplat_get_storage_order exposes the permutation) and every kBoxSplats consecutive stored splats carry a
-// bounding box.  Pass 0 tests a chunk's boxes first and skips the dead ones whole: no position is loaded, no key computed.
+// bounding box.  When an earlier frame saw less than 70 % of the cloud, Sort starts with box_cull_kernel: one thread per box,
+// the live boxes listed in storage order; pass 0 then runs over the LISTED boxes only -- its chunks are made of live boxes, so
+// its work is proportional to what can be seen, not to N.  (First attempt, r4: a per-chunk mask of live 1024-splat boxes tested
+// inside pass 0 -- exact, but no faster: 40-64 % of such boxes are live for a rank that sees 17 % of the splats, every chunk
+// still ran all its phases, and the box test sat on each chunk's critical path.)
 // box_live is CONSERVATIVE: it returns false only if cull_key returns false for every splat the box can contain, so the
-// visible set and the keys are exactly those of the per-splat test.
+// visible set and the keys are exactly those of the per-splat test, and the listed boxes keep storage order, so ties do too.
 // ------------------------------------------------------------------------------------------
-constexpr int kBoxSplats = 1024;         // stored splats per bounding box: 2 / 4 / 8 boxes per pass-0 chunk
+constexpr int kBoxSplats = 256;          // stored splats per bounding box (four wave rows): 8 / 16 / 32 boxes per pass-0 chunk
+constexpr int kBoxGroup = 256;           // boxes per workgroup of box_cull_kernel = entries per segment of the live list
 struct CullBox {                         // 32 bytes
     float4 lo;                           // min x, y, z of the finite positions; .w = max footprint bound (pos4.w) of the box
     float4 hi;                           // max x, y, z; .w unused.  lo.x > hi.x: no finite position in the box
@@ -251,21 +256,75 @@ __device__ __forceinline__ bool box_live(const CullBox& b, const FrameParams& fp
     return true;
 }
 
-// live-box mask of chunk `chunk` (NB boxes per chunk, bit k = box chunk * NB + k): evaluated by the first NB lanes of the
-// workgroup's first wave, returned to every thread through s_word.  Contains one barrier.
-template <int NB>
-__device__ __forceinline__ uint32_t chunk_live_mask(const CullBox* __restrict__ boxes, uint32_t nboxes, uint32_t chunk,
-                                                    const FrameParams& fp, uint32_t* s_word)
+// The live boxes of the current Sort: workgroup g of box_cull_kernel leaves the live ones of its kBoxGroup boxes, ascending, in
+// list[g * kBoxGroup ...] and their number in cnt[g] (g < wgs <= 256: up to 2^24 splats).  list == nullptr: no list, pass 0
+// walks the whole cloud.
+struct LiveBoxes {
+    const uint32_t* list;
+    const uint32_t* cnt;
+    uint32_t wgs;
+    uint32_t n_storage;                  // splats in the cloud (the last box may be partial)
+};
+
+__global__ __launch_bounds__(kBoxGroup) void box_cull_kernel(const CullBox* __restrict__ boxes, uint32_t nboxes, FrameParams fp,
+                                                             uint32_t* __restrict__ list, uint32_t* __restrict__ cnt)
 {
-    if (threadIdx.x < 64) {
-        bool l = false;
-        const uint32_t bi = chunk * NB + threadIdx.x;
-        if (threadIdx.x < NB && bi < nboxes) l = box_live(boxes[bi], fp);
-        const unsigned long long mk = __ballot(l);
-        if (threadIdx.x == 0) *s_word = (uint32_t)mk;
-    }
+    __shared__ uint32_t s_w[kBoxGroup / 64];
+    const uint32_t b = blockIdx.x * kBoxGroup + threadIdx.x;
+    const bool l = b < nboxes && box_live(boxes[b], fp);
+    const unsigned long long m = __ballot(l);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_w[w] = (uint32_t)__popcll(m);
     __syncthreads();
-    return *s_word;
+    uint32_t off = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kBoxGroup / 64; ++k) {
+        if (k < w) off += s_w[k];
+        total += s_w[k];
+    }
+    if (l) list[blockIdx.x * kBoxGroup + off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
+    if (threadIdx.x == 0) cnt[blockIdx.x] = total;
+}
+
+// exclusive prefix of the segment counts: s_lpre[g] = live boxes before segment g, s_lpre[256] = all of them.  Every thread of a
+// workgroup of >= 256 threads must call it (WAVES = its waves; s_tmp: WAVES words).  Ends with a barrier.
+template <int WAVES>
+__device__ __forceinline__ void live_prefix(const LiveBoxes& lb, uint32_t* s_lpre, uint32_t* s_tmp)
+{
+    const uint32_t t = threadIdx.x;
+    uint32_t v = (t < 256u && t < lb.wgs) ? lb.cnt[t] : 0u;
+    const uint32_t c = v;
+    const int lane = t & 63, w = t >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t x = __shfl_up(v, d, 64);
+        if (lane >= d) v += x;
+    }
+    if (lane == 63) s_tmp[w] = v;
+    __syncthreads();
+    uint32_t off = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < WAVES; ++k) {
+        const uint32_t x = s_tmp[k];
+        if (k < w) off += x;
+        total += x;
+    }
+    if (t < 256u) s_lpre[t] = v + off - c;
+    if (t == 0u) s_lpre[256] = total;
+    __syncthreads();
+}
+
+// storage box number of the vb-th live box (0xFFFFFFFF beyond the last)
+__device__ __forceinline__ uint32_t live_box_at(const LiveBoxes& lb, const uint32_t* s_lpre, uint32_t vb)
+{
+    if (vb >= s_lpre[256]) return 0xFFFFFFFFu;
+    uint32_t lo = 0, hi = 255;                  // last segment g with s_lpre[g] <= vb
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        const uint32_t mid = (lo + hi + 1u) >> 1;
+        if (s_lpre[mid] <= vb) lo = mid; else hi = mid - 1u;
+    }
+    return lb.list[lo * kBoxGroup + (vb - s_lpre[lo])];
 }
 
 template <int MODE>
@@ -355,10 +414,9 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
                                                           FrameParams fp,
                                                           const uint32_t* __restrict__ col_totals = nullptr,
                                                           uint32_t* __restrict__ bincnt = nullptr, uint32_t gsup = 0u,
-                                                          const CullBox* __restrict__ boxes = nullptr, uint32_t nboxes = 0u,
-                                                          uint32_t* __restrict__ cmask = nullptr)
+                                                          LiveBoxes lb = LiveBoxes{nullptr, nullptr, 0u, 0u})
 {
-    // MODE_CULL with boxes != nullptr: chunk-level cull over a spatially ordered cloud, see ws_upsweep / box_live
+    // MODE_CULL with lb.list != nullptr: pass 0 over the listed live boxes only (virtual positions), see ws_upsweep / box_live
     // MODE_PAIR with bincnt != nullptr (r3): the input is ordered by (column, rank) and carries the row in its top byte, so
     // counting the words per (row, column) here gives every bin's list length before the partition has run: the
     // downsweep's extra workgroup turns the counts into the bins' list offsets (tile_table_role) and the two launches
@@ -373,11 +431,17 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
     __shared__ uint32_t s_bin[MODE == MODE_PAIR ? kPairCols * 256 : 1];
     __shared__ uint32_t s_col[MODE == MODE_PAIR ? 257 : 1];       // first input position of each column
     __shared__ uint32_t s_tmp4[4];
-    __shared__ uint32_t s_live;
+    constexpr int BPC = CHUNK / kBoxSplats;
+    __shared__ uint32_t s_lpre[MODE == MODE_CULL ? 257 : 1], s_box[MODE == MODE_CULL ? BPC : 1];
+    const bool compact = MODE == MODE_CULL && lb.list != nullptr;
     if (gsum_zero != nullptr)
         for (uint32_t row = blockIdx.x; row < gsum_zero_rows; row += gridDim.x) gsum_zero[(size_t)row * 256 + threadIdx.x] = 0u;
     uint32_t n = d_n ? *d_n : n_static;
     if (n > n_cap) n = n_cap;
+    if (compact) {
+        live_prefix<kThreads / 64>(lb, s_lpre, s_tmp4);
+        n = s_lpre[256] * (uint32_t)kBoxSplats;
+    }
     const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
     const bool count_bins = MODE == MODE_PAIR && bincnt != nullptr;
     if (count_bins) {
@@ -389,16 +453,7 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
         __syncthreads();
     }
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        uint32_t live = 0xFFFFFFFFu;
-        if (MODE == MODE_CULL && boxes != nullptr) {
-            live = chunk_live_mask<(CHUNK >= kBoxSplats ? CHUNK / kBoxSplats : 1)>(boxes, nboxes, chunk, fp, &s_live);
-            if (threadIdx.x == 0) cmask[chunk] = live;
-            if (live == 0u) {                  // workgroup-uniform: a dead chunk only zeroes its histogram row
-                hist[(size_t)chunk * 256 + threadIdx.x] = 0u;
-                __syncthreads();
-                continue;
-            }
-        }
+        if (compact && threadIdx.x < (uint32_t)BPC) s_box[threadIdx.x] = live_box_at(lb, s_lpre, chunk * BPC + threadIdx.x);
         s_hist[threadIdx.x] = 0;
         if (count_bins)
 #pragma unroll
@@ -442,17 +497,26 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
             // straight-line form: every load of the chunk is in flight before the first LDS atomic (one_col: the counts land
             // in s_bin[0][row], i.e. column c0)
             if (MODE == MODE_CULL) {
-                float4 pp[MODE == MODE_CULL ? ITEMS : 1];          // clamped loads, all in flight together (see below)
-                // (row r = 256 consecutive splats of box r * 256 / kBoxSplats: a dead box's rows load one hot address)
-#pragma unroll
-                for (int r = 0; r < ITEMS; ++r)
-                    pp[r] = pos[((live >> (r * kThreads / kBoxSplats)) & 1u) ? min(base + r * kThreads + threadIdx.x, n - 1u) : min(base, n - 1u)];
+                float4 pp[MODE == MODE_CULL ? ITEMS : 1];          // unconditional loads, all in flight together (see below)
+                // storage index of virtual position i (== i without a list); `in`: the position holds a splat
+                auto locate = [&](uint32_t i, bool& in) -> uint32_t {
+                    if (!compact) { in = i < n; return i; }
+                    const uint32_t e = i - base, bx = s_box[e / kBoxSplats], st = bx * kBoxSplats + (e % kBoxSplats);
+                    in = bx != 0xFFFFFFFFu && st < lb.n_storage;
+                    return st;
+                };
 #pragma unroll
                 for (int r = 0; r < ITEMS; ++r) {
-                    if (!((live >> (r * kThreads / kBoxSplats)) & 1u)) continue;        // workgroup-uniform
-                    const uint32_t i = base + r * kThreads + threadIdx.x;
+                    bool in;
+                    const uint32_t st = locate(base + r * kThreads + threadIdx.x, in);
+                    pp[r] = pos[in ? st : 0u];
+                }
+#pragma unroll
+                for (int r = 0; r < ITEMS; ++r) {
+                    bool in;
+                    (void)locate(base + r * kThreads + threadIdx.x, in);
                     uint32_t key;
-                    if (i < n && cull_key(pp[r], fp, key)) atomicAdd(&s_hist[digit_of<MODE>(key, shift)], 1u);
+                    if (in && cull_key(pp[r], fp, key)) atomicAdd(&s_hist[digit_of<MODE>(key, shift)], 1u);
                 }
             } else {
                 // unconditional (clamped) loads first: under `if (i < n)` the compiler waits for every load before it
@@ -716,9 +780,9 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE != MODE_PAIR && SORT
                                                             uint32_t* __restrict__ tile_order = nullptr,
                                                             uint32_t* __restrict__ queue = nullptr,
                                                             int ntiles = 0, int do_order = 0, uint32_t gsup = 0u,
-                                                            const uint32_t* __restrict__ cmask = nullptr)
+                                                            LiveBoxes lb = LiveBoxes{nullptr, nullptr, 0u, 0u})
 {
-    // cmask != nullptr (MODE_CULL): live-box masks of the chunks from radix_upsweep; dead chunks / boxes are skipped
+    // lb.list != nullptr (MODE_CULL): pass 0 over the listed live boxes only (virtual positions), see ws_upsweep
     // gsum != nullptr: scan-free path -- hist holds raw per-chunk counts, prefixes come from the group tables;
     // otherwise hist holds exclusive prefixes and totals the digit totals (radix_scan*).
     // totals_out != nullptr: workgroup 0 publishes the digit totals (the row totals tile_start_kernel needs).
@@ -744,8 +808,15 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE != MODE_PAIR && SORT
         nworkers = gridDim.x - 1u;
         wb = blockIdx.x - 1u;
     }
+    constexpr int BPC = CHUNK / kBoxSplats;
+    __shared__ uint32_t s_lpre[MODE == MODE_CULL ? 257 : 1], s_box[MODE == MODE_CULL ? BPC : 1];
+    const bool compact = MODE == MODE_CULL && lb.list != nullptr;
     uint32_t n = d_n ? *d_n : n_static;
     if (n > n_cap) n = n_cap;
+    if (compact) {
+        live_prefix<kThreads / 64>(lb, s_lpre, s_tmp);
+        n = s_lpre[256] * (uint32_t)kBoxSplats;
+    }
     const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
@@ -772,11 +843,7 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE != MODE_PAIR && SORT
     const bool xmap = MODE == MODE_PAIR && (do_order & 2) && (nworkers >= nchunks || (nworkers & 7u) == 0u);
     for (uint32_t cidx = wb; cidx < nchunks; cidx += nworkers) {
         const uint32_t chunk = xmap ? xcd_contiguous(cidx, nchunks) : cidx;
-        uint32_t live = 0xFFFFFFFFu;
-        if (MODE == MODE_CULL && cmask != nullptr) {
-            live = cmask[chunk];                   // workgroup-uniform
-            if (live == 0u) continue;
-        }
+        if (compact && threadIdx.x < (uint32_t)BPC) s_box[threadIdx.x] = live_box_at(lb, s_lpre, chunk * BPC + threadIdx.x);   // (barriers follow)
         // this chunk's exclusive prefix per digit (thread = digit): issued first, consumed after the local ranking
         const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk, reinterpret_cast<uint4*>(s_keys), gsup)
                                                      : hist[(size_t)chunk * 256 + threadIdx.x];
@@ -794,24 +861,35 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE != MODE_PAIR && SORT
         // fifth wave per SIMD: 16-byte loads)
         constexpr int kPosBatch = 4;
         float4 pp[MODE == MODE_CULL ? kPosBatch : 1];
-        // (the wave's sub-chunk of 64 * ITEMS splats lies in one box -- 512 or 1024 splats -- or covers whole boxes)
-        const bool wave_live = MODE != MODE_CULL || ((live >> (((uint32_t)w * (64 * ITEMS)) / kBoxSplats)) & 1u) != 0u;
+        // storage index of virtual position i (== i without a list); `in`: the position holds a splat
+        auto locate = [&](uint32_t i, bool& in) -> uint32_t {
+            if (!compact) { in = i < n; return i; }
+            const uint32_t e = i - chunk * CHUNK, bx = s_box[e / kBoxSplats], st = bx * kBoxSplats + (e % kBoxSplats);
+            in = bx != 0xFFFFFFFFu && st < lb.n_storage;
+            return st;
+        };
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             if (MODE == MODE_CULL && (r % kPosBatch) == 0) {
 #pragma unroll
                 for (int k = 0; k < kPosBatch; ++k)
-                    if (r + k < ITEMS) pp[k] = pos[wave_live ? min(base + (r + k) * 64 + lane, n - 1u) : min(chunk * CHUNK, n - 1u)];
+                    if (r + k < ITEMS) {
+                        bool in;
+                        const uint32_t st = locate(base + (r + k) * 64 + lane, in);
+                        pp[k] = pos[in ? st : 0u];
+                    }
             }
             const uint32_t i = base + r * 64 + lane;
-            valid[r] = (i < n) && wave_live;
+            valid[r] = i < n;
             key[r] = 0;
             val[r] = 0;
-            if (valid[r]) {
-                if (MODE == MODE_CULL) {
-                    valid[r] = cull_key(pp[r % kPosBatch], fp, key[r]);
-                    val[r] = i;
-                } else {
+            if (MODE == MODE_CULL) {
+                bool in;
+                const uint32_t st = locate(i, in);
+                valid[r] = in && cull_key(pp[r % kPosBatch], fp, key[r]);
+                val[r] = st;
+            } else if (valid[r]) {
+                {
                     key[r] = keys_in[i];
                     if (HAS_VALUES) val[r] = vals_in[i];
                 }
@@ -1057,41 +1135,37 @@ __global__ __launch_bounds__(THREADS) void ws_upsweep(const uint32_t* __restrict
                                                       uint32_t* __restrict__ hist,
                                                       uint32_t* __restrict__ gsum_acc, int gshift,
                                                       uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_words,
-                                                      FrameParams fp, const CullBox* __restrict__ boxes = nullptr,
-                                                      uint32_t nboxes = 0u, uint32_t* __restrict__ cmask = nullptr)
+                                                      FrameParams fp, LiveBoxes lb = LiveBoxes{nullptr, nullptr, 0u, 0u})
 {
-    // boxes != nullptr (CULL, spatially ordered cloud): the chunk's bounding boxes are tested first (box_live); the mask of live
-    // boxes goes to cmask[chunk] for the downsweep, dead boxes are neither loaded nor keyed, a dead chunk only zeroes its row
+    // lb.list != nullptr (CULL, spatially ordered cloud, box_cull_kernel has run): the pass walks the LISTED boxes only.  A chunk
+    // is BPC consecutive live boxes; element e of chunk c is splat box[c * BPC + e / kBoxSplats] * kBoxSplats + e % kBoxSplats;
+    // raw_keys / vmask / the histogram rows are indexed by the VIRTUAL position c * CHUNK + e, which is dense.
     constexpr int CHUNK = THREADS * ITEMS;
     constexpr int WAVES = THREADS / 64;
-    constexpr int NB = CHUNK / kBoxSplats;                     // boxes per chunk: 2, 4 or 8
-    static_assert(CHUNK % kBoxSplats == 0 && (THREADS % kBoxSplats == 0 || kBoxSplats % THREADS == 0), "rows must not straddle boxes");
+    constexpr int BPC = CHUNK / kBoxSplats;                    // boxes per chunk: 8, 16 or 32
+    static_assert(CHUNK % kBoxSplats == 0 && kBoxSplats % 64 == 0 && THREADS >= 256, "a wave row lies in one box");
     __shared__ uint32_t s_hist[kWsMaxBins];
     __shared__ uint32_t s_min[WAVES];
-    __shared__ uint32_t s_live;
+    __shared__ uint32_t s_lpre[CULL ? 257 : 1], s_box[CULL ? BPC : 1], s_tmpw[WAVES];
+    const bool compact = CULL && lb.list != nullptr;
     // the group table of the pass before this one (its consumer finished one launch ago) is cleared for the next frame
     if (gsum_zero != nullptr)
         for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < gsum_zero_words; i += gridDim.x * THREADS) gsum_zero[i] = 0u;
     if (CULL && blockIdx.x == 0 && threadIdx.x == 0) *minkey_next = 0xFFFFFFFFu;      // the other frame parity's word
     uint32_t n = d_n ? *d_n : n_static;
     if (n > n_cap) n = n_cap;
+    if (compact) {
+        live_prefix<WAVES>(lb, s_lpre, s_tmpw);
+        n = s_lpre[256] * (uint32_t)kBoxSplats;                 // virtual positions (the cloud's last box may be partial: see `in`)
+    }
     int shift, bits;
     ws_digit_range(pass, CULL ? 0u : *minkey_cur, shift, bits);
     const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
     const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
     uint32_t mk = 0xFFFFFFFFu;
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        uint32_t live = 0xFFFFFFFFu;
-        if (CULL && boxes != nullptr) {
-            live = chunk_live_mask<NB>(boxes, nboxes, chunk, fp, &s_live);
-            if (threadIdx.x == 0) cmask[chunk] = live;
-            if (live == 0u) {                  // workgroup-uniform: nothing of this chunk can be seen
-                for (uint32_t d = threadIdx.x; d < nbins; d += THREADS) hist[(size_t)chunk * nbins + d] = 0u;
-                __syncthreads();               // (s_live is rewritten by the next chunk)
-                continue;
-            }
-        }
         for (uint32_t d = threadIdx.x; d < nbins; d += THREADS) s_hist[d] = 0u;
+        if (compact && threadIdx.x < (uint32_t)BPC) s_box[threadIdx.x] = live_box_at(lb, s_lpre, chunk * BPC + threadIdx.x);
         __syncthreads();
         // unconditional (clamped) loads first, so that all of them are in flight together: under `if (i < n)` the
         // compiler waits for each load before it issues the next (r3, seen in the ISA).  The cull pass over 8192-key chunks
@@ -1104,24 +1178,36 @@ __global__ __launch_bounds__(THREADS) void ws_upsweep(const uint32_t* __restrict
         const uint32_t base = chunk * CHUNK + (uint32_t)sub * (IPS * THREADS);
         float4 pp[CULL ? IPS : 1];
         uint32_t kk[CULL ? 1 : IPS];
-        // row r of the chunk = THREADS consecutive splats inside box (sub * IPS + r) * THREADS / kBoxSplats: a dead box's rows
-        // load one hot address instead of their positions (the loads stay unconditional) and skip the key arithmetic
-        auto row_live = [&](int r) { return CULL ? ((live >> (((uint32_t)sub * IPS + r) * THREADS / kBoxSplats)) & 1u) != 0u : true; };
+        // storage index of virtual position i (== i without a list); `in`: the position holds a splat
+        auto locate = [&](uint32_t i, bool& in) -> uint32_t {
+            if (!compact) { in = i < n; return i; }
+            const uint32_t e = i - chunk * CHUNK, bx = s_box[e / kBoxSplats], st = bx * kBoxSplats + (e % kBoxSplats);
+            in = bx != 0xFFFFFFFFu && st < lb.n_storage;
+            return st;
+        };
 #pragma unroll
         for (int r = 0; r < IPS; ++r) {
-            const uint32_t ic = min(base + r * THREADS + threadIdx.x, n - 1u);          // n >= 1 inside this loop
-            if (CULL) pp[r] = pos[row_live(r) ? ic : min(chunk * CHUNK, n - 1u)];
-            else kk[r] = keys_in[ic];
+            const uint32_t i = base + r * THREADS + threadIdx.x;
+            if (CULL) {
+                bool in;
+                const uint32_t st = locate(i, in);
+                pp[r] = pos[in ? st : 0u];                                              // (the cloud has >= 1 splat inside this loop)
+            } else {
+                kk[r] = keys_in[min(i, n - 1u)];                                        // n >= 1 inside this loop
+            }
         }
 #pragma unroll
         for (int r = 0; r < IPS; ++r) {
-            if (CULL && !row_live(r)) continue;                                         // workgroup-uniform
             const uint32_t i = base + r * THREADS + threadIdx.x;
             uint32_t key = 0u;
             bool ok = false;
-            if (i < n) {
-                if (CULL) ok = cull_key(pp[r], fp, key);
-                else { key = kk[r]; ok = true; }
+            if (CULL) {
+                bool in;
+                (void)locate(i, in);
+                if (in) ok = cull_key(pp[r], fp, key);
+            } else if (i < n) {
+                key = kk[r];
+                ok = true;
             }
             if (CULL) {
                 const unsigned long long m = __ballot(ok);
@@ -1170,10 +1256,10 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, const unsigned long long* __restrict__ vmask,
     const uint32_t* __restrict__ d_n, uint32_t n_static, uint32_t n_cap, int pass, const uint32_t* __restrict__ minkey_cur,
     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ gsum, int gshift, uint32_t* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out, uint32_t* __restrict__ d_count_out, int xcd_map, const uint32_t* __restrict__ cmask = nullptr)
+    uint32_t* __restrict__ vals_out, uint32_t* __restrict__ d_count_out, int xcd_map, LiveBoxes lb = LiveBoxes{nullptr, nullptr, 0u, 0u})
 {
-    // cmask != nullptr (CULL): the live-box mask ws_upsweep left per chunk; a dead chunk is skipped whole, a dead box's wave
-    // ranks nothing (its raw keys / visibility words were never written).
+    // lb.list != nullptr (CULL): pass 0 over the listed boxes only, see ws_upsweep -- keys_in / vmask are indexed by virtual
+    // position, the value written is the splat's STORAGE index.
     // xcd_map: workgroup b runs on XCD b % 8; chunk = xcd_contiguous(b) gives every XCD a contiguous range of chunks, so
     // the digit runs that neighbouring chunks write next to each other meet in ONE L2 instead of being written to HBM
     // as partial lines by several (the per-XCD L2s are not coherent; every one writes back its own bytes of a shared line)
@@ -1187,9 +1273,16 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
     uint32_t* s_gd = s_cnt + WAVES * (kWsMaxBins / 2);          // nbins: global position minus chunk-local position
     uint32_t* s_tmp = s_gd + kWsMaxBins;                        // WAVES words
     uint4* s_part = reinterpret_cast<uint4*>(s_keys);           // THREADS uint4 of row-sum scratch (s_keys not live yet)
+    constexpr int BPC = CHUNK / kBoxSplats;
+    __shared__ uint32_t s_lpre[CULL ? 257 : 1], s_box[CULL ? BPC : 1];
+    const bool compact = CULL && lb.list != nullptr;
 
     uint32_t n = d_n ? *d_n : n_static;
     if (n > n_cap) n = n_cap;
+    if (compact) {
+        live_prefix<WAVES>(lb, s_lpre, s_tmp);
+        n = s_lpre[256] * (uint32_t)kBoxSplats;
+    }
     int shift, bits;
     ws_digit_range(pass, CULL ? 0u : *minkey_cur, shift, bits);
     const uint32_t nbins = 1u << bits, dmask = nbins - 1u, Q = nbins >> 2, half = nbins >> 1;
@@ -1219,11 +1312,7 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
 
     for (uint32_t cidx = blockIdx.x; cidx < nchunks; cidx += gridDim.x) {
         const uint32_t chunk = (xcd_map && (gridDim.x >= nchunks || (gridDim.x & 7u) == 0u)) ? xcd_contiguous(cidx, nchunks) : cidx;
-        uint32_t live = 0xFFFFFFFFu;
-        if (CULL && cmask != nullptr) {
-            live = cmask[chunk];                   // workgroup-uniform
-            if (live == 0u) continue;
-        }
+        if (compact && t < BPC) s_box[t] = live_box_at(lb, s_lpre, chunk * BPC + (uint32_t)t);      // (barriers follow before its use)
         // this chunk's exclusive prefix per digit: the group rows before its group + the chunk rows before it in the group
         const uint32_t g = chunk >> gshift;
         uint4 pre[QPT];
@@ -1250,9 +1339,12 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
             const uint32_t i = base + r * 64 + lane;
             valid[r] = i < n;
             if (CULL) {
-                // (box of this row: 64 consecutive splats, never across a box boundary)
-                valid[r] = valid[r] && ((live >> (((uint32_t)w * (64 * ITEMS) + r * 64) / kBoxSplats)) & 1u) && ((vm[r] >> lane) & 1ull);
+                valid[r] = valid[r] && ((vm[r] >> lane) & 1ull);
                 val[r] = i;
+                if (compact) {                        // virtual position -> storage index (a row of 64 lies in one box)
+                    const uint32_t e = i - chunk * CHUNK;
+                    val[r] = s_box[e / kBoxSplats] * kBoxSplats + (e % kBoxSplats);
+                }
             }
         }
         uint32_t* wcnt = s_cnt + (uint32_t)w * half;

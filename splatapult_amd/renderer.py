@@ -268,10 +268,11 @@ class SplatRenderer:
         return out[:self._n]
 
     def cull_boxes(self):
-        """(live, total) bounding boxes of the latest Sort's chunk-level cull; (0, 0) for a cloud in upload order"""
-        a, b = C.c_uint32(), C.c_uint32()
-        _capi.check(self._ctx, self._lib.msplat_debug_get_cull_boxes(self._ctx, C.byref(a), C.byref(b)))
-        return a.value, b.value
+        """(live, total, listed): bounding boxes that can hold a visible splat for the latest Sort's camera / boxes in the cloud
+        ((0, 0) for a cloud in upload order); listed: that Sort's first pass walked only the listed live boxes"""
+        a, b, l = C.c_uint32(), C.c_uint32(), C.c_int()
+        _capi.check(self._ctx, self._lib.msplat_debug_get_cull_boxes(self._ctx, C.byref(a), C.byref(b), C.byref(l)))
+        return a.value, b.value, bool(l.value)
 
     def sorted_keys(self):
         out = np.empty(max(self._n, 1), np.uint32)

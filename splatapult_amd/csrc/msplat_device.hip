@@ -694,7 +694,7 @@ static int spatial_reorder(msplat_ctx* ctx)
     const float4* pos = (const float4*)st.pos4.p;
     const uint32_t mrows = std::min(div_up(N, kThreads), 1024u);
     void* mpart = nullptr;
-    hipError_t e = hipMalloc(&mpart, (size_t)mrows * 7 * sizeof(double));
+    hipError_t e = hipMalloc(&mpart, (size_t)mrows * kMoments * sizeof(double));
     if (e != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(npos); (void)hipFree(nrec);
@@ -815,9 +815,7 @@ int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t s
                 for (int k = 25; k < 32; ++k) d[k] = 0.0f;
             }
             float* p = stage_pos.data() + j * 4;
-            // .w = rho^2 * trace(Sigma), rho^2 = 2 ln(256 alpha): world-space footprint bound for the band cull
-            const float rho2 = 2.0f * std::log(256.0f * d[3]);
-            p[0] = d[0]; p[1] = d[1]; p[2] = d[2]; p[3] = rho2 > 0.0f ? rho2 * (d[16] + d[20] + d[24]) : 0.0f;
+            p[0] = d[0]; p[1] = d[1]; p[2] = d[2]; p[3] = footprint_bound(d + 16, d[3]);      // .w: footprint bound for the band cull
         }
         HIP_TRY(ctx, hipMemcpy((char*)ctx->recs.p + base * F4 * 16, stage_rec.data(), cnt * F4 * 16, hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy((char*)ctx->pos4.p + base * 16, stage_pos.data(), cnt * 16, hipMemcpyHostToDevice));

@@ -135,6 +135,33 @@ __device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t n)
     return base + idx;
 }
 
+// World-space footprint bound of a splat, kept in pos4.w for the band-restricted cull: rho^2 * lambda_max(Sigma) with
+// rho^2 = 2 ln(256 alpha) (the fragment shader's discard radius) -- every projected variance M Sigma M^T is at most |M|^2 times
+// the largest eigenvalue.  (r1-r3 used trace(Sigma), 1.7x the radius of an isotropic splat: a rank of an 8-way row-sharded
+// frame then kept 17 % of the visible splats for 12.5 % of the rows.)  Closed form for a symmetric 3x3, in double, + 1e-5.
+// S = Sigma as stored: column-major 3x3 (S[3c + r]).  0 when alpha <= 1/256 (the splat can never pass the discard test).
+__host__ __device__ inline float footprint_bound(const float* S, float alpha)
+{
+    const float rho2 = 2.0f * logf(256.0f * alpha);
+    if (!(rho2 > 0.0f)) return 0.0f;
+    const double a00 = S[0], a11 = S[4], a22 = S[8];
+    const double a01 = 0.5 * ((double)S[1] + S[3]), a02 = 0.5 * ((double)S[2] + S[6]), a12 = 0.5 * ((double)S[5] + S[7]);
+    const double tr = a00 + a11 + a22, q = tr / 3.0;
+    const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+    const double p2 = (a00 - q) * (a00 - q) + (a11 - q) * (a11 - q) + (a22 - q) * (a22 - q) + 2.0 * p1;
+    double lmax = q;
+    if (p2 > 0.0) {
+        const double p = sqrt(p2 / 6.0);
+        const double b00 = (a00 - q) / p, b11 = (a11 - q) / p, b22 = (a22 - q) / p, b01 = a01 / p, b02 = a02 / p, b12 = a12 / p;
+        double r = 0.5 * (b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02));
+        r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+        lmax = q + 2.0 * p * cos(acos(r) / 3.0);
+    }
+    if (!(lmax <= tr)) lmax = tr;                       // NaN / negative-eigenvalue junk: fall back to the trace (also a bound for PSD)
+    if (!(lmax >= 0.0)) lmax = 0.0;
+    return (float)((double)rho2 * lmax * (1.0 + 1e-5));
+}
+
 // presort_compute.glsl:38-55.  Operation order identical to oracle/msplat_oracle.c (orc_cull_key)
 // so that keys and the visible set are bit-exact.
 __device__ __forceinline__ bool cull_key(const float4 p, const FrameParams& fp, uint32_t& key)
@@ -151,8 +178,8 @@ __device__ __forceinline__ bool cull_key(const float4 p, const FrameParams& fp, 
         if (fp.band_cull) {
             // Band-restricted cull (never active on a single GPU, where the reference's cull
             // must be reproduced exactly).  Conservative bound on the footprint's y half-extent:
-            //   ey^2 = rho^2 (M1 Sigma M1^T + 0.3) <= |J1|^2 |W|^2 * (rho^2 trace Sigma) + 0.3 rho^2_max,
-            // p.w = rho^2 trace(Sigma) precomputed at upload (0 when alpha <= 1/256: never visible).
+            //   ey^2 = rho^2 (M1 Sigma M1^T + 0.3) <= |J1|^2 |W|^2 * (rho^2 lambda_max(Sigma)) + 0.3 rho^2_max,
+            // p.w = rho^2 lambda_max(Sigma) precomputed at upload (footprint_bound; 0 when alpha <= 1/256: never visible).
             if (!(p.w > 0.0f)) return false;
             // (a bound, not parity arithmetic: v_rcp_f32 instead of IEEE divisions, the 1 ulp is inside the 0.2 % + 1.5 px margin)
             const float* v = fp.view;
@@ -1507,66 +1534,71 @@ __global__ __launch_bounds__(64) void ingest_kernel(const char* __restrict__ raw
             s = s + B[2 * 3 + r] * R[2 * 3 + c];
             f[16 + c * 3 + r] = s;
         }
-    // .w = rho^2 * trace(Sigma), rho^2 = 2 ln(256 alpha): world-space footprint bound for the band cull
-    const float rho2 = 2.0f * logf(256.0f * f[3]);
-    pos4[i] = make_float4(f[0], f[1], f[2], rho2 > 0.0f ? rho2 * (f[16] + f[20] + f[24]) : 0.0f);
+    pos4[i] = make_float4(f[0], f[1], f[2], footprint_bound(&f[16], f[3]));      // .w: world-space footprint bound for the band cull
 #pragma unroll
     for (int k = 0; k < F4; ++k) recs[i * F4 + k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
 }
 
 // ------------------------------------------------------------------------------------------
-// Spatial storage order (round 4; see box_live above).  Upload-time only: the moments of the positions, a 30-bit Morton code
-// per splat (10 bits per axis over mean +- 3 sigma, outliers clamped to the border cells), a stable sort of the codes with the
-// 8-bit radix passes above (ties keep upload order), a gather of the cloud into that order and one bounding box per
-// kBoxSplats stored splats.  Nothing of this changes a pixel: draw order is by depth key, ties by STORAGE order.
+// Spatial storage order (round 4; see box_live above).  Upload-time only: the moments of the positions and of the footprint
+// bounds, a 32-bit code per splat (2 bits of size class above a 30-bit Morton code: 10 bits per axis over mean +- 3 sigma,
+// outliers clamped to the border cells), a stable sort of the codes with the 8-bit radix passes above (ties keep upload
+// order), a gather of the cloud into that order and one bounding box per kBoxSplats stored splats.  Draw order is by depth key,
+// ties by STORAGE order.
 // ------------------------------------------------------------------------------------------
 // (two stages with a fixed summation order and no atomics: every device of a group, and every run, must arrive at the same
 //  storage order bit for bit -- tie order is part of the frame)
+constexpr int kMoments = 10;
 __global__ __launch_bounds__(kThreads) void cloud_moments_kernel(const float4* __restrict__ pos, uint32_t n,
-                                                                 double* __restrict__ part /* [gridDim.x][7] */)
+                                                                 double* __restrict__ part /* [gridDim.x][kMoments] */)
 {
-    __shared__ double s_w[kThreads / 64][7];
-    double s[7] = {0, 0, 0, 0, 0, 0, 0};           // sum xyz, sum of squares xyz, count of finite positions
+    __shared__ double s_w[kThreads / 64][kMoments];
+    // sum xyz, sum of squares xyz, count of finite positions; sum, sum of squares, count of log2(footprint bound) where it is > 0
+    double s[kMoments] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         const float4 p = pos[i];
         if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
             s[0] += p.x; s[1] += p.y; s[2] += p.z;
             s[3] += (double)p.x * p.x; s[4] += (double)p.y * p.y; s[5] += (double)p.z * p.z;
             s[6] += 1.0;
+            if (p.w > 0.0f && isfinite(p.w)) {
+                const double l = (double)log2f(p.w);
+                s[7] += l; s[8] += l * l; s[9] += 1.0;
+            }
         }
     }
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < kMoments; ++k) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) s[k] += __shfl_xor(s[k], d, 64);
         if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6][k] = s[k];
     }
     __syncthreads();
-    if (threadIdx.x < 7) {
+    if (threadIdx.x < kMoments) {
         double t = 0.0;
         for (int w = 0; w < kThreads / 64; ++w) t += s_w[w][threadIdx.x];
-        part[(size_t)blockIdx.x * 7 + threadIdx.x] = t;
+        part[(size_t)blockIdx.x * kMoments + threadIdx.x] = t;
     }
 }
 
 __global__ __launch_bounds__(kThreads) void cloud_moments_finish(const double* __restrict__ part, uint32_t rows,
-                                                                 double* __restrict__ acc /* 7 */)
+                                                                 double* __restrict__ acc /* kMoments */)
 {
-    __shared__ double s_t[kThreads][7];
-    double s[7] = {0, 0, 0, 0, 0, 0, 0};
+    __shared__ double s_t[kThreads][kMoments];
+    double s[kMoments] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t r = threadIdx.x; r < rows; r += kThreads)
 #pragma unroll
-        for (int k = 0; k < 7; ++k) s[k] += part[(size_t)r * 7 + k];
+        for (int k = 0; k < kMoments; ++k) s[k] += part[(size_t)r * kMoments + k];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) s_t[threadIdx.x][k] = s[k];
+    for (int k = 0; k < kMoments; ++k) s_t[threadIdx.x][k] = s[k];
     __syncthreads();
     for (int half = kThreads / 2; half >= 1; half >>= 1) {
         if ((int)threadIdx.x < half)
 #pragma unroll
-            for (int k = 0; k < 7; ++k) s_t[threadIdx.x][k] += s_t[threadIdx.x + half][k];
+            for (int k = 0; k < kMoments; ++k) s_t[threadIdx.x][k] += s_t[threadIdx.x + half][k];
         __syncthreads();
     }
-    if (threadIdx.x < 7) acc[threadIdx.x] = s_t[0][threadIdx.x];
+    if (threadIdx.x < kMoments) acc[threadIdx.x] = s_t[0][threadIdx.x];
 }
 
 __device__ __forceinline__ uint32_t morton_spread10(uint32_t v)      // 10 bits -> every third bit
@@ -1597,7 +1629,16 @@ __global__ __launch_bounds__(kThreads) void morton_kernel(const float4* __restri
         const float t = (c[k] - (float)mean) / (6.0f * sd) + 0.5f;                // mean +- 3 sigma -> [0, 1]
         q[k] = isfinite(t) ? fminf(fmaxf(t, 0.0f), 1.0f) * 1023.0f : 0.0f;
     }
-    code[i] = morton_spread10((uint32_t)q[0]) | (morton_spread10((uint32_t)q[1]) << 1) | (morton_spread10((uint32_t)q[2]) << 2);
+    // Size class in the two top bits: a box's reach on screen is its extent plus its LARGEST footprint, and the largest of
+    // 256 log-normal sizes is several times the typical one -- splats are therefore grouped by footprint bound first (z = deviation
+    // of log2(bound) from its mean in sigmas: <= 0.5 | <= 1.25 | <= 2 | the rest, ~69 / 20 / 9 / 2 %), by position inside a class.
+    uint32_t cls = 3u;
+    if (p.w > 0.0f && isfinite(p.w) && acc[9] > 0.0) {
+        const double lm = acc[7] / acc[9], lv = acc[8] / acc[9] - lm * lm;
+        const float z = (log2f(p.w) - (float)lm) / (float)sqrt(lv > 1e-12 ? lv : 1e-12);
+        cls = z <= 0.5f ? 0u : (z <= 1.25f ? 1u : (z <= 2.0f ? 2u : 3u));
+    }
+    code[i] = (cls << 30) | morton_spread10((uint32_t)q[0]) | (morton_spread10((uint32_t)q[1]) << 1) | (morton_spread10((uint32_t)q[2]) << 2);
     index[i] = i;
 }
 

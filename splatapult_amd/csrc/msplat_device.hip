@@ -1243,7 +1243,9 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
         const uint32_t last_V = ctx->h_flags ? __atomic_load_n(ctx->h_flags + 1, __ATOMIC_RELAXED) : 0u;
         const uint32_t items0 = ctx->ws_items;
         const uint32_t items12 = (items0 == 16u && last_V != 0u && (uint64_t)last_V + (last_V >> 2) <= (2u << 20)) ? 8u : items0;
-        uint32_t items = items0;
+        const LiveBoxes lb = list_live_boxes(ctx, fp, last_V);       // (launches box_cull_kernel when the view is a partial one)
+        // pass 0 over listed boxes: fewer chunks than the cloud has, so 4096-key chunks keep the CUs covered (as for passes 1, 2)
+        uint32_t items = lb.list != nullptr ? 8u : items0;
         int wgrid = grid_for(div_up(N, ctx->ws_threads * items));
         const uint32_t* dV = d_V;
         const int wsx = 1;          // XCD-contiguous chunk ranges in the downsweeps
@@ -1267,7 +1269,6 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
             hipLaunchKernelGGL((ws_upsweep<CULLF, 4, 2 * kWsThreads>), dim3(wgrid), dim3(2 * kWsThreads), 0, s, __VA_ARGS__); \
         else MSPLAT_WS(ws_upsweep, CULLF, MSPLAT_NO_LDS, __VA_ARGS__);                                                    \
     } while (0)
-        const LiveBoxes lb = list_live_boxes(ctx, fp, last_V);       // (launches box_cull_kernel when the view is a partial one)
         MSPLAT_WS_UP(true, (const uint32_t*)nullptr, pos, kB, vm, (const uint32_t*)nullptr, N, N, 0, mk_cur,
                   mk_next, whist, gt(0), gsh, gt(-1), gw, fp, lb);
         MSPLAT_WS(ws_downsweep, true, ws_downsweep_lds, (const uint32_t*)kB, (const uint32_t*)nullptr, (const unsigned long long*)vm,

@@ -1415,6 +1415,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                         div_up(cap, kPairChunk) <= ctx->hist2_stride;                  // (the tables hold every chunk the capacity allows)
     uint32_t* gB1 = (uint32_t*)ctx->gsumB1.p;
     uint32_t* gB2 = (uint32_t*)ctx->gsumB2.p;
+    static const int xcdg = getenv("MSPLAT_DEV_XCDG") ? atoi(getenv("MSPLAT_DEV_XCDG")) : 0;      // EXPERIMENT (r4 item 3): to be fixed or removed
     // (bin1_upsweep also clears the row pass's group table: its consumer, the previous frame's row downsweep, is long done)
 #define MSPLAT_BIN1(CH)                                                                                                       \
     do {                                                                                                                      \
@@ -1428,14 +1429,14 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                                (const uint32_t*)ctx->rect.p, d_V, (const uint32_t*)ctx->hist1.p, ctx->hist1_stride,           \
                                (const uint32_t*)totals1, (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags,        \
                                async_overflow_flag ? 1 : 0, fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, \
-                               0, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,                                  \
+                               xcdg, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,                               \
                                (uint32_t)nhelp, fp.tiles_x, ctx->gsupB1);                                                     \
         else                                                                                                                  \
             hipLaunchKernelGGL((bin1_downsweep<false, CH>), dim3(g1 + nhelp), dim3(kThreads), 0, s,                           \
                                (const uint32_t*)ctx->rect.p, d_V, (const uint32_t*)ctx->hist1.p, ctx->hist1_stride,           \
                                (const uint32_t*)totals1, (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags,        \
                                async_overflow_flag ? 1 : 0, fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, \
-                               0, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,                                  \
+                               xcdg, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,                               \
                                (uint32_t)nhelp, fp.tiles_x, ctx->gsupB1);                                                     \
     } while (0)
     // (bin1_upsweep also clears the row pass's group table: its consumer, the previous frame's row downsweep, is long done)

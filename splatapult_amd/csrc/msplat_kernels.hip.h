@@ -162,6 +162,17 @@ __host__ __device__ inline float footprint_bound(const float* S, float alpha)
     return (float)((double)rho2 * lmax * (1.0 + 1e-5));
 }
 
+// Milder form: only GROUPS of g consecutive chunks share an XCD (workgroups p and p + 8 of every block of 8 g, which are
+// dispatched right after one another): the partial cache lines at the seams between the runs that g neighbouring chunks write
+// next to each other are then merged in that XCD's L2 before they go to HBM, without giving each XCD one long region of the
+// output.  Identity on the last, incomplete block.
+__device__ __forceinline__ uint32_t xcd_grouped(uint32_t b, uint32_t n, uint32_t g)
+{
+    const uint32_t blk = 8u * g, p = b % blk, base = b - p;
+    if (base + blk > n) return b;
+    return base + (p & 7u) * g + (p >> 3);
+}
+
 // presort_compute.glsl:38-55.  Operation order identical to oracle/msplat_oracle.c (orc_cull_key)
 // so that keys and the visible set are bit-exact.
 __device__ __forceinline__ bool cull_key(const float4 p, const FrameParams& fp, uint32_t& key)
@@ -2134,7 +2145,9 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && BIN_CHUNK == kBinChunk) ?
     const uint32_t cpp = ((uint32_t)tiles_x + kHeavyParts - 1u) / kHeavyParts;      // columns per part
     for (uint32_t cidx = helper ? hchunk : mb; cidx < nchunks; cidx += nmain) {
         // (xcd_map: see ws_downsweep -- the (chunk, column) runs of neighbouring chunks are adjacent in memory)
-        const uint32_t chunk = (!helper && xcd_map && (nmain >= nchunks || (nmain & 7u) == 0u)) ? xcd_contiguous(cidx, nchunks) : cidx;
+        const uint32_t chunk = (!helper && xcd_map > 1 && (nmain >= nchunks || nmain % (8u * (uint32_t)xcd_map) == 0u))
+                                   ? xcd_grouped(cidx, nchunks, (uint32_t)xcd_map)
+                                   : ((!helper && xcd_map == 1 && (nmain >= nchunks || (nmain & 7u) == 0u)) ? xcd_contiguous(cidx, nchunks) : cidx);
         // this workgroup's columns of the chunk: all of them, or one block of a heavy chunk
         uint32_t c_lo = 0u, c_hi = 255u;
         if (helper || (nhelp != 0u && heavy_flag[chunk])) {       // (no helpers launched: no chunk is split, no flag to read)

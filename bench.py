@@ -125,7 +125,8 @@ def measure(E, args, key, ply=None, primary=True):
 
     P = max(1, args.frames_in_flight)
     r = SplatRenderer(device=E.local_rank, fb_format=wl["fb"], stream=stream.cuda_stream,
-                      enable_timing=args.timing_stride, frames_in_flight=P)
+                      enable_timing=args.timing_stride, frames_in_flight=P,
+                      async_submit=None if args.async_submit < 0 else bool(args.async_submit))
 
     def init(rr):
         # a file is rendered the way the app would: Ply::Parse on the host + GaussianCloud::ImportPly's math on the GPU
@@ -201,7 +202,12 @@ def measure(E, args, key, ply=None, primary=True):
             ev.record(stream)
             fb_free[rr.frame_slot] = ev
 
+    live = [r]            # renderers whose queued calls (async_submit: a worker thread per in-flight context) must be ISSUED
+                          # before a device synchronisation means "the frames are done"
+
     def sync_all():
+        for x in live:
+            x.synchronize()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -221,7 +227,7 @@ def measure(E, args, key, ply=None, primary=True):
         t0 = time.perf_counter()
         for s in range(args.steps):
             frame(first_step + s)
-        enq = time.perf_counter() - t0            # host time to issue the frames (launch-rate bound check)
+        enq = time.perf_counter() - t0            # host time to hand over the frames (the launches are issued by worker threads)
         sync_all()
         el = time.perf_counter() - t0
         if world > 1:
@@ -250,6 +256,7 @@ def measure(E, args, key, ply=None, primary=True):
         rs = SplatRenderer(device=E.local_rank, fb_format=wl["fb"], stream=stream.cuda_stream, enable_timing=4,
                            frames_in_flight=1)     # stage events on every 4th frame: they cost a few us each
         init(rs)
+        live.append(rs)
         if world > 1:
             rs.set_band_plan(lay_kind, tiles_y, world, rank, block_rows=lay_k, band_cull=(views == 1))
         rs_sets = [fb_sets[0]]
@@ -388,6 +395,7 @@ def measure(E, args, key, ply=None, primary=True):
                    "views": views, "framebuffer": wl["fb"],
                    "sharding": ("bin rows of %d px over %d ranks, layout %s" % (TILE, world, lay)) if world > 1 else "none (one GPU)",
                    "frames_in_flight": P, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                   "async_submit": bool(r._async),
                    "visible_V": V, "pairs_D": D_total, "pairs_binned_32px": float(np.mean(Dbin)),
                    "drawn": float(np.mean(drawn)), "D_over_N": D_total / max(1, n),
                    "longest_bin_list": longest_list, "pair_capacity": pair_cap_end, "pair_capacity_initial": pair_cap0,
@@ -449,6 +457,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="frames overlapped on the GPU (one context + stream + framebuffer per frame in flight, one shared "
                          "cloud); 1 = strictly serial frames (latency mode)")
+    ap.add_argument("--async-submit", type=int, default=-1,
+                    help="msplat_config.async_submit of the in-flight contexts: 1 = a worker thread per context issues its launches, "
+                         "0 = the calling thread does (A/B); default: on with frames in flight")
     ap.add_argument("--timing-stride", type=int, default=8,
                     help="record per-stage hipEvents on every n-th frame of the timed region (0 = never)")
     args = ap.parse_args()

@@ -78,8 +78,18 @@ typedef struct msplat_config {
                                /* value other than the two named ones means AUTO                               */
     int32_t spatial_order;     /* MSPLAT_SPATIAL_* (r4): may the library store the cloud in its own (Morton)  */
                                /* order so that the cull can skip whole chunks?  A shorter struct_size = AUTO  */
-    int32_t reserved0;         /* must be 0                                                                    */
+    int32_t async_submit;      /* r4: != 0: msplat_sort and device-output msplat_render return at once; their   */
+                               /* launches are issued by a worker thread of the context (frames in flight)     */
 } msplat_config;
+
+/* msplat_config.async_submit.  Issuing a frame (~14 kernel launches) costs the host ~55 us.  A caller that keeps several frames
+ * in flight on several contexts from ONE thread therefore starts the k-th context k x 55 us after the first -- a stagger that a
+ * short block of frames pays at both ends.  With async_submit every such context owns a worker thread: msplat_sort and
+ * msplat_render with out_is_device = 1 copy their arguments (the caller's arrays may be reused at once), queue the call and return
+ * MSPLAT_OK; the worker issues the launches in call order.  Every other entry point of the context first waits until the worker
+ * has ISSUED what is queued (that is host work, microseconds; never a wait for the GPU), so msplat_stream_wait / msplat_wait_event /
+ * the getters behave as without it.  A queued call that fails is reported by the next msplat_synchronize (MSPLAT_ERR_* of the
+ * first failure).  Host-output renders stay synchronous.  The SplatRenderer shims switch it on in SetFramesInFlight. */
 
 /* msplat_config.spatial_order -- the STORAGE order of the uploaded cloud and the tie rule of the sort.
  * The reference culls per splat over the whole cloud every frame (shader/presort_compute.glsl:31-57 dispatched over N,

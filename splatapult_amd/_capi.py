@@ -30,7 +30,7 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("fb_format", C.c_int32),
                 ("srgb", C.c_int32), ("t_epsilon", C.c_float), ("pair_capacity", C.c_uint64),
                 ("stream", C.c_void_p), ("enable_timing", C.c_int32), ("compositor_waves", C.c_int32),
-                ("rank_mode", C.c_int32), ("frame_mode", C.c_int32), ("spatial_order", C.c_int32), ("reserved0", C.c_int32)]
+                ("rank_mode", C.c_int32), ("frame_mode", C.c_int32), ("spatial_order", C.c_int32), ("async_submit", C.c_int32)]
 
 
 class AttrOffsets(C.Structure):

@@ -15,8 +15,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -58,6 +62,50 @@ struct CloudStore {
 constexpr uint64_t kSpatialMinSplats = 1ull << 18;
 
 }  // namespace
+
+// msplat_config.async_submit (r4): msplat_sort and device-output msplat_render of the context return at once and their launches
+// are issued by a worker thread that belongs to the context.  One frame is ~14 launches = ~55 us of host time; with several frames
+// in flight issued round-robin from ONE thread the k-th context starts k x 55 us after the first, and a short block of frames
+// (the driver times 20) pays that stagger at its start and again at its end.  With a worker per context the caller's thread only
+// copies 38 floats per call.  Everything else on the context first waits for the worker to have ISSUED what is queued (never
+// for the GPU); a failed queued call is reported by the next msplat_synchronize.
+struct AsyncWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv, cv_idle;
+    std::deque<std::function<int()>> q;
+    bool busy = false, quit = false;
+    int err_code = 0;
+    std::string err_msg;
+
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return quit || !q.empty(); });
+            if (q.empty()) return;              // quit, nothing left
+            std::function<int()> t = std::move(q.front());
+            q.pop_front();
+            busy = true;
+            lk.unlock();
+            t();
+            lk.lock();
+            busy = false;
+            if (q.empty()) cv_idle.notify_all();
+        }
+    }
+    void post(std::function<int()> t)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        q.push_back(std::move(t));
+        cv.notify_one();
+    }
+    void drain()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_idle.wait(lk, [&] { return q.empty() && !busy; });
+    }
+};
 
 constexpr uint32_t kFusedMaxChunks = 1u << 20;     // scan-free passes up to this many chunk rows: with the two-level group tables (r3) a
                                                // prefix is <= nchunks / 128 + 34 rows, so every table qualifies (r2, one level: 8192 rows,
@@ -163,6 +211,7 @@ struct msplat_ctx {
     bool comp_kernel_timed = false;
     uint32_t comp_kernel_sets_mask = 0;
 
+    std::unique_ptr<AsyncWorker> worker;     // msplat_config.async_submit
     bool atomic_rank = true;    // LDS atomics hand out ranks in lane order (probed at create)
     int comp_waves = 8192;      // compositor grid (persistent waves; measured best of 2k..8k); MSPLAT_COMP_WAVES overrides
     bool comp_waves_auto = true;   // nobody chose a pool size: up to 20 k work items every item gets its own wave (r2: a wave
@@ -182,6 +231,13 @@ int fail(msplat_ctx* c, int code, const char* fmt, ...)
     g_last_error = buf;
     if (c) c->err = buf;
     return code;
+}
+
+// waits until the context's worker thread (if any) has issued everything queued; no-op on the worker itself
+thread_local const msplat_ctx* g_on_worker_of = nullptr;
+inline void drain_async(msplat_ctx* c)
+{
+    if (c && c->worker && g_on_worker_of != c) c->worker->drain();
 }
 
 #define HIP_TRY(c, expr)                                                                          \
@@ -241,6 +297,7 @@ int msplat_tile_size(void) { return kBin; }
 
 const char* msplat_last_error(const msplat_ctx* ctx)
 {
+    drain_async(const_cast<msplat_ctx*>(ctx));          // (a queued call may be writing the text)
     if (ctx) return ctx->err.c_str();
     return g_last_error.c_str();
 }
@@ -378,6 +435,21 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         g_last_error = msg;
         return rc;
     }
+    if (c.async_submit != 0) {
+        try {
+            ctx->worker.reset(new AsyncWorker);
+            AsyncWorker* w = ctx->worker.get();
+            const msplat_ctx* self = ctx;
+            const int dev = ctx->device;
+            w->th = std::thread([w, self, dev] {
+                (void)hipSetDevice(dev);
+                g_on_worker_of = self;
+                w->run();
+            });
+        } catch (const std::exception&) {
+            ctx->worker.reset();          // no thread: the context simply issues its own launches
+        }
+    }
     *out = ctx;
     return MSPLAT_OK;
 }
@@ -385,6 +457,13 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
 void msplat_destroy(msplat_ctx* ctx)
 {
     if (!ctx) return;
+    if (ctx->worker) {
+        ctx->worker->drain();
+        { std::lock_guard<std::mutex> lk(ctx->worker->mu); ctx->worker->quit = true; }
+        ctx->worker->cv.notify_all();
+        if (ctx->worker->th.joinable()) ctx->worker->th.join();
+        ctx->worker.reset();
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->pos4 = Buf{};
@@ -441,6 +520,17 @@ static int poll_async_overflow(msplat_ctx* ctx, std::string& msg)
 int msplat_synchronize(msplat_ctx* ctx)
 {
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if (ctx->worker && g_on_worker_of != ctx) {
+        ctx->worker->drain();
+        int code = 0;
+        std::string msg;
+        { std::lock_guard<std::mutex> lk(ctx->worker->mu); code = ctx->worker->err_code; msg = ctx->worker->err_msg; ctx->worker->err_code = 0; }
+        if (code) {
+            (void)hipSetDevice(ctx->device);
+            (void)hipStreamSynchronize(ctx->stream);
+            return fail(ctx, code, "a queued msplat_sort / msplat_render failed: %s", msg.c_str());
+        }
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     std::string msg;
@@ -452,6 +542,7 @@ int msplat_synchronize(msplat_ctx* ctx)
 // costs a few clock reads per batch, so it is off by default)
 int msplat_set_tile_probe(msplat_ctx* ctx, int enable)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if (enable && !ctx->probe.p) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -468,6 +559,7 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
 // on targets with a depth attachment).  bits = 0: colour-only target, the default.
 int msplat_set_depth_test(msplat_ctx* ctx, int depth_bits)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if (depth_bits != 0 && depth_bits != 24 && depth_bits != 32)
         return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_set_depth_test: depth_bits must be 0, 24 or 32 (got %d)", depth_bits);
@@ -487,6 +579,7 @@ int msplat_set_depth_test(msplat_ctx* ctx, int depth_bits)
 // order without early termination (the draw-order compositor of msplat_set_depth_test, with or without a depth buffer).
 int msplat_set_target_emulation(msplat_ctx* ctx, int rop)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if (rop != MSPLAT_ROP_NONE && rop != MSPLAT_ROP_RGBA8 && rop != MSPLAT_ROP_RGBA16F)
         return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_set_target_emulation: rop must be MSPLAT_ROP_NONE, _RGBA8 or _RGBA16F (got %d)", rop);
@@ -502,6 +595,8 @@ int msplat_set_target_emulation(msplat_ctx* ctx, int rop)
 // (one frame's latency-bound sort/binning launches fill the gaps of another frame's compositor).
 int msplat_attach_cloud(msplat_ctx* ctx, msplat_ctx* owner)
 {
+    drain_async(ctx);
+    drain_async(owner);
     if (!ctx || !owner) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_attach_cloud: NULL argument");
     if (ctx == owner) return MSPLAT_OK;
     if (!owner->has_cloud || !owner->store) return fail(ctx, MSPLAT_ERR_NO_CLOUD, "msplat_attach_cloud: owner has no cloud");
@@ -521,6 +616,7 @@ void* msplat_get_stream(msplat_ctx* ctx) { return ctx ? (void*)ctx->stream : nul
 // the context's stream, without blocking the host.
 int msplat_stream_wait(msplat_ctx* ctx, void* stream)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if ((hipStream_t)stream == ctx->stream) return MSPLAT_OK;
@@ -534,6 +630,7 @@ int msplat_stream_wait(msplat_ctx* ctx, void* stream)
 // framebuffer that the next frame on this context will overwrite).
 int msplat_wait_event(msplat_ctx* ctx, void* event)
 {
+    drain_async(ctx);
     if (!ctx || !event) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_wait_event: NULL argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)event, 0));
@@ -764,6 +861,7 @@ static int spatial_reorder(msplat_ctx* ctx)
 int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t stride_bytes,
                         const msplat_attr_offsets* off, int full_sh)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if ((!aos && n) || !off) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_upload_cloud: NULL argument");
     if (stride_bytes % 4 != 0) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "stride must be a multiple of 4");
@@ -831,6 +929,7 @@ int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t s
 int msplat_upload_ply_vertices(msplat_ctx* ctx, const void* vertices, uint64_t n, const msplat_ply_layout* layout,
                                int full_sh)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if ((!vertices && n) || !layout) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_upload_ply_vertices: NULL argument");
     const uint32_t vs = layout->vertex_size;
@@ -952,6 +1051,7 @@ static int build_sprite(msplat_ctx* ctx, const uint8_t* rgba8, uint32_t w, uint3
 
 int msplat_set_point_sprite(msplat_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     return build_sprite(ctx, rgba8, width, height);
 }
@@ -959,6 +1059,7 @@ int msplat_set_point_sprite(msplat_ctx* ctx, const uint8_t* rgba8, uint32_t widt
 int msplat_upload_points(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t stride_bytes,
                          uint32_t position_offset, uint32_t color_offset)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if (!aos && n) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_upload_points: NULL argument");
     if (stride_bytes % 4 != 0 || position_offset + 16u > stride_bytes || color_offset + 16u > stride_bytes)
@@ -994,6 +1095,7 @@ int msplat_upload_points(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t 
 // device cloud -> reference AoS layout (100 B / 244 B records, gaussiancloud.cpp:32-56); parity tests
 int msplat_download_cloud(msplat_ctx* ctx, void* aos_out, uint64_t cap_bytes)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if (!ctx->has_cloud) return fail(ctx, MSPLAT_ERR_NO_CLOUD, "no cloud uploaded");
     if (ctx->point_mode) return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "msplat_download_cloud: the context holds a point cloud");
@@ -1024,6 +1126,7 @@ int msplat_download_cloud(msplat_ctx* ctx, void* aos_out, uint64_t cap_bytes)
 
 int msplat_set_band_cull(msplat_ctx* ctx, int enable)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     ctx->band_cull = enable != 0;
     return MSPLAT_OK;
@@ -1031,6 +1134,7 @@ int msplat_set_band_cull(msplat_ctx* ctx, int enable)
 
 int msplat_set_band_layout(msplat_ctx* ctx, int32_t first_row, int32_t row_count, int32_t block, int32_t stride)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if (first_row < 0 || row_count < 0 || block < 1 || stride < block)
         return fail(ctx, MSPLAT_ERR_INVALID_ARG,
@@ -1046,6 +1150,7 @@ int msplat_set_band_layout(msplat_ctx* ctx, int32_t first_row, int32_t row_count
 
 int msplat_set_band(msplat_ctx* ctx, int32_t row_mod, int32_t row_rem)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if (row_mod < 1 || row_rem < 0 || row_rem >= row_mod)
         return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_set_band: need row_mod >= 1 and 0 <= row_rem < row_mod");
@@ -1193,8 +1298,45 @@ static LiveBoxes list_live_boxes(msplat_ctx* ctx, const FrameParams& fp, uint32_
     return lb;
 }
 
+struct FrameArgs {            // the caller's four arrays, copied: a queued call outlives them
+    float cam[16], proj[16], vp[4], nf[2];
+    bool load(const float* c, const float* p, const float* v, const float* n)
+    {
+        if (!c || !p || !v || !n) return false;
+        std::memcpy(cam, c, sizeof(cam)); std::memcpy(proj, p, sizeof(proj)); std::memcpy(vp, v, sizeof(vp)); std::memcpy(nf, n, sizeof(nf));
+        return true;
+    }
+};
+
+// result of a queued call: the first real failure is kept for msplat_synchronize (MSPLAT_ERR_PAIR_OVERFLOW_EARLIER is about a
+// past frame and already handled -- the buffer has grown)
+static int note_async_result(msplat_ctx* ctx, int rc)
+{
+    if (rc != MSPLAT_OK && rc != MSPLAT_ERR_PAIR_OVERFLOW_EARLIER) {
+        std::lock_guard<std::mutex> lk(ctx->worker->mu);
+        if (ctx->worker->err_code == 0) { ctx->worker->err_code = rc; ctx->worker->err_msg = ctx->err; }
+    }
+    return rc;
+}
+
+static int sort_impl(msplat_ctx* ctx, const float cameraMat[16], const float projMat[16], const float viewport[4], const float nearFar[2]);
+static int render_impl(msplat_ctx* ctx, const float cameraMat[16], const float projMat[16], const float viewport[4],
+                       const float nearFar[2], void* rgba, uint64_t pitch_bytes, int out_is_device);
+
 int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[16],
                 const float viewport[4], const float nearFar[2])
+{
+    if (ctx && ctx->worker && g_on_worker_of != ctx) {
+        FrameArgs a;
+        if (!a.load(cameraMat, projMat, viewport, nearFar)) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL matrix/viewport argument");
+        ctx->worker->post([ctx, a] { return note_async_result(ctx, sort_impl(ctx, a.cam, a.proj, a.vp, a.nf)); });
+        return MSPLAT_OK;
+    }
+    return sort_impl(ctx, cameraMat, projMat, viewport, nearFar);
+}
+
+static int sort_impl(msplat_ctx* ctx, const float cameraMat[16], const float projMat[16],
+                     const float viewport[4], const float nearFar[2])
 {
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if (!ctx->has_cloud) return fail(ctx, MSPLAT_ERR_NO_CLOUD, "msplat_sort: no cloud uploaded");
@@ -1561,6 +1703,24 @@ int msplat_render(msplat_ctx* ctx, const float cameraMat[16], const float projMa
                   const float viewport[4], const float nearFar[2],
                   void* rgba, uint64_t pitch_bytes, int out_is_device)
 {
+    if (ctx && ctx->worker && g_on_worker_of != ctx) {
+        if (out_is_device && rgba) {
+            FrameArgs a;
+            if (!a.load(cameraMat, projMat, viewport, nearFar)) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL matrix/viewport argument");
+            ctx->worker->post([ctx, a, rgba, pitch_bytes] {
+                return note_async_result(ctx, render_impl(ctx, a.cam, a.proj, a.vp, a.nf, rgba, pitch_bytes, 1));
+            });
+            return MSPLAT_OK;
+        }
+        ctx->worker->drain();           // a host image is filled before the call returns: nothing to defer
+    }
+    return render_impl(ctx, cameraMat, projMat, viewport, nearFar, rgba, pitch_bytes, out_is_device);
+}
+
+static int render_impl(msplat_ctx* ctx, const float cameraMat[16], const float projMat[16],
+                       const float viewport[4], const float nearFar[2],
+                       void* rgba, uint64_t pitch_bytes, int out_is_device)
+{
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if (!ctx->has_cloud) return fail(ctx, MSPLAT_ERR_NO_CLOUD, "msplat_render: no cloud uploaded");
     if (!ctx->has_sort) return fail(ctx, MSPLAT_ERR_NO_SORT, "msplat_render: msplat_sort has not been called");
@@ -1631,6 +1791,7 @@ int msplat_render(msplat_ctx* ctx, const float cameraMat[16], const float projMa
 
 int msplat_sort_count(msplat_ctx* ctx, uint32_t* v)
 {
+    drain_async(ctx);
     if (!ctx || !v) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
     if (!ctx->has_sort) return fail(ctx, MSPLAT_ERR_NO_SORT, "no sort yet");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1652,6 +1813,7 @@ static int copy_sorted(msplat_ctx* ctx, const Buf& src, uint32_t* dst, uint32_t 
 
 int msplat_get_sorted_indices(msplat_ctx* ctx, uint32_t* dst, uint32_t cap)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     int rc = copy_sorted(ctx, ctx->valA, dst, cap);
     if (rc == MSPLAT_OK && ctx->store && ctx->store->reordered) {      // storage slots -> upload indices
@@ -1667,6 +1829,7 @@ int msplat_get_sorted_indices(msplat_ctx* ctx, uint32_t* dst, uint32_t cap)
 // was not reordered; *reordered says which).  Equal depth keys are drawn in ascending storage slot.
 int msplat_get_storage_order(msplat_ctx* ctx, uint32_t* dst, uint64_t cap, int* reordered)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if (!ctx->has_cloud) return fail(ctx, MSPLAT_ERR_NO_CLOUD, "no cloud uploaded");
     const bool ro = ctx->store && ctx->store->reordered;
@@ -1682,6 +1845,7 @@ int msplat_get_storage_order(msplat_ctx* ctx, uint32_t* dst, uint64_t cap, int* 
 // order); *listed = 1 when that Sort's pass 0 walked the listed boxes only.  Runs box_cull_kernel on demand; synchronises.
 int msplat_debug_get_cull_boxes(msplat_ctx* ctx, uint32_t* live, uint32_t* total, int* listed)
 {
+    drain_async(ctx);
     if (!ctx || !live || !total) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
     if (!ctx->has_sort) return fail(ctx, MSPLAT_ERR_NO_SORT, "no sort yet");
     *live = *total = 0;
@@ -1710,12 +1874,14 @@ int msplat_debug_get_cull_boxes(msplat_ctx* ctx, uint32_t* live, uint32_t* total
 
 int msplat_get_sorted_keys(msplat_ctx* ctx, uint32_t* dst, uint32_t cap)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     return copy_sorted(ctx, ctx->keyA, dst, cap);
 }
 
 int msplat_get_stats(msplat_ctx* ctx, msplat_stats* out)
 {
+    drain_async(ctx);
     if (!ctx || !out) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1749,6 +1915,7 @@ int msplat_get_stats(msplat_ctx* ctx, msplat_stats* out)
 
 int msplat_get_timings(msplat_ctx* ctx, msplat_timings* out)
 {
+    drain_async(ctx);
     if (!ctx || !out) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
     std::memset(out, 0, sizeof(*out));
     if (!ctx->ev_ok) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "context created without enable_timing");
@@ -1785,6 +1952,7 @@ int msplat_get_timings(msplat_ctx* ctx, msplat_timings* out)
 
 int msplat_debug_get_projected(msplat_ctx* ctx, float* rec12, uint32_t* rect, uint32_t cap)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if (!ctx->has_render) return fail(ctx, MSPLAT_ERR_NO_SORT, "no render yet");
     uint32_t v = 0;
@@ -1803,6 +1971,7 @@ int msplat_debug_get_projected(msplat_ctx* ctx, float* rec12, uint32_t* rect, ui
 // MSPLAT_BALLOT_RANK=1.
 int msplat_debug_verify_order(msplat_ctx* ctx, uint32_t* key_violations, uint32_t* list_violations)
 {
+    drain_async(ctx);
     if (!ctx || !key_violations || !list_violations) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
     if (!ctx->has_sort) return fail(ctx, MSPLAT_ERR_NO_SORT, "no sort yet");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1823,6 +1992,7 @@ int msplat_debug_verify_order(msplat_ctx* ctx, uint32_t* key_violations, uint32_
 
 int msplat_debug_get_tile_probe8(msplat_ctx* ctx, uint32_t* dst, uint32_t tile_cap)
 {
+    drain_async(ctx);
     if (!ctx || !dst) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
     if (!ctx->probe.p || !ctx->probe_on)
         return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile probe not enabled (msplat_set_tile_probe, or MSPLAT_TILE_PROBE=1 before msplat_create)");
@@ -1840,6 +2010,7 @@ int msplat_debug_get_tile_probe8(msplat_ctx* ctx, uint32_t* dst, uint32_t tile_c
 // and 48-byte records it did fetch, records that survived the exact footprint test, (pixel, splat) evaluations
 int msplat_get_composite_work(msplat_ctx* ctx, msplat_composite_work* out)
 {
+    drain_async(ctx);
     if (!ctx || !out) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
     std::memset(out, 0, sizeof(*out));
     if (!ctx->probe.p || !ctx->probe_on)
@@ -1874,6 +2045,7 @@ int msplat_get_composite_work(msplat_ctx* ctx, msplat_composite_work* out)
 int msplat_debug_get_tile_lists(msplat_ctx* ctx, uint32_t* tile_start, uint32_t tile_cap,
                                 uint32_t* pairs, uint64_t pair_cap)
 {
+    drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     if (!ctx->has_render) return fail(ctx, MSPLAT_ERR_NO_SORT, "no render yet");
     HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -84,6 +84,7 @@ public:
             c.stream = nullptr;
             c.compositor_waves = 1280;       // frames share the CUs (measured r3: 768 .. 2048)
             c.frame_mode = MSPLAT_FRAMES_IN_FLIGHT;   // kernels that co-schedule well with other frames' kernels (+2-3 %)
+            c.async_submit = 1;                       // a worker thread per context issues its launches (msplat.h)
         }
         for (int k = 0; k < framesInFlight; ++k) {
             msplat_ctx* h = nullptr;

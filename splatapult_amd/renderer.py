@@ -45,7 +45,7 @@ class _FrameArgs:
 class SplatRenderer:
     def __init__(self, device=0, fb_format="fp32", t_epsilon=-1.0, pair_capacity=0, stream=None,
                  enable_timing=False, frames_in_flight=1, rank_mode=_capi.RANK_AUTO, frame_mode=None,
-                 spatial_order=_capi.SPATIAL_AUTO):
+                 spatial_order=_capi.SPATIAL_AUTO, async_submit=None):
         """frames_in_flight > 1: every Sort moves on to the next of that many contexts (own stream and
         per-frame buffers, ONE shared cloud -- msplat_attach_cloud), so successive frames overlap on the
         GPU; Render and the getters use the context of the latest Sort.  `stream` is only used with depth 1;
@@ -65,6 +65,9 @@ class SplatRenderer:
         self._timing = enable_timing
         self._rank_mode = int(rank_mode)       # msplat_config.rank_mode (RANK_AUTO / RANK_BALLOT)
         self._spatial = int(spatial_order)     # msplat_config.spatial_order (SPATIAL_AUTO / _ON / _OFF)
+        # msplat_config.async_submit: Sort / device-output Render are queued to a worker thread of their context (default: on
+        # with frames in flight -- the frames' launches are then issued concurrently instead of one context after the other)
+        self._async = (self._depth > 1) if async_submit is None else bool(async_submit)
         # msplat_config.frame_mode: kernels for one frame at a time, or for contexts that share the GPU with other frames in
         # flight (msplat.h, MSPLAT_FRAMES_*)
         self._frame_mode = int(frame_mode) if frame_mode is not None else (_capi.FRAMES_IN_FLIGHT if self._depth > 1 else _capi.FRAMES_AUTO)
@@ -115,6 +118,7 @@ class SplatRenderer:
         cfg.rank_mode = self._rank_mode
         cfg.frame_mode = self._frame_mode
         cfg.spatial_order = self._spatial
+        cfg.async_submit = 1 if self._async else 0
         for k in range(self._depth):
             if isinstance(self._stream, (list, tuple)):       # one caller-owned stream per frame in flight
                 cfg.stream = self._stream[k]
@@ -220,7 +224,7 @@ class SplatRenderer:
             _capi.check(h, self._lib.msplat_set_target_emulation(h, mode))
 
     def synchronize(self):
-        """blocks until every frame in flight has finished"""
+        """blocks until every frame in flight has been issued (async_submit) AND has finished on the GPU"""
         for h in self._ctxs:
             _capi.check(h, self._lib.msplat_synchronize(h))
 

@@ -1594,3 +1594,46 @@ def test_spatial_order_through_the_file_path_and_shared_clouds(tmp_path, monkeyp
     np.testing.assert_array_equal(imgs[0], imgs[2])
     ref = oracle_frame(dl, True, cam, proj, vp, nf, r=r)
     check_image(imgs[0], ref["image"], budget=ref["budget"])
+
+
+def test_async_submit_queues_calls_and_defers_their_errors():
+    """msplat_config.async_submit (on by default with frames in flight): Sort / device-output Render return at once and a worker
+    thread of the context issues the launches; a queued call that fails is reported by the next synchronize, once; getters wait
+    for the worker; the frames are those of a context that issues its own launches"""
+    import torch
+    from splatapult_amd import _capi
+    cloud = scenes.synth_cloud(30000, 93, log_scale_mean=-3.4)
+    W, H = 480, 270
+    Hpad = (H + bin_px() - 1) // bin_px() * bin_px()
+    cam, proj, vp, nf = scenes.default_view(W, H, yaw=0.2)
+    dev = torch.device("cuda", 0)
+    ra = make_renderer(cloud, frames_in_flight=2)                       # async by default
+    rs = make_renderer(cloud, frames_in_flight=2, async_submit=False)   # the calling thread issues the launches
+    fa = [torch.zeros((Hpad, W, 4), dtype=torch.float32, device=dev) for _ in range(6)]
+    fs = [torch.zeros((Hpad, W, 4), dtype=torch.float32, device=dev) for _ in range(6)]
+    for k in range(6):
+        c = camera.translate_local(cam, dx=0.02 * k)
+        for rr, f in ((ra, fa), (rs, fs)):
+            rr.Sort(c, proj, vp, nf)
+            rr.Render(c, proj, vp, nf, out_ptr=f[k].data_ptr(), pitch_bytes=W * 16)
+    assert ra.sort_count() == rs.sort_count() > 0                        # a getter waits for the queued Sort
+    ra.synchronize(); rs.synchronize()
+    for k in range(6):
+        assert torch.equal(fa[k], fs[k])
+    # a queued Render with an unsupported viewport returns OK and surfaces at synchronize ...
+    ra.Sort(cam, proj, vp, nf)
+    ra.Render(cam, proj, [0, 0, 9000, 9000], nf, out_ptr=fa[0].data_ptr(), pitch_bytes=9000 * 16)
+    with pytest.raises(_capi.MsplatError) as ei:
+        ra.synchronize()
+    assert ei.value.code == _capi.ERR_UNSUPPORTED and "queued" in str(ei.value)
+    ra.synchronize()                                                      # ... once
+    # ... while the synchronous context reports it at the call
+    rs.Sort(cam, proj, vp, nf)
+    with pytest.raises(_capi.MsplatError):
+        rs.Render(cam, proj, [0, 0, 9000, 9000], nf, out_ptr=fs[0].data_ptr(), pitch_bytes=9000 * 16)
+    # the context keeps working
+    ra.Sort(cam, proj, vp, nf)
+    ra.Render(cam, proj, vp, nf, out_ptr=fa[1].data_ptr(), pitch_bytes=W * 16)
+    ra.synchronize()
+    img = ra.Render(cam, proj, vp, nf)                                    # host output: synchronous, after the queue
+    np.testing.assert_array_equal(img, fa[1][:H].cpu().numpy())

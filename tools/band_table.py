@@ -149,13 +149,13 @@ def main_fif(args):
 
     def measure():
         frames(2 * P + 4)
-        torch.cuda.synchronize()
+        r.synchronize()
         blocks = []
         nblk = max(5, min(40, int(0.15 / max(1e-4, args.block * 2e-4))))
         for b in range(nblk):
             t0 = time.perf_counter()
             frames(args.block, 11 + b * args.block)
-            torch.cuda.synchronize()
+            r.synchronize()                       # (issued by the contexts' worker threads, then finished on the GPU)
             blocks.append(time.perf_counter() - t0)
         med = float(np.median(blocks))
         st = r.stats()
@@ -164,7 +164,7 @@ def main_fif(args):
 
     r.set_band(1, 0)
     frames(400)
-    torch.cuda.synchronize()
+    r.synchronize()
     whole = measure()
     out = {"workload": wl["desc"], "frames_in_flight": P, "block_frames": args.block, "bin_rows": R, "bin_px": T,
            "single_gpu": whole, "worlds": {}, "xgmi_link_GBps": XGMI_LINK / 1e9,

@@ -1557,7 +1557,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                         div_up(cap, kPairChunk) <= ctx->hist2_stride;                  // (the tables hold every chunk the capacity allows)
     uint32_t* gB1 = (uint32_t*)ctx->gsumB1.p;
     uint32_t* gB2 = (uint32_t*)ctx->gsumB2.p;
-    static const int xcdg = getenv("MSPLAT_DEV_XCDG") ? atoi(getenv("MSPLAT_DEV_XCDG")) : 0;      // EXPERIMENT (r4 item 3): to be fixed or removed
+    static const int xcdg = getenv("MSPLAT_DEV_XCDG") ? atoi(getenv("MSPLAT_DEV_XCDG")) : 8;      // EXPERIMENT (r4 item 3): to be fixed or removed
     // (bin1_upsweep also clears the row pass's group table: its consumer, the previous frame's row downsweep, is long done)
 #define MSPLAT_BIN1(CH)                                                                                                       \
     do {                                                                                                                      \
@@ -1677,11 +1677,19 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         // = 5.82 / 5.76 / 5.79 k frames/s, i.e. no effect there)
         const int prio_mode = ordered ? 1 : 0;
         const int grid = (int)std::min<uint32_t>(comp_items, comp_pool);
-        if (f16)
-            hipExtLaunchKernelGGL(composite_kernel<true>, dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
+        static const bool dev_mfma = getenv("MSPLAT_DEV_COMP") && std::string(getenv("MSPLAT_DEV_COMP")) == "mfma";     // EXPERIMENT (r4 item 4)
+        if (dev_mfma) {
+            if (f16)
+                hipExtLaunchKernelGGL((composite_kernel<true, true>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
+                                      cap, ord, d_queue, comp_items, probe, prio_mode);
+            else
+                hipExtLaunchKernelGGL((composite_kernel<false, true>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
+                                      cap, ord, d_queue, comp_items, probe, prio_mode);
+        } else if (f16)
+            hipExtLaunchKernelGGL((composite_kernel<true, false>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
                                   cap, ord, d_queue, comp_items, probe, prio_mode);
         else
-            hipExtLaunchKernelGGL(composite_kernel<false>, dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
+            hipExtLaunchKernelGGL((composite_kernel<false, false>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
                                   cap, ord, d_queue, comp_items, probe, prio_mode);
         ctx->comp_kernel_timed = timed;
     } else {

@@ -191,6 +191,10 @@ def measure(E, args, key, ply=None, primary=True):
         rr.Sort(cams[0], projs[0], vp, nf)                      # sort once with view 0 (app.cpp:603-606)
         fbs = sets[rr.frame_slot % Pn]
         state["fbs"] = fbs
+        if views == 2 and gathers is None and not args.no_stereo_batch:
+            # both eyes in one chain of launches (msplat_render_stereo): same pixels as the two Render calls below
+            rr.RenderStereo(cams, projs, vp, nf, out_ptrs=[fbs[0].data_ptr(), fbs[1].data_ptr()], pitch_bytes=W * bpp)
+            return
         for v in range(views):
             rr.Render(cams[v], projs[v], vp, nf, out_ptr=fbs[v].data_ptr(), pitch_bytes=W * bpp)
             if gathers is not None:
@@ -396,6 +400,7 @@ def measure(E, args, key, ply=None, primary=True):
                    "sharding": ("bin rows of %d px over %d ranks, layout %s" % (TILE, world, lay)) if world > 1 else "none (one GPU)",
                    "frames_in_flight": P, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                    "async_submit": bool(r._async),
+                   "stereo": ("one chain for both eyes (msplat_render_stereo)" if not args.no_stereo_batch else "one Render per eye") if views == 2 else None,
                    "visible_V": V, "pairs_D": D_total, "pairs_binned_32px": float(np.mean(Dbin)),
                    "drawn": float(np.mean(drawn)), "D_over_N": D_total / max(1, n),
                    "longest_bin_list": longest_list, "pair_capacity": pair_cap_end, "pair_capacity_initial": pair_cap0,
@@ -457,6 +462,8 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="frames overlapped on the GPU (one context + stream + framebuffer per frame in flight, one shared "
                          "cloud); 1 = strictly serial frames (latency mode)")
+    ap.add_argument("--no-stereo-batch", action="store_true",
+                    help="two-view workloads: one Render per eye (the reference's call pattern) instead of msplat_render_stereo (A/B)")
     ap.add_argument("--async-submit", type=int, default=-1,
                     help="msplat_config.async_submit of the in-flight contexts: 1 = a worker thread per context issues its launches, "
                          "0 = the calling thread does (A/B); default: on with frames in flight")

@@ -296,6 +296,18 @@ int msplat_render(msplat_ctx* ctx, const float cameraMat[16], const float projMa
                   const float viewport[4], const float nearFar[2],
                   void* rgba, uint64_t pitch_bytes, int out_is_device);
 
+/* Two views of the latest Sort in ONE chain of launches -- the reference's VR frame: Sort with the first eye's matrices, then
+ * Render per eye (src/app.cpp:603-607).  Same arguments and results as
+ *     msplat_render(ctx, cameraMat0, projMat0, viewport, nearFar, rgba0, pitch_bytes, out_is_device);
+ *     msplat_render(ctx, cameraMat1, projMat1, viewport, nearFar, rgba1, pitch_bytes, out_is_device);
+ * bit for bit, but projection, binning and compositing each run once over both views' work (6 launches instead of 12:
+ * BASELINE configs[4], 2 x 2016 x 2240, 0.50 -> 0.44 ms per stereo frame).  Device targets of a plain splat context take that
+ * form; host targets, banded contexts, point clouds, depth-test / render-target emulation, clouds beyond 2^23 splats and
+ * viewports taller than 4096 px are rendered view after view. */
+int msplat_render_stereo(msplat_ctx* ctx, const float cameraMat0[16], const float projMat0[16], const float cameraMat1[16],
+                         const float projMat1[16], const float viewport[4], const float nearFar[2], void* rgba0, void* rgba1,
+                         uint64_t pitch_bytes, int out_is_device);
+
 /* blocks until everything queued on the context's stream has finished */
 int msplat_synchronize(msplat_ctx* ctx);
 

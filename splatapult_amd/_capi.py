@@ -97,6 +97,7 @@ SYMBOLS = [
     ("msplat_group_synchronize", C.c_int, [C.c_void_p]),
     ("msplat_sort", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16]),
     ("msplat_render", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16, C.c_void_p, C.c_uint64, C.c_int]),
+    ("msplat_render_stereo", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16, _F16, _F16, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
     ("msplat_synchronize", C.c_int, [C.c_void_p]),
     ("msplat_read_image", C.c_int, [C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("msplat_points_create", C.c_void_p, [C.c_int]),

@@ -164,6 +164,7 @@ struct msplat_ctx {
     Buf counters;   // uint32[16]: 0=V, 1=D, 2=overflow, 4=drawn, 6..7=pairs16 (u64), 8=probe
     Buf queue;      // uint32[kQueueShards * kQueueStride]: the compositors' sharded work queue heads
     // render state
+    uint64_t rank_cap = 0;      // draw-order ranks rec2d / rect / hist1 ... are sized for: N, or 2 N + 64 once msplat_render_stereo ran
     Buf rec2d;      // float4[3*N]
     Buf rect;       // uint32[N]
     Buf zq;         // uint32[N] quantised window depth per rank (only with msplat_set_depth_test)
@@ -744,6 +745,7 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
     }
     if ((rc = buf_alloc(ctx, ctx->live_list, ((size_t)div_up(div_up(alloc_n, kBoxSplats), kBoxGroup) * kBoxGroup + 16) * 4))) return rc;
     if ((rc = buf_alloc(ctx, ctx->live_cnt, 256 * 4))) return rc;
+    ctx->rank_cap = alloc_n;
     if ((rc = buf_alloc(ctx, ctx->rec2d, alloc_n * 48))) return rc;
     if ((rc = buf_alloc(ctx, ctx->rect, alloc_n * 4))) return rc;
     if (ctx->depth_bits != 0 && (rc = buf_alloc(ctx, ctx->zq, alloc_n * 4))) return rc;
@@ -1237,6 +1239,8 @@ static int make_frame_params(msplat_ctx* ctx, const float cameraMat[16], const f
     fp.band_cull = (ctx->band_cull && ctx->banded && !ctx->point_mode) ? 1 : 0;   // points carry no footprint bound
     fp.depth_bits = ctx->depth_bits;
     fp.rop = ctx->rop;
+    fp.views = 1;
+    fp.rows_view = rows_full;
     fp.view_scale2 = 0.0f;
     for (int c = 0; c < 3; ++c)
         fp.view_scale2 = std::max(fp.view_scale2, fp.view[c * 4] * fp.view[c * 4] + fp.view[c * 4 + 1] * fp.view[c * 4 + 1] +
@@ -1505,12 +1509,16 @@ static int sort_impl(msplat_ctx* ctx, const float cameraMat[16], const float pro
     return MSPLAT_OK;
 }
 
-static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, size_t pitch, bool async_overflow_flag)
+static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, size_t pitch, bool async_overflow_flag,
+                         void* d_out1 = nullptr)
 {
     hipStream_t s = ctx->stream;
-    const uint32_t N = (uint32_t)ctx->N;
+    const bool stereo = fp.views == 2;          // two views in one chain: ranks [0, V) and [V1, V1 + V), bin rows stacked
+    // (rank-indexed launches cover the cloud; with two views 2 N + 64 ranks)
+    const uint32_t N = stereo ? (uint32_t)(2 * ctx->N + 64) : (uint32_t)ctx->N;
     uint32_t* counters = (uint32_t*)ctx->counters.p;
-    uint32_t *d_V = counters + 0, *d_D = counters + 1, *d_overflow = counters + 2, *d_queue = (uint32_t*)ctx->queue.p;
+    uint32_t *d_Vsort = counters + 0, *d_D = counters + 1, *d_overflow = counters + 2, *d_queue = (uint32_t*)ctx->queue.p;
+    uint32_t* d_V = stereo ? counters + 9 : d_Vsort;       // ranks the binning walks (written by project_kernel for two views)
     const int ntiles = fp.tiles_x * fp.tiles_y;
     const uint32_t cap = (uint32_t)ctx->pair_cap;
 
@@ -1523,13 +1531,13 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                            (const float4*)ctx->pos4.p, (const float4*)ctx->recs.p, fp, ctx->sprite_params,
                            (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr);
     else if (ctx->full_sh)
-        hipLaunchKernelGGL(project_kernel<true>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
+        hipLaunchKernelGGL(project_kernel<true>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_Vsort,
                            (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
-                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr);
+                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr, stereo ? d_V : nullptr);
     else
-        hipLaunchKernelGGL(project_kernel<false>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
+        hipLaunchKernelGGL(project_kernel<false>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_Vsort,
                            (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
-                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr);
+                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr, stereo ? d_V : nullptr);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][3], s));
 
     // pass 1: stable partition by tile column, enumerated from the rank-ordered rectangles
@@ -1572,14 +1580,14 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                                (const uint32_t*)totals1, (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags,        \
                                async_overflow_flag ? 1 : 0, fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, \
                                xcdg, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,                               \
-                               (uint32_t)nhelp, fp.tiles_x, ctx->gsupB1);                                                     \
+                               (uint32_t)nhelp, fp.tiles_x, ctx->gsupB1, (const uint32_t*)d_Vsort);                           \
         else                                                                                                                  \
             hipLaunchKernelGGL((bin1_downsweep<false, CH>), dim3(g1 + nhelp), dim3(kThreads), 0, s,                           \
                                (const uint32_t*)ctx->rect.p, d_V, (const uint32_t*)ctx->hist1.p, ctx->hist1_stride,           \
                                (const uint32_t*)totals1, (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags,        \
                                async_overflow_flag ? 1 : 0, fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, \
                                xcdg, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,                               \
-                               (uint32_t)nhelp, fp.tiles_x, ctx->gsupB1);                                                     \
+                               (uint32_t)nhelp, fp.tiles_x, ctx->gsupB1, (const uint32_t*)d_Vsort);                           \
     } while (0)
     // (bin1_upsweep also clears the row pass's group table: its consumer, the previous frame's row downsweep, is long done)
     MSPLAT_BIN1(kBinChunk);
@@ -1590,7 +1598,8 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     // themselves: they walk the bins in storage order (`tile_order` + 65536 holds 0, 1, 2, ...).
     const bool wave_comp = !ctx->point_mode && ctx->depth_bits == 0 && ctx->rop == 0;
     const uint32_t comp_items = (uint32_t)ntiles * 4u;
-    const uint32_t comp_pool = (ctx->comp_waves_auto && comp_items <= 20480u) ? comp_items : (uint32_t)ctx->comp_waves;
+    // (every item on its own wave up to 20 k items, 40 k for two views in one chain: BASELINE configs[4] has 2 x 17.6 k)
+    const uint32_t comp_pool = (ctx->comp_waves_auto && comp_items <= (stereo ? 40960u : 20480u)) ? comp_items : (uint32_t)ctx->comp_waves;
     const bool ordered = !(wave_comp && comp_pool < comp_items);
     // r3: the upsweep of the row pass also counts the pairs per bin, and one extra workgroup of its downsweep turns the
     // counts into the list offsets (+ the heaviest-first order when it is wanted): tile_start_kernel / tile_order_kernel
@@ -1628,7 +1637,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][4], s));
 
     // persistent compositor: a fixed pool of waves pulls (bin, quadrant) items; never more waves than items
-    const int cgrid = std::min(ntiles * 4, ctx->comp_waves);     // work items = (bin, quadrant)
+    const int cgrid = std::min(ntiles * 4, ctx->comp_waves);     // work items = (bin, quadrant) (the draw-order compositors)
     // (frames in flight: serialising the compositor launches of the contexts sharing a cloud with an event
     //  gate was measured r1 -- no gain over letting the hardware queues interleave them, dropped)
     if (ntiles > 0 && ctx->probe_on && ctx->probe.p && (ctx->point_mode || ctx->depth_bits != 0 || ctx->rop != 0))
@@ -1681,16 +1690,16 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         if (dev_mfma) {
             if (f16)
                 hipExtLaunchKernelGGL((composite_kernel<true, true>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
-                                      cap, ord, d_queue, comp_items, probe, prio_mode);
+                                      cap, ord, d_queue, comp_items, probe, prio_mode, d_out1);
             else
                 hipExtLaunchKernelGGL((composite_kernel<false, true>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
-                                      cap, ord, d_queue, comp_items, probe, prio_mode);
+                                      cap, ord, d_queue, comp_items, probe, prio_mode, d_out1);
         } else if (f16)
             hipExtLaunchKernelGGL((composite_kernel<true, false>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
-                                  cap, ord, d_queue, comp_items, probe, prio_mode);
+                                  cap, ord, d_queue, comp_items, probe, prio_mode, d_out1);
         else
             hipExtLaunchKernelGGL((composite_kernel<false, false>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
-                                  cap, ord, d_queue, comp_items, probe, prio_mode);
+                                  cap, ord, d_queue, comp_items, probe, prio_mode, d_out1);
         ctx->comp_kernel_timed = timed;
     } else {
         ctx->comp_kernel_timed = false;
@@ -1795,6 +1804,98 @@ static int render_impl(msplat_ctx* ctx, const float cameraMat[16], const float p
         if ((rc = ensure_pair_capacity(ctx, need))) return rc;
     }
     return fail(ctx, MSPLAT_ERR_PAIR_OVERFLOW, "pair buffer could not be grown");
+}
+
+// buffers indexed by draw-order rank, for 2 N + 64 ranks (two views in one chain)
+static int ensure_stereo_ranks(msplat_ctx* ctx)
+{
+    const uint64_t need = 2 * std::max<uint64_t>(ctx->N, 1) + 64;
+    if (ctx->rank_cap >= need) return MSPLAT_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc;
+    if ((rc = buf_alloc(ctx, ctx->rec2d, need * 48))) return rc;
+    if ((rc = buf_alloc(ctx, ctx->rect, need * 4))) return rc;
+    if ((rc = buf_alloc(ctx, ctx->heavy_flag, (size_t)div_up(need, kBinChunk) + 64))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->heavy_flag.p, 0, ctx->heavy_flag.bytes, ctx->stream));
+    ctx->hist1_stride = std::max(1u, div_up(need, kBinChunk));
+    if ((rc = buf_alloc(ctx, ctx->hist1, (size_t)256 * ctx->hist1_stride * 4))) return rc;
+    if ((rc = alloc_group_table(ctx, ctx->gsumB1, ctx->gsumB1_rows, ctx->hist1_stride, ctx->gsupB1))) return rc;
+    ctx->rank_cap = need;
+    return MSPLAT_OK;
+}
+
+static int render_stereo_impl(msplat_ctx* ctx, const float cam0[16], const float proj0[16], const float cam1[16], const float proj1[16],
+                              const float viewport[4], const float nearFar[2], void* rgba0, void* rgba1, uint64_t pitch_bytes,
+                              int out_is_device);
+
+// Two views of ONE Sort (the reference's VR frame: Sort with the first eye, Render per eye -- src/app.cpp:603-607) as a single
+// chain of launches: projection, binning and compositing each run once over both views' work instead of twice in a row (half
+// the launches, twice the work per launch: 0.50 -> 0.44 ms at BASELINE configs[4]).  Per view the arithmetic, the bin lists and
+// the pixels are exactly those of two msplat_render calls.  Falls back to those two calls for banded contexts, point clouds,
+// depth-test / render-target emulation, clouds beyond 2^23 splats and viewports taller than 4096 (128 bin rows per view).
+int msplat_render_stereo(msplat_ctx* ctx, const float cameraMat0[16], const float projMat0[16], const float cameraMat1[16],
+                         const float projMat1[16], const float viewport[4], const float nearFar[2], void* rgba0, void* rgba1,
+                         uint64_t pitch_bytes, int out_is_device)
+{
+    if (ctx && ctx->worker && g_on_worker_of != ctx) {
+        if (out_is_device && rgba0 && rgba1) {
+            FrameArgs a, b;
+            if (!a.load(cameraMat0, projMat0, viewport, nearFar) || !b.load(cameraMat1, projMat1, viewport, nearFar))
+                return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL matrix/viewport argument");
+            ctx->worker->post([ctx, a, b, rgba0, rgba1, pitch_bytes] {
+                return note_async_result(ctx, render_stereo_impl(ctx, a.cam, a.proj, b.cam, b.proj, a.vp, a.nf, rgba0, rgba1, pitch_bytes, 1));
+            });
+            return MSPLAT_OK;
+        }
+        ctx->worker->drain();
+    }
+    return render_stereo_impl(ctx, cameraMat0, projMat0, cameraMat1, projMat1, viewport, nearFar, rgba0, rgba1, pitch_bytes, out_is_device);
+}
+
+static int render_stereo_impl(msplat_ctx* ctx, const float cam0[16], const float proj0[16], const float cam1[16], const float proj1[16],
+                              const float viewport[4], const float nearFar[2], void* rgba0, void* rgba1, uint64_t pitch_bytes,
+                              int out_is_device)
+{
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if (!ctx->has_cloud) return fail(ctx, MSPLAT_ERR_NO_CLOUD, "msplat_render_stereo: no cloud uploaded");
+    if (!ctx->has_sort) return fail(ctx, MSPLAT_ERR_NO_SORT, "msplat_render_stereo: msplat_sort has not been called");
+    if (!rgba0 || !rgba1) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_render_stereo: a target is NULL");
+    FrameParams fp, fp1;
+    int rc = make_frame_params(ctx, cam0, proj0, viewport, nearFar, fp);
+    if (!rc) rc = make_frame_params(ctx, cam1, proj1, viewport, nearFar, fp1);
+    if (rc) return rc;
+    const bool batched = !ctx->banded && !ctx->point_mode && ctx->depth_bits == 0 && ctx->rop == 0 && ctx->N <= (1ull << 23) &&
+                         2 * fp.tiles_y <= 256 && out_is_device;
+    if (!batched) {      // the plain form: one render per view (host targets are filled one after the other anyway)
+        rc = render_impl(ctx, cam0, proj0, viewport, nearFar, rgba0, pitch_bytes, out_is_device);
+        if (rc && rc != MSPLAT_ERR_PAIR_OVERFLOW_EARLIER) return rc;
+        const int rc1 = render_impl(ctx, cam1, proj1, viewport, nearFar, rgba1, pitch_bytes, out_is_device);
+        return rc1 ? rc1 : rc;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bpp = ctx->cfg.fb_format == MSPLAT_FB_RGBA16F ? 8 : 16;
+    const size_t tight = (size_t)fp.width * bpp;
+    if (pitch_bytes == 0) pitch_bytes = tight;
+    if (pitch_bytes < tight || pitch_bytes % bpp != 0)
+        return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_render_stereo: pitch %llu too small / misaligned for width %d",
+                    (unsigned long long)pitch_bytes, fp.width);
+    if ((rc = ensure_stereo_ranks(ctx))) return rc;
+    fp.views = 2;
+    fp.rows_view = fp.tiles_y;
+    fp.tiles_y = 2 * fp.rows_view;
+    std::memcpy(fp.view1, fp1.view, sizeof(fp.view1));
+    std::memcpy(fp.proj1, fp1.proj, sizeof(fp.proj1));
+    std::memcpy(fp.eye1, fp1.eye, sizeof(fp.eye1));
+    ctx->last_fp = fp;
+    if (ctx->tables_dirty && (rc = clear_frame_tables(ctx))) return rc;
+    std::string pending_msg;
+    const int pending = poll_async_overflow(ctx, pending_msg);
+    if (pending == MSPLAT_ERR_HIP) return pending;
+    rc = launch_render(ctx, fp, rgba0, pitch_bytes, true, rgba1);
+    if (rc) return rc;
+    ctx->has_render = true;
+    if (pending) return fail(ctx, MSPLAT_ERR_PAIR_OVERFLOW_EARLIER, "%s", pending_msg.c_str());
+    return MSPLAT_OK;
 }
 
 int msplat_sort_count(msplat_ctx* ctx, uint32_t* v)

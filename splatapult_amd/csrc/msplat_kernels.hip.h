@@ -63,6 +63,11 @@ struct FrameParams {
     float view_scale2;          // largest squared column norm of mat3(view) (1 for a rigid camera)
     int depth_bits;             // 0 = colour-only target (no depth test); 24 / 32 = emulated depth buffer
     int rop;                    // 0 = float accumulation; 1 = RGBA8, 2 = RGBA16F render-target rounding after every blend
+    // Two views in ONE render chain (msplat_render_stereo, r4): the second view's matrices; its splats are the draw-order ranks
+    // [V1, V1 + V) with V1 = V rounded up to 64 (a projection wave never straddles the views), its bin rows follow the first
+    // view's: rows_view .. 2 rows_view - 1.  views == 1: everything above describes the only view.
+    int views, rows_view;
+    float view1[16], proj1[16], eye1[3];
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1739,7 +1744,7 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
                                                                FrameParams fp,
                                                                float4* __restrict__ out_rec,
                                                                uint32_t* __restrict__ out_rect,
-                                                               uint32_t* __restrict__ out_zq)
+                                                               uint32_t* __restrict__ out_zq, uint32_t* __restrict__ d_Veff = nullptr)
 {
     // Records are 256 B (full SH) or 128 B (base) and line aligned.  The gather by sorted index is
     // done cooperatively: F4 consecutive lanes fetch one whole record (coalesced 256/128 B), the wave
@@ -1751,10 +1756,17 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
     __shared__ __attribute__((aligned(16))) float s_stage[64 * STRIDE];
     const uint32_t V = *d_V;
     const int lane = threadIdx.x;
-    if (blockIdx.x * kProjThreads >= V) return;
+    // two views in one chain (FrameParams.views == 2): ranks [0, V) are view 0, [V1, V1 + V) view 1; the gap gets empty rectangles
+    const uint32_t V1 = (V + 63u) & ~63u;
+    const uint32_t total = fp.views == 2 ? V1 + V : V;
+    if (d_Veff != nullptr && blockIdx.x == 0 && lane == 0) *d_Veff = total;       // what the binning passes walk
+    if (blockIdx.x * kProjThreads >= total) return;
     const uint32_t r = blockIdx.x * kProjThreads + lane;
-    const bool valid = r < V;
-    const uint32_t i = valid ? sorted_idx[r] : 0u;
+    const bool second = fp.views == 2 && blockIdx.x * kProjThreads >= V1;         // wave-uniform
+    const uint32_t rl = second ? r - V1 : r;                                       // rank inside the view
+    const bool valid = rl < V;
+    if (!valid && r < total) out_rect[r] = kRectEmpty;                             // (the gap between the views, and nothing else)
+    const uint32_t i = valid ? sorted_idx[rl] : 0u;
     {
         const int sub = lane % F4;
         float4 tmp[F4];
@@ -1779,8 +1791,9 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
     }
     if (!valid) return;
     const float x = f[0], y = f[1], z = f[2], alpha = f[3];
-    const float* vm = fp.view;
-    const float* pm = fp.proj;
+    const float* vm = second ? fp.view1 : fp.view;
+    const float* pm = second ? fp.proj1 : fp.proj;
+    const float* eye = second ? fp.eye1 : fp.eye;
 
     // t = viewMat * vec4(pos, 1)   -- same op order as the oracle (reject tests must not flip)
     float t[4];
@@ -1837,7 +1850,7 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
     const float i11 = m00 / det;
 
     // colour: 0.5 + SH(v), no clamp (splat_vert.glsl:51-127,206-207)
-    const float dx = x - fp.eye[0], dy = y - fp.eye[1], dz = z - fp.eye[2];
+    const float dx = x - eye[0], dy = y - eye[1], dz = z - eye[2];
     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
     const float vx = dx / len, vy = dy / len, vz = dz / len;
     float b[FULL_SH ? 16 : 4];
@@ -1914,6 +1927,7 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
                 ty0 = v0;
                 ty1 = v1;
             }
+            if (second) { ty0 += fp.rows_view; ty1 += fp.rows_view; }         // the second view's bins follow the first's
             if (ty0 <= ty1) {
                 rect = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
             }
@@ -2082,8 +2096,9 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && BIN_CHUNK == kBinChunk) ?
                                                            uint32_t* __restrict__ totals_out, int xcd_map,
                                                            const uint32_t* __restrict__ heavy,
                                                            const uint8_t* __restrict__ heavy_flag, uint32_t nhelp, int tiles_x,
-                                                           uint32_t gsup)
+                                                           uint32_t gsup, const uint32_t* __restrict__ d_V_report = nullptr)
 {
+    // d_V_report: the Sort's own V for the host-mapped hint (with two views in one chain d_V counts the ranks of both)
     // The first nhelp workgroups are helpers for the heavy chunks (bin1_upsweep; first, so that they start with the launch):
     // helper h takes column block 1 + h % (kHeavyParts - 1) of chunk heavy[1 + h / (kHeavyParts - 1)] and exits at once when
     // there is no such chunk; the other nmain workgroups walk the chunks (grid-stride), a heavy chunk's main workgroup keeps
@@ -2120,7 +2135,7 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && BIN_CHUNK == kBinChunk) ?
         if (!helper && mb == 0u && threadIdx.x == 255) {
             *d_D = incl;
             if (host_words != nullptr) {
-                __hip_atomic_store(host_words + 1, V, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(host_words + 1, d_V_report ? *d_V_report : V, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(host_words + 2, incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(host_words + 3, heavy[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // heavy chunks wanted
             }
@@ -2476,8 +2491,10 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
                                                                  FrameParams fp, uint32_t cap,
                                                                  const uint32_t* __restrict__ order,
                                                                  uint32_t* __restrict__ queue, uint32_t ntiles,
-                                                                 uint32_t* __restrict__ probe, int prio_levels)
+                                                                 uint32_t* __restrict__ probe, int prio_levels,
+                                                                 void* __restrict__ out1 = nullptr)
 {
+    // out1: the second view's target (FrameParams.views == 2: bin rows >= rows_view belong to it)
     // Lane (lx, ly) owns pixels (x0+lx, y0 + 4k + ly), k = 0..3: strip k is the 16x4 pixel block of
     // rows 4k..4k+3.  Per splat the exponent is split into a part shared by the four strips and a
     // 2-FMA part per strip; strips the splat's y-range cannot reach, or whose 64 pixels are all
@@ -2522,7 +2539,8 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
     const int quad = (int)quadrant;
     const int bvy = bin / fp.tiles_x;
     const int tx = (bin - bvy * fp.tiles_x) * 2 + (quad & 1);
-    const int ty = band_real_row(fp, bvy) * 2 + (quad >> 1);
+    const bool second = fp.views == 2 && bvy >= fp.rows_view;
+    const int ty = (second ? bvy - fp.rows_view : band_real_row(fp, bvy)) * 2 + (quad >> 1);
     if (tx * kTile >= fp.width || ty * kTile >= fp.height) {      // work item entirely outside the image
         if (gridDim.x >= ntiles) break;
         uint32_t nq = 0;
@@ -2794,7 +2812,7 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         if (inside[k]) {
-            char* row = (char*)out + (size_t)(ybase + 4 * k) * pitch_bytes;
+            char* row = (char*)(second ? out1 : out) + (size_t)(ybase + 4 * k) * pitch_bytes;
             if (F16) {
                 union { _Float16 h[4]; uint2 u; } pk;
                 pk.h[0] = (_Float16)cr[k >> 1][k & 1]; pk.h[1] = (_Float16)cg[k >> 1][k & 1]; pk.h[2] = (_Float16)cb[k >> 1][k & 1]; pk.h[3] = (_Float16)1.0f;

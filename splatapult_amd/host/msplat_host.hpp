@@ -171,6 +171,33 @@ public:
         if (rc != MSPLAT_OK) std::fprintf(stderr, "[msplat][%c] Render: %s\n", Level(rc), msplat_last_error(ctx));
     }
 
+    // Both eyes of the latest Sort in one chain of launches (msplat_render_stereo): what the XR callback does with two Render
+    // calls (app.cpp:603-607), for device targets at half the launches.  target1: the second eye's image (same pitch / kind as
+    // the SetRenderTarget one, which receives the first eye).
+    template <class Mat4, class Vec4, class Vec2>
+    void RenderStereo(const Mat4& cameraMat0, const Mat4& projMat0, const Mat4& cameraMat1, const Mat4& projMat1, const Vec4& viewport,
+                      const Vec2& nearFar, void* target1)
+    {
+        static_assert(sizeof(Mat4) == 64 && sizeof(Vec4) == 16 && sizeof(Vec2) == 8, "glm-compatible layout expected");
+        if (!target || !target1) {
+            std::fprintf(stderr, "[msplat][E] RenderStereo: no render target set (SetRenderTarget / target1)\n");
+            return;
+        }
+        if (group) {         // a device group renders its rows per view
+            Render(cameraMat0, projMat0, viewport, nearFar);
+            void* keep = target;
+            target = target1;
+            Render(cameraMat1, projMat1, viewport, nearFar);
+            target = keep;
+            return;
+        }
+        const int rc = msplat_render_stereo(ctx, reinterpret_cast<const float*>(&cameraMat0), reinterpret_cast<const float*>(&projMat0),
+                                            reinterpret_cast<const float*>(&cameraMat1), reinterpret_cast<const float*>(&projMat1),
+                                            reinterpret_cast<const float*>(&viewport), reinterpret_cast<const float*>(&nearFar), target,
+                                            target1, targetPitch, targetIsDevice ? 1 : 0);
+        if (rc != MSPLAT_OK) std::fprintf(stderr, "[msplat][%c] RenderStereo: %s\n", Level(rc), msplat_last_error(ctx));
+    }
+
     // replaces "the currently bound GL framebuffer" (app.cpp:1000-1035)
     void SetRenderTarget(void* rgba, uint64_t pitchBytes, bool isDevicePointer)
     {

@@ -191,6 +191,26 @@ class SplatRenderer:
         _capi.check(self._ctx, self._lib.msplat_render(self._ctx, c, p, v, nf, out.ctypes.data, 0, 0))
         return out
 
+    def RenderStereo(self, cameraMats, projMats, viewport, nearFar, out_ptrs=None, pitch_bytes=0):
+        """both eyes of the latest Sort in ONE chain of launches (msplat_render_stereo; the reference renders them one after the
+        other, app.cpp:603-607): same pixels as two Render calls.  out_ptrs: two device pointers (asynchronous), else two host
+        arrays are returned"""
+        a0, a1 = self._args, getattr(self, "_args1", None)
+        if a1 is None:
+            a1 = self._args1 = _FrameArgs()
+        c0, p0, v, nf = a0.load(cameraMats[0], projMats[0], viewport, nearFar)
+        c1, p1, _, _ = a1.load(cameraMats[1], projMats[1], viewport, nearFar)
+        if out_ptrs is not None:
+            _capi.check(self._ctx, self._lib.msplat_render_stereo(self._ctx, c0, p0, c1, p1, v, nf, C.c_void_p(out_ptrs[0]),
+                                                                  C.c_void_p(out_ptrs[1]), pitch_bytes, 1))
+            return None
+        W, H = int(a0.vp[2]), int(a0.vp[3])
+        dt = np.float16 if self._fb_format == _capi.FB_RGBA16F else np.float32
+        outs = [np.zeros((H, W, 4), dt), np.zeros((H, W, 4), dt)]
+        _capi.check(self._ctx, self._lib.msplat_render_stereo(self._ctx, c0, p0, c1, p1, v, nf, outs[0].ctypes.data,
+                                                              outs[1].ctypes.data, 0, 0))
+        return outs
+
     # -- extensions -------------------------------------------------------------------------
     def set_band(self, row_mod, row_rem, band_cull=False):
         """interleaved rows: this renderer owns the bin rows t with t % row_mod == row_rem"""

@@ -1637,3 +1637,55 @@ def test_async_submit_queues_calls_and_defers_their_errors():
     ra.synchronize()
     img = ra.Render(cam, proj, vp, nf)                                    # host output: synchronous, after the queue
     np.testing.assert_array_equal(img, fa[1][:H].cpu().numpy())
+
+
+@pytest.mark.parametrize("fb", ["fp32", "fp16"])
+def test_render_stereo_is_bit_identical_to_two_renders(fb):
+    """msplat_render_stereo (r4): both eyes of one Sort in ONE chain of launches -- view 1's splats are the ranks behind view 0's,
+    its bin rows are stacked on view 0's -- against the reference's call pattern, one Render per eye (app.cpp:603-607): the same
+    pixels bit for bit, on a ragged viewport (360 = 11.25 bin rows), repeated (the tables it leaves), with frames in flight, and
+    through the view-after-view fallbacks (host targets, a banded context)"""
+    import torch
+    cloud = scenes.synth_cloud(50000, 95, log_scale_mean=-3.3)
+    W, H = 648, 360
+    Hpad = (H + bin_px() - 1) // bin_px() * bin_px()
+    cam0 = camera.pose((0.0, 0.0, 7.0), 0.15)
+    eyes = [camera.translate_local(cam0, dx=-0.032), camera.translate_local(cam0, dx=+0.032)]
+    projs = [camera.create_projection(-1.0, 0.8, 0.95, -0.95), camera.create_projection(-0.8, 1.0, 0.95, -0.95)]
+    vp, nf = [0, 0, W, H], scenes.NF
+    tdt, bpp = (torch.float16, 8) if fb == "fp16" else (torch.float32, 16)
+    dev = torch.device("cuda", 0)
+    r = make_renderer(cloud, fb_format=fb)
+    r.Sort(eyes[0], projs[0], vp, nf)
+    ref = [r.Render(eyes[e], projs[e], vp, nf) for e in range(2)]                 # one Render per eye (host images)
+    assert not np.array_equal(ref[0], ref[1])
+    for depth in (1, 2):
+        rs = make_renderer(cloud, fb_format=fb, frames_in_flight=depth)
+        fbs = [[torch.zeros((Hpad, W, 4), dtype=tdt, device=dev) for _ in range(2)] for _ in range(3)]
+        for k in range(3):                                                       # three frames: the self-cleaning tables, both parities
+            rs.Sort(eyes[0], projs[0], vp, nf)
+            rs.RenderStereo(eyes, projs, vp, nf, out_ptrs=[t.data_ptr() for t in fbs[k]], pitch_bytes=W * bpp)
+        rs.synchronize()
+        for k in range(3):
+            for e in range(2):
+                np.testing.assert_array_equal(fbs[k][e][:H].cpu().numpy(), ref[e])
+        assert rs.verify_order() == (0, 0)
+        st = rs.stats()
+        assert st["tiles_y"] == 2 * ((H + bin_px() - 1) // bin_px())              # the two views' bin rows, stacked
+        # a mono Render on the same context afterwards is unaffected
+        rs.Sort(eyes[0], projs[0], vp, nf)
+        np.testing.assert_array_equal(rs.Render(eyes[1], projs[1], vp, nf), ref[1])
+    # fallbacks: host targets and a banded context render view after view -- same pixels
+    r.Sort(eyes[0], projs[0], vp, nf)
+    both = r.RenderStereo(eyes, projs, vp, nf)
+    np.testing.assert_array_equal(both[0], ref[0])
+    np.testing.assert_array_equal(both[1], ref[1])
+    rb = make_renderer(cloud, fb_format=fb)
+    rb.set_band(2, 1)
+    rb.Sort(eyes[0], projs[0], vp, nf)
+    fb2 = [torch.zeros((Hpad, W, 4), dtype=tdt, device=dev) for _ in range(2)]
+    rb.RenderStereo(eyes, projs, vp, nf, out_ptrs=[t.data_ptr() for t in fb2], pitch_bytes=W * bpp)
+    rb.synchronize()
+    rows = np.arange(H) // bin_px() % 2 == 1
+    for e in range(2):
+        np.testing.assert_array_equal(fb2[e][:H].cpu().numpy()[rows], ref[e][rows])

@@ -180,6 +180,8 @@ def measure(E, args, key, ply=None, primary=True):
         from splatapult_amd.dist import BandGather
         gathers = [BandGather(tiles_y, W, fdt, dev, rank, world, tile=TILE, layout=lay_kind, block_rows=lay_k) for _ in range(views)]
     state = {"fbs": fb_sets[0]}
+    stereo_batch = views == 2 and gathers is None and not args.no_stereo_batch       # both eyes in one chain of launches
+    launches_per_frame = 1 if stereo_batch else views                                 # compositor launches (and render chains) per frame
 
     def frame(step, rr=r, sets=fb_sets):
         cams = cams_for(step)
@@ -191,7 +193,7 @@ def measure(E, args, key, ply=None, primary=True):
         rr.Sort(cams[0], projs[0], vp, nf)                      # sort once with view 0 (app.cpp:603-606)
         fbs = sets[rr.frame_slot % Pn]
         state["fbs"] = fbs
-        if views == 2 and gathers is None and not args.no_stereo_batch:
+        if stereo_batch:
             # both eyes in one chain of launches (msplat_render_stereo): same pixels as the two Render calls below
             rr.RenderStereo(cams, projs, vp, nf, out_ptrs=[fbs[0].data_ptr(), fbs[1].data_ptr()], pitch_bytes=W * bpp)
             return
@@ -292,9 +294,13 @@ def measure(E, args, key, ply=None, primary=True):
         # (no gather here: only the compositor's own counters are wanted; every view's launch is probed)
         cams = cams_for(args.warmup + s * 7)
         rs.Sort(cams[0], projs[0], vp, nf)
-        for v in range(views):
-            rs.Render(cams[v], projs[v], vp, nf, out_ptr=rs_sets[0][v].data_ptr(), pitch_bytes=W * bpp)
+        if stereo_batch:                   # ONE compositor launch covers both eyes
+            rs.RenderStereo(cams, projs, vp, nf, out_ptrs=[t.data_ptr() for t in rs_sets[0]], pitch_bytes=W * bpp)
             works.append(rs.composite_work())
+        else:
+            for v in range(views):
+                rs.Render(cams[v], projs[v], vp, nf, out_ptr=rs_sets[0][v].data_ptr(), pitch_bytes=W * bpp)
+                works.append(rs.composite_work())
         st = rs.stats()
         Vs.append(st["sort_count"]); Ds.append(st["pairs_tile16"]); drawn.append(st["drawn"]); Dbin.append(st["pairs"])
     rs.set_tile_probe(False)
@@ -321,8 +327,8 @@ def measure(E, args, key, ply=None, primary=True):
     B_frame = 16.0 * n + (8 + 68 + S + 48) * V + (52.0 * D_total + W * H * bpp) * views
     Dbin_mean = float(np.mean(Dbin))
     # dominant kernel: composite_kernel, one launch per view, measured with the GPU to itself (serial phase)
-    fb_bytes = (W * H * bpp) / world
-    B_formula = 52.0 * D + fb_bytes                         # every (splat, 16x16 tile) pair fetched
+    fb_bytes = (W * H * bpp) / world * (views / launches_per_frame)
+    B_formula = 52.0 * D * (views / launches_per_frame if views > 1 else 1.0) + fb_bytes      # every (splat, 16x16 tile) pair fetched
     comp_serial_ms = (prof_serial or {}).get("composite_kernel", 0.0) or (prof_serial or {}).get("composite", 0.0)
     comp_overlap_ms = prof.get("composite_kernel", 0.0) or prof.get("composite", 0.0)
     if work:
@@ -353,16 +359,17 @@ def measure(E, args, key, ply=None, primary=True):
     # (rectangle read; every (splat, 32-px bin) pair word written, read, written, read), and for the compositor what its
     # front-to-back walk really fetched (probe) + the framebuffer -- over the stage's time; none of them can exceed 1
     stages = None
+    vpl = views / launches_per_frame           # views per render chain (2 when both eyes run as one chain)
     if prof_serial and prof_serial.get("sort_total", 0) > 0:
         # (stereo: projection, binning and the compositor run once per view; their stage times and bytes are per Render call)
-        sb = {"sort": 16.0 * n + 76.0 * V, "project": (S + 48.0) * V, "binning": 4.0 * V + 16.0 * Dbin_mean, "composite": B_used}
+        sb = {"sort": 16.0 * n + 76.0 * V, "project": vpl * (S + 48.0) * V, "binning": vpl * 4.0 * V + 16.0 * Dbin_mean, "composite": B_used}
         st_ms = {"sort": prof_serial["sort_total"], "project": prof_serial["project"], "binning": prof_serial["binning"],
                  "composite": comp_serial_ms}
         stages = {k: {"bytes": sb[k], "us": 1e3 * st_ms[k], "frac": min(1.0, sb[k] / max(st_ms[k] * 1e-3, 1e-12) / HBM_PEAK)}
                   for k in sb}
         stages["bytes_definition"] = ("sort 16 N + 76 V; project 292 V; binning 4 V + 16 D32 (D32 = (splat, 32-px bin) pairs); composite = bytes "
                                       "fetched (probe) + framebuffer; us = stage time of a serial frame (per Render call for stereo)")
-    B_moved = (16.0 * n + 76.0 * V) + views * ((S + 48.0) * V + 4.0 * V + 16.0 * Dbin_mean + B_used)
+    B_moved = (16.0 * n + 76.0 * V) + launches_per_frame * (vpl * ((S + 48.0) * V + 4.0 * V) + 16.0 * Dbin_mean + B_used)
     roof = {
         "kernel": "composite_kernel", "bound": "hbm", "limiter": "valu (exp + blend per pixel-splat); the HBM fraction is honest-but-low",
         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,

@@ -1565,7 +1565,10 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                         div_up(cap, kPairChunk) <= ctx->hist2_stride;                  // (the tables hold every chunk the capacity allows)
     uint32_t* gB1 = (uint32_t*)ctx->gsumB1.p;
     uint32_t* gB2 = (uint32_t*)ctx->gsumB2.p;
-    static const int xcdg = getenv("MSPLAT_DEV_XCDG") ? atoi(getenv("MSPLAT_DEV_XCDG")) : 8;      // EXPERIMENT (r4 item 3): to be fixed or removed
+    // column pass: groups of 8 consecutive chunks share an XCD (xcd_grouped): the seams between the runs neighbouring chunks write
+    // merge in that XCD's L2.  Measured r4 (serial binning, groups of 0 / 2 / 4 / 8 / 16 / 32): 6 M / 4096^2 328 / 320 / 316 / 315 /
+    // 315 / 313 us, scene-like 6 M 201 / 194 / 194 / 195, 1 M unchanged (57); the fully XCD-contiguous mapping of r3 was slower.
+    const int xcdg = 8;
     // (bin1_upsweep also clears the row pass's group table: its consumer, the previous frame's row downsweep, is long done)
 #define MSPLAT_BIN1(CH)                                                                                                       \
     do {                                                                                                                      \
@@ -1686,19 +1689,11 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         // = 5.82 / 5.76 / 5.79 k frames/s, i.e. no effect there)
         const int prio_mode = ordered ? 1 : 0;
         const int grid = (int)std::min<uint32_t>(comp_items, comp_pool);
-        static const bool dev_mfma = getenv("MSPLAT_DEV_COMP") && std::string(getenv("MSPLAT_DEV_COMP")) == "mfma";     // EXPERIMENT (r4 item 4)
-        if (dev_mfma) {
-            if (f16)
-                hipExtLaunchKernelGGL((composite_kernel<true, true>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
-                                      cap, ord, d_queue, comp_items, probe, prio_mode, d_out1);
-            else
-                hipExtLaunchKernelGGL((composite_kernel<false, true>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
-                                      cap, ord, d_queue, comp_items, probe, prio_mode, d_out1);
-        } else if (f16)
-            hipExtLaunchKernelGGL((composite_kernel<true, false>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
+        if (f16)
+            hipExtLaunchKernelGGL(composite_kernel<true>, dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
                                   cap, ord, d_queue, comp_items, probe, prio_mode, d_out1);
         else
-            hipExtLaunchKernelGGL((composite_kernel<false, false>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
+            hipExtLaunchKernelGGL(composite_kernel<false>, dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
                                   cap, ord, d_queue, comp_items, probe, prio_mode, d_out1);
         ctx->comp_kernel_timed = timed;
     } else {

@@ -2483,7 +2483,7 @@ constexpr int kCompOcc = 5;        // waves per SIMD the register allocation lea
 // tw = Ts w' = T w exactly as before (powers of two), colours accumulate unchanged and Ts -= 2^118 tw.  The bias costs 4 bits
 // of the exponent's absolute precision (|e - 118| ~ 2^7 instead of <= 2^3): a relative error of 3e-6 in w.  Only e == -8
 // exactly (w == 1/256, which the reference discards) is kept: a measure-zero threshold flip.
-template <bool F16, bool MFMA = false>
+template <bool F16>
 __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const uint32_t* __restrict__ tile_start,
                                                                  const uint32_t* __restrict__ pairs,
                                                                  const float4* __restrict__ rec,
@@ -2499,18 +2499,11 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
     // rows 4k..4k+3.  Per splat the exponent is split into a part shared by the four strips and a
     // 2-FMA part per strip; strips the splat's y-range cannot reach, or whose 64 pixels are all
     // saturated, are skipped with scalar branches.
-    __shared__ float4 s_rec[MFMA ? 1 : (kCompThreads + 1) * 3];
-    // MFMA (r4 experiment): the exponents of FOUR staged records at a time come from the matrix pipe:
-    // e = c0 + c1 u + c2 v + c3 u^2 + c4 u v + c5 v^2 is a K = 5 contraction of per-record coefficients with per-pixel monomials
-    // on top of c0.  v_mfma_f32_4x4x1_16b_f32: sixteen independent 4x4 blocks, lane l = (block l / 4, column j = l % 4); its A
-    // operand is row i = l % 4 of its block, its B operand its OWN column, and its four result registers hold D[0..3][j]: with
-    // A(lane) = coefficient k of record (l % 4) and B(lane) = monomial k of the lane's pixel, D[i] accumulates e(record i, own
-    // pixel) -- exact fp32 (one rounding per product, like an fmaf chain).  Staged layout: s_a[slot] = {c1, c2, c3, c4, c5},
-    // s_c0 / s_r / s_g / s_b[slot] read four records at a time; the list is padded to a multiple of four with records that
-    // vanish (c0 = -1e30).
-    constexpr int kSlots = kCompThreads + 4;
-    __shared__ __attribute__((aligned(16))) float s_a[MFMA ? kSlots * 8 : 4];
-    __shared__ __attribute__((aligned(16))) float s_c0[MFMA ? kSlots : 4], s_r[MFMA ? kSlots : 4], s_g[MFMA ? kSlots : 4], s_b[MFMA ? kSlots : 4];
+    __shared__ float4 s_rec[(kCompThreads + 1) * 3];
+    // (r4, measured and removed: the exponents of four staged records at a time from the matrix pipe -- e is a K = 5 contraction
+    //  of per-record coefficients with per-pixel monomials on top of c0; v_mfma_f32_4x4x1_16b_f32, 3.5 per record instead of 3
+    //  scalar + 4 packed FMAs; bit-compatible images.  20 % fewer non-MFMA VALU instructions, and the launch 14 % LONGER (81 -> 92 us):
+    //  the MFMAs take the same issue port, SQ_ACTIVE_INST_VALU fell by 4 % only.  DESIGN.md 4, profiles/r04_pmc_sq_compositor_mfma.txt)
 
     // Persistent waves + dynamic queue: per-tile work varies by >10x (list length, early saturation),
     // so tiles are pulled heaviest-first from `order` instead of being bound to a workgroup index.
@@ -2675,20 +2668,7 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
             rel = rel && (inside_box || emax > -8.05f - kBias);
             const uint64_t relmask = __ballot(rel);
             n = (uint32_t)__popcll(relmask);
-            if (MFMA) {
-                if (lane < 4) {                       // padding behind the n survivors (overwritten where a survivor lands)
-                    const int ps = (int)n + lane;
-                    *reinterpret_cast<float4*>(&s_a[ps * 8]) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    s_a[ps * 8 + 4] = 0.0f;
-                    s_c0[ps] = -1.0e30f; s_r[ps] = 0.0f; s_g[ps] = 0.0f; s_b[ps] = 0.0f;
-                }
-                if (rel) {
-                    const int slot = __popcll(relmask & ((1ull << lane) - 1ull));
-                    *reinterpret_cast<float4*>(&s_a[slot * 8]) = make_float4(c1, c2, qa, qb);
-                    s_a[slot * 8 + 4] = qc;
-                    s_c0[slot] = c0; s_r[slot] = p1.z; s_g[slot] = p1.w; s_b[slot] = p2.x;
-                }
-            } else if (rel) {
+            if (rel) {
                 const int slot = __popcll(relmask & ((1ull << lane) - 1ull));
                 // the four values the packed instructions broadcast (c5, r, g, b) sit at even dwords of the 16-byte reads: they
                 // land in even VGPRs, which a packed operand can name directly (an odd one costs a v_mov)
@@ -2713,51 +2693,7 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
         probe_words += cntA;
         probe_recs += cnt;
         const uint64_t probe_t1 = probe ? clock64() : 0ull;
-        if (MFMA && n != 0u) {
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            const int sub = lane & 3;
-            const float uu = u * u;
-            float vs[NS], uv[NS], v2[NS];
-#pragma unroll
-            for (int k = 0; k < NS; ++k) { vs[k] = vp[k >> 1][k & 1]; uv[k] = u * vs[k]; v2[k] = vs[k] * vs[k]; }
-#pragma unroll 1
-            for (uint32_t j = 0; j < n; j += 4u) {
-                const float4 a4 = *reinterpret_cast<const float4*>(&s_a[(j + sub) * 8]);       // c1 c2 c3 c4 of record j + lane % 4
-                const float a5 = s_a[(j + sub) * 8 + 4];                                        // c5
-                const float4 c0q = *reinterpret_cast<const float4*>(&s_c0[j]);                   // broadcast reads: records j .. j + 3
-                const float4 rq = *reinterpret_cast<const float4*>(&s_r[j]);
-                const float4 gq = *reinterpret_cast<const float4*>(&s_g[j]);
-                const float4 bq = *reinterpret_cast<const float4*>(&s_b[j]);
-                // shared by the four strips: c0 + c1 u + c3 u^2
-                v4f base = (v4f){c0q.x, c0q.y, c0q.z, c0q.w};
-                base = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.x, u, base, 0, 0, 0);
-                base = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.z, uu, base, 0, 0, 0);
-                v4f e[NS];
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    e[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.y, vs[k], base, 0, 0, 0);         // + c2 v
-                    e[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.w, uv[k], e[k], 0, 0, 0);         // + c4 u v
-                    e[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(a5, v2[k], e[k], 0, 0, 0);           // + c5 v^2
-                }
-                const float rr[4] = {rq.x, rq.y, rq.z, rq.w}, gg[4] = {gq.x, gq.y, gq.z, gq.w}, bb[4] = {bq.x, bq.y, bq.z, bq.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const v2f vr = (v2f){rr[i], rr[i]}, vg = (v2f){gg[i], gg[i]}, vb = (v2f){bb[i], bb[i]};
-#pragma unroll
-                    for (int h = 0; h < NP; ++h) {
-                        v2f w;
-                        w.x = __builtin_amdgcn_exp2f(e[2 * h][i]);
-                        w.y = __builtin_amdgcn_exp2f(e[2 * h + 1][i]);
-                        const v2f tw = T[h] * w;
-                        cr[h] = __builtin_elementwise_fma(tw, vr, cr[h]);
-                        cg[h] = __builtin_elementwise_fma(tw, vg, cg[h]);
-                        cb[h] = __builtin_elementwise_fma(tw, vb, cb[h]);
-                        T[h] = __builtin_elementwise_fma(tw, (v2f){-kScale, -kScale}, T[h]);
-                    }
-                }
-            }
-        }
-        if (!MFMA && n != 0u) {
+        if (n != 0u) {
             float4 a = s_rec[0];          // c5, c0, r, c1
             float4 b = s_rec[1];          // g, c2, b, c3
             float c4 = s_rec[2].x;

@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# PyTorch-ROCm bundles its own copy of the HIP runtime (torch/lib/libamdhip64.so); libmsplat.so links the system one.  Whichever
+# is loaded FIRST serves the whole process; when libmsplat.so came first, torch's later CUDA initialisation failed with "No HIP
+# GPUs are available" (seen r4 on a test selection in which no earlier test had imported torch).  bench.py imports torch first too.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -95,6 +95,7 @@ def measure(E, args, key, ply=None, primary=True):
 
     rank, world, dev, stream = E.rank, E.world, E.dev, E.stream
     wl = dict(WORKLOADS[key])
+    wl["key"] = key
     W, H, views = wl["W"], wl["H"], wl["views"]
     scene_cams = None
     scene_dir = None
@@ -469,6 +470,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="frames overlapped on the GPU (one context + stream + framebuffer per frame in flight, one shared "
                          "cloud); 1 = strictly serial frames (latency mode)")
+    ap.add_argument("--peer-store-check", action="store_true",
+                    help="(run by rank 0 of an N > 1 bench in a child process) one process, --gpus devices: msplat_group_* renders two "
+                         "poses with peer stores into device 0's framebuffer and compares them bit for bit with a single context")
     ap.add_argument("--no-stereo-batch", action="store_true",
                     help="two-view workloads: one Render per eye (the reference's call pattern) instead of msplat_render_stereo (A/B)")
     ap.add_argument("--async-submit", type=int, default=-1,
@@ -482,6 +486,8 @@ def main():
     import torch.distributed as dist
     import __graft_entry__ as graft
 
+    if args.peer_store_check:
+        return peer_store_check(args)
     E = Env()
     E.rank = int(os.environ.get("RANK", "0"))
     E.world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -564,6 +570,55 @@ def process_group_report(E, torch, dist):
             "distinct_devices": len({(r["host"], r["pci_bus_id"] or r["device"]) for r in allr})}
 
 
+def peer_store_check(args):
+    """child process of an N > 1 bench (rank 0 spawns it while the other ranks wait at a host barrier): the single-process
+    device group (msplat_group_*: every device's compositor stores its rows into device 0's framebuffer through the peer mapping,
+    no RCCL) against a plain single context, two orbit poses, bit for bit.  Prints one JSON line."""
+    import torch
+    from splatapult_amd import SplatRenderer, SplatRendererGroup, camera, synthetic, _capi
+    wl = WORKLOADS[args.workload]
+    W, H, views, G = wl["W"], wl["H"], wl["views"], args.gpus
+    out = {"devices": list(range(G)), "bit_exact": None, "peer_store_ranks": None, "error": None, "poses": [5, 37]}
+    try:
+        cloud = synthetic.make_cloud(wl["n"], seed=wl["seed"], full_sh=True, pos_sigma=wl["pos_sigma"])
+        lay = args.layout
+        kind, k = (lay.split(":")[0], int(lay.split(":")[1])) if ":" in lay else (("block", 1) if lay == "auto" else (lay, 1))
+        T = _capi.lib().msplat_tile_size()
+        if lay == "auto":
+            kind, k = "block", max(1, ((H + T - 1) // T) // (2 * G))
+        dev = torch.device("cuda", 0)
+        tdt, bpp = (torch.float16, 8) if wl["fb"] == "fp16" else (torch.float32, 16)
+        bits = torch.int16 if wl["fb"] == "fp16" else torch.int32
+        vp, nf = [0, 0, W, H], [camera.Z_NEAR, camera.Z_FAR]
+        projs = [camera.perspective(camera.FOVY, W / H)] if views == 1 else \
+            [camera.create_projection(-1.0, 0.8, 0.95, -0.95), camera.create_projection(-0.8, 1.0, 0.95, -0.95)]
+        ref = SplatRenderer(device=0, fb_format=wl["fb"])
+        g = SplatRendererGroup(list(range(G)), fb_format=wl["fb"], layout=kind, block_rows=k, band_cull=(views == 1))
+        if not ref.Init(cloud, False, False) or not g.Init(cloud, False, False):
+            raise RuntimeError(ref.last_error() or g.last_error())
+        out["peer_store_ranks"] = [i for i in range(g.size) if g.peer_store(i)]
+        a, b = torch.zeros((H, W, 4), dtype=tdt, device=dev), torch.zeros((H, W, 4), dtype=tdt, device=dev)
+        ok = True
+        for step in out["poses"]:
+            c = camera.orbit(wl["cam_z"], 2.0 * math.pi * step / 64.0)
+            cams = [c] if views == 1 else [camera.translate_local(c, dx=-0.032), camera.translate_local(c, dx=+0.032)]
+            ref.Sort(cams[0], projs[0], vp, nf)
+            g.Sort(cams[0], projs[0], vp, nf)
+            for v in range(views):
+                a.zero_(); b.zero_()
+                torch.cuda.synchronize(dev)
+                ref.Render(cams[v], projs[v], vp, nf, out_ptr=a.data_ptr(), pitch_bytes=W * bpp)
+                g.Render(cams[v], projs[v], vp, nf, out_ptr=b.data_ptr(), pitch_bytes=W * bpp)
+                ref.synchronize(); g.synchronize()
+                ok = ok and bool((a.view(bits) == b.view(bits)).all().item())
+        out["bit_exact"] = ok
+        g.close(); ref.close()
+    except Exception as e:
+        out["error"] = "%s: %s" % (type(e).__name__, e)
+    print(json.dumps(out))
+    return 0
+
+
 def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf, cloud, lay_kind, lay_k, primary):
     """Rank 0 renders two orbit poses UNBANDED on a plain single context and compares them bit for bit with the frame the ranks
     rendered in bands and gathered into its framebuffer (the bench's own exchange: grouped send / receive over RCCL, or gloo in
@@ -572,7 +627,7 @@ def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf,
     mapping) renders the same poses too.  Outside every timed region."""
     import torch
     import torch.distributed as dist
-    from splatapult_amd import SplatRenderer, SplatRendererGroup
+    from splatapult_amd import SplatRenderer
     rank, world, dev, stream = E.rank, E.world, E.dev, E.stream
     W, H, views = wl["W"], wl["H"], wl["views"]
     bpp = 8 if wl["fb"] == "fp16" else 16
@@ -585,7 +640,7 @@ def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf,
 
     res = {"bit_exact": True, "poses": poses, "exchange": dist.get_backend(), "values_compared": 0, "values_different": 0,
            "max_abs_diff": 0.0, "peer_store": None}
-    ref, ref_fbs, keep = None, None, {}
+    ref, ref_fbs = None, None
     if rank == 0:
         ref = SplatRenderer(device=E.local_rank, fb_format=wl["fb"], stream=stream.cuda_stream, frames_in_flight=1)
         init(ref)
@@ -602,7 +657,6 @@ def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf,
             for v in range(views):
                 ref.Render(cams[v], projs[v], vp, nf, out_ptr=ref_fbs[v].data_ptr(), pitch_bytes=W * bpp)
             torch.cuda.synchronize(dev)
-            keep[k] = [t.clone() for t in ref_fbs]
             for v in range(views):
                 a, b = rs_sets[0][v][:H], ref_fbs[v][:H]
                 ne = int((a.view(bits) != b.view(bits)).sum().item())
@@ -610,27 +664,22 @@ def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf,
                 res["values_different"] += ne
                 if ne:
                     res["max_abs_diff"] = max(res["max_abs_diff"], float((a.float() - b.float()).abs().max().item()))
-    # the other exchange form: one process, one context per device, peer stores into device 0's framebuffer
-    if rank == 0 and primary and not E.one_dev and torch.cuda.device_count() >= world:
-        ps = {"devices": list(range(world)), "bit_exact": None, "peer_store_ranks": None, "error": None}
+    # the other exchange form: one process, one context per device, peer stores into device 0's framebuffer.  Run in a CHILD
+    # process (bench.py --peer-store-check): a fault on that path must not take the bench line with it
+    if rank == 0 and primary and not E.one_dev and torch.cuda.device_count() >= world and not args.ply:
+        import subprocess
+        ps = {"devices": list(range(world)), "bit_exact": None, "error": None}
         try:
-            g = SplatRendererGroup(list(range(world)), fb_format=wl["fb"], layout=lay_kind, block_rows=lay_k, band_cull=(views == 1))
-            if not g.Init(cloud, False, False):
-                raise RuntimeError(g.last_error())
-            ps["peer_store_ranks"] = [i for i in range(g.size) if g.peer_store(i)]
-            gfb = torch.zeros_like(rs_sets[0][0])
-            ok = True
-            for k in poses:
-                cams = cams_for(k)
-                gfb.zero_()
-                torch.cuda.synchronize(dev)
-                g.Sort(cams[0], projs[0], vp, nf)
-                for v in range(views):
-                    g.Render(cams[v], projs[v], vp, nf, out_ptr=gfb.data_ptr(), pitch_bytes=W * bpp)
-                    g.synchronize()
-                    ok = ok and bool((gfb[:H].view(bits) == keep[k][v][:H].view(bits)).all().item())
-            ps["bit_exact"] = ok
-            g.close()
+            cmd = [sys.executable, os.path.abspath(__file__), "--peer-store-check", "--gpus", str(world), "--workload", wl["key"],
+                   "--layout", "%s:%d" % (lay_kind, lay_k) if lay_kind == "block" else lay_kind]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")
+                   and not k.startswith("TORCHELASTIC")}
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode == 0 and lines:
+                ps = json.loads(lines[-1])
+            else:
+                ps["error"] = "exit %d: %s" % (p.returncode, (p.stderr or p.stdout)[-400:])
         except Exception as e:                      # reported, not fatal: the bench's own exchange is the gather above
             ps["error"] = "%s: %s" % (type(e).__name__, e)
         res["peer_store"] = ps

@@ -78,3 +78,13 @@ def test_bench_two_ranks_one_device_control_flow():
     assert gc["poses"] == [5, 37] and gc["exchange"] == "gloo"
     assert "over 2 ranks" in d["config"]["sharding"] and "layout" in d["config"]["sharding"]
     assert d["gather"]["bytes_into_rank0_per_frame"] > 0
+
+
+def test_bench_peer_store_check_child_mode():
+    """what rank 0 of an N > 1 bench runs in a child process: the one-process device group against a single context, bit for bit
+    (one device here: the mode, its JSON and the comparison; distinct devices: tests/test_gpu_parity.py, multi-GPU boxes only)"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--peer-store-check", "--gpus", "1", "--workload", "tiny"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    assert d["error"] is None and d["bit_exact"] is True and d["devices"] == [0] and d["poses"] == [5, 37]

@@ -1345,6 +1345,59 @@ def test_device_group_renders_the_single_context_frame(devices, layout, k, cull,
         g.close()
 
 
+def _hip_device_count():
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        c = ctypes.c_int(0)
+        return c.value if hip.hipGetDeviceCount(ctypes.byref(c)) != 0 else c.value
+    except OSError:
+        return 0
+
+
+@pytest.mark.parametrize("exchange", ["peer", "copy"])
+def test_device_group_over_distinct_devices(exchange, monkeypatch):
+    """msplat_group over REAL distinct GPUs (skipped on a one-GPU box): the peer mapping towards device 0 and the
+    cross-device stream waits, the per-device kernel attributes (the three-pass sort's dynamic LDS on devices 1..), both exchange
+    forms; and the ordering contract of msplat_group_render -- DISTINCT consecutive frames into ONE framebuffer with a consumer
+    queued on context 0's stream between them: every consumer sees its own frame complete, no rank overwrites rows early"""
+    import torch
+    from splatapult_amd import SplatRendererGroup
+    ndev = min(_hip_device_count(), torch.cuda.device_count())
+    if ndev < 2:
+        pytest.skip("needs two GPUs (found %d)" % ndev)
+    if exchange == "copy":
+        monkeypatch.setenv("MSPLAT_GROUP_EXCHANGE", "copy")
+    devices = list(range(min(ndev, 4)))
+    cloud = scenes.synth_cloud(300000, 56, log_scale_mean=-3.6)          # large enough for the spatial storage order (AUTO)
+    W, H = 1280, 720
+    proj, vp, nf = camera.perspective(camera.FOVY, W / H), [0, 0, W, H], scenes.NF
+    cams = [camera.orbit(7.0, 0.3 * k) for k in range(6)]
+    r = make_renderer(cloud)
+    refs = []
+    for cam in cams:
+        r.Sort(cam, proj, vp, nf)
+        refs.append(r.Render(cam, proj, vp, nf))
+    g = SplatRendererGroup(devices, layout="block", block_rows=2, band_cull=True)
+    assert g.Init(cloud), g.last_error()
+    assert all(g.peer_store(i) == (exchange == "peer") for i in range(1, g.size))
+    fb = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    keep = [torch.empty_like(fb) for _ in cams]
+    import ctypes as C
+    from splatapult_amd import _capi
+    s0 = torch.cuda.ExternalStream(_capi.lib().msplat_get_stream(g.context(0)), device="cuda:0")
+    for k, cam in enumerate(cams):                                       # nothing synchronises inside this loop
+        g.Sort(cam, proj, vp, nf)
+        g.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)
+        with torch.cuda.stream(s0):                                      # the consumer of frame k, on context 0's stream
+            keep[k].copy_(fb, non_blocking=True)
+    g.synchronize()
+    torch.cuda.synchronize()
+    for k in range(len(cams)):
+        np.testing.assert_array_equal(keep[k].cpu().numpy(), refs[k])
+    g.close()
+
+
 def test_device_group_errors():
     from splatapult_amd import SplatRendererGroup, _capi
     g = SplatRendererGroup([0, 99])

@@ -343,7 +343,7 @@ def measure(E, args, key, ply=None, primary=True):
     # (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE in their own passes, gfx950 x2 correction on FETCH_SIZE);
     # the committed summary is only quoted for the workload it was measured on
     traffic, tsrc = None, None
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, key))
         if world == 1 and os.path.exists(tpath):
             try:

@@ -10,6 +10,8 @@ T=${1:-r04}
 mkdir -p gpurun_out
 ( time timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -rsP ) > gpurun_out/${T}_gpu_tests.log 2>&1
 grep -E "passed|failed|SKIPPED|check_image:" gpurun_out/${T}_gpu_tests.log | head -20
+( time timeout 600 python tools/soak.py --frames 3000 ) > gpurun_out/${T}_soak.log 2>&1
+tail -4 gpurun_out/${T}_soak.log
 timeout 600 python bench.py > gpurun_out/${T}_cfg2_bench.json 2> gpurun_out/${T}_cfg2_bench.err
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${T}_cfg2_bench_steps20.json 2> gpurun_out/${T}_cfg2_bench_steps20.err
 timeout 600 python bench.py --frames-in-flight 1 --no-cpu-baseline > gpurun_out/${T}_cfg2_bench_serial.json 2> gpurun_out/${T}_cfg2_bench_serial.err

@@ -1,6 +1,9 @@
 /*
  * msplat_oracle.c -- CPU ORACLE (test infrastructure; see msplat_oracle.h for the rules).
- * PARITY UNPINNED for the shader arithmetic (no runnable reference, no reference tests).
+ * PARITY PINNED (round 4) for the shader arithmetic: the reference's own shader FILES, executed on Mesa llvmpipe by oracle/glref,
+ * give the same visible sets and 32-bit keys bit for bit and the same framebuffers within SURVEY 8c's tolerance
+ * (tests/test_reference_shaders.py: 15 cases; committed outputs tests/golden/glref_*.npz).  Not pinned: glm's host-side closed
+ * forms (below), the ROP's internal precision on 8-bit / fp16 targets (implementation-defined in GL), the point-cloud shaders.
  *
  * Literal restatement, function by function, of the reference's hot path:
  *   shader/presort_compute.glsl:31-57            -> orc_cull_key / orc_presort

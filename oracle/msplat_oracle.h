@@ -5,13 +5,14 @@
  * and bench.py's cpu_baseline leg may load it.  The product (libmsplat.so) never links,
  * loads or calls anything in oracle/.
  *
- * PARITY UNPINNED: the reference's arithmetic for this path lives in GLSL 4.60 shaders that
- * need an OpenGL driver; they cannot be compiled or run in the build container, and the
- * reference ships no tests / golden vectors for them.  This file is a
- * literal C restatement of those shaders, cross-checked against an independent numpy
- * restatement (oracle/np_oracle.py) and the hand-computed sanity values of SURVEY.md 8c.
- * Only the PLY parser is pinned against the real reference (oracle/_ref, built from
- * /root/reference/src/ply.cpp by oracle/Makefile).
+ * PARITY PINNED (round 4): the reference's arithmetic for this path lives in GLSL 4.60 shaders behind an OpenGL driver and the
+ * reference ships no tests / golden vectors for them.  This file is a literal C restatement of those
+ * shaders.  It is pinned by running the shaders themselves: oracle/glref (a window-system-free loader for Mesa's llvmpipe)
+ * compiles /root/reference/shader/presort_compute.glsl and splat_{vert,geom,frag}.glsl where they lie and executes them with
+ * the reference's GL state; tests/test_reference_shaders.py compares -- visible set and keys exact, framebuffers within SURVEY
+ * 8c's tolerance -- and tests/golden/glref_*.npz carry those outputs to machines without the reference.  Also pinned: the PLY
+ * parser (oracle/_ref/libref_ply.so, built from /root/reference/src/ply.cpp by oracle/Makefile).  Cross-checks that predate
+ * the shader runs stay: an independent numpy restatement (oracle/np_oracle.py), SURVEY 8c's hand-computed values.
  *
  * Conventions: all matrices are float[16], column-major like glm (m[col*4+row]);
  * cameraMat = camera-to-world; viewport = (x, y, W, H); nearFar = (near, far).

@@ -1,7 +1,7 @@
 """Independent numpy restatement of the reference hot path (TEST INFRASTRUCTURE ONLY).
 
 Written separately from msplat_oracle.c (vectorised, per-stage) so that the two restatements
-check each other.  PARITY UNPINNED: the reference's shaders cannot run here.
+check each other (r4: the C restatement is also pinned against the reference's shaders executed on Mesa llvmpipe, oracle/glref).
 
 Follows: shader/presort_compute.glsl:31-57, shader/splat_vert.glsl:51-127,153-222,
 shader/splat_geom.glsl:22-54, shader/splat_frag.glsl:18-42, src/app.cpp:153-160,

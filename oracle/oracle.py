@@ -1,7 +1,7 @@
 """ctypes face of the C oracle (oracle/msplat_oracle.c).
 
 TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
-cpu_baseline leg; never by the product package.  PARITY UNPINNED (see msplat_oracle.h).
+cpu_baseline leg; never by the product package.  PARITY PINNED against the reference's shaders run on llvmpipe (see msplat_oracle.h).
 """
 import ctypes as C
 import os

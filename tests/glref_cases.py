@@ -1,0 +1,52 @@
+"""Scenes of the reference-shader fixtures (tests/golden/glref_*.npz): shared by the generator (tests/golden/make_glref_golden.py,
+which runs the reference's shaders on Mesa llvmpipe in the build container) and by the GPU test that compares the HIP path with
+those outputs (tests/test_gpu_reference_shaders.py).  Clouds come from the seeded, language-independent generator; the fixture
+stores a digest of the records it was made from."""
+import hashlib
+import os
+
+import numpy as np
+
+from splatapult_amd import camera
+from tests import scenes
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def digest(aos):
+    return hashlib.sha256(np.ascontiguousarray(aos, np.float32).tobytes()).hexdigest()
+
+
+def _cfg1():
+    g = np.load(os.path.join(GOLDEN, "test_ply_cfg1.npz"))
+    return g["aos_nosh"], g["cam"], g["proj"]
+
+
+def cases():
+    """name -> dict(aos, full_sh, srgb, cam, proj, W, H, nf, render_cam, render_proj)"""
+    out = {}
+    aos, cam, proj = _cfg1()
+    out["cfg1_test_ply_nosh"] = dict(aos=aos, full_sh=False, srgb=False, cam=cam, proj=proj, W=640, H=480)
+    c = scenes.synth_cloud(3000, 31, log_scale_mean=-3.0)
+    cam, proj, _, _ = scenes.default_view(256, 144, yaw=0.0)
+    out["synth_sh3"] = dict(aos=c.as_array(), full_sh=True, srgb=False, cam=cam, proj=proj, W=256, H=144)
+    c = scenes.synth_cloud(8000, 33, full_sh=False, log_scale_mean=-3.0)
+    cam, proj, _, _ = scenes.default_view(256, 144, yaw=2.2, z=1.0)
+    out["synth_sh0_inside"] = dict(aos=c.as_array(), full_sh=False, srgb=False, cam=cam, proj=proj, W=256, H=144)
+    c = scenes.cloud_from_attrs(scenes.hard_attrs(3000, 11))
+    cam, proj, _, _ = scenes.default_view(256, 192, yaw=0.7)
+    out["hard_cases"] = dict(aos=c.as_array(), full_sh=True, srgb=False, cam=cam, proj=proj, W=256, H=192)
+    c = scenes.synth_cloud(4000, 35, log_scale_mean=-3.2)
+    cam, proj, _, _ = scenes.default_view(256, 144, yaw=0.3)
+    out["srgb_define"] = dict(aos=c.as_array(), full_sh=True, srgb=True, cam=cam, proj=proj, W=256, H=144)
+    c = scenes.synth_cloud(6000, 36, log_scale_mean=-3.1)
+    cam0 = camera.pose((0.0, 0.0, 6.0))
+    eyes = [camera.translate_local(cam0, dx=-0.032), camera.translate_local(cam0, dx=+0.032)]
+    projs = [camera.create_projection(-1.0, 0.8, 0.95, -0.95), camera.create_projection(-0.8, 1.0, 0.95, -0.95)]
+    out["second_eye"] = dict(aos=c.as_array(), full_sh=True, srgb=False, cam=eyes[0], proj=projs[0], W=216, H=240,
+                             render_cam=eyes[1], render_proj=projs[1])
+    for v in out.values():
+        v.setdefault("render_cam", None)
+        v.setdefault("render_proj", None)
+        v["nf"] = list(scenes.NF)
+    return out

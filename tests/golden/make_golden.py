@@ -5,8 +5,9 @@
 
 The reference's hot path (GLSL shaders behind an OpenGL driver) cannot run in the build container
 and the reference ships no tests or golden vectors, so the expected outputs here come
-from this repo's CPU oracle (oracle/msplat_oracle.c) -- PARITY UNPINNED for the shader arithmetic.
-What IS pinned against the real reference:
+from this repo's CPU oracle (oracle/msplat_oracle.c).  (Since r4 the reference's shaders DO run here -- on Mesa llvmpipe through
+oracle/glref -- and the fixtures made from THEIR outputs are tests/golden/glref_*.npz, make_glref_golden.py; the oracle is pinned
+against them.)  What these older fixtures pin against the real reference:
   * test.ply / test_vr.json are the reference's own data files (data/test.ply, data/test_vr.json);
   * the PLY vertex block and property offsets in test_ply_cfg1.npz are read with the reference's own
     parser (oracle/_ref/libref_ply.so, built from /root/reference/src/ply.cpp).

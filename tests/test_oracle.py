@@ -1,7 +1,7 @@
 """CPU tests of the oracle itself (no GPU): the C restatement against (a) the hand-derived sanity
 values of SURVEY.md 8c for the reference's only fixture, (b) the committed golden vectors,
-(c) the independent numpy restatement.  The shader arithmetic is PARITY UNPINNED (no runnable
-reference); these tests pin the oracle against everything that exists."""
+(c) the independent numpy restatement, (d, r4) the committed outputs of the reference's OWN shaders executed on Mesa llvmpipe
+(tests/golden/glref_*.npz; the live comparison, where the reference checkout exists: tests/test_reference_shaders.py)."""
 import os
 
 import numpy as np
@@ -347,3 +347,23 @@ def test_tiled_cpu_baseline_config1_and_second_view_and_row_window(golden_dir):
     # empty cloud / everything culled
     e = orc.render_frame_tiled(np.zeros((0, 61), np.float32), True, cam, proj, vp, nf, nthreads=2)
     assert e["V"] == 0 and (e["image"][..., :3] == 0).all() and (e["image"][..., 3] == 1).all()
+
+
+def test_oracle_matches_the_reference_shader_fixtures():
+    """tests/golden/glref_*.npz = what the reference's own shaders computed on Mesa llvmpipe (tests/golden/make_glref_golden.py).
+    The C restatement reproduces them: visible set and keys exactly, framebuffers within SURVEY 8c's tolerance -- so the oracle is
+    pinned to the reference's shader code wherever this suite runs (the live comparison: tests/test_reference_shaders.py)."""
+    from tests import glref_cases
+    for name, c in sorted(glref_cases.cases().items()):
+        g = np.load(os.path.join(glref_cases.GOLDEN, "glref_%s.npz" % name))
+        assert str(g["digest"]) == glref_cases.digest(c["aos"]), name
+        vp = [0, 0, c["W"], c["H"]]
+        mvp = orc.mat4_mul(c["proj"], orc.mat4_inverse(c["cam"]))
+        keys, idx = orc.presort(c["aos"], mvp, c["nf"][1])
+        np.testing.assert_array_equal(idx, g["idx"])
+        np.testing.assert_array_equal(keys, g["keys"])
+        res = orc.render_frame(c["aos"], c["full_sh"], c["cam"], c["proj"], vp, c["nf"], render_cam=c["render_cam"],
+                               render_proj=c["render_proj"], srgb=c["srgb"], nthreads=4)
+        np.testing.assert_array_equal(res["sorted_idx"], g["draw_order"])
+        d = np.abs(res["image"][..., :3].astype(np.float64) - g["rgb"])
+        assert d.max() <= 5e-3 and d.mean() <= 1e-4 and (d <= 1e-4).mean() >= 0.999, (name, d.max(), d.mean())

@@ -50,3 +50,26 @@ def cases():
         v.setdefault("render_proj", None)
         v["nf"] = list(scenes.NF)
     return out
+
+
+# BASELINE configs[1] -- the configuration the metric is quoted on: 1 M synthetic splats, SH3, 1920x1080, camera at (0, 0, 7).  The
+# reference's shaders render the whole frame (3 s on llvmpipe); a full float image is 25 MB, so the fixture keeps a 512 x 256 window
+# around the centre, an 8x8 box-mean of the whole frame, and digests of the shader's keys / indices.
+CFG2_WINDOW = (412, 668, 704, 1216)          # rows y0:y1, columns x0:x1 (GL convention: row 0 = bottom)
+
+
+def config2():
+    from splatapult_amd import synthetic
+    cloud = synthetic.make_cloud(1_000_000, seed=0x5EED1234, full_sh=True, pos_sigma=1.5)
+    cam, proj, _, _ = scenes.default_view(1920, 1080, z=7.0)
+    return dict(aos=cloud.as_array(), full_sh=True, srgb=False, cam=cam, proj=proj, W=1920, H=1080, nf=list(scenes.NF),
+                render_cam=None, render_proj=None)
+
+
+def box_mean8(rgb):
+    H, W = rgb.shape[0] // 8 * 8, rgb.shape[1] // 8 * 8
+    return rgb[:H, :W].astype(np.float64).reshape(H // 8, 8, W // 8, 8, 3).mean(axis=(1, 3)).astype(np.float32)
+
+
+def u32_digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a, np.uint32).tobytes()).hexdigest()

@@ -11,6 +11,8 @@ them on llvmpipe with the reference's GL state (oracle/glref/glref.c cites every
   rgb ................. splat_vert + splat_geom + splat_frag through GL's rasteriser and blender, RGBA32F target: (H, W, 3) float32
                         (alpha is 1 everywhere -- asserted here -- and not stored)
   gl_version .......... the GL implementation that executed the shaders
+glref_cfg2_1m_1080p.npz is BASELINE configs[1] itself (1 M splats, SH3, 1920x1080): sha-256 digests of the shader's keys / indices /
+the draw order, a 512 x 256 window of its image and 8x8 box means of the whole frame (a full float image would be 25 MB).
 No reference source or shader text is stored."""
 import os
 import sys
@@ -42,6 +44,23 @@ def main():
                             gl_version=version)
         print("%-24s V %6d  lit %6d  %7.0f KB  (%s)" % (name, keys.shape[0], int((img[..., :3].sum(-1) != 0).sum()),
                                                          os.path.getsize(path) / 1024.0, version))
+
+    # BASELINE configs[1], whole frame through the reference's shaders; window + 8x8 box means + digests are kept
+    c = glref_cases.config2()
+    version = glref.init(True, False)
+    vp = [0, 0, c["W"], c["H"]]
+    mvp = orc.mat4_mul(c["proj"], orc.mat4_inverse(c["cam"]))
+    keys, idx = glref.presort(c["aos"], mvp, c["nf"])
+    sk, si = orc.sort(keys, idx)
+    eye = np.asarray(c["cam"], np.float32).reshape(16)[12:15].copy()
+    img = glref.render(c["aos"], si, orc.mat4_inverse(c["cam"]), c["proj"], vp, c["nf"], eye)
+    assert (img[..., 3] == 1.0).all()
+    y0, y1, x0, x1 = glref_cases.CFG2_WINDOW
+    path = os.path.join(glref_cases.GOLDEN, "glref_cfg2_1m_1080p.npz")
+    np.savez_compressed(path, digest=glref_cases.digest(c["aos"]), V=keys.shape[0], keys_digest=glref_cases.u32_digest(keys),
+                        idx_digest=glref_cases.u32_digest(idx), order_digest=glref_cases.u32_digest(si),
+                        window=img[y0:y1, x0:x1, :3].copy(), mean8=glref_cases.box_mean8(img[..., :3]), gl_version=version)
+    print("%-24s V %6d  lit %6d  %7.0f KB" % ("cfg2_1m_1080p", keys.shape[0], int((img[..., :3].sum(-1) != 0).sum()), os.path.getsize(path) / 1024.0))
 
 
 if __name__ == "__main__":

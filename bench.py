@@ -552,16 +552,12 @@ def main():
 def process_group_report(E, torch, dist):
     """what the LIVE process group says: backend, world size, and every rank's device (ordinal, PCI bus id, name), so that a
     run on N distinct GPUs can be told from N ranks on one"""
-    import ctypes
-    bus = None
-    try:
-        hip = ctypes.CDLL("libamdhip64.so")
-        buf = ctypes.create_string_buffer(64)
-        if hip.hipDeviceGetPCIBusId(buf, 64, ctypes.c_int(E.local_rank)) == 0:
-            bus = buf.value.decode()
-    except OSError:
-        pass
     props = torch.cuda.get_device_properties(E.dev)
+    bus = None
+    if hasattr(props, "pci_bus_id"):                # asked of the runtime torch already holds (no second HIP runtime by dlopen)
+        bus = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, getattr(props, "pci_device_id", 0))
+    if getattr(props, "uuid", None) is not None:
+        bus = (bus or "") + " " + str(props.uuid)
     mine = {"rank": E.rank, "local_rank": E.local_rank, "device": int(E.dev.index), "pci_bus_id": bus, "name": props.name,
             "host": os.uname().nodename, "pid": os.getpid()}
     allr = [None] * dist.get_world_size()

@@ -131,12 +131,12 @@ struct msplat_ctx {
     Buf keyA, keyB, valA, valB;   // uint32[N]; final sorted result in keyA/valA
     Buf hist;       // uint32[256 * hist_stride]
     uint32_t hist_stride = 0;
-    // scan-free path (msplat_kernels.hip.h, radix_upsweep): per-group histogram sums, one row of 256 per 32 chunks
+    // scan-free path (msplat_sort.hip.h, radix_upsweep): per-group histogram sums, one row of 256 per 32 chunks
     Buf gsumS[2];   // sort passes alternate between the two
     Buf gsumB1, gsumB2;     // binning: column pass / row pass
     uint32_t gsumS_rows = 0, gsumB1_rows = 0, gsumB2_rows = 0;
     uint32_t gsupS = 0, gsupB1 = 0, gsupB2 = 0;     // supergroup rows at the head of each table (the group rows follow)
-    // wide-digit 3-pass sort (r3, msplat_kernels.hip.h ws_*): histogram rows of up to 2048 digits per chunk, one group
+    // wide-digit 3-pass sort (r3, msplat_sort.hip.h ws_*): histogram rows of up to 2048 digits per chunk, one group
     // table per pass, one visibility bit per splat, the visible set's minimum key per frame parity (counters[10..11])
     Buf wsHist, wsGsum[3], vmask;
     Buf live_list, live_cnt;    // live bounding boxes of the latest Sort that ran box_cull_kernel (spatially ordered clouds)
@@ -765,7 +765,7 @@ static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, cons
 static void launch_scan(hipStream_t s, bool small, uint32_t* hist, uint32_t hist_stride, const uint32_t* d_n,
                         uint32_t n_static, uint32_t n_cap, uint32_t chunk, uint32_t* totals);
 
-// Spatial storage order (r4, msplat_kernels.hip.h: box_live).  Called at the end of an upload, the cloud being on the device in
+// Spatial storage order (r4, msplat_common.hip.h: box_live).  Called at the end of an upload, the cloud being on the device in
 // UPLOAD order: Morton codes of the positions, a stable sort of (code, upload index) with the library's own 8-bit radix passes,
 // the cloud gathered into that order, one bounding box per kBoxSplats slots.  From then on slot j holds upload index
 // order_host[j]; everything that reports splat numbers (msplat_get_sorted_indices, msplat_download_cloud) maps back.
@@ -1280,7 +1280,7 @@ static int clear_frame_tables(msplat_ctx* ctx)
     return MSPLAT_OK;
 }
 
-// Chunk-level cull (msplat_kernels.hip.h, box_live): for a spatially ordered cloud of which an EARLIER frame saw less than 70 %
+// Chunk-level cull (msplat_common.hip.h, box_live): for a spatially ordered cloud of which an EARLIER frame saw less than 70 %
 // (host-mapped V, read without synchronising; 0 = no frame yet) Sort starts with box_cull_kernel and pass 0 walks the listed
 // live boxes only.  Either form gives the same visible set, keys and order; the choice only matters for speed: the extra launch
 // costs ~4 us, which a view of the whole cloud (BASELINE configs[1]: V = 0.99 N) would pay for nothing.
@@ -1360,7 +1360,7 @@ static int sort_impl(msplat_ctx* ctx, const float cameraMat[16], const float pro
     const float4* pos = (const float4*)ctx->pos4.p;
     uint32_t *kA = (uint32_t*)ctx->keyA.p, *kB = (uint32_t*)ctx->keyB.p;
     uint32_t *vA = (uint32_t*)ctx->valA.p, *vB = (uint32_t*)ctx->valB.p;
-    // chunk size by cloud size (msplat_kernels.hip.h, kSortItems): 2048 keys up to 2 M splats, 4096 beyond
+    // chunk size by cloud size (msplat_common.hip.h, kSortItems): 2048 keys up to 2 M splats, 4096 beyond
     const bool large = ctx->N > (2u << 20);
     const uint32_t chunk = (uint32_t)kThreads * (large ? kSortItemsLarge : kSortItems);
     const int grid = grid_for(div_up(N, chunk));
@@ -1373,7 +1373,7 @@ static int sort_impl(msplat_ctx* ctx, const float cameraMat[16], const float pro
     const int tset = (int)(ctx->sort_sets % msplat_ctx::kEvSets);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][0], s));
     if (ctx->wide_sort) {
-        // three passes of 10 + (8..11) + (8..11) key bits (msplat_kernels.hip.h, ws_*): 6 launches.
+        // three passes of 10 + (8..11) + (8..11) key bits (msplat_sort.hip.h, ws_*): 6 launches.
         // pass 0: positions -> raw keys + visibility bits in keyB / vmask -> (keyA, valA); pass 1: A -> B; pass 2: B -> A
         uint32_t* mk_cur = counters + 10 + (ctx->sort_parity & 1u);
         uint32_t* mk_next = counters + 10 + ((ctx->sort_parity ^ 1u) & 1u);

@@ -64,3 +64,44 @@ def render(aos, sorted_idx, view_mat, proj_mat, viewport, near_far, eye, target=
                                 tgt, int(depth_bits), img.ctypes.data_as(C.POINTER(C.c_float))) != 0:
         raise RuntimeError("glref_render: " + _lib.glref_last_error().decode())
     return img
+
+
+def uploaded_sprite(sprite_rgba8):
+    """what Image::Load leaves in Image::data for an RGBA PNG decoded top row first (src/core/image.cpp:108-114, 128-158): rows
+    flipped, colour bytes replaced by uint8((c / 255.0f * (a / 255.0f)) * 255.0f) in float arithmetic (truncating)"""
+    t = np.ascontiguousarray(sprite_rgba8[::-1], np.uint8).copy()
+    a = t[..., 3].astype(np.float32) / np.float32(255.0)
+    for c in range(3):
+        t[..., c] = ((t[..., c].astype(np.float32) / np.float32(255.0)) * a * np.float32(255.0)).astype(np.uint8)
+    return t
+
+
+def points_render(points, sorted_idx, model_view, proj_mat, viewport, sprite_rgba8, srgb=False, depth_bits=0, want_mips=False):
+    """PointRenderer::Render's draw on the reference's point shaders (pointrenderer.cpp:168-195).  points: (N, 8) float32
+    (position.xyzw, color.rgba); sprite_rgba8: (h, w, 4) uint8 as decoded from the PNG (top row first).  Returns the (H, W, 4)
+    float32 image, row 0 = bottom (and the list of mip levels llvmpipe's glGenerateMipmap made, when asked)."""
+    W, H = int(viewport[2]), int(viewport[3])
+    img = np.zeros((H, W, 4), np.float32)
+    pts = np.ascontiguousarray(points, np.float32)
+    si = np.ascontiguousarray(sorted_idx, np.uint32)
+    up = uploaded_sprite(sprite_rgba8)
+    th, tw = up.shape[:2]
+    sizes, w, h = [], tw, th
+    while True:
+        sizes.append((h, w))
+        if w == 1 and h == 1:
+            break
+        w, h = max(1, w // 2), max(1, h // 2)
+    mips = np.zeros(sum(a * b for a, b in sizes) * 4, np.float32) if want_mips else None
+    if _lib.glref_points_render(_f(pts), pts.shape[0], _u(si), si.shape[0], _f(model_view), _f(proj_mat), _f(viewport),
+                                up.ctypes.data_as(C.POINTER(C.c_uint8)), tw, th, 1 if srgb else 0, int(depth_bits),
+                                img.ctypes.data_as(C.POINTER(C.c_float)),
+                                mips.ctypes.data_as(C.POINTER(C.c_float)) if want_mips else None) != 0:
+        raise RuntimeError("glref_points_render: " + _lib.glref_last_error().decode())
+    if not want_mips:
+        return img
+    out, o = [], 0
+    for (h, w) in sizes:
+        out.append(mips[o:o + h * w * 4].reshape(h, w, 4).copy())
+        o += h * w * 4
+    return img, out

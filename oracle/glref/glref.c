@@ -70,9 +70,11 @@ GLF(PFNGLREADPIXELSPROC, glReadPixels); GLF(PFNGLPIXELSTOREIPROC, glPixelStorei)
 GLF(PFNGLGENRENDERBUFFERSPROC, glGenRenderbuffers); GLF(PFNGLBINDRENDERBUFFERPROC, glBindRenderbuffer);
 GLF(PFNGLRENDERBUFFERSTORAGEPROC, glRenderbufferStorage); GLF(PFNGLFRAMEBUFFERRENDERBUFFERPROC, glFramebufferRenderbuffer);
 GLF(PFNGLDELETERENDERBUFFERSPROC, glDeleteRenderbuffers);
+GLF(PFNGLGENERATEMIPMAPPROC, glGenerateMipmap); GLF(PFNGLACTIVETEXTUREPROC, glActiveTexture); GLF(PFNGLUNIFORM1IPROC, glUniform1i);
+GLF(PFNGLUNIFORM1FPROC, glUniform1f); GLF(PFNGLGETTEXIMAGEPROC, glGetTexImage);
 
 static int g_ready = 0, g_full_sh = 0;
-static GLuint g_presort = 0, g_splat = 0;
+static GLuint g_presort = 0, g_splat = 0, g_point = 0;
 static GLuint g_splat_cfg[2][2];          /* [full_sh][srgb]: the splat program per pair of defines, compiled on first use */
 static char g_version[256], g_dir[1024];
 
@@ -160,6 +162,9 @@ int glref_init(const char* shader_dir, int full_sh, int srgb)
     /* the shaders say "#version 460"; llvmpipe of this Mesa advertises 4.5 and implements what they use */
     setenv("MESA_GL_VERSION_OVERRIDE", "4.6", 1);
     setenv("MESA_GLSL_VERSION_OVERRIDE", "460", 1);
+    /* texture sampling (the point sprites only; the splat shaders sample nothing): float filtering and per-pixel level of detail
+     * instead of llvmpipe's 8-bit fixed-point filter weights and per-quad LOD -- the most exact form this GL offers */
+    setenv("GALLIVM_PERF", "no_aos_sampling,no_quad_lod", 0);
     void* drv = dlopen("/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so", RTLD_NOW | RTLD_GLOBAL);
     if (!drv) return fail("dlopen swrast_dri.so: %s", dlerror());
     const __DRIextension** (*get_exts)(void) = (const __DRIextension** (*)(void))dlsym(drv, "__driDriverGetExtensions_swrast");
@@ -208,6 +213,8 @@ int glref_init(const char* shader_dir, int full_sh, int srgb)
     LOAD(PFNGLGENRENDERBUFFERSPROC, glGenRenderbuffers); LOAD(PFNGLBINDRENDERBUFFERPROC, glBindRenderbuffer);
     LOAD(PFNGLRENDERBUFFERSTORAGEPROC, glRenderbufferStorage); LOAD(PFNGLFRAMEBUFFERRENDERBUFFERPROC, glFramebufferRenderbuffer);
     LOAD(PFNGLDELETERENDERBUFFERSPROC, glDeleteRenderbuffers);
+    LOAD(PFNGLGENERATEMIPMAPPROC, glGenerateMipmap); LOAD(PFNGLACTIVETEXTUREPROC, glActiveTexture); LOAD(PFNGLUNIFORM1IPROC, glUniform1i);
+    LOAD(PFNGLUNIFORM1FPROC, glUniform1f); LOAD(PFNGLGETTEXIMAGEPROC, glGetTexImage);
 #undef LOAD
     snprintf(g_version, sizeof(g_version), "%s / %s / GLSL %s", (const char*)pglGetString(GL_VERSION), (const char*)pglGetString(GL_RENDERER),
              (const char*)pglGetString(GL_SHADING_LANGUAGE_VERSION));
@@ -374,4 +381,109 @@ int glref_render(const float* aos, uint32_t n, const uint32_t* sorted_idx, uint3
                  const float viewport[4], const float nearFar[2], const float eye[3], float* rgba_out)
 {
     return glref_render_target(aos, n, sorted_idx, count, viewMat, projMat, viewport, nearFar, eye, 0, 0, rgba_out);
+}
+
+/* PointRenderer::Render's draw (pointrenderer.cpp:168-195) on the reference's point_vert / point_geom / point_frag, with the texture
+ * PointRenderer::Init makes of the sprite (pointrenderer.cpp:54-63, core/texture.cpp:47-77: GL_RGBA8 or GL_SRGB8_ALPHA8 from 8-bit
+ * RGBA, glGenerateMipmap, LinearMipmapLinear / Linear, ClampToEdge) and App's Clear() state.
+ * points: n x 8 floats (position.xyzw, color.rgba -- PointCloud's interleaved record, BuildVertexArrayObject :198-226);
+ * sprite_rgba8: tw x th texels AS UPLOADED, i.e. after Image::Load's row flip and 8-bit alpha pre-multiplication (the caller
+ * restates that host code); srgb_tex: Image::isSRGB (= isFramebufferSRGBEnabled, :60).  depth_bits as in glref_render_target.
+ * mips_out (optional): the float RGBA texels of every mip level the GL made, level after level (what glGenerateMipmap produced). */
+int glref_points_render(const float* points, uint32_t n, const uint32_t* sorted_idx, uint32_t count, const float modelViewMat[16],
+                        const float projMat[16], const float viewport[4], const uint8_t* sprite_rgba8, int tw, int th, int srgb_tex,
+                        int depth_bits, float* rgba_out, float* mips_out)
+{
+    if (!g_ready) return fail("glref_init has not run");
+    if (!g_point) {
+        GLuint vs = compile(GL_VERTEX_SHADER, g_dir, "point_vert.glsl", "");
+        GLuint gs = vs ? compile(GL_GEOMETRY_SHADER, g_dir, "point_geom.glsl", "") : 0;
+        GLuint fs = gs ? compile(GL_FRAGMENT_SHADER, g_dir, "point_frag.glsl", "") : 0;
+        if (!fs) return -1;
+        g_point = link_program(vs, gs, fs);
+        if (!g_point) return -1;
+    }
+    const int W = (int)viewport[2], H = (int)viewport[3];
+    GLuint vao, vbo, ebo, tex, fbo, rbo = 0, sprite;
+    pglGenVertexArrays(1, &vao);
+    pglBindVertexArray(vao);
+    pglGenBuffers(1, &vbo);
+    pglBindBuffer(GL_ARRAY_BUFFER, vbo);
+    pglBufferData(GL_ARRAY_BUFFER, (GLsizeiptr)n * 32, points, GL_STATIC_DRAW);
+    pglGenBuffers(1, &ebo);
+    pglBindBuffer(GL_ELEMENT_ARRAY_BUFFER, ebo);
+    pglBufferData(GL_ELEMENT_ARRAY_BUFFER, (GLsizeiptr)count * 4, sorted_idx, GL_STATIC_DRAW);
+    const char* names[2] = {"position", "color"};
+    for (int k = 0; k < 2; ++k) {
+        const GLint loc = pglGetAttribLocation(g_point, names[k]);
+        if (loc < 0) return fail("attribute %s not active in the point program", names[k]);
+        pglEnableVertexAttribArray((GLuint)loc);
+        pglVertexAttribPointer((GLuint)loc, 4, GL_FLOAT, GL_FALSE, 32, (const void*)(size_t)(k * 16));
+    }
+    /* Texture::Texture(image, params), core/texture.cpp:47-77 */
+    pglGenTextures(1, &sprite);
+    pglBindTexture(GL_TEXTURE_2D, sprite);
+    pglTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_LINEAR_MIPMAP_LINEAR);
+    pglTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_LINEAR);
+    pglTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE);
+    pglTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE);
+    pglPixelStorei(GL_UNPACK_ALIGNMENT, 1);
+    pglTexImage2D(GL_TEXTURE_2D, 0, srgb_tex ? GL_SRGB8_ALPHA8 : GL_RGBA, tw, th, 0, GL_RGBA, GL_UNSIGNED_BYTE, sprite_rgba8);
+    pglGenerateMipmap(GL_TEXTURE_2D);
+    if (mips_out) {
+        float* o = mips_out;
+        pglPixelStorei(GL_PACK_ALIGNMENT, 1);
+        for (int l = 0, w = tw, h = th;; ++l) {
+            pglGetTexImage(GL_TEXTURE_2D, l, GL_RGBA, GL_FLOAT, o);
+            o += (size_t)w * h * 4;
+            if (w == 1 && h == 1) break;
+            w = w > 1 ? w / 2 : 1;
+            h = h > 1 ? h / 2 : 1;
+        }
+    }
+    pglGenTextures(1, &tex);
+    pglBindTexture(GL_TEXTURE_2D, tex);
+    pglTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA32F, W, H, 0, GL_RGBA, GL_FLOAT, NULL);
+    pglTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+    pglTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+    pglGenFramebuffers(1, &fbo);
+    pglBindFramebuffer(GL_FRAMEBUFFER, fbo);
+    pglFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, tex, 0);
+    if (depth_bits) {
+        pglGenRenderbuffers(1, &rbo);
+        pglBindRenderbuffer(GL_RENDERBUFFER, rbo);
+        pglRenderbufferStorage(GL_RENDERBUFFER, depth_bits == 32 ? GL_DEPTH_COMPONENT32F : GL_DEPTH_COMPONENT24, W, H);
+        pglFramebufferRenderbuffer(GL_FRAMEBUFFER, GL_DEPTH_ATTACHMENT, GL_RENDERBUFFER, rbo);
+    }
+    if (pglCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) return fail("framebuffer incomplete");
+    pglViewport(0, 0, W, H);
+    pglEnable(GL_BLEND);
+    pglBlendEquation(GL_FUNC_ADD);
+    pglBlendFunc(GL_ONE, GL_ONE_MINUS_SRC_ALPHA);
+    pglClearColor(0.0f, 0.0f, 0.0f, 1.0f);
+    pglClear(GL_COLOR_BUFFER_BIT | GL_DEPTH_BUFFER_BIT);
+    pglEnable(GL_DEPTH_TEST);
+    pglUseProgram(g_point);
+    pglUniformMatrix4fv(pglGetUniformLocation(g_point, "modelViewMat"), 1, GL_FALSE, modelViewMat);
+    pglUniformMatrix4fv(pglGetUniformLocation(g_point, "projMat"), 1, GL_FALSE, projMat);
+    pglUniform1f(pglGetUniformLocation(g_point, "pointSize"), 0.02f);                              /* pointrenderer.cpp:182 */
+    pglUniform1f(pglGetUniformLocation(g_point, "invAspectRatio"), 1.0f / (viewport[2] / viewport[3]));   /* :176-183 */
+    pglActiveTexture(GL_TEXTURE0);
+    pglBindTexture(GL_TEXTURE_2D, sprite);
+    pglUniform1i(pglGetUniformLocation(g_point, "colorTex"), 0);
+    pglDrawElements(GL_POINTS, (GLsizei)count, GL_UNSIGNED_INT, NULL);
+    pglFinish();
+    pglPixelStorei(GL_PACK_ALIGNMENT, 1);
+    pglReadPixels(0, 0, W, H, GL_RGBA, GL_FLOAT, rgba_out);
+    const GLenum e = pglGetError();
+    pglBindFramebuffer(GL_FRAMEBUFFER, 0);
+    pglDeleteFramebuffers(1, &fbo);
+    if (rbo) pglDeleteRenderbuffers(1, &rbo);
+    pglDeleteTextures(1, &tex);
+    pglDeleteTextures(1, &sprite);
+    pglBindVertexArray(0);
+    pglDeleteVertexArrays(1, &vao);
+    pglDeleteBuffers(1, &vbo);
+    pglDeleteBuffers(1, &ebo);
+    return e == GL_NO_ERROR ? 0 : fail("GL error 0x%x in glref_points_render", e);
 }

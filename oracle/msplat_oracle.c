@@ -778,7 +778,17 @@ int orc_build_sprite(const uint8_t* rgba8_top_first, int w, int h, int srgb, flo
                 for (int c = 0; c < 4; ++c) {
                     float a = chain[(cur + (size_t)j0 * lw + i0) * 4 + c], b = chain[(cur + (size_t)j0 * lw + i1) * 4 + c];
                     float cc = chain[(cur + (size_t)j1 * lw + i0) * 4 + c], d = chain[(cur + (size_t)j1 * lw + i1) * 4 + c];
-                    chain[(next + (size_t)j * nw + i) * 4 + c] = (((a + b) + cc) + d) * 0.25f;
+                    float m = (((a + b) + cc) + d) * 0.25f;
+                    /* a derived level has the base level's format (GL 4.6 8.14.4): 8-bit unorm, sRGB-encoded for colour when the
+                     * texture is GL_SRGB8_ALPHA8 -- the filter runs on decoded values, the result is stored at 8 bits (round to
+                     * nearest; llvmpipe's own levels are within one 8-bit step of this: tests/test_reference_shaders.py) */
+                    if (srgb && c < 3) {
+                        float e = m <= 0.0031308f ? m * 12.92f : 1.055f * powf(m, 1.0f / 2.4f) - 0.055f;
+                        m = srgb_to_linear(floorf(e * 255.0f + 0.5f) / 255.0f);
+                    } else {
+                        m = floorf(m * 255.0f + 0.5f) / 255.0f;
+                    }
+                    chain[(next + (size_t)j * nw + i) * 4 + c] = m;
                 }
             }
         cur = next;

@@ -1018,7 +1018,8 @@ static int build_sprite(msplat_ctx* ctx, const uint8_t* rgba8, uint32_t w, uint3
             }
             o[3] = alpha;
         }
-    // mip chain: 2x2 box filter down to 1x1 (glGenerateMipmap, core/texture.cpp:76)
+    // mip chain: 2x2 box filter down to 1x1, every level stored at 8 bits like the GL_RGBA8 / GL_SRGB8_ALPHA8 texture's own
+    // levels (glGenerateMipmap, core/texture.cpp:76)
     int lw = (int)w, lh = (int)h, level = 0;
     size_t off = 0;
     sp.off[0] = 0;
@@ -1033,7 +1034,17 @@ static int build_sprite(msplat_ctx* ctx, const uint8_t* rgba8, uint32_t w, uint3
                 for (int c = 0; c < 4; ++c) {
                     const float a = chain[(off + (size_t)j0 * lw + i0) * 4 + c], b = chain[(off + (size_t)j0 * lw + i1) * 4 + c];
                     const float cc = chain[(off + (size_t)j1 * lw + i0) * 4 + c], d = chain[(off + (size_t)j1 * lw + i1) * 4 + c];
-                    chain[(noff + (size_t)j * nw + i) * 4 + c] = (((a + b) + cc) + d) * 0.25f;
+                    float m = (((a + b) + cc) + d) * 0.25f;
+                    // a derived level has the base level's 8-bit format (GL 4.6 8.14.4; sRGB-encoded colour for GL_SRGB8_ALPHA8):
+                    // filtered on decoded values, stored rounded to 8 bits, decoded again for sampling
+                    if (srgb && c < 3) {
+                        const float e = m <= 0.0031308f ? m * 12.92f : 1.055f * std::pow(m, 1.0f / 2.4f) - 0.055f;
+                        const float q = std::floor(e * 255.0f + 0.5f) / 255.0f;
+                        m = q <= 0.04045f ? q / 12.92f : std::pow((q + 0.055f) / 1.055f, 2.4f);
+                    } else {
+                        m = std::floor(m * 255.0f + 0.5f) / 255.0f;
+                    }
+                    chain[(noff + (size_t)j * nw + i) * 4 + c] = m;
                 }
             }
         off = noff;

@@ -13,6 +13,8 @@ them on llvmpipe with the reference's GL state (oracle/glref/glref.c cites every
   gl_version .......... the GL implementation that executed the shaders
 glref_cfg2_1m_1080p.npz is BASELINE configs[1] itself (1 M splats, SH3, 1920x1080): sha-256 digests of the shader's keys / indices /
 the draw order, a 512 x 256 window of its image and 8x8 box means of the whole frame (a full float image would be 25 MB).
+glref_points.npz: the point-cloud renderer's shaders (point_vert / point_geom / point_frag + the sprite texture) for the scenes of
+glref_cases.point_cases(): image and draw order per scene.
 No reference source or shader text is stored."""
 import os
 import sys
@@ -61,6 +63,24 @@ def main():
                         idx_digest=glref_cases.u32_digest(idx), order_digest=glref_cases.u32_digest(si),
                         window=img[y0:y1, x0:x1, :3].copy(), mean8=glref_cases.box_mean8(img[..., :3]), gl_version=version)
     print("%-24s V %6d  lit %6d  %7.0f KB" % ("cfg2_1m_1080p", keys.shape[0], int((img[..., :3].sum(-1) != 0).sum()), os.path.getsize(path) / 1024.0))
+
+    # PointRenderer: shader/point_{vert,geom,frag}.glsl with the sprite texture (pointrenderer.cpp:54-63, 168-195)
+    out = {}
+    for name, c in glref_cases.point_cases().items():
+        version = glref.init(True, False)
+        vp = [0, 0, c["W"], c["H"]]
+        mvp = orc.mat4_mul(c["proj"], orc.mat4_inverse(c["cam"]))
+        keys, idx = glref.presort(np.ascontiguousarray(c["points"][:, :4]), mvp, c["nf"])
+        sk, si = orc.sort(keys, idx)
+        img = glref.points_render(c["points"], si, orc.mat4_inverse(c["cam"]), c["proj"], vp, c["sprite"], srgb=c["srgb"],
+                                  depth_bits=c["depth_bits"])
+        assert (img[..., 3] == 1.0).all()
+        out[name + "_rgb"] = img[..., :3].copy()
+        out[name + "_order"] = si
+        out[name + "_digest"] = glref_cases.digest(c["points"]) + glref_cases.digest(c["sprite"].astype(np.float32))
+    path = os.path.join(glref_cases.GOLDEN, "glref_points.npz")
+    np.savez_compressed(path, gl_version=version, **out)
+    print("%-24s %7.0f KB" % ("points", os.path.getsize(path) / 1024.0))
 
 
 if __name__ == "__main__":

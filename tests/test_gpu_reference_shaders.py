@@ -83,3 +83,36 @@ def test_baseline_config2_matches_the_reference_shaders():
         d.max(), d.mean(), (d <= 1e-4).mean(), dm.max()))
     assert d.mean() <= 1e-4 and (d <= 1e-4).mean() >= 0.999 and d.max() <= 5e-3
     assert dm.max() <= 1e-3 and dm.mean() <= 1e-5
+
+
+@pytest.mark.parametrize("name", sorted(glref_cases.point_cases()))
+def test_point_renderer_matches_the_reference_point_shaders(name):
+    """PointRenderer on the MI355X against shader/point_{vert,geom,frag}.glsl as llvmpipe executed them with the GL
+    texture of core/texture.cpp (glref_points.npz).  Draw order exact; magnified sprites (GL_LINEAR, no level of detail) to float
+    rounding; minified ones within glref_cases.POINT_MINIFIED_TOL (llvmpipe's level of detail is 0.045 below the specification's and
+    its mip levels round differently: tests/test_reference_shaders.py measures both); pixels whose centre is within 1/400 pixel of a
+    quad edge are decided by GL's sub-pixel vertex snapping and are only counted"""
+    from splatapult_amd import PointRenderer
+    c = glref_cases.point_cases()[name]
+    g = np.load(os.path.join(glref_cases.GOLDEN, "glref_points.npz"))
+    assert str(g[name + "_digest"]) == glref_cases.digest(c["points"]) + glref_cases.digest(c["sprite"].astype(np.float32))
+    vp = [0, 0, c["W"], c["H"]]
+    r = PointRenderer(device=0)
+    assert r.Init(c["points"], c["srgb"], sprite=c["sprite"]), r.last_error()
+    if c["depth_bits"]:
+        r.set_depth_test(c["depth_bits"])
+    img = r.Render(c["cam"], c["proj"], vp, c["nf"])
+    np.testing.assert_array_equal(r.sorted_indices(), g[name + "_order"])
+    fr = orc.points_frame(c["points"], c["sprite"], c["cam"], c["proj"], vp, c["nf"], srgb=c["srgb"], depth_bits=c["depth_bits"])
+    edge = glref_cases.point_edge_mask(fr["pts"], c["W"], c["H"])
+    d = np.abs(img[..., :3] - g[name + "_rgb"]).max(axis=-1)
+    lit = g[name + "_rgb"].sum(-1) > 0
+    print("HIP point renderer vs reference point shaders (%s): max |diff| %.3g off the quad edges, mean over lit %.3g, %d edge pixels "
+          "of which %d differ" % (name, d[~edge].max(), d[lit].mean(), int(edge.sum()), int((d[edge] > 0.03).sum())))
+    assert (img[..., 3] == 1.0).all()
+    if c["kind"] == "magnified":
+        assert d[~edge].max() <= 2e-5
+    else:
+        assert d[~edge].max() <= glref_cases.POINT_MINIFIED_TOL and d[lit].mean() <= 5e-3
+    assert ((img[..., :3].sum(-1) > 0) == lit)[~edge].all()
+    assert (d[edge] > 0.03).sum() <= 8

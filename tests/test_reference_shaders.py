@@ -162,3 +162,106 @@ def test_baseline_config2_whole_frame():
     c = glref_cases.config2()
     st = check_against_shaders(c["aos"], True, c["cam"], c["proj"], 1920, 1080)
     assert st["V"] > 980_000
+
+
+# ---- PointRenderer on shader/point_{vert,geom,frag}.glsl and a GL texture made like core/texture.cpp makes it ----
+def _points_through_shaders(c):
+    from tests import glref_cases
+    glref.init(True)
+    vp = [0, 0, c["W"], c["H"]]
+    mvp = orc.mat4_mul(c["proj"], orc.mat4_inverse(c["cam"]))
+    gk, gi = glref.presort(np.ascontiguousarray(c["points"][:, :4]), mvp, c["nf"])      # PointRenderer uses the same pre-sort shader
+    fr = orc.points_frame(c["points"], c["sprite"], c["cam"], c["proj"], vp, c["nf"], srgb=c["srgb"], depth_bits=c["depth_bits"])
+    sk, si = orc.sort(gk, gi)
+    np.testing.assert_array_equal(si, fr["sorted_idx"])
+    img = glref.points_render(c["points"], si, orc.mat4_inverse(c["cam"]), c["proj"], vp, c["sprite"], srgb=c["srgb"],
+                              depth_bits=c["depth_bits"])
+    return fr, img, glref_cases.point_edge_mask(fr["pts"], c["W"], c["H"])
+
+
+def test_point_shaders_magnified_sprites_are_reproduced_exactly():
+    """vertex + geometry shader (clip-space quad), rasterised coverage, uv interpolation, GL_LINEAR magnification, the fragment
+    shader's pre-multiplied colour and the blend: everything but the level of detail"""
+    from tests import glref_cases
+    c = glref_cases.point_cases()["points_magnified"]
+    fr, img, edge = _points_through_shaders(c)
+    assert fr["pts"]["lambda"].max() < 0 and fr["V"] == 60
+    d = np.abs(img - fr["image"]).max(axis=-1)
+    print("point shaders vs oracle, magnified: max |diff| %.3g over %d lit pixels (%d on a quad edge)" % (
+        d[~edge].max(), int((fr["image"][..., :3].sum(-1) > 0).sum()), int(edge.sum())))
+    assert d[~edge].max() <= 2e-5 and (d[edge] > 1e-3).sum() <= 4
+    assert (img[..., 3] == 1.0).all()
+
+
+@pytest.mark.parametrize("name", ["points_minified", "points_minified_srgb_depth24"])
+def test_point_shaders_minified_sprites_within_the_lod_tolerance(name):
+    """LinearMipmapLinear between deep levels; sRGB texels; GL_DEPTH_TEST live (no discard in point_frag.glsl: transparent corners
+    write depth).  GL leaves rho's approximation and the levels' rounding to the implementation: see POINT_MINIFIED_TOL"""
+    from tests import glref_cases
+    c = glref_cases.point_cases()[name]
+    fr, img, edge = _points_through_shaders(c)
+    assert fr["pts"]["lambda"].min() > 3
+    d = np.abs(img - fr["image"]).max(axis=-1)
+    lit = fr["image"][..., :3].sum(-1) > 0
+    print("point shaders vs oracle, %s: max |diff| %.3g (mean over lit %.3g), %d lit pixels, %d within 1/400 px of a quad edge "
+          "of which %d differ" % (name, d[~edge].max(), d[lit].mean(), int(lit.sum()), int(edge.sum()), int((d[edge] > 0.03).sum())))
+    assert d[~edge].max() <= glref_cases.POINT_MINIFIED_TOL and d[lit].mean() <= 5e-3
+    assert ((img[..., :3].sum(-1) > 0) == lit)[~edge].all()             # the same pixels are covered
+    assert (d[edge] > 0.03).sum() <= 8
+    assert (img[..., 3] == 1.0).all()
+
+
+def test_point_sprite_levels_and_the_level_of_detail_of_llvmpipe():
+    """(a) level 0 of the GL texture is the oracle's level 0 exactly; glGenerateMipmap's levels are the oracle's (2x2 box, stored at 8
+    bits) to one 8-bit step.  (b) one sprite at many sizes: exact while magnified; at an integer level of detail one 8-bit step;
+    in between llvmpipe blends the two levels with a level of detail 0.045 below the specification's log2(rho) -- with that
+    offset applied to the oracle the two agree to one 8-bit step again, i.e. nothing else differs"""
+    import ctypes as C
+    from tests import glref_cases
+    glref.init(True)
+    tex = glref_cases.point_sprite(64)
+    L = orc.lib()
+    W, H = 640, 480
+    proj = camera.perspective(camera.FOVY, W / H)
+    pts = np.array([[0, 0, 0, 1, 1, 1, 1, 1]], np.float32)
+    for srgb in (False, True):
+        chain = np.zeros((64 * 64 * 4 // 3 + 64) * 4, np.float32)
+        off = np.zeros(14, np.uint32)
+        levels = L.orc_build_sprite(tex.ctypes.data, 64, 64, int(srgb), chain.ctypes.data_as(C.POINTER(C.c_float)),
+                                    off.ctypes.data_as(C.POINTER(C.c_uint32)))
+        assert levels == 7
+        worst_exact, worst_offset = 0.0, 0.0
+        for dist in (0.1, 0.15, 0.3, 0.7, 1.0, 1.5, 2.0, 3.0, 4.0):
+            cam = camera.pose((0.013, 0.007, dist))
+            fr = orc.points_frame(pts, tex, cam, proj, [0, 0, W, H], scenes.NF, srgb=srgb)
+            img, mips = glref.points_render(pts, fr["sorted_idx"], orc.mat4_inverse(cam), proj, [0, 0, W, H], tex, srgb=srgb, want_mips=True)
+            lam = float(fr["pts"][0]["lambda"])
+            d = float(np.abs(img - fr["image"]).max())
+            if lam <= 0:
+                assert d <= 1e-6, (dist, lam, d)                       # GL_LINEAR magnification: bit for bit
+                continue
+            p2 = fr["pts"].copy()
+            p2["lambda"] = np.float32(lam - 0.045)
+            img2 = np.zeros((H, W, 4), np.float32)
+            L.orc_points_composite(1, p2.ctypes.data, chain.ctypes.data_as(C.POINTER(C.c_float)), off.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                   64, 64, levels, W, H, img2.ctypes.data_as(C.POINTER(C.c_float)), 0)
+            d2 = float(np.abs(img - img2).max())
+            worst_exact, worst_offset = max(worst_exact, d), max(worst_offset, d2)
+            step = (2.5 if srgb else 1.0) / 255.0        # (an 8-bit step of an sRGB-encoded level is up to 2.3 steps in linear light)
+            assert d2 <= step + 1e-3, (dist, lam, d, d2)
+            if abs(lam - round(lam)) < 1e-3:
+                assert d <= step + 1e-3, (dist, lam, d)
+        print("one sprite, srgb %d: max |diff| %.3g at the specification's level of detail, %.3g at llvmpipe's (-0.045)" % (
+            srgb, worst_exact, worst_offset))
+        assert worst_exact <= glref_cases.POINT_MINIFIED_TOL
+        # (a) the levels themselves; glGetTexImage returns the stored (sRGB-encoded) bytes: encode the oracle's decoded levels
+        w = 64
+        for l in range(levels):
+            mine = chain[off[l] * 4:(off[l] + w * w) * 4].reshape(w, w, 4).astype(np.float64)
+            if srgb:
+                lin = mine[..., :3]
+                mine[..., :3] = np.where(lin <= 0.0031308, lin * 12.92, 1.055 * np.power(lin, 1 / 2.4) - 0.055)
+            dl = np.abs(mine - mips[l]).max()
+            # (every level is made from the level above, so a step of difference there carries over: two steps in the sRGB encoding)
+            assert dl <= (2e-6 if l == 0 else (2.0 if srgb else 1.0) / 255.0 + 1e-5), (srgb, l, dl)
+            w = max(1, w // 2)

@@ -164,6 +164,19 @@ def test_baseline_config2_whole_frame():
     assert st["V"] > 980_000
 
 
+def test_baseline_config5_second_eye_at_full_resolution():
+    """BASELINE configs[4]'s geometry -- 1 M splats, 2016 x 2240 per eye, asymmetric XR frusta, ONE sort with the first eye's camera
+    (app.cpp:603-607) -- the SECOND eye, drawn in the first eye's order, through the reference's shaders (RGBA32F target: the
+    fp16 target's rounding is the GL implementation's, see test_render_targets_round_after_every_blend)"""
+    from tests import glref_cases
+    c = glref_cases.config2()
+    cam0 = c["cam"]
+    eyes = [camera.translate_local(cam0, dx=-0.032), camera.translate_local(cam0, dx=+0.032)]
+    projs = [camera.create_projection(-1.0, 0.8, 0.95, -0.95), camera.create_projection(-0.8, 1.0, 0.95, -0.95)]
+    st = check_against_shaders(c["aos"], True, eyes[0], projs[0], 2016, 2240, render_cam=eyes[1], render_proj=projs[1])
+    assert st["V"] > 900_000 and st["lit"] > 2_000_000
+
+
 # ---- SURVEY 8f-4: PointRenderer on shader/point_{vert,geom,frag}.glsl and a GL texture made like core/texture.cpp makes it ----
 def _points_through_shaders(c):
     from tests import glref_cases

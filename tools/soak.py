@@ -2,7 +2,8 @@
 """tools/soak.py -- a few thousand frames over poses that make the frame change its kernel selection from frame to frame
 (visible count above / below 2 M: chunk size of sort passes 1 and 2; heavy chunks of the column pass present / absent:
 helper workgroups; pair counts above / below the scan-free limit), one frame at a time, with four frames in flight, and as one
-rank of a row-sharded frame (block layout, band-culled sort).
+rank of a row-sharded frame (block layout, band-culled sort), and with both eyes of a stereo pair in one chain of launches
+(four in flight).
 
 Every stateful shortcut of the frame is exercised across those switches: the self-cleaning group tables, the per-parity
 minimum-key and heavy-chunk words, the host-mapped hints of an earlier frame.  Checked: every render of a pose is
@@ -49,14 +50,15 @@ def main(argv=None):
     rng = np.random.default_rng(7)
     order = rng.integers(0, len(poses), size=args.frames)
     failures = 0
-    for kind in ("serial", "in flight", "band"):
-        depth = 4 if kind == "in flight" else 1
+    for kind in ("serial", "in flight", "band", "stereo in flight"):
+        depth = 4 if "in flight" in kind else 1
+        stereo = kind.startswith("stereo")
         r = SplatRenderer(device=0, frames_in_flight=depth)
         assert r.Init(gc, False, False), r.last_error()
         if kind == "band":        # rank 1 of 4 under the block layout, band-culled sort: virtual rows, V a fraction of the cloud's
             r.set_band_plan("block", (H + 31) // 32, 4, 1, block_rows=2, band_cull=True)
         Hpad = (H + 31) // 32 * 32           # the compositor writes whole bins
-        fbs = [torch.zeros((Hpad, W, 4), dtype=torch.float32, device=dev) for _ in range(depth)]
+        fbs = [torch.zeros(((2 if stereo else 1) * Hpad, W, 4), dtype=torch.float32, device=dev) for _ in range(depth)]      # stereo: the eyes one above the other
         first, counts = {}, {}
         t0 = time.time()
         pending = []                      # (pose index, framebuffer slot) of frames not yet checked
@@ -73,7 +75,11 @@ def main(argv=None):
                         print("MISMATCH %s frame %d pose %d: %d pixels differ" % (kind, f, pp, int((first[pp] != img).any(-1).sum())))
                 pending = []
             r.Sort(poses[p], proj, vp, nf)
-            r.Render(poses[p], proj, vp, nf, out_ptr=fbs[slot].data_ptr(), pitch_bytes=W * 16)
+            if stereo:        # both eyes in one chain of launches (msplat_render_stereo), in the first eye's order
+                eyes = [camera.translate_local(poses[p], dx=-0.032), camera.translate_local(poses[p], dx=+0.032)]
+                r.RenderStereo(eyes, [proj, proj], vp, nf, out_ptrs=[fbs[slot].data_ptr(), fbs[slot][Hpad:].data_ptr()], pitch_bytes=W * 16)
+            else:
+                r.Render(poses[p], proj, vp, nf, out_ptr=fbs[slot].data_ptr(), pitch_bytes=W * 16)
             pending.append((int(p), slot))
             if f % 97 == 0:
                 r.synchronize()

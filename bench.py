@@ -125,9 +125,10 @@ def measure(E, args, key, ply=None, primary=True):
     n = wl["n"]
 
     P = max(1, args.frames_in_flight)
+    two_pass = {"auto": _capi.TWO_PASS_AUTO, "on": _capi.TWO_PASS_ON, "off": _capi.TWO_PASS_OFF}[args.two_pass]
     r = SplatRenderer(device=E.local_rank, fb_format=wl["fb"], stream=stream.cuda_stream,
                       enable_timing=args.timing_stride, frames_in_flight=P,
-                      async_submit=None if args.async_submit < 0 else bool(args.async_submit))
+                      async_submit=None if args.async_submit < 0 else bool(args.async_submit), two_pass=two_pass)
 
     def init(rr):
         # a file is rendered the way the app would: Ply::Parse on the host + GaussianCloud::ImportPly's math on the GPU
@@ -255,13 +256,15 @@ def measure(E, args, key, ply=None, primary=True):
     prof = dict(sort_total=0.0, render_total=0.0, project=0.0, binning=0.0, composite=0.0, composite_kernel=0.0)
     if args.timing_stride > 0:
         prof = r.timings()                        # sampled stage events of the overlapped frames
+    tp_flight = r.two_pass_info()                 # the latest frame of the timed region (None: one pass)
+    tp_frames_flight, tp_share_flight = r.two_pass_state()
 
     # ---- serial phase: the same frames one at a time on ONE stream (clean per-kernel durations, latency) ----
     if P == 1:
         rs, rs_sets = r, fb_sets
     else:
         rs = SplatRenderer(device=E.local_rank, fb_format=wl["fb"], stream=stream.cuda_stream, enable_timing=4,
-                           frames_in_flight=1)     # stage events on every 4th frame: they cost a few us each
+                           frames_in_flight=1, two_pass=two_pass)     # stage events on every 4th frame: they cost a few us each
         init(rs)
         live.append(rs)
         if world > 1:
@@ -279,6 +282,8 @@ def measure(E, args, key, ply=None, primary=True):
     sync_all()
     serial_ms = 1e3 * (time.perf_counter() - t0) / SER
     prof_serial = rs.timings() if (args.timing_stride > 0 or P > 1) else None
+    tp_serial = rs.two_pass_info()                 # None: the serial frames ran in one pass
+    tp_share_serial = rs.two_pass_state()[1]
     lat = []
     for s in range(16):
         torch.cuda.synchronize(dev)
@@ -364,13 +369,23 @@ def measure(E, args, key, ply=None, primary=True):
     if prof_serial and prof_serial.get("sort_total", 0) > 0:
         # (stereo: projection, binning and the compositor run once per view; their stage times and bytes are per Render call)
         sb = {"sort": 16.0 * n + 76.0 * V, "project": vpl * (S + 48.0) * V, "binning": vpl * 4.0 * V + 16.0 * Dbin_mean, "composite": B_used}
+        if tp_serial:
+            # two-pass frames: pass 1 projects its share, the gate reads 20 B per splat behind the cut (index + centre) and writes
+            # / rewrites rectangles, pass 2 projects what passes it; both binning chains read every rectangle and move their own pairs
+            sb["project"] = (S + 48.0) * (tp_serial["splats_pass1"] + tp_serial["splats_pass2"]) + 28.0 * tp_serial["visible"]
+            sb["binning"] = 2 * 4.0 * tp_serial["visible"] + 16.0 * (tp_serial["pairs_pass1"] + tp_serial["pairs_pass2"])
         st_ms = {"sort": prof_serial["sort_total"], "project": prof_serial["project"], "binning": prof_serial["binning"],
                  "composite": comp_serial_ms}
         stages = {k: {"bytes": sb[k], "us": 1e3 * st_ms[k], "frac": min(1.0, sb[k] / max(st_ms[k] * 1e-3, 1e-12) / HBM_PEAK)}
                   for k in sb}
         stages["bytes_definition"] = ("sort 16 N + 76 V; project 292 V; binning 4 V + 16 D32 (D32 = (splat, 32-px bin) pairs); composite = bytes "
-                                      "fetched (probe) + framebuffer; us = stage time of a serial frame (per Render call for stereo)")
+                                      "fetched (probe) + framebuffer; us = stage time of a serial frame (per Render call for stereo)"
+                                      + ("; TWO-PASS frames: project 292 (splats of pass 1 + splats that passed the gate) + 28 V, binning 8 V + 16 "
+                                         "(pairs of pass 1 + pairs of pass 2), composite = the single pass's fetched bytes (a lower bound: "
+                                         "unfinished bins are walked twice)" if tp_serial else ""))
     B_moved = (16.0 * n + 76.0 * V) + launches_per_frame * (vpl * ((S + 48.0) * V + 4.0 * V) + 16.0 * Dbin_mean + B_used)
+    if tp_serial and stages:
+        B_moved = stages["sort"]["bytes"] + stages["project"]["bytes"] + stages["binning"]["bytes"] + B_used
     roof = {
         "kernel": "composite_kernel", "bound": "hbm", "limiter": "valu (exp + blend per pixel-splat); the HBM fraction is honest-but-low",
         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
@@ -408,6 +423,9 @@ def measure(E, args, key, ply=None, primary=True):
                    "sharding": ("bin rows of %d px over %d ranks, layout %s" % (TILE, world, lay)) if world > 1 else "none (one GPU)",
                    "frames_in_flight": P, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                    "async_submit": bool(r._async),
+                   "two_pass": {"mode": args.two_pass,
+                                "timed_region": dict(tp_flight, frames_total=tp_frames_flight, share_pass1=tp_share_flight) if tp_flight else None,
+                                "serial_frames": dict(tp_serial, share_pass1=tp_share_serial) if tp_serial else None},
                    "stereo": ("one chain for both eyes (msplat_render_stereo)" if not args.no_stereo_batch else "one Render per eye") if views == 2 else None,
                    "visible_V": V, "pairs_D": D_total, "pairs_binned_32px": float(np.mean(Dbin)),
                    "drawn": float(np.mean(drawn)), "D_over_N": D_total / max(1, n),
@@ -475,6 +493,8 @@ def main():
                          "poses with peer stores into device 0's framebuffer and compares them bit for bit with a single context")
     ap.add_argument("--no-stereo-batch", action="store_true",
                     help="two-view workloads: one Render per eye (the reference's call pattern) instead of msplat_render_stereo (A/B)")
+    ap.add_argument("--two-pass", default="auto", choices=["auto", "on", "off"],
+                    help="msplat_config.two_pass: Renders in two passes with occlusion feedback (same pixels; A/B)")
     ap.add_argument("--async-submit", type=int, default=-1,
                     help="msplat_config.async_submit of the in-flight contexts: 1 = a worker thread per context issues its launches, "
                          "0 = the calling thread does (A/B); default: on with frames in flight")

@@ -80,7 +80,29 @@ typedef struct msplat_config {
                                /* order so that the cull can skip whole chunks?  A shorter struct_size = AUTO  */
     int32_t async_submit;      /* r4: != 0: msplat_sort and device-output msplat_render return at once; their   */
                                /* launches are issued by a worker thread of the context (frames in flight)     */
+    int32_t two_pass;          /* MSPLAT_TWO_PASS_* (r4): may a Render run as two passes with occlusion feedback */
+                               /* (same pixels, less work)?  A shorter struct_size = AUTO                      */
+    int32_t reserved0;         /* 0 */
 } msplat_config;
+
+/* msplat_config.two_pass -- a frame in two passes with occlusion feedback (splatapult_amd/csrc/msplat_occlusion.hip.h).
+ * The compositor stops a tile when its pixels are saturated, but projection and binning process every visible splat: most of
+ * the (splat, bin) pairs they produce are never read (76 % at BASELINE config 2, 87 % at config 4, 98 % with a camera inside a
+ * scene).  A two-pass Render first projects, bins and composites the NEAREST splats only; tiles saturated by them are final;
+ * a 16-byte test per remaining splat (centre + footprint bound against the map of unfinished bins) then decides whether its
+ * 256-byte record is fetched at all, and only the unfinished bins are binned and composited again -- from complete lists, from
+ * scratch.  The image is bit for bit the image of the single pass (every finished tile saw exactly the list entries the
+ * single pass would have consumed, in the same batches), whatever share of the splats goes into the first pass; that share is
+ * steered from counts an earlier frame left in host-mapped memory, never waited for.
+ * AUTO: clouds of >= 262 144 splats on the splat compositor (no emulated depth test / render-target rounding / points / two
+ * views in one chain), after the context's first 8 frames, not while the tile probe is on.  A two-pass frame costs ~9 more
+ * launches: it is a throughput feature (frames in flight, large clouds), neutral for a 1 M-splat frame rendered alone.
+ * After a two-pass Render, msplat_get_stats().pairs / drawn and the debug list getters describe the SECOND pass. */
+enum {
+    MSPLAT_TWO_PASS_AUTO = 0,
+    MSPLAT_TWO_PASS_ON = 1,
+    MSPLAT_TWO_PASS_OFF = 2
+};
 
 /* msplat_config.async_submit.  Issuing a frame (~14 kernel launches) costs the host ~55 us.  A caller that keeps several frames
  * in flight on several contexts from ONE thread therefore starts the k-th context k x 55 us after the first -- a stagger that a
@@ -399,6 +421,14 @@ int msplat_debug_get_tile_lists(msplat_ctx* ctx, uint32_t* tile_start, uint32_t 
  * ascending in draw-order rank): counts of violations, both 0 on a healthy context.  Guards the lane-ordered LDS-atomic
  * ranking, which msplat_create probes but the hardware does not document (MSPLAT_BALLOT_RANK=1 selects the ballot path) */
 int msplat_debug_verify_order(msplat_ctx* ctx, uint32_t* key_violations, uint32_t* list_violations);
+/* two-pass frames (msplat_config.two_pass): share > 0 pins the share of the visible splats that goes into the first pass (tests:
+ * any value gives the same pixels), 0 hands it back to the feedback loop.  two_pass_frames: Renders of the context that ran in
+ * two passes so far; share_now: the share the next one would use. */
+int msplat_debug_two_pass(msplat_ctx* ctx, float share, uint64_t* two_pass_frames, float* share_now);
+/* what the context's latest two-pass Render did (synchronises): out[0] = two-pass Renders so far (0: the rest is meaningless),
+ * [1] = visible splats projected by pass 1, [2] = splats behind the cut that passed the gate and were projected by pass 2,
+ * [3] = (splat, bin) pairs binned by pass 1, [4] = by pass 2, [5] = bins pass 1 left unfinished, [6] = bins, [7] = visible splats */
+int msplat_get_two_pass_info(msplat_ctx* ctx, uint64_t out[8]);
 
 /* compositor probe (performance analysis, bench statistics): per (bin, quadrant) work item 8 words
  * {shader clocks, records composited, batches staged, inner-loop clocks, pair words fetched, records fetched,

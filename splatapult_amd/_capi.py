@@ -16,6 +16,7 @@ ROP_NONE, ROP_RGBA8, ROP_RGBA16F = 0, 1, 2
 RANK_AUTO, RANK_BALLOT = 0, 1
 FRAMES_AUTO, FRAMES_SERIAL, FRAMES_IN_FLIGHT = 0, 1, 2
 SPATIAL_AUTO, SPATIAL_ON, SPATIAL_OFF = 0, 1, 2
+TWO_PASS_AUTO, TWO_PASS_ON, TWO_PASS_OFF = 0, 1, 2          # msplat_config.two_pass
 BANDS_CONTIGUOUS, BANDS_INTERLEAVED, BANDS_BLOCK_INTERLEAVED = 0, 1, 2
 BAND_KINDS = {"contiguous": BANDS_CONTIGUOUS, "interleaved": BANDS_INTERLEAVED, "block": BANDS_BLOCK_INTERLEAVED}
 
@@ -30,7 +31,8 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("fb_format", C.c_int32),
                 ("srgb", C.c_int32), ("t_epsilon", C.c_float), ("pair_capacity", C.c_uint64),
                 ("stream", C.c_void_p), ("enable_timing", C.c_int32), ("compositor_waves", C.c_int32),
-                ("rank_mode", C.c_int32), ("frame_mode", C.c_int32), ("spatial_order", C.c_int32), ("async_submit", C.c_int32)]
+                ("rank_mode", C.c_int32), ("frame_mode", C.c_int32), ("spatial_order", C.c_int32), ("async_submit", C.c_int32),
+                ("two_pass", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class AttrOffsets(C.Structure):
@@ -128,6 +130,8 @@ SYMBOLS = [
     ("msplat_debug_get_tile_probe8", C.c_int, [C.c_void_p, _U32P, C.c_uint32]),
     ("msplat_set_tile_probe", C.c_int, [C.c_void_p, C.c_int]),
     ("msplat_debug_verify_order", C.c_int, [C.c_void_p, _U32P, _U32P]),
+    ("msplat_debug_two_pass", C.c_int, [C.c_void_p, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]),
+    ("msplat_get_two_pass_info", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("msplat_get_composite_work", C.c_int, [C.c_void_p, C.POINTER(CompositeWork)]),
     ("msplat_cloud_create", C.c_void_p, [C.c_int]),
     ("msplat_cloud_destroy", None, [C.c_void_p]),

@@ -29,8 +29,10 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
                                                          uint32_t* __restrict__ gsum_acc,
                                                          uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_rows,
                                                          uint32_t* __restrict__ heavy, uint32_t* __restrict__ heavy_next,
-                                                         uint8_t* __restrict__ heavy_flag, uint32_t heavy_slots, uint32_t gsup)
+                                                         uint8_t* __restrict__ heavy_flag, uint32_t heavy_slots, uint32_t gsup,
+                                                         int keep_overflow = 0)
 {
+    // keep_overflow: second binning chain of a two-pass frame -- the first chain's overflow verdict stays
     // Heavy chunks (r3).  The ranks are in depth order, so the huge far-away splats of a real scene (sky, background) are the
     // FIRST ranks: a few chunks hold half of all the pairs (scene-like 6 M cloud: 25 of 2344 chunks, 500 k pairs each against
     // 11 k), and the column pass lasted as long as the slowest of them.  A chunk with more than kHeavyPairs pairs is put on a
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
     // chunks the downsweep's grid has helper workgroups for (the host sizes it from an earlier frame's count; a chunk that
     // gets no slot is processed unsplit -- slower, never wrong).
     // per-frame reset of the sticky overflow flag (set later in the frame by bin1_downsweep): saves a memset launch
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *d_overflow = 0u; heavy_next[0] = 0u; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { if (!keep_overflow) *d_overflow = 0u; heavy_next[0] = 0u; }
     if (gsum_zero != nullptr)      // scan-free path, see radix_upsweep
         for (uint32_t row = blockIdx.x; row < gsum_zero_rows; row += gridDim.x) gsum_zero[(size_t)row * 256 + threadIdx.x] = 0u;
     __shared__ uint32_t s_diff[kThreads + 1];
@@ -114,8 +116,10 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && BIN_CHUNK == kBinChunk) ?
                                                            uint32_t* __restrict__ totals_out, int xcd_map,
                                                            const uint32_t* __restrict__ heavy,
                                                            const uint8_t* __restrict__ heavy_flag, uint32_t nhelp, int tiles_x,
-                                                           uint32_t gsup, const uint32_t* __restrict__ d_V_report = nullptr)
+                                                           uint32_t gsup, const uint32_t* __restrict__ d_V_report = nullptr,
+                                                           uint32_t* __restrict__ host_D2 = nullptr, uint32_t seq = 0u)
 {
+    // host_D2 (host-mapped): second binning chain of a two-pass frame -- its pair count, for the host's choice of the next share
     // d_V_report: the Sort's own V for the host-mapped hint (with two views in one chain d_V counts the ranks of both)
     // The first nhelp workgroups are helpers for the heavy chunks (bin1_upsweep; first, so that they start with the launch):
     // helper h takes column block 1 + h % (kHeavyParts - 1) of chunk heavy[1 + h / (kHeavyParts - 1)] and exits at once when
@@ -156,6 +160,10 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && BIN_CHUNK == kBinChunk) ?
                 __hip_atomic_store(host_words + 1, d_V_report ? *d_V_report : V, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(host_words + 2, incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(host_words + 3, heavy[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // heavy chunks wanted
+            }
+            if (host_D2 != nullptr) {
+                __hip_atomic_store(host_D2, incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(host_D2 + 2, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // ... of which frame
             }
             if (incl > cap) {
                 *d_overflow = incl;

@@ -110,9 +110,14 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
                                                                  const uint32_t* __restrict__ order,
                                                                  uint32_t* __restrict__ queue, uint32_t ntiles,
                                                                  uint32_t* __restrict__ probe, int prio_levels,
-                                                                 void* __restrict__ out1 = nullptr)
+                                                                 void* __restrict__ out1 = nullptr,
+                                                                 uint32_t* __restrict__ fin = nullptr,
+                                                                 const uint8_t* __restrict__ binfin = nullptr)
 {
     // out1: the second view's target (FrameParams.views == 2: bin rows >= rows_view belong to it)
+    // Two-pass frame (msplat_occlusion.hip.h).  fin (pass 1): fin[bin * 4 + quadrant] = 1 when the item's walk ended because
+    // every strip was saturated (or the item has no pixels), 0 when it ended with its list.  binfin (pass 2): items of
+    // finished bins are skipped -- their pixels are final.
     // Lane (lx, ly) owns pixels (x0+lx, y0 + 4k + ly), k = 0..3: strip k is the 16x4 pixel block of
     // rows 4k..4k+3.  Per splat the exponent is split into a part shared by the four strips and a
     // 2-FMA part per strip; strips the splat's y-range cannot reach, or whose 64 pixels are all
@@ -152,7 +157,9 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
     const int tx = (bin - bvy * fp.tiles_x) * 2 + (quad & 1);
     const bool second = fp.views == 2 && bvy >= fp.rows_view;
     const int ty = (second ? bvy - fp.rows_view : band_real_row(fp, bvy)) * 2 + (quad >> 1);
-    if (tx * kTile >= fp.width || ty * kTile >= fp.height) {      // work item entirely outside the image
+    if (tx * kTile >= fp.width || ty * kTile >= fp.height || (binfin != nullptr && binfin[bin] != 0)) {
+        // work item entirely outside the image, or (pass 2 of a two-pass frame) its bin was finished by pass 1
+        if (fin != nullptr && threadIdx.x == 0) fin[bin * 4 + quad] = 1u;
         if (gridDim.x >= ntiles) break;
         uint32_t nq = 0;
         if (threadIdx.x == 0) nq = queue_next(queue, ntiles);
@@ -237,7 +244,9 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
     uint64_t probe_inner = 0;
     // pair words / records whose loads have been issued so far (the prefetch pipeline runs two / one batches ahead)
     uint32_t probe_words = min(end - start, 2u * (uint32_t)kCompThreads), probe_recs = cnt;
+    uint32_t last_cnt = (uint32_t)kCompThreads;       // entries of the batch composited last (a walk that never starts counts as full)
     while (cnt != 0u && alive != 0u) {
+        last_cnt = cnt;
         // stage: every lane turns its list entry into the coefficients of e(u, v) in tile-centred coordinates and tests
         // it against the tile; the survivors are compacted into LDS in list order (near to far).  Straight-line code on
         // purpose: the CU has ONE scalar unit for its four SIMDs and this is the dependent chain between two batches --
@@ -353,6 +362,11 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
         __syncthreads();
     }
 
+    // (pass 1 of a two-pass frame) final?  The walk must have ended because every strip was saturated, and the batch that
+    // saturated it must have been a FULL one: the strips are only tested between batches, so the single pass composites all 64
+    // entries of that batch -- batches count from the list's end, and a short last batch of the truncated list would be a longer
+    // one there.
+    if (fin != nullptr && lane == 0) fin[bin * 4 + quad] = (alive == 0u && last_cnt == (uint32_t)kCompThreads) ? 1u : 0u;
     if (probe != nullptr && lane == 0) {
         probe[tile * 8 + 0] = (uint32_t)(clock64() - probe_t0);        // shader clocks, whole tile
         probe[tile * 8 + 1] = probe_n;          // splats composited (after culling / saturation)

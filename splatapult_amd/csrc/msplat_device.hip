@@ -203,7 +203,7 @@ struct msplat_ctx {
     // per-stage hipEvent sets, recorded on every `timing_stride`-th call so that the event markers
     // (a few us of pipeline bubble each) do not perturb a throughput run; averaged by msplat_get_timings
     static constexpr int kEvSets = 32;
-    hipEvent_t ev[kEvSets][8]{};   // [6],[7] = exact dispatch start/stop of the compositor (hipExtLaunchKernelGGL)
+    hipEvent_t ev[kEvSets][13]{};  // [6],[7] = exact dispatch start/stop of the compositor (hipExtLaunchKernelGGL); [8..12]: second pass of a two-pass frame
     bool ev_ok = false;
     int timing_stride = 1;
     uint64_t sort_calls = 0, render_calls = 0;
@@ -211,6 +211,18 @@ struct msplat_ctx {
     int cur_render_set = -1;
     bool comp_kernel_timed = false;
     uint32_t comp_kernel_sets_mask = 0;
+    uint32_t two_pass_sets_mask = 0;         // timing sets recorded by two-pass frames
+    // two-pass frame with occlusion feedback (msplat_occlusion.hip.h)
+    Buf occ, occ_mask, occ_fin, occ_binfin, occ_live, occ_boxdead;
+    int two_pass_mode = MSPLAT_TWO_PASS_AUTO;
+    float occ_frac = 0.25f;                  // share of the visible splats that goes into pass 1
+    uint32_t occ_streak = 0;                 // consecutive two-pass frames submitted (their feedback describes two-pass frames)
+    uint32_t occ_seq = 0, occ_change_seq = 0;   // number of the latest two-pass frame; first frame that ran with the current share
+    uint32_t occ_off = 0;                    // AUTO: frames left of a single-pass period after two passes did not pay
+    uint32_t occ_strikes = 0, occ_backoff = 512; // ... decided after three looks; the pause doubles every time
+    bool occ_pinned = false;                 // msplat_debug_two_pass: the share is fixed
+    bool last_render_two_pass = false;
+    uint64_t frames_rendered = 0, frames_two_pass = 0;
 
     std::unique_ptr<AsyncWorker> worker;     // msplat_config.async_submit
     bool atomic_rank = true;    // LDS atomics hand out ranks in lane order (probed at create)
@@ -325,6 +337,8 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: bad fb_format %d", c.fb_format);
     if (c.spatial_order < MSPLAT_SPATIAL_AUTO || c.spatial_order > MSPLAT_SPATIAL_OFF)
         return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: bad spatial_order %d", c.spatial_order);
+    if (c.two_pass < MSPLAT_TWO_PASS_AUTO || c.two_pass > MSPLAT_TWO_PASS_OFF)
+        return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: bad two_pass %d", c.two_pass);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -336,6 +350,7 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
     ctx->cfg = c;
     ctx->device = c.device;
     if (ctx->cfg.t_epsilon < 0.0f) ctx->cfg.t_epsilon = 1.0f / 16384.0f;
+    ctx->two_pass_mode = c.two_pass;
     e = hipSetDevice(ctx->device);
     if (e != hipSuccess) {
         delete ctx;
@@ -474,7 +489,8 @@ void msplat_destroy(msplat_ctx* ctx)
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     Buf* all[] = {&ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist, &ctx->gsumS[0], &ctx->gsumS[1], &ctx->gsumB1, &ctx->gsumB2,
                   &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->totals1, &ctx->tile_start, &ctx->tile_order,
-                  &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe, &ctx->zq, &ctx->sprite, &ctx->queue,
+                  &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe, &ctx->zq, &ctx->sprite, &ctx->queue, &ctx->occ, &ctx->occ_mask, &ctx->occ_fin,
+                  &ctx->occ_binfin, &ctx->occ_live, &ctx->occ_boxdead,
                   &ctx->wsHist, &ctx->wsGsum[0], &ctx->wsGsum[1], &ctx->wsGsum[2], &ctx->vmask, &ctx->bincnt, &ctx->heavy, &ctx->heavy_flag,
                   &ctx->live_list, &ctx->live_cnt};
     for (Buf* b : all) buf_free(ctx, *b);
@@ -1520,6 +1536,76 @@ static int sort_impl(msplat_ctx* ctx, const float cameraMat[16], const float pro
     return MSPLAT_OK;
 }
 
+// Should this Render run as two passes (msplat_occlusion.hip.h), and with what share of the visible splats in pass 1?  Host
+// side only: reads what EARLIER frames of this context left in host-mapped memory (never waits); any answer gives the same
+// pixels.  Feedback of a two-pass frame: [4] pairs of pass 1, [8] pairs of pass 2, [5] unfinished bins.
+constexpr uint64_t kTwoPassMinSplats = 1u << 18;
+constexpr float kOccFracMin = 1.0f / 256.0f, kOccFracMax = 0.75f;
+static bool occlusion_plan(msplat_ctx* ctx, const FrameParams& fp, bool stereo, float& frac)
+{
+    ctx->frames_rendered++;
+    auto no = [&]() { ctx->occ_streak = 0; return false; };
+    if (ctx->two_pass_mode == MSPLAT_TWO_PASS_OFF) return no();
+    if (stereo || ctx->point_mode || ctx->depth_bits != 0 || ctx->rop != 0 || ctx->probe_on) return no();
+    if (fp.tiles_x * fp.tiles_y <= 0 || (fp.tiles_x + 1) * (fp.tiles_y + 1) > kOccSatMax) return no();      // (the table of unfinished bins)
+    const bool forced = ctx->two_pass_mode == MSPLAT_TWO_PASS_ON;
+    if (!forced) {
+        if (ctx->N < kTwoPassMinSplats || ctx->frames_rendered <= 8) return no();
+        if (ctx->occ_off != 0u) {                // a single-pass period; then try again from the default share
+            if (--ctx->occ_off == 0u) ctx->occ_frac = 0.25f;
+            return no();
+        }
+    }
+    const size_t nbins = (size_t)fp.tiles_x * fp.tiles_y;
+    if (buf_alloc(ctx, ctx->occ, 64) || buf_alloc(ctx, ctx->occ_mask, (size_t)kOccSatMax * 2 + 64) ||
+        buf_alloc(ctx, ctx->occ_fin, nbins * 16 + 64) || buf_alloc(ctx, ctx->occ_binfin, nbins + 64) ||
+        buf_alloc(ctx, ctx->occ_live, ((size_t)ctx->N + 64) * 4) || buf_alloc(ctx, ctx->occ_boxdead, 2048 * 4 + 64)) {
+        ctx->err.clear();                        // (no memory for the extra buffers: the frame runs in one pass)
+        return no();
+    }
+    // steer the share: pass 2 should stay well below pass 1 (a flat optimum: tools/occlusion_potential.py).  The feedback names
+    // its frame (occ_seq): only a frame that ran with the CURRENT share is evidence for changing it -- the host may be many
+    // frames ahead of the GPU
+    if (ctx->h_flags && !ctx->occ_pinned) {
+        const uint32_t s1 = __atomic_load_n(ctx->h_flags + 9, __ATOMIC_RELAXED), s2 = __atomic_load_n(ctx->h_flags + 10, __ATOMIC_RELAXED);
+        const uint32_t d1 = __atomic_load_n(ctx->h_flags + 4, __ATOMIC_RELAXED), d2 = __atomic_load_n(ctx->h_flags + 8, __ATOMIC_RELAXED);
+        if (s1 == s2 && s1 != 0u && (int32_t)(s1 - ctx->occ_change_seq) >= 0 && d1 != 0u) {
+            const float ratio = (float)d2 / (float)d1;
+            const uint32_t unfinished = __atomic_load_n(ctx->h_flags + 5, __ATOMIC_RELAXED);
+            const float ufrac = (float)unfinished / (float)nbins;
+            float next = ctx->occ_frac;
+            // A bin pass 1 does not finish is composited twice.  Where a third of the bins never saturate whatever the share (a
+            // cloud seen from outside: its rim), the second compositor launch and the second binning chain cost more than the
+            // skipped splats save (BASELINE config 2: 6.2 k -> 5.3 k frames/s): AUTO goes back to one pass and tries again later,
+            // with a longer pause every time.
+            if (ufrac > 0.3f) {
+                if (!forced && ++ctx->occ_strikes >= 3u) {
+                    ctx->occ_strikes = 0u;
+                    ctx->occ_off = ctx->occ_backoff;
+                    ctx->occ_backoff = std::min(ctx->occ_backoff * 2u, 16384u);
+                    return no();
+                }
+                next = std::min(kOccFracMax, ctx->occ_frac * 1.5f);
+            } else {
+                ctx->occ_strikes = 0u;
+                if (ratio > 0.6f) next = std::min(kOccFracMax, ctx->occ_frac * 1.25f);
+                else if (ratio < 0.15f) next = std::max(kOccFracMin, ctx->occ_frac * 0.85f);
+            }
+            if (next != ctx->occ_frac) {
+                ctx->occ_frac = next;
+                ctx->occ_change_seq = ctx->occ_seq + 1u;       // the first frame that runs with it
+            } else if (ufrac > 0.3f) {
+                ctx->occ_change_seq = ctx->occ_seq + 1u;       // (the share is at its maximum: count the next strike on a new frame)
+            }
+        }
+    }
+    ctx->occ_seq++;                              // this frame's number (never 0)
+    if (ctx->occ_seq == 0u) ctx->occ_seq = 1u;
+    ctx->occ_streak++;
+    frac = ctx->occ_frac;
+    return true;
+}
+
 static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, size_t pitch, bool async_overflow_flag,
                          void* d_out1 = nullptr)
 {
@@ -1537,6 +1623,14 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const int tset = (int)(ctx->render_sets % msplat_ctx::kEvSets);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][2], s));
     const int pgrid = std::max(1u, div_up(N, kProjThreads));
+    // Two-pass frame with occlusion feedback (msplat_occlusion.hip.h): the nearest R1 splats first, then only what the bins
+    // they did not saturate still need.  Same pixels; chosen per frame (occlusion_plan).
+    float occ_frac = 0.0f;
+    const bool two_pass = occlusion_plan(ctx, fp, stereo, occ_frac);
+    uint32_t* occ = (uint32_t*)ctx->occ.p;
+    if (two_pass)
+        hipLaunchKernelGGL(occ_plan_kernel, dim3(1), dim3(64), 0, s, (const uint32_t*)d_Vsort, occ_frac, occ);
+    const uint32_t* d_cut = two_pass ? occ : nullptr;
     if (ctx->point_mode)
         hipLaunchKernelGGL(point_project_kernel, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
                            (const float4*)ctx->pos4.p, (const float4*)ctx->recs.p, fp, ctx->sprite_params,
@@ -1544,12 +1638,16 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     else if (ctx->full_sh)
         hipLaunchKernelGGL(project_kernel<true>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_Vsort,
                            (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
-                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr, stereo ? d_V : nullptr);
+                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr, stereo ? d_V : nullptr, d_cut);
     else
         hipLaunchKernelGGL(project_kernel<false>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_Vsort,
                            (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
-                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr, stereo ? d_V : nullptr);
+                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr, stereo ? d_V : nullptr, d_cut);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][3], s));
+
+    // binning + compositor over the current rectangles: once per frame, twice for a two-pass frame
+    // (ev_bin / ev_c0 / ev_c1: the timing events of this chain; fin / binfin: see composite_kernel)
+    auto chain = [&](int keep_overflow, uint32_t* fin, const uint8_t* binfin, int ev_bin, int ev_c0, int ev_c1) -> int {
 
     // pass 1: stable partition by tile column, enumerated from the rank-ordered rectangles
     uint32_t* totals1 = (uint32_t*)ctx->totals1.p;
@@ -1585,7 +1683,8 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     do {                                                                                                                      \
         hipLaunchKernelGGL(bin1_upsweep<CH>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,               \
                            (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_overflow, fused1 ? gB1 : nullptr, gB2,               \
-                           ctx->gsumB2_rows, hv_cur, hv_next, (uint8_t*)ctx->heavy_flag.p, heavy_slots, ctx->gsupB1);         \
+                           ctx->gsumB2_rows, hv_cur, hv_next, (uint8_t*)ctx->heavy_flag.p, heavy_slots, ctx->gsupB1,          \
+                           keep_overflow);                                                                                    \
         if (!fused1)                                                                                                          \
             launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V, 0u, N, bchunk, totals1);     \
         if (ctx->atomic_rank)                                                                                                 \
@@ -1594,14 +1693,16 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                                (const uint32_t*)totals1, (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags,        \
                                async_overflow_flag ? 1 : 0, fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, \
                                xcdg, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,                               \
-                               (uint32_t)nhelp, fp.tiles_x, ctx->gsupB1, (const uint32_t*)d_Vsort);                           \
+                               (uint32_t)nhelp, fp.tiles_x, ctx->gsupB1, (const uint32_t*)d_Vsort,                            \
+                               (keep_overflow && ctx->d_flags) ? ctx->d_flags + 8 : (uint32_t*)nullptr, ctx->occ_seq);        \
         else                                                                                                                  \
             hipLaunchKernelGGL((bin1_downsweep<false, CH>), dim3(g1 + nhelp), dim3(kThreads), 0, s,                           \
                                (const uint32_t*)ctx->rect.p, d_V, (const uint32_t*)ctx->hist1.p, ctx->hist1_stride,           \
                                (const uint32_t*)totals1, (uint32_t*)ctx->pairsA.p, cap, d_D, d_overflow, ctx->d_flags,        \
                                async_overflow_flag ? 1 : 0, fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, \
                                xcdg, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,                               \
-                               (uint32_t)nhelp, fp.tiles_x, ctx->gsupB1, (const uint32_t*)d_Vsort);                           \
+                               (uint32_t)nhelp, fp.tiles_x, ctx->gsupB1, (const uint32_t*)d_Vsort,                            \
+                               (keep_overflow && ctx->d_flags) ? ctx->d_flags + 8 : (uint32_t*)nullptr, ctx->occ_seq);        \
     } while (0)
     // (bin1_upsweep also clears the row pass's group table: its consumer, the previous frame's row downsweep, is long done)
     MSPLAT_BIN1(kBinChunk);
@@ -1648,7 +1749,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
             hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)ctx->tile_start.p, ntiles,
                                (uint32_t*)ctx->tile_order.p, d_queue);
     }
-    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][4], s));
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][ev_bin], s));
 
     // persistent compositor: a fixed pool of waves pulls (bin, quadrant) items; never more waves than items
     const int cgrid = std::min(ntiles * 4, ctx->comp_waves);     // work items = (bin, quadrant) (the draw-order compositors)
@@ -1687,7 +1788,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     } else if (ntiles > 0) {
         // on sampled frames the dominant kernel gets exact dispatch begin/end events (the plain stream
         // markers around the stages can be processed while the previous kernel is still draining)
-        hipEvent_t e0 = timed ? ctx->ev[tset][6] : nullptr, e1 = timed ? ctx->ev[tset][7] : nullptr;
+        hipEvent_t e0 = timed ? ctx->ev[tset][ev_c0] : nullptr, e1 = timed ? ctx->ev[tset][ev_c1] : nullptr;
         uint32_t* probe = ctx->probe_on ? (uint32_t*)ctx->probe.p : nullptr;
         if (probe) HIP_TRY(ctx, hipMemsetAsync(probe, 0, (size_t)ntiles * 8 * kProbeWords * sizeof(uint32_t), s));
         const uint32_t* ts = (const uint32_t*)ctx->tile_start.p;
@@ -1702,17 +1803,55 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         const int grid = (int)std::min<uint32_t>(comp_items, comp_pool);
         if (f16)
             hipExtLaunchKernelGGL(composite_kernel<true>, dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
-                                  cap, ord, d_queue, comp_items, probe, prio_mode, d_out1);
+                                  cap, ord, d_queue, comp_items, probe, prio_mode, d_out1, fin, binfin);
         else
             hipExtLaunchKernelGGL(composite_kernel<false>, dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
-                                  cap, ord, d_queue, comp_items, probe, prio_mode, d_out1);
+                                  cap, ord, d_queue, comp_items, probe, prio_mode, d_out1, fin, binfin);
         ctx->comp_kernel_timed = timed;
     } else {
         ctx->comp_kernel_timed = false;
     }
+    return MSPLAT_OK;
+    };      // chain
+
+    int crc = chain(0, two_pass ? (uint32_t*)ctx->occ_fin.p : nullptr, nullptr, 4, 6, 7);
+    if (crc) return crc;
+    if (two_pass) {
+        if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][8], s));
+        hipLaunchKernelGGL(occ_mask_kernel, dim3(1), dim3(kThreads), 0, s, (const uint32_t*)ctx->occ_fin.p, fp.tiles_x, fp.tiles_y,
+                           (uint8_t*)ctx->occ_binfin.p, (uint16_t*)ctx->occ_mask.p, occ);
+        // spatially ordered cloud: whole boxes of 256 stored splats are dropped before any centre is fetched
+        const uint32_t nboxes = (ctx->store && ctx->store->reordered && ctx->store->boxes.p) ? ctx->store->nboxes : 0u;
+        const uint32_t boxwords = ((nboxes + (uint32_t)kThreads - 1u) / (uint32_t)kThreads) * ((uint32_t)kThreads / 32u);
+        const bool use_boxes = nboxes != 0u && boxwords <= 2048u && ctx->occ_boxdead.p != nullptr;
+        if (use_boxes)
+            hipLaunchKernelGGL(occ_box_kernel, dim3(div_up(nboxes, kThreads)), dim3(kThreads), 0, s, (const CullBox*)ctx->store->boxes.p,
+                               nboxes, fp, (const uint16_t*)ctx->occ_mask.p, (uint32_t*)ctx->occ_boxdead.p);
+        hipLaunchKernelGGL(occ_gate_kernel, dim3(std::max(1u, div_up(N, kOccGateRanks))), dim3(kThreads), 0, s, (const uint32_t*)ctx->valA.p,
+                           (const uint32_t*)d_Vsort, occ, (const float4*)ctx->pos4.p, (uint32_t*)ctx->rect.p, fp,
+                           (const uint16_t*)ctx->occ_mask.p, (uint32_t*)ctx->occ_live.p, ctx->d_flags, (const uint32_t*)d_D, ctx->occ_seq,
+                           use_boxes ? (const uint32_t*)ctx->occ_boxdead.p : (const uint32_t*)nullptr, boxwords);
+        // the listed ranks behind the cut (occ[1] of them)
+        if (ctx->full_sh)
+            hipLaunchKernelGGL(project_kernel<true>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, (const uint32_t*)(occ + 1),
+                               (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, (uint32_t*)nullptr,
+                               ctx->d_flags ? ctx->d_flags + 7 : (uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)ctx->occ_live.p);
+        else
+            hipLaunchKernelGGL(project_kernel<false>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, (const uint32_t*)(occ + 1),
+                               (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, (uint32_t*)nullptr,
+                               ctx->d_flags ? ctx->d_flags + 7 : (uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)ctx->occ_live.p);
+        if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][9], s));
+        const bool timed1 = ctx->comp_kernel_timed;
+        crc = chain(1, nullptr, (const uint8_t*)ctx->occ_binfin.p, 10, 11, 12);
+        if (crc) return crc;
+        ctx->comp_kernel_timed = ctx->comp_kernel_timed && timed1;
+        ctx->frames_two_pass++;
+    }
+    ctx->last_render_two_pass = two_pass;
     if (timed) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][5], s));
         if (ctx->comp_kernel_timed) ctx->comp_kernel_sets_mask |= 1u << tset; else ctx->comp_kernel_sets_mask &= ~(1u << tset);
+        if (two_pass) ctx->two_pass_sets_mask |= 1u << tset; else ctx->two_pass_sets_mask &= ~(1u << tset);
         ctx->render_sets++;
     }
     if (hipGetLastError() != hipSuccess) {
@@ -2046,15 +2185,24 @@ int msplat_get_timings(msplat_ctx* ctx, msplat_timings* out)
     const uint32_t nr = std::min<uint32_t>(ctx->render_sets, msplat_ctx::kEvSets);
     for (uint32_t k = 0; k < nr; ++k) {
         float a = 0, b = 0, c = 0, d = 0;
+        const bool two = (ctx->two_pass_sets_mask & (1u << k)) != 0u;     // a two-pass frame: every stage ran twice
         HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev[k][2], ctx->ev[k][5]));
         HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev[k][2], ctx->ev[k][3]));
         HIP_TRY(ctx, hipEventElapsedTime(&c, ctx->ev[k][3], ctx->ev[k][4]));
-        HIP_TRY(ctx, hipEventElapsedTime(&d, ctx->ev[k][4], ctx->ev[k][5]));
+        HIP_TRY(ctx, hipEventElapsedTime(&d, ctx->ev[k][4], ctx->ev[k][two ? 8 : 5]));
+        if (two) {
+            float b2 = 0, c2 = 0, d2 = 0;
+            HIP_TRY(ctx, hipEventElapsedTime(&b2, ctx->ev[k][8], ctx->ev[k][9]));      // mask + gate + second projection
+            HIP_TRY(ctx, hipEventElapsedTime(&c2, ctx->ev[k][9], ctx->ev[k][10]));
+            HIP_TRY(ctx, hipEventElapsedTime(&d2, ctx->ev[k][10], ctx->ev[k][5]));
+            b += b2; c += c2; d += d2;
+        }
         out->render_total += a / nr; out->project += b / nr; out->binning += c / nr; out->composite += d / nr;
         if (ctx->comp_kernel_sets_mask & (1u << k)) {
-            float e = 0;
+            float e = 0, e2 = 0;
             HIP_TRY(ctx, hipEventElapsedTime(&e, ctx->ev[k][6], ctx->ev[k][7]));
-            out->reserved[1] += e;       // summed here, averaged below
+            if (two) HIP_TRY(ctx, hipEventElapsedTime(&e2, ctx->ev[k][11], ctx->ev[k][12]));
+            out->reserved[1] += e + e2;  // summed here, averaged below
             out->reserved[2] += 1.0f;
         }
     }
@@ -2084,6 +2232,37 @@ int msplat_debug_get_projected(msplat_ctx* ctx, float* rec12, uint32_t* rect, ui
 // for the lane-ordered LDS-atomic ranking (probed at msplat_create, not documented hardware behaviour): call it in
 // debug builds or every few hundred frames; non-zero counts mean the context should be re-created with
 // MSPLAT_BALLOT_RANK=1.
+int msplat_debug_two_pass(msplat_ctx* ctx, float share, uint64_t* two_pass_frames, float* share_now)
+{
+    drain_async(ctx);
+    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
+    if (!(share >= 0.0f && share <= 1.0f)) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_debug_two_pass: share %g not in [0, 1]", (double)share);
+    ctx->occ_pinned = share > 0.0f;
+    if (ctx->occ_pinned) ctx->occ_frac = share;
+    if (two_pass_frames) *two_pass_frames = ctx->frames_two_pass;
+    if (share_now) *share_now = ctx->occ_frac;
+    return MSPLAT_OK;
+}
+
+int msplat_get_two_pass_info(msplat_ctx* ctx, uint64_t out[8])
+{
+    drain_async(ctx);
+    if (!ctx || !out) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    out[0] = ctx->frames_two_pass;
+    if (!ctx->last_render_two_pass || !ctx->h_flags) { out[0] = ctx->last_render_two_pass ? out[0] : 0; return MSPLAT_OK; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    out[1] = __atomic_load_n(ctx->h_flags + 6, __ATOMIC_RELAXED);
+    out[2] = __atomic_load_n(ctx->h_flags + 7, __ATOMIC_RELAXED);
+    out[3] = __atomic_load_n(ctx->h_flags + 4, __ATOMIC_RELAXED);
+    out[4] = __atomic_load_n(ctx->h_flags + 8, __ATOMIC_RELAXED);
+    out[5] = __atomic_load_n(ctx->h_flags + 5, __ATOMIC_RELAXED);
+    out[6] = (uint64_t)ctx->last_fp.tiles_x * (uint64_t)ctx->last_fp.tiles_y;
+    out[7] = __atomic_load_n(ctx->h_flags + 1, __ATOMIC_RELAXED);
+    return MSPLAT_OK;
+}
+
 int msplat_debug_verify_order(msplat_ctx* ctx, uint32_t* key_violations, uint32_t* list_violations)
 {
     drain_async(ctx);

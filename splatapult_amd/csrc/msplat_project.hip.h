@@ -42,8 +42,13 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
                                                                FrameParams fp,
                                                                float4* __restrict__ out_rec,
                                                                uint32_t* __restrict__ out_rect,
-                                                               uint32_t* __restrict__ out_zq, uint32_t* __restrict__ d_Veff = nullptr)
+                                                               uint32_t* __restrict__ out_zq, uint32_t* __restrict__ d_Veff = nullptr,
+                                                               const uint32_t* __restrict__ d_cut = nullptr,
+                                                               const uint32_t* __restrict__ rank_list = nullptr)
 {
+    // Two-pass frame (msplat_occlusion.hip.h).  d_cut: pass 1 -- ranks below *d_cut (a multiple of 64) only get an empty
+    // rectangle, their records are not fetched.  rank_list: pass 2 -- the *d_V ranks to project are listed (any order); records
+    // and rectangles are stored by rank as always.
     // Records are 256 B (full SH) or 128 B (base) and line aligned.  The gather by sorted index is
     // done cooperatively: F4 consecutive lanes fetch one whole record (coalesced 256/128 B), the wave
     // stages 64 records in LDS, then every lane reads its own record back (stride 68/36 dwords keeps
@@ -59,11 +64,19 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
     const uint32_t total = fp.views == 2 ? V1 + V : V;
     if (d_Veff != nullptr && blockIdx.x == 0 && lane == 0) *d_Veff = total;       // what the binning passes walk
     if (blockIdx.x * kProjThreads >= total) return;
-    const uint32_t r = blockIdx.x * kProjThreads + lane;
+    uint32_t r = blockIdx.x * kProjThreads + lane;
     const bool second = fp.views == 2 && blockIdx.x * kProjThreads >= V1;         // wave-uniform
-    const uint32_t rl = second ? r - V1 : r;                                       // rank inside the view
+    uint32_t rl = second ? r - V1 : r;                                             // rank inside the view
     const bool valid = rl < V;
-    if (!valid && r < total) out_rect[r] = kRectEmpty;                             // (the gap between the views, and nothing else)
+    if (rank_list != nullptr) {                                                    // (one view; slot -> rank)
+        r = rl = valid ? rank_list[r] : 0u;
+    } else {
+        if (!valid && r < total) out_rect[r] = kRectEmpty;                         // (the gap between the views, and nothing else)
+        if (d_cut != nullptr && blockIdx.x * kProjThreads < *d_cut) {              // wave-uniform: behind the cut of pass 1
+            if (valid) out_rect[r] = kRectEmpty;
+            return;
+        }
+    }
     const uint32_t i = valid ? sorted_idx[rl] : 0u;
     {
         const int sub = lane % F4;

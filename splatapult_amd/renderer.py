@@ -45,7 +45,7 @@ class _FrameArgs:
 class SplatRenderer:
     def __init__(self, device=0, fb_format="fp32", t_epsilon=-1.0, pair_capacity=0, stream=None,
                  enable_timing=False, frames_in_flight=1, rank_mode=_capi.RANK_AUTO, frame_mode=None,
-                 spatial_order=_capi.SPATIAL_AUTO, async_submit=None):
+                 spatial_order=_capi.SPATIAL_AUTO, async_submit=None, two_pass=_capi.TWO_PASS_AUTO):
         """frames_in_flight > 1: every Sort moves on to the next of that many contexts (own stream and
         per-frame buffers, ONE shared cloud -- msplat_attach_cloud), so successive frames overlap on the
         GPU; Render and the getters use the context of the latest Sort.  `stream` is only used with depth 1;
@@ -68,6 +68,8 @@ class SplatRenderer:
         # msplat_config.async_submit: Sort / device-output Render are queued to a worker thread of their context (default: on
         # with frames in flight -- the frames' launches are then issued concurrently instead of one context after the other)
         self._async = (self._depth > 1) if async_submit is None else bool(async_submit)
+        # msplat_config.two_pass: may a Render run as two passes with occlusion feedback (same pixels, less work)?
+        self._two_pass = int(two_pass)
         # msplat_config.frame_mode: kernels for one frame at a time, or for contexts that share the GPU with other frames in
         # flight (msplat.h, MSPLAT_FRAMES_*)
         self._frame_mode = int(frame_mode) if frame_mode is not None else (_capi.FRAMES_IN_FLIGHT if self._depth > 1 else _capi.FRAMES_AUTO)
@@ -119,6 +121,7 @@ class SplatRenderer:
         cfg.frame_mode = self._frame_mode
         cfg.spatial_order = self._spatial
         cfg.async_submit = 1 if self._async else 0
+        cfg.two_pass = self._two_pass
         for k in range(self._depth):
             if isinstance(self._stream, (list, tuple)):       # one caller-owned stream per frame in flight
                 cfg.stream = self._stream[k]
@@ -344,6 +347,27 @@ class SplatRenderer:
         w = _capi.CompositeWork()
         _capi.check(self._ctx, self._lib.msplat_get_composite_work(self._ctx, C.byref(w)))
         return {k: int(getattr(w, k)) for k, _ in _capi.CompositeWork._fields_}
+
+    def two_pass_state(self, share=0.0):
+        """(two-pass Renders so far, share of the visible splats the next one puts into its first pass) summed / taken over the
+        contexts; share > 0 pins the share (msplat_debug_two_pass), 0 leaves it to the feedback loop"""
+        frames, now = 0, 0.0
+        for h in self._ctxs:
+            a, b = C.c_uint64(), C.c_float()
+            _capi.check(h, self._lib.msplat_debug_two_pass(h, float(share), C.byref(a), C.byref(b)))
+            frames += a.value
+            now = b.value
+        return frames, now
+
+    def two_pass_info(self):
+        """what the latest two-pass Render of the current context did (msplat_get_two_pass_info), None if its latest Render ran in
+        one pass"""
+        out = (C.c_uint64 * 8)()
+        _capi.check(self._ctx, self._lib.msplat_get_two_pass_info(self._ctx, out))
+        if out[0] == 0:
+            return None
+        keys = ("frames", "splats_pass1", "splats_pass2", "pairs_pass1", "pairs_pass2", "bins_unfinished", "bins", "visible")
+        return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def verify_order(self):
         """on-device self-check: (violations of the sorted-key / tie order, violations of the bin-list order); (0, 0) = healthy"""

@@ -37,7 +37,8 @@ def test_signatures_are_plain_c_no_framework_types():
 def test_version_and_struct_sizes():
     L = _capi.lib()
     assert b"msplat" in L.msplat_version_string()
-    assert C.sizeof(_capi.Config) == 64 and _capi.Config.rank_mode.offset == 48 and _capi.Config.spatial_order.offset == 56
+    assert C.sizeof(_capi.Config) == 72 and _capi.Config.rank_mode.offset == 48 and _capi.Config.spatial_order.offset == 56
+    assert _capi.Config.two_pass.offset == 64
     assert C.sizeof(_capi.AttrOffsets) == 64
     assert C.sizeof(_capi.Stats) == 64 and C.sizeof(_capi.Timings) == 32
 
@@ -79,12 +80,22 @@ def test_bad_arguments_are_rejected_without_a_context():
     assert rc in (_capi.OK, _capi.ERR_NO_DEVICE)
     if rc == _capi.OK:
         L.msplat_destroy(h)
-    # ... a shorter size, a larger one, an unknown rank_mode or spatial_order are not
-    for size, mode, spatial in ((44, 0, 0), (72, 0, 0), (C.sizeof(_capi.Config), 7, 0), (C.sizeof(_capi.Config), 0, 3)):
+    # ... and the struct of the first r4 builds, which ended before two_pass
+    cfg = _capi.Config()
+    cfg.struct_size = 64
+    cfg.t_epsilon = -1.0
+    rc = L.msplat_create(C.byref(h), C.byref(cfg))
+    assert rc in (_capi.OK, _capi.ERR_NO_DEVICE)
+    if rc == _capi.OK:
+        L.msplat_destroy(h)
+    # ... a shorter size, a larger one, an unknown rank_mode, spatial_order or two_pass are not
+    for size, mode, spatial, two in ((44, 0, 0, 0), (80, 0, 0, 0), (C.sizeof(_capi.Config), 7, 0, 0), (C.sizeof(_capi.Config), 0, 3, 0),
+                                     (C.sizeof(_capi.Config), 0, 0, 3)):
         cfg = _capi.Config()
         cfg.struct_size = size
         cfg.rank_mode = mode
         cfg.spatial_order = spatial
+        cfg.two_pass = two
         h = C.c_void_p()
         assert L.msplat_create(C.byref(h), C.byref(cfg)) == _capi.ERR_INVALID_ARG and not h.value
     assert L.msplat_sort(None, None, None, None, None) == _capi.ERR_INVALID_ARG

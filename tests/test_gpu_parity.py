@@ -1742,3 +1742,85 @@ def test_render_stereo_is_bit_identical_to_two_renders(fb):
     rows = np.arange(H) // bin_px() % 2 == 1
     for e in range(2):
         np.testing.assert_array_equal(fb2[e][:H].cpu().numpy()[rows], ref[e][rows])
+
+
+# ---- two-pass frames with occlusion feedback (msplat_config.two_pass, r4) ----
+def _two_pass_pair(cloud, **kw):
+    from splatapult_amd import _capi
+    a = make_renderer(cloud, two_pass=_capi.TWO_PASS_OFF, **kw)
+    b = make_renderer(cloud, two_pass=_capi.TWO_PASS_ON, **kw)
+    return a, b
+
+
+@pytest.mark.parametrize("share", [1.0 / 64.0, 0.1, 0.3, 0.75, 1.0])
+def test_two_pass_frames_are_bit_identical_to_single_pass(share):
+    """any share of the visible splats in the first pass gives the pixels of the single pass, bit for bit: a dense cloud seen from
+    outside (most tiles saturate), the same from inside (near splats cover the screen), a sparse one (hardly any tile saturates:
+    pass 2 redoes nearly everything), a ragged viewport"""
+    cases = [(scenes.synth_cloud(120000, 301, log_scale_mean=-2.6), dict(z=5.0, yaw=0.3), 640, 360),
+             (scenes.synth_cloud(120000, 301, log_scale_mean=-2.6), dict(z=0.8, yaw=2.0), 640, 360),
+             (scenes.synth_cloud(20000, 302, log_scale_mean=-4.2), dict(z=7.0, yaw=0.0), 517, 293),
+             (scenes.cloud_from_attrs(scenes.hard_attrs(6000, 17)), dict(z=6.0, yaw=0.7), 400, 300)]
+    frames = 0
+    for cloud, view, W, H in cases:
+        a, b = _two_pass_pair(cloud)
+        b.two_pass_state(share)
+        for k in range(3):
+            cam, proj, vp, nf = scenes.default_view(W, H, z=view["z"], yaw=view["yaw"] + 0.4 * k)
+            a.Sort(cam, proj, vp, nf); b.Sort(cam, proj, vp, nf)
+            ia, ib = a.Render(cam, proj, vp, nf), b.Render(cam, proj, vp, nf)
+            np.testing.assert_array_equal(ia, ib)
+            assert a.sort_count() == b.sort_count()
+            frames += 1
+        assert b.two_pass_state(share)[0] == 3 and a.two_pass_state()[0] == 0
+        assert b.verify_order() == (0, 0)
+    assert frames == 12
+
+
+def test_two_pass_with_bands_fp16_frames_in_flight_and_the_feedback_loop():
+    """the same identity for a rank of a row-sharded frame (block layout, band-culled sort: virtual rows in the mask), the fp16
+    target, device output with four frames in flight, and with the share left to the feedback loop over a moving camera"""
+    import torch
+    from splatapult_amd import _capi
+    cloud = scenes.synth_cloud(150000, 303, log_scale_mean=-2.8)
+    W, H = 800, 448
+    tiles_y = (H + bin_px() - 1) // bin_px()
+    for g in range(3):
+        a, b = _two_pass_pair(cloud)
+        for r in (a, b):
+            r.set_band_plan("block", tiles_y, 3, g, block_rows=2, band_cull=True)
+        b.two_pass_state(0.2)
+        for k in range(2):
+            cam, proj, vp, nf = scenes.default_view(W, H, z=4.0, yaw=0.5 + k)
+            a.Sort(cam, proj, vp, nf); b.Sort(cam, proj, vp, nf)
+            np.testing.assert_array_equal(a.Render(cam, proj, vp, nf), b.Render(cam, proj, vp, nf))
+        assert b.two_pass_state(0.2)[0] == 2
+    a, b = _two_pass_pair(cloud, fb_format="fp16")
+    cam, proj, vp, nf = scenes.default_view(W, H, z=4.0, yaw=0.2)
+    a.Sort(cam, proj, vp, nf); b.Sort(cam, proj, vp, nf)
+    np.testing.assert_array_equal(a.Render(cam, proj, vp, nf), b.Render(cam, proj, vp, nf))
+    # four frames in flight, the share steered by the feedback of earlier frames
+    dev = torch.device("cuda", 0)
+    Hpad = tiles_y * bin_px()
+    a, b = _two_pass_pair(cloud, frames_in_flight=4)
+    n = 48
+    fa = [torch.zeros((Hpad, W, 4), dtype=torch.float32, device=dev) for _ in range(n)]
+    fb = [torch.zeros((Hpad, W, 4), dtype=torch.float32, device=dev) for _ in range(n)]
+    for k in range(n):
+        cam, proj, vp, nf = scenes.default_view(W, H, z=4.0 - 0.05 * k, yaw=0.05 * k)
+        for r, f in ((a, fa), (b, fb)):
+            r.Sort(cam, proj, vp, nf)
+            r.Render(cam, proj, vp, nf, out_ptr=f[k].data_ptr(), pitch_bytes=W * 16)
+    a.synchronize(); b.synchronize()
+    for k in range(n):
+        assert torch.equal(fa[k], fb[k]), k
+    frames, share = b.two_pass_state()
+    assert frames == n and 1.0 / 256.0 <= share <= 0.75
+    print("two-pass frames in flight: share of the visible splats in pass 1 after %d frames: %.3f" % (n, share))
+    # AUTO: off for a small cloud and during a context's first frames
+    c = make_renderer(cloud)
+    for k in range(12):
+        cam, proj, vp, nf = scenes.default_view(W, H, z=4.0, yaw=0.1 * k)
+        c.Sort(cam, proj, vp, nf)
+        c.Render(cam, proj, vp, nf)
+    assert c.two_pass_state()[0] == 0                       # 150 k splats: below the AUTO size

@@ -30,8 +30,10 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
                                                          uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_rows,
                                                          uint32_t* __restrict__ heavy, uint32_t* __restrict__ heavy_next,
                                                          uint8_t* __restrict__ heavy_flag, uint32_t heavy_slots, uint32_t gsup,
-                                                         int keep_overflow = 0)
+                                                         int keep_overflow = 0, const uint32_t* __restrict__ d_first = nullptr)
 {
+    // d_first (pass 1 of a two-pass frame): the chunks start at rank *d_first (a multiple of BIN_CHUNK): the ranks below it have
+    // empty rectangles and are not walked
     // keep_overflow: second binning chain of a two-pass frame -- the first chain's overflow verdict stays
     // Heavy chunks (r3).  The ranks are in depth order, so the huge far-away splats of a real scene (sky, background) are the
     // FIRST ranks: a few chunks hold half of all the pairs (scene-like 6 M cloud: 25 of 2344 chunks, 500 k pairs each against
@@ -48,17 +50,18 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
     __shared__ uint32_t s_diff[kThreads + 1];
     __shared__ uint32_t s_tmp[4];
     const uint32_t V = *d_V;
-    const uint32_t nchunks = (V + BIN_CHUNK - 1) / BIN_CHUNK;
+    const uint32_t first = d_first != nullptr ? min(*d_first, V) : 0u;
+    const uint32_t nchunks = (V - first + BIN_CHUNK - 1) / BIN_CHUNK;
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         s_diff[threadIdx.x] = 0;
         if (threadIdx.x == 0) s_diff[kThreads] = 0;
         __syncthreads();
         uint32_t rcs[BIN_CHUNK / kThreads];          // clamped loads, all in flight together (V >= 1 here)
 #pragma unroll
-        for (int k = 0; k < BIN_CHUNK / kThreads; ++k) rcs[k] = rect[min(chunk * BIN_CHUNK + k * kThreads + threadIdx.x, V - 1u)];
+        for (int k = 0; k < BIN_CHUNK / kThreads; ++k) rcs[k] = rect[min(first + chunk * BIN_CHUNK + k * kThreads + threadIdx.x, V - 1u)];
 #pragma unroll
         for (int k = 0; k < BIN_CHUNK / kThreads; ++k) {
-            const uint32_t r = chunk * BIN_CHUNK + k * kThreads + threadIdx.x;
+            const uint32_t r = first + chunk * BIN_CHUNK + k * kThreads + threadIdx.x;
             if (r < V) {
                 const uint32_t rc = rcs[k];
                 const uint32_t tx0 = rc & 255u, ty0 = (rc >> 8) & 255u, tx1 = (rc >> 16) & 255u, ty1 = rc >> 24;
@@ -117,8 +120,10 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && BIN_CHUNK == kBinChunk) ?
                                                            const uint32_t* __restrict__ heavy,
                                                            const uint8_t* __restrict__ heavy_flag, uint32_t nhelp, int tiles_x,
                                                            uint32_t gsup, const uint32_t* __restrict__ d_V_report = nullptr,
-                                                           uint32_t* __restrict__ host_D2 = nullptr, uint32_t seq = 0u)
+                                                           uint32_t* __restrict__ host_D2 = nullptr, uint32_t seq = 0u,
+                                                           const uint32_t* __restrict__ d_first = nullptr)
 {
+    // d_first: see bin1_upsweep
     // host_D2 (host-mapped): second binning chain of a two-pass frame -- its pair count, for the host's choice of the next share
     // d_V_report: the Sort's own V for the host-mapped hint (with two views in one chain d_V counts the ranks of both)
     // The first nhelp workgroups are helpers for the heavy chunks (bin1_upsweep; first, so that they start with the launch):
@@ -141,7 +146,8 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && BIN_CHUNK == kBinChunk) ?
     __shared__ __attribute__((aligned(16))) uint16_t s_owner[kOwnerCap];
     uint4* s_part = reinterpret_cast<uint4*>(s_owner);      // 16 KB, not live while the row sums run
     const uint32_t V = *d_V;
-    const uint32_t nchunks = (V + BIN_CHUNK - 1) / BIN_CHUNK;
+    const uint32_t first = d_first != nullptr ? min(*d_first, V) : 0u;
+    const uint32_t nchunks = (V - first + BIN_CHUNK - 1) / BIN_CHUNK;
     const bool helper = blockIdx.x < nhelp;
     const uint32_t nmain = gridDim.x - nhelp, mb = blockIdx.x - nhelp;       // main workgroups / this one's index among them
     const int lane = threadIdx.x & 63;
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && BIN_CHUNK == kBinChunk) ?
             c_hi = c_lo + cpp - 1u;
         }
         const uint32_t chunk_pre = (gsum != nullptr) ? group_prefix(hist, gsum, chunk, s_part, gsup) : hist[(size_t)chunk * 256 + threadIdx.x];
-        const uint32_t rbase = chunk * BIN_CHUNK;
+        const uint32_t rbase = first + chunk * BIN_CHUNK;
         uint32_t rc[PER], woff[PER], wsum = 0;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {

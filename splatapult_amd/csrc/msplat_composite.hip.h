@@ -111,13 +111,19 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
                                                                  uint32_t* __restrict__ queue, uint32_t ntiles,
                                                                  uint32_t* __restrict__ probe, int prio_levels,
                                                                  void* __restrict__ out1 = nullptr,
-                                                                 uint32_t* __restrict__ fin = nullptr,
-                                                                 const uint8_t* __restrict__ binfin = nullptr)
+                                                                 uint32_t* __restrict__ fin = nullptr, int occ_pass = 0,
+                                                                 float4* __restrict__ state = nullptr,
+                                                                 const uint32_t* __restrict__ d_nbins = nullptr)
 {
+    // d_nbins (pass 2 of a two-pass frame): `order` lists *d_nbins bins -- the unfinished ones -- and the items are theirs alone
+    if (d_nbins != nullptr) ntiles = *d_nbins * 4u;
     // out1: the second view's target (FrameParams.views == 2: bin rows >= rows_view belong to it)
-    // Two-pass frame (msplat_occlusion.hip.h).  fin (pass 1): fin[bin * 4 + quadrant] = 1 when the item's walk ended because
-    // every strip was saturated (or the item has no pixels), 0 when it ended with its list.  binfin (pass 2): items of
-    // finished bins are skipped -- their pixels are final.
+    // Two-pass frame (msplat_occlusion.hip.h), occ_pass 1 / 2; fin[bin * 4 + quadrant] and state[y * width + x] = (r, g, b, 2^118 T)
+    // carry a tile from one to the other.  Pass 1 walks WHOLE batches only: a tile whose strips are all saturated after one of
+    // them is final (fin = 0xFFFFFFFF, pixels written); otherwise it stops in front of the first incomplete batch, leaves its
+    // accumulators in `state` and the number of entries it composited in fin.  Pass 2 skips the final tiles and RESUMES the others
+    // at that entry of their complete list.  Batches count from the list's end and pass 1's list is a suffix of the complete one,
+    // so the walk is cut at a batch boundary of the single pass: same batches, same strip tests between them, same pixels.
     // Lane (lx, ly) owns pixels (x0+lx, y0 + 4k + ly), k = 0..3: strip k is the 16x4 pixel block of
     // rows 4k..4k+3.  Per splat the exponent is split into a part shared by the four strips and a
     // 2-FMA part per strip; strips the splat's y-range cannot reach, or whose 64 pixels are all
@@ -157,9 +163,9 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
     const int tx = (bin - bvy * fp.tiles_x) * 2 + (quad & 1);
     const bool second = fp.views == 2 && bvy >= fp.rows_view;
     const int ty = (second ? bvy - fp.rows_view : band_real_row(fp, bvy)) * 2 + (quad >> 1);
-    if (tx * kTile >= fp.width || ty * kTile >= fp.height || (binfin != nullptr && binfin[bin] != 0)) {
-        // work item entirely outside the image, or (pass 2 of a two-pass frame) its bin was finished by pass 1
-        if (fin != nullptr && threadIdx.x == 0) fin[bin * 4 + quad] = 1u;
+    if (tx * kTile >= fp.width || ty * kTile >= fp.height || (occ_pass == 2 && fin[bin * 4 + quad] == 0xFFFFFFFFu)) {
+        // work item entirely outside the image, or (pass 2 of a two-pass frame) the tile was finished by pass 1
+        if (occ_pass == 1 && threadIdx.x == 0) fin[bin * 4 + quad] = 0xFFFFFFFFu;
         if (gridDim.x >= ntiles) break;
         uint32_t nq = 0;
         if (threadIdx.x == 0) nq = queue_next(queue, ntiles);
@@ -189,6 +195,7 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
     uint32_t start = tile_start[bin], end = tile_start[bin + 1];
     if (start > cap) start = cap;
     if (end > cap) end = cap;
+    if (occ_pass == 2) end -= min(fin[bin * 4 + quad], end - start);       // resume: the entries pass 1 composited are the list's last
 
     // Accumulators are kept as strip PAIRS (0,1) and (2,3): gfx950 executes a plain wave64 fp32 VALU
     // op in ~4 cycles but a packed v_pk_{fma,mul,add}_f32 does two per lane in the same slot (measured:
@@ -203,6 +210,15 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
     }
 #pragma unroll
     for (int k = 0; k < NS; ++k) inside[k] = (x < fp.width) && (ybase + 4 * k < fp.height);
+    if (occ_pass == 2) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (inside[k]) {
+                const float4 st = state[(size_t)(ybase + 4 * k) * fp.width + x];
+                cr[k >> 1][k & 1] = st.x; cg[k >> 1][k & 1] = st.y; cb[k >> 1][k & 1] = st.z; T[k >> 1][k & 1] = st.w;
+            }
+        }
+    }
     // The exponent is evaluated as a polynomial in TILE-CENTRED pixel coordinates (|u|, |v| <= 7.5: no cancellation
     // trouble): e(u, v) = c0 + c1 u + c2 v + c3 u^2 + c4 u v + c5 v^2, coefficients per staged record.  Per record and lane
     // that is 3 scalar FMAs for the u part plus 2 packed FMAs per strip pair -- the centre-relative form (dx, dy, base,
@@ -214,7 +230,8 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
     for (int h = 0; h < NP; ++h) vp[h] = (v2f){fy0 + 8.0f * h - yc, fy0 + 8.0f * h + 4.0f - yc};
     uint32_t alive = 0;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) alive |= (__ballot(inside[k]) != 0ull) ? (1u << k) : 0u;
+    for (int k = 0; k < NS; ++k)
+        alive |= (__ballot(inside[k] && (occ_pass != 2 || T[k >> 1][k & 1] >= fp.t_eps * kScale)) != 0ull) ? (1u << k) : 0u;
 
     // Three-stage software pipeline over batches of 64 list entries (nearest first):
     //   ranks of batch b+2 and records of batch b+1 are in flight while batch b is composited,
@@ -244,9 +261,9 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
     uint64_t probe_inner = 0;
     // pair words / records whose loads have been issued so far (the prefetch pipeline runs two / one batches ahead)
     uint32_t probe_words = min(end - start, 2u * (uint32_t)kCompThreads), probe_recs = cnt;
-    uint32_t last_cnt = (uint32_t)kCompThreads;       // entries of the batch composited last (a walk that never starts counts as full)
-    while (cnt != 0u && alive != 0u) {
-        last_cnt = cnt;
+    uint32_t consumed = 0;                            // (pass 1) entries composited: whole batches
+    while (cnt != 0u && alive != 0u && !(occ_pass == 1 && cnt < (uint32_t)kCompThreads)) {
+        consumed += cnt;
         // stage: every lane turns its list entry into the coefficients of e(u, v) in tile-centred coordinates and tests
         // it against the tile; the survivors are compacted into LDS in list order (near to far).  Straight-line code on
         // purpose: the CU has ONE scalar unit for its four SIMDs and this is the dependent chain between two batches --
@@ -362,11 +379,9 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
         __syncthreads();
     }
 
-    // (pass 1 of a two-pass frame) final?  The walk must have ended because every strip was saturated, and the batch that
-    // saturated it must have been a FULL one: the strips are only tested between batches, so the single pass composites all 64
-    // entries of that batch -- batches count from the list's end, and a short last batch of the truncated list would be a longer
-    // one there.
-    if (fin != nullptr && lane == 0) fin[bin * 4 + quad] = (alive == 0u && last_cnt == (uint32_t)kCompThreads) ? 1u : 0u;
+    // (pass 1 of a two-pass frame) final, or to be resumed by pass 2?
+    const bool carry = occ_pass == 1 && alive != 0u;
+    if (occ_pass == 1 && lane == 0) fin[bin * 4 + quad] = carry ? consumed : 0xFFFFFFFFu;
     if (probe != nullptr && lane == 0) {
         probe[tile * 8 + 0] = (uint32_t)(clock64() - probe_t0);        // shader clocks, whole tile
         probe[tile * 8 + 1] = probe_n;          // splats composited (after culling / saturation)
@@ -377,9 +392,15 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
         probe[tile * 8 + 6] = end - start;      // length of the bin list
         probe[tile * 8 + 7] = 1u;               // work item ran
     }
+    if (carry) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+            if (inside[k])
+                state[(size_t)(ybase + 4 * k) * fp.width + x] = make_float4(cr[k >> 1][k & 1], cg[k >> 1][k & 1], cb[k >> 1][k & 1], T[k >> 1][k & 1]);
+    }
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-        if (inside[k]) {
+        if (inside[k] && !carry) {
             char* row = (char*)(second ? out1 : out) + (size_t)(ybase + 4 * k) * pitch_bytes;
             if (F16) {
                 union { _Float16 h[4]; uint2 u; } pk;

@@ -213,7 +213,7 @@ struct msplat_ctx {
     uint32_t comp_kernel_sets_mask = 0;
     uint32_t two_pass_sets_mask = 0;         // timing sets recorded by two-pass frames
     // two-pass frame with occlusion feedback (msplat_occlusion.hip.h)
-    Buf occ, occ_mask, occ_fin, occ_binfin, occ_live, occ_boxdead;
+    Buf occ, occ_mask, occ_fin, occ_state, occ_live, occ_boxdead, occ_unf;
     int two_pass_mode = MSPLAT_TWO_PASS_AUTO;
     float occ_frac = 0.25f;                  // share of the visible splats that goes into pass 1
     uint32_t occ_streak = 0;                 // consecutive two-pass frames submitted (their feedback describes two-pass frames)
@@ -490,7 +490,7 @@ void msplat_destroy(msplat_ctx* ctx)
     Buf* all[] = {&ctx->keyA, &ctx->keyB, &ctx->valA, &ctx->valB, &ctx->hist, &ctx->gsumS[0], &ctx->gsumS[1], &ctx->gsumB1, &ctx->gsumB2,
                   &ctx->totals, &ctx->counters, &ctx->rec2d, &ctx->rect, &ctx->totals1, &ctx->tile_start, &ctx->tile_order,
                   &ctx->hist1, &ctx->pairsA, &ctx->pairsB, &ctx->hist2, &ctx->fb, &ctx->probe, &ctx->zq, &ctx->sprite, &ctx->queue, &ctx->occ, &ctx->occ_mask, &ctx->occ_fin,
-                  &ctx->occ_binfin, &ctx->occ_live, &ctx->occ_boxdead,
+                  &ctx->occ_state, &ctx->occ_live, &ctx->occ_boxdead, &ctx->occ_unf,
                   &ctx->wsHist, &ctx->wsGsum[0], &ctx->wsGsum[1], &ctx->wsGsum[2], &ctx->vmask, &ctx->bincnt, &ctx->heavy, &ctx->heavy_flag,
                   &ctx->live_list, &ctx->live_cnt};
     for (Buf* b : all) buf_free(ctx, *b);
@@ -1540,6 +1540,7 @@ static int sort_impl(msplat_ctx* ctx, const float cameraMat[16], const float pro
 // side only: reads what EARLIER frames of this context left in host-mapped memory (never waits); any answer gives the same
 // pixels.  Feedback of a two-pass frame: [4] pairs of pass 1, [8] pairs of pass 2, [5] unfinished bins.
 constexpr uint64_t kTwoPassMinSplats = 1u << 18;
+constexpr int kProjGridTwoPass = 4096;       // one-wave workgroups of the grid-stride forms of project_kernel (9 fit a CU)
 constexpr float kOccFracMin = 1.0f / 256.0f, kOccFracMax = 0.75f;
 static bool occlusion_plan(msplat_ctx* ctx, const FrameParams& fp, bool stereo, float& frac)
 {
@@ -1547,6 +1548,7 @@ static bool occlusion_plan(msplat_ctx* ctx, const FrameParams& fp, bool stereo, 
     auto no = [&]() { ctx->occ_streak = 0; return false; };
     if (ctx->two_pass_mode == MSPLAT_TWO_PASS_OFF) return no();
     if (stereo || ctx->point_mode || ctx->depth_bits != 0 || ctx->rop != 0 || ctx->probe_on) return no();
+    if (!ctx->scan_free) return no();            // (the chunk offset of pass 1's column pass exists in the scan-free form only)
     if (fp.tiles_x * fp.tiles_y <= 0 || (fp.tiles_x + 1) * (fp.tiles_y + 1) > kOccSatMax) return no();      // (the table of unfinished bins)
     const bool forced = ctx->two_pass_mode == MSPLAT_TWO_PASS_ON;
     if (!forced) {
@@ -1558,8 +1560,8 @@ static bool occlusion_plan(msplat_ctx* ctx, const FrameParams& fp, bool stereo, 
     }
     const size_t nbins = (size_t)fp.tiles_x * fp.tiles_y;
     if (buf_alloc(ctx, ctx->occ, 64) || buf_alloc(ctx, ctx->occ_mask, (size_t)kOccSatMax * 2 + 64) ||
-        buf_alloc(ctx, ctx->occ_fin, nbins * 16 + 64) || buf_alloc(ctx, ctx->occ_binfin, nbins + 64) ||
-        buf_alloc(ctx, ctx->occ_live, ((size_t)ctx->N + 64) * 4) || buf_alloc(ctx, ctx->occ_boxdead, 2048 * 4 + 64)) {
+        buf_alloc(ctx, ctx->occ_fin, nbins * 16 + 64) || buf_alloc(ctx, ctx->occ_state, (size_t)fp.width * fp.height * 16 + 64) ||
+        buf_alloc(ctx, ctx->occ_live, ((size_t)ctx->N + 64) * 4) || buf_alloc(ctx, ctx->occ_boxdead, 2048 * 4 + 64) || buf_alloc(ctx, ctx->occ_unf, nbins * 4 + 64)) {
         ctx->err.clear();                        // (no memory for the extra buffers: the frame runs in one pass)
         return no();
     }
@@ -1615,7 +1617,8 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const uint32_t N = stereo ? (uint32_t)(2 * ctx->N + 64) : (uint32_t)ctx->N;
     uint32_t* counters = (uint32_t*)ctx->counters.p;
     uint32_t *d_Vsort = counters + 0, *d_D = counters + 1, *d_overflow = counters + 2, *d_queue = (uint32_t*)ctx->queue.p;
-    uint32_t* d_V = stereo ? counters + 9 : d_Vsort;       // ranks the binning walks (written by project_kernel for two views)
+    uint32_t* d_Vframe = stereo ? counters + 9 : d_Vsort;  // ranks the binning walks (written by project_kernel for two views)
+    uint32_t* d_V = d_Vframe;
     const int ntiles = fp.tiles_x * fp.tiles_y;
     const uint32_t cap = (uint32_t)ctx->pair_cap;
 
@@ -1636,18 +1639,25 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                            (const float4*)ctx->pos4.p, (const float4*)ctx->recs.p, fp, ctx->sprite_params,
                            (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr);
     else if (ctx->full_sh)
-        hipLaunchKernelGGL(project_kernel<true>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_Vsort,
+        hipLaunchKernelGGL(project_kernel<true>, dim3(two_pass ? std::min(pgrid, kProjGridTwoPass) : pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_Vsort,
                            (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
                            ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr, stereo ? d_V : nullptr, d_cut);
     else
-        hipLaunchKernelGGL(project_kernel<false>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_Vsort,
+        hipLaunchKernelGGL(project_kernel<false>, dim3(two_pass ? std::min(pgrid, kProjGridTwoPass) : pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_Vsort,
                            (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
                            ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr, stereo ? d_V : nullptr, d_cut);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][3], s));
 
     // binning + compositor over the current rectangles: once per frame, twice for a two-pass frame
     // (ev_bin / ev_c0 / ev_c1: the timing events of this chain; fin / binfin: see composite_kernel)
-    auto chain = [&](int keep_overflow, uint32_t* fin, const uint8_t* binfin, int ev_bin, int ev_c0, int ev_c1) -> int {
+    auto chain = [&](int keep_overflow, int occ_pass, int ev_bin, int ev_c0, int ev_c1) -> int {
+    uint32_t* fin = occ_pass ? (uint32_t*)ctx->occ_fin.p : nullptr;
+    float4* state = occ_pass ? (float4*)ctx->occ_state.p : nullptr;
+    // second chain of a two-pass frame: the binning walks occ[4] ranks (V, or 0 when pass 1 left no bin unfinished), the
+    // compositor the listed unfinished bins
+    uint32_t* d_V = occ_pass == 2 ? occ + 4 : d_Vframe;
+    const uint32_t* d_nbins = occ_pass == 2 ? occ + 2 : nullptr;
+    const uint32_t* d_first = occ_pass == 1 ? occ : nullptr;      // pass 1 bins the ranks from the cut on
 
     // pass 1: stable partition by tile column, enumerated from the rank-ordered rectangles
     uint32_t* totals1 = (uint32_t*)ctx->totals1.p;
@@ -1684,7 +1694,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         hipLaunchKernelGGL(bin1_upsweep<CH>, dim3(g1), dim3(kThreads), 0, s, (const uint32_t*)ctx->rect.p, d_V,               \
                            (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_overflow, fused1 ? gB1 : nullptr, gB2,               \
                            ctx->gsumB2_rows, hv_cur, hv_next, (uint8_t*)ctx->heavy_flag.p, heavy_slots, ctx->gsupB1,          \
-                           keep_overflow);                                                                                    \
+                           keep_overflow, d_first);                                                                           \
         if (!fused1)                                                                                                          \
             launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist1.p, ctx->hist1_stride, d_V, 0u, N, bchunk, totals1);     \
         if (ctx->atomic_rank)                                                                                                 \
@@ -1694,7 +1704,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                                async_overflow_flag ? 1 : 0, fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, \
                                xcdg, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,                               \
                                (uint32_t)nhelp, fp.tiles_x, ctx->gsupB1, (const uint32_t*)d_Vsort,                            \
-                               (keep_overflow && ctx->d_flags) ? ctx->d_flags + 8 : (uint32_t*)nullptr, ctx->occ_seq);        \
+                               (keep_overflow && ctx->d_flags) ? ctx->d_flags + 8 : (uint32_t*)nullptr, ctx->occ_seq, d_first); \
         else                                                                                                                  \
             hipLaunchKernelGGL((bin1_downsweep<false, CH>), dim3(g1 + nhelp), dim3(kThreads), 0, s,                           \
                                (const uint32_t*)ctx->rect.p, d_V, (const uint32_t*)ctx->hist1.p, ctx->hist1_stride,           \
@@ -1702,7 +1712,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                                async_overflow_flag ? 1 : 0, fused1 ? (const uint32_t*)gB1 : nullptr, fused1 ? totals1 : nullptr, \
                                xcdg, (const uint32_t*)hv_cur, (const uint8_t*)ctx->heavy_flag.p,                               \
                                (uint32_t)nhelp, fp.tiles_x, ctx->gsupB1, (const uint32_t*)d_Vsort,                            \
-                               (keep_overflow && ctx->d_flags) ? ctx->d_flags + 8 : (uint32_t*)nullptr, ctx->occ_seq);        \
+                               (keep_overflow && ctx->d_flags) ? ctx->d_flags + 8 : (uint32_t*)nullptr, ctx->occ_seq, d_first); \
     } while (0)
     // (bin1_upsweep also clears the row pass's group table: its consumer, the previous frame's row downsweep, is long done)
     MSPLAT_BIN1(kBinChunk);
@@ -1794,7 +1804,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         const uint32_t* ts = (const uint32_t*)ctx->tile_start.p;
         const uint32_t* pb = (const uint32_t*)ctx->pairsB.p;
         const float4* r2 = (const float4*)ctx->rec2d.p;
-        const uint32_t* ord = (const uint32_t*)ctx->tile_order.p + (ordered ? 0 : 65536);
+        const uint32_t* ord = occ_pass == 2 ? (const uint32_t*)ctx->occ_unf.p : (const uint32_t*)ctx->tile_order.p + (ordered ? 0 : 65536);
         const bool f16 = ctx->cfg.fb_format == MSPLAT_FB_RGBA16F;
         // wave issue priority by item number where the items are numbered heaviest-first (every item on its own wave); none for
         // persistent waves that walk the bins in storage order (r3, 4 frames in flight: none / by item number / by list length
@@ -1803,10 +1813,10 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         const int grid = (int)std::min<uint32_t>(comp_items, comp_pool);
         if (f16)
             hipExtLaunchKernelGGL(composite_kernel<true>, dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
-                                  cap, ord, d_queue, comp_items, probe, prio_mode, d_out1, fin, binfin);
+                                  cap, ord, d_queue, comp_items, probe, occ_pass == 2 ? 0 : prio_mode, d_out1, fin, occ_pass, state, d_nbins);
         else
             hipExtLaunchKernelGGL(composite_kernel<false>, dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
-                                  cap, ord, d_queue, comp_items, probe, prio_mode, d_out1, fin, binfin);
+                                  cap, ord, d_queue, comp_items, probe, occ_pass == 2 ? 0 : prio_mode, d_out1, fin, occ_pass, state, d_nbins);
         ctx->comp_kernel_timed = timed;
     } else {
         ctx->comp_kernel_timed = false;
@@ -1814,12 +1824,12 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     return MSPLAT_OK;
     };      // chain
 
-    int crc = chain(0, two_pass ? (uint32_t*)ctx->occ_fin.p : nullptr, nullptr, 4, 6, 7);
+    int crc = chain(0, two_pass ? 1 : 0, 4, 6, 7);
     if (crc) return crc;
     if (two_pass) {
         if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][8], s));
         hipLaunchKernelGGL(occ_mask_kernel, dim3(1), dim3(kThreads), 0, s, (const uint32_t*)ctx->occ_fin.p, fp.tiles_x, fp.tiles_y,
-                           (uint8_t*)ctx->occ_binfin.p, (uint16_t*)ctx->occ_mask.p, occ);
+                           (uint16_t*)ctx->occ_mask.p, occ, (const uint32_t*)d_Vsort, (uint32_t*)ctx->occ_unf.p);
         // spatially ordered cloud: whole boxes of 256 stored splats are dropped before any centre is fetched
         const uint32_t nboxes = (ctx->store && ctx->store->reordered && ctx->store->boxes.p) ? ctx->store->nboxes : 0u;
         const uint32_t boxwords = ((nboxes + (uint32_t)kThreads - 1u) / (uint32_t)kThreads) * ((uint32_t)kThreads / 32u);
@@ -1833,16 +1843,16 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                            use_boxes ? (const uint32_t*)ctx->occ_boxdead.p : (const uint32_t*)nullptr, boxwords);
         // the listed ranks behind the cut (occ[1] of them)
         if (ctx->full_sh)
-            hipLaunchKernelGGL(project_kernel<true>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, (const uint32_t*)(occ + 1),
+            hipLaunchKernelGGL(project_kernel<true>, dim3(std::min(pgrid, kProjGridTwoPass)), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, (const uint32_t*)(occ + 1),
                                (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, (uint32_t*)nullptr,
                                ctx->d_flags ? ctx->d_flags + 7 : (uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)ctx->occ_live.p);
         else
-            hipLaunchKernelGGL(project_kernel<false>, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, (const uint32_t*)(occ + 1),
+            hipLaunchKernelGGL(project_kernel<false>, dim3(std::min(pgrid, kProjGridTwoPass)), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, (const uint32_t*)(occ + 1),
                                (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, (uint32_t*)nullptr,
                                ctx->d_flags ? ctx->d_flags + 7 : (uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)ctx->occ_live.p);
         if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][9], s));
         const bool timed1 = ctx->comp_kernel_timed;
-        crc = chain(1, nullptr, (const uint8_t*)ctx->occ_binfin.p, 10, 11, 12);
+        crc = chain(1, 2, 10, 11, 12);
         if (crc) return crc;
         ctx->comp_kernel_timed = ctx->comp_kernel_timed && timed1;
         ctx->frames_two_pass++;

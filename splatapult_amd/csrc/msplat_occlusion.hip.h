@@ -6,17 +6,18 @@
 // config 2, 13 % at config 4 and 2 % on a scene-like cloud (tools/occlusion_potential.py).  The two-pass frame uses the
 // compositor's own verdict, and its pixels are BIT FOR BIT those of the single pass:
 //   pass 1   the nearest R1 splats (ranks >= cut = V - R1; the reference's draw order is far to near, the lists are walked from
-//            their end): projected, binned, composited.  A tile whose walk ended because its pixels were saturated after a
-//            FULL batch of 64 entries -- not because its list ended -- has seen exactly the entries the single pass would have
-//            seen, in the same batches (they count from the list's end): its pixels are final, and so is a bin whose four
-//            tiles all ended that way.
+//            their end): projected, binned, composited in WHOLE batches of 64 entries.  Batches count from the list's end and
+//            this list is a suffix of the complete one, so every batch is a batch of the single pass.  A tile saturated after one
+//            of them is final; any other stops in front of its first incomplete batch and leaves its accumulators (r, g, b, T per
+//            pixel, fp32) and the number of entries it composited.
 //   gate     the unfinished bins form a summed-area table (any block of bins is tested with four reads).  A splat of pass 1
 //            keeps its rectangle only if it touches an unfinished
 //            bin; a splat behind the cut is tested with a conservative screen box from its centre and its footprint bound
 //            (pos4.w, the bound of the band-restricted cull) BEFORE its 256-byte record is fetched, and is projected only if
 //            that box touches one.
 //   pass 2   the surviving rectangles of ALL ranks are binned again: an unfinished bin gets its complete list (a splat that
-//            touches it passes the gate by construction) and is composited from scratch; finished bins are skipped.
+//            touches it passes the gate by construction), whose last entries are the ones pass 1 composited: its unfinished
+//            tiles RESUME behind them -- at a batch boundary of the single pass; finished tiles are skipped.
 // Any R1 is correct; it only decides how much work is left.  The host steers it from the pair counts of an earlier frame
 // (host-mapped words, never waited for).  Contract: src/splatrenderer.cpp:315-343 + shader/splat_*.glsl + the blend state of
 // src/app.cpp:144-164 -- the image of Render() is unchanged.
@@ -32,7 +33,8 @@ namespace msplat {
 // [0, col] (virtual rows in band mode, like the rectangles); row 0 and column 0 are zero.  uint16: at most kOccSatMax entries.
 constexpr int kOccSatMax = 24576;             // (tiles_x + 1) (tiles_y + 1): 4096 x 4096 pixels need 129 x 129
 
-// occ[0] = cut (first rank of pass 1, a multiple of 64), occ[1] = splats behind the cut that pass the gate, occ[2] = unfinished bins
+// occ[0] = cut (first rank of pass 1, a multiple of 1024 = kBinChunk), occ[1] = splats behind the cut that pass the gate, occ[2] = unfinished bins,
+// occ[4] = ranks the second binning chain walks (occ_mask_kernel)
 __global__ __launch_bounds__(64) void occ_plan_kernel(const uint32_t* __restrict__ d_V, float frac, uint32_t* __restrict__ occ)
 {
     if (threadIdx.x == 0) {
@@ -41,37 +43,36 @@ __global__ __launch_bounds__(64) void occ_plan_kernel(const uint32_t* __restrict
         r1 = (r1 + 63u) & ~63u;
         if (r1 < 64u) r1 = 64u;
         uint32_t cut = r1 >= V ? 0u : V - r1;
-        cut &= ~63u;                          // whole waves of the projection lie on one side of it
+        cut &= ~1023u;                        // whole chunks of the column pass (and waves of the projection) lie on one side of it
         occ[0] = cut;
         occ[1] = 0u;
         occ[2] = 0u;
     }
 }
 
-// ONE workgroup: fin[bin * 4 + quadrant] (composite_kernel, pass 1) -> binfin[bin], the summed-area table of the unfinished bins
+// ONE workgroup: fin[bin * 4 + quadrant] (composite_kernel, pass 1) -> the summed-area table of the bins with a tile to resume
 // (built in LDS: a row prefix per thread, then a column prefix per thread), their number
 __global__ __launch_bounds__(kThreads) void occ_mask_kernel(const uint32_t* __restrict__ fin, int tiles_x, int tiles_y,
-                                                            uint8_t* __restrict__ binfin, uint16_t* __restrict__ sat,
-                                                            uint32_t* __restrict__ occ)
+                                                            uint16_t* __restrict__ sat, uint32_t* __restrict__ occ,
+                                                            const uint32_t* __restrict__ d_V, uint32_t* __restrict__ unf_bins)
 {
+    // also: unf_bins[0 .. occ[2]) = the unfinished bins (any order: the compositor's second launch walks these alone), and
+    // occ[4] = the rank count the second binning chain walks: V, or 0 when no bin is left (its kernels then find no work)
     __shared__ uint16_t s_sat[kOccSatMax];
     __shared__ uint32_t s_cnt;
     const int stride = tiles_x + 1, nbins = tiles_x * tiles_y, nsat = stride * (tiles_y + 1);
     if (threadIdx.x == 0) s_cnt = 0u;
     for (int i = threadIdx.x; i < nsat; i += kThreads) s_sat[i] = 0;
     __syncthreads();
-    uint32_t mine = 0;
     for (int bin = threadIdx.x; bin < nbins; bin += kThreads) {
         const uint4 f = *reinterpret_cast<const uint4*>(fin + (size_t)bin * 4);
-        const bool unfinished = !(f.x != 0u && f.y != 0u && f.z != 0u && f.w != 0u);
-        binfin[bin] = unfinished ? 0 : 1;
+        const bool unfinished = (f.x & f.y & f.z & f.w) != 0xFFFFFFFFu;      // a tile that is not final (composite_kernel, occ_pass 1)
         if (unfinished) {
             const int row = bin / tiles_x, col = bin - row * tiles_x;
             s_sat[(row + 1) * stride + col + 1] = 1;
-            ++mine;
+            unf_bins[atomicAdd(&s_cnt, 1u)] = (uint32_t)bin;
         }
     }
-    if (mine) atomicAdd(&s_cnt, mine);
     __syncthreads();
     for (int row = 1 + (int)threadIdx.x; row <= tiles_y; row += kThreads) {
         uint32_t run = 0;
@@ -90,7 +91,10 @@ __global__ __launch_bounds__(kThreads) void occ_mask_kernel(const uint32_t* __re
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nsat; i += kThreads) sat[i] = s_sat[i];
-    if (threadIdx.x == 0) occ[2] = s_cnt;
+    if (threadIdx.x == 0) {
+        occ[2] = s_cnt;
+        occ[4] = s_cnt != 0u ? *d_V : 0u;
+    }
 }
 
 // does the block of bins [tx0, tx1] x [ty0, ty1] (virtual rows) contain an unfinished bin?  Four reads of the summed-area table

@@ -35,48 +35,17 @@ __device__ __forceinline__ uint32_t quantise_depth(float ndcz, int depth_bits)
 
 constexpr int kProjThreads = 64;          // one wave per workgroup: wave-private LDS staging, no block barriers
 
+// one wave-block of 64 ranks: cooperative gather of the records, then the vertex + geometry stage per lane (rank r, rank rl inside
+// its view; lanes with !valid take part in the gather only).  s_stage: 64 * STRIDE floats of wave-private LDS.
 template <bool FULL_SH>
-__global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* __restrict__ sorted_idx,
-                                                               const uint32_t* __restrict__ d_V,
-                                                               const float4* __restrict__ recs,
-                                                               FrameParams fp,
-                                                               float4* __restrict__ out_rec,
-                                                               uint32_t* __restrict__ out_rect,
-                                                               uint32_t* __restrict__ out_zq, uint32_t* __restrict__ d_Veff = nullptr,
-                                                               const uint32_t* __restrict__ d_cut = nullptr,
-                                                               const uint32_t* __restrict__ rank_list = nullptr)
+__device__ __forceinline__ void project_block(const uint32_t r, const uint32_t rl, const bool valid, const bool second, const int lane,
+                                              const uint32_t* __restrict__ sorted_idx, const float4* __restrict__ recs,
+                                              const FrameParams& fp, float4* __restrict__ out_rec, uint32_t* __restrict__ out_rect,
+                                              uint32_t* __restrict__ out_zq, float* s_stage)
 {
-    // Two-pass frame (msplat_occlusion.hip.h).  d_cut: pass 1 -- ranks below *d_cut (a multiple of 64) only get an empty
-    // rectangle, their records are not fetched.  rank_list: pass 2 -- the *d_V ranks to project are listed (any order); records
-    // and rectangles are stored by rank as always.
-    // Records are 256 B (full SH) or 128 B (base) and line aligned.  The gather by sorted index is
-    // done cooperatively: F4 consecutive lanes fetch one whole record (coalesced 256/128 B), the wave
-    // stages 64 records in LDS, then every lane reads its own record back (stride 68/36 dwords keeps
-    // the ds_read_b128 accesses conflict free).
     constexpr int F4 = FULL_SH ? 16 : 8;
     constexpr int RPI = 64 / F4;              // records fetched per wave-wide load instruction
     constexpr int STRIDE = F4 * 4 + 4;        // dwords
-    __shared__ __attribute__((aligned(16))) float s_stage[64 * STRIDE];
-    const uint32_t V = *d_V;
-    const int lane = threadIdx.x;
-    // two views in one chain (FrameParams.views == 2): ranks [0, V) are view 0, [V1, V1 + V) view 1; the gap gets empty rectangles
-    const uint32_t V1 = (V + 63u) & ~63u;
-    const uint32_t total = fp.views == 2 ? V1 + V : V;
-    if (d_Veff != nullptr && blockIdx.x == 0 && lane == 0) *d_Veff = total;       // what the binning passes walk
-    if (blockIdx.x * kProjThreads >= total) return;
-    uint32_t r = blockIdx.x * kProjThreads + lane;
-    const bool second = fp.views == 2 && blockIdx.x * kProjThreads >= V1;         // wave-uniform
-    uint32_t rl = second ? r - V1 : r;                                             // rank inside the view
-    const bool valid = rl < V;
-    if (rank_list != nullptr) {                                                    // (one view; slot -> rank)
-        r = rl = valid ? rank_list[r] : 0u;
-    } else {
-        if (!valid && r < total) out_rect[r] = kRectEmpty;                         // (the gap between the views, and nothing else)
-        if (d_cut != nullptr && blockIdx.x * kProjThreads < *d_cut) {              // wave-uniform: behind the cut of pass 1
-            if (valid) out_rect[r] = kRectEmpty;
-            return;
-        }
-    }
     const uint32_t i = valid ? sorted_idx[rl] : 0u;
     {
         const int sub = lane % F4;
@@ -258,6 +227,64 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
     // depth-buffer emulation (composite_depth_kernel): the quad's fragments all carry the centre's depth
     // (splat_geom.glsl:93-101 offsets only x and y); window z = 0.5 ndc.z + 0.5 (default glDepthRange)
     if (out_zq != nullptr) out_zq[r] = quantise_depth(ndcz, fp.depth_bits);
+}
+
+template <bool FULL_SH>
+__global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* __restrict__ sorted_idx,
+                                                               const uint32_t* __restrict__ d_V,
+                                                               const float4* __restrict__ recs,
+                                                               FrameParams fp,
+                                                               float4* __restrict__ out_rec,
+                                                               uint32_t* __restrict__ out_rect,
+                                                               uint32_t* __restrict__ out_zq, uint32_t* __restrict__ d_Veff = nullptr,
+                                                               const uint32_t* __restrict__ d_cut = nullptr,
+                                                               const uint32_t* __restrict__ rank_list = nullptr)
+{
+    // Two-pass frame (msplat_occlusion.hip.h).  d_cut: pass 1 -- ranks below *d_cut (a multiple of 64) only get an empty
+    // rectangle, their records are not fetched.  rank_list: pass 2 -- the *d_V ranks to project are listed (any order); records
+    // and rectangles are stored by rank as always.
+    // Records are 256 B (full SH) or 128 B (base) and line aligned.  The gather by sorted index is
+    // done cooperatively: F4 consecutive lanes fetch one whole record (coalesced 256/128 B), the wave
+    // stages 64 records in LDS, then every lane reads its own record back (stride 68/36 dwords keeps
+    // the ds_read_b128 accesses conflict free).
+    constexpr int F4 = FULL_SH ? 16 : 8;
+    constexpr int RPI = 64 / F4;              // records fetched per wave-wide load instruction
+    constexpr int STRIDE = F4 * 4 + 4;        // dwords
+    __shared__ __attribute__((aligned(16))) float s_stage[64 * STRIDE];
+    const uint32_t V = *d_V;
+    const int lane = threadIdx.x;
+    // two views in one chain (FrameParams.views == 2): ranks [0, V) are view 0, [V1, V1 + V) view 1; the gap gets empty rectangles
+    const uint32_t V1 = (V + 63u) & ~63u;
+    const uint32_t total = fp.views == 2 ? V1 + V : V;
+    if (d_Veff != nullptr && blockIdx.x == 0 && lane == 0) *d_Veff = total;       // what the binning passes walk
+    if (rank_list != nullptr) {
+        // pass 2 of a two-pass frame: the listed ranks, grid-stride (the list is short: a grid sized for the cloud would be ~10^5
+        // workgroups that find nothing -- 35 us at 6 M splats)
+        for (uint32_t s0 = blockIdx.x * kProjThreads; s0 < V; s0 += gridDim.x * kProjThreads) {
+            const bool ok = s0 + lane < V;
+            const uint32_t rk = ok ? rank_list[s0 + lane] : 0u;
+            project_block<FULL_SH>(rk, rk, ok, false, lane, sorted_idx, recs, fp, out_rec, out_rect, out_zq, s_stage);
+            __syncthreads();              // s_stage is reused
+        }
+        return;
+    }
+    if (d_cut != nullptr) {
+        // pass 1 of a two-pass frame: ranks [cut, V) are projected (grid-stride), the ranks behind the cut get empty rectangles
+        const uint32_t cut = *d_cut;
+        for (uint32_t i = blockIdx.x * kProjThreads + lane; i < cut; i += gridDim.x * kProjThreads) out_rect[i] = kRectEmpty;
+        for (uint32_t r0 = cut + blockIdx.x * kProjThreads; r0 < V; r0 += gridDim.x * kProjThreads) {
+            project_block<FULL_SH>(r0 + lane, r0 + lane, r0 + lane < V, false, lane, sorted_idx, recs, fp, out_rec, out_rect, out_zq, s_stage);
+            __syncthreads();
+        }
+        return;
+    }
+    if (blockIdx.x * kProjThreads >= total) return;
+    const uint32_t r = blockIdx.x * kProjThreads + lane;
+    const bool second = fp.views == 2 && blockIdx.x * kProjThreads >= V1;         // wave-uniform
+    const uint32_t rl = second ? r - V1 : r;                                       // rank inside the view
+    const bool valid = rl < V;
+    if (!valid && r < total) out_rect[r] = kRectEmpty;                             // (the gap between the views, and nothing else)
+    project_block<FULL_SH>(r, rl, valid, second, lane, sorted_idx, recs, fp, out_rec, out_rect, out_zq, s_stage);
 }
 
 __device__ __forceinline__ uint32_t rect_width(uint32_t rc)

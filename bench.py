@@ -135,6 +135,8 @@ def measure(E, args, key, ply=None, primary=True):
         ok = rr.InitFromPly(ply, True, False) if from_file else rr.Init(cloud, False, False)
         if not ok:
             raise SystemExit("Init failed: " + rr.last_error())
+        if args.two_pass_share > 0.0:
+            rr.two_pass_state(args.two_pass_share)
 
     init(r)
     pair_cap0 = int(max(4 << 20, 32 * n))           # the library's initial (splat, bin) pair capacity: max(4 M, 32 N)
@@ -257,7 +259,7 @@ def measure(E, args, key, ply=None, primary=True):
     if args.timing_stride > 0:
         prof = r.timings()                        # sampled stage events of the overlapped frames
     tp_flight = r.two_pass_info()                 # the latest frame of the timed region (None: one pass)
-    tp_frames_flight, tp_share_flight = r.two_pass_state()
+    tp_frames_flight, tp_share_flight = r.two_pass_state(args.two_pass_share)
 
     # ---- serial phase: the same frames one at a time on ONE stream (clean per-kernel durations, latency) ----
     if P == 1:
@@ -283,7 +285,7 @@ def measure(E, args, key, ply=None, primary=True):
     serial_ms = 1e3 * (time.perf_counter() - t0) / SER
     prof_serial = rs.timings() if (args.timing_stride > 0 or P > 1) else None
     tp_serial = rs.two_pass_info()                 # None: the serial frames ran in one pass
-    tp_share_serial = rs.two_pass_state()[1]
+    tp_share_serial = rs.two_pass_state(args.two_pass_share)[1]
     lat = []
     for s in range(16):
         torch.cuda.synchronize(dev)
@@ -495,6 +497,8 @@ def main():
                     help="two-view workloads: one Render per eye (the reference's call pattern) instead of msplat_render_stereo (A/B)")
     ap.add_argument("--two-pass", default="auto", choices=["auto", "on", "off"],
                     help="msplat_config.two_pass: Renders in two passes with occlusion feedback (same pixels; A/B)")
+    ap.add_argument("--two-pass-share", type=float, default=0.0,
+                    help="pin the share of the visible splats in the first pass (msplat_debug_two_pass; 0 = the library's feedback loop)")
     ap.add_argument("--async-submit", type=int, default=-1,
                     help="msplat_config.async_submit of the in-flight contexts: 1 = a worker thread per context issues its launches, "
                          "0 = the calling thread does (A/B); default: on with frames in flight")

@@ -1824,3 +1824,19 @@ def test_two_pass_with_bands_fp16_frames_in_flight_and_the_feedback_loop():
         c.Sort(cam, proj, vp, nf)
         c.Render(cam, proj, vp, nf)
     assert c.two_pass_state()[0] == 0                       # 150 k splats: below the AUTO size
+    # ... on for a large dense one after the context's first 8 frames (and off again for the probe / stats frames)
+    big = scenes.synth_cloud(300000, 304, log_scale_mean=-2.9)
+    a = make_renderer(big, two_pass=_capi.TWO_PASS_OFF)
+    c = make_renderer(big)
+    for k in range(24):
+        cam, proj, vp, nf = scenes.default_view(W, H, z=3.0, yaw=0.07 * k)
+        a.Sort(cam, proj, vp, nf); c.Sort(cam, proj, vp, nf)
+        np.testing.assert_array_equal(a.Render(cam, proj, vp, nf), c.Render(cam, proj, vp, nf))
+    frames, share = c.two_pass_state()
+    info = c.two_pass_info()
+    assert frames >= 8 and info is not None and info["splats_pass1"] < info["visible"]
+    print("two-pass AUTO on 300 k splats: %d of 24 frames, share %.3f, latest frame: %s" % (frames, share, info))
+    c.set_tile_probe(True)
+    c.Sort(cam, proj, vp, nf)
+    np.testing.assert_array_equal(a.Render(cam, proj, vp, nf), c.Render(cam, proj, vp, nf))
+    assert c.two_pass_info() is None and c.stats()["pairs"] == a.stats()["pairs"]

@@ -219,7 +219,9 @@ struct msplat_ctx {
     uint32_t occ_streak = 0;                 // consecutive two-pass frames submitted (their feedback describes two-pass frames)
     uint32_t occ_seq = 0, occ_change_seq = 0;   // number of the latest two-pass frame; first frame that ran with the current share
     uint32_t occ_off = 0;                    // AUTO: frames left of a single-pass period after two passes did not pay
-    uint32_t occ_strikes = 0, occ_backoff = 512; // ... decided after three looks; the pause doubles every time
+    uint32_t occ_strikes = 0, occ_backoff = 1024; // ... decided after three looks; the pause doubles every time
+    int occ_state_auto = 0;                  // AUTO: 0 one pass, 1 probing (occ_probe_left frames), 2 waiting for the probe's feedback, 3 two passes
+    uint32_t occ_probe_left = 0;
     bool occ_pinned = false;                 // msplat_debug_two_pass: the share is fixed
     bool last_render_two_pass = false;
     uint64_t frames_rendered = 0, frames_two_pass = 0;
@@ -1551,55 +1553,95 @@ static bool occlusion_plan(msplat_ctx* ctx, const FrameParams& fp, bool stereo, 
     if (!ctx->scan_free) return no();            // (the chunk offset of pass 1's column pass exists in the scan-free form only)
     if (fp.tiles_x * fp.tiles_y <= 0 || (fp.tiles_x + 1) * (fp.tiles_y + 1) > kOccSatMax) return no();      // (the table of unfinished bins)
     const bool forced = ctx->two_pass_mode == MSPLAT_TWO_PASS_ON;
-    if (!forced) {
-        if (ctx->N < kTwoPassMinSplats || ctx->frames_rendered <= 8) return no();
-        if (ctx->occ_off != 0u) {                // a single-pass period; then try again from the default share
-            if (--ctx->occ_off == 0u) ctx->occ_frac = 0.25f;
-            return no();
-        }
-    }
+    if (!forced && (ctx->N < kTwoPassMinSplats || ctx->frames_rendered <= 8)) return no();
     const size_t nbins = (size_t)fp.tiles_x * fp.tiles_y;
-    if (buf_alloc(ctx, ctx->occ, 64) || buf_alloc(ctx, ctx->occ_mask, (size_t)kOccSatMax * 2 + 64) ||
-        buf_alloc(ctx, ctx->occ_fin, nbins * 16 + 64) || buf_alloc(ctx, ctx->occ_state, (size_t)fp.width * fp.height * 16 + 64) ||
-        buf_alloc(ctx, ctx->occ_live, ((size_t)ctx->N + 64) * 4) || buf_alloc(ctx, ctx->occ_boxdead, 2048 * 4 + 64) || buf_alloc(ctx, ctx->occ_unf, nbins * 4 + 64)) {
-        ctx->err.clear();                        // (no memory for the extra buffers: the frame runs in one pass)
-        return no();
-    }
-    // steer the share: pass 2 should stay well below pass 1 (a flat optimum: tools/occlusion_potential.py).  The feedback names
-    // its frame (occ_seq): only a frame that ran with the CURRENT share is evidence for changing it -- the host may be many
-    // frames ahead of the GPU
-    if (ctx->h_flags && !ctx->occ_pinned) {
+
+    // Feedback of an earlier two-pass frame (host-mapped, never waited for): [4] pairs of pass 1, [8] pairs of pass 2, [5] bins
+    // pass 1 left unfinished, [9] / [10] the number of the frame the words of pass 1 / pass 2 describe.  Only a frame that ran
+    // with the CURRENT share is evidence -- the host may be a hundred frames ahead of the GPU.
+    bool fresh = false;
+    float ratio = 0.0f, ufrac = 0.0f;
+    if (ctx->h_flags) {
         const uint32_t s1 = __atomic_load_n(ctx->h_flags + 9, __ATOMIC_RELAXED), s2 = __atomic_load_n(ctx->h_flags + 10, __ATOMIC_RELAXED);
         const uint32_t d1 = __atomic_load_n(ctx->h_flags + 4, __ATOMIC_RELAXED), d2 = __atomic_load_n(ctx->h_flags + 8, __ATOMIC_RELAXED);
         if (s1 == s2 && s1 != 0u && (int32_t)(s1 - ctx->occ_change_seq) >= 0 && d1 != 0u) {
-            const float ratio = (float)d2 / (float)d1;
-            const uint32_t unfinished = __atomic_load_n(ctx->h_flags + 5, __ATOMIC_RELAXED);
-            const float ufrac = (float)unfinished / (float)nbins;
-            float next = ctx->occ_frac;
-            // A bin pass 1 does not finish is composited twice.  Where a third of the bins never saturate whatever the share (a
-            // cloud seen from outside: its rim), the second compositor launch and the second binning chain cost more than the
-            // skipped splats save (BASELINE config 2: 6.2 k -> 5.3 k frames/s): AUTO goes back to one pass and tries again later,
-            // with a longer pause every time.
+            fresh = true;
+            ratio = (float)d2 / (float)d1;
+            ufrac = (float)__atomic_load_n(ctx->h_flags + 5, __ATOMIC_RELAXED) / (float)nbins;
+        }
+    }
+    auto set_share = [&](float next) {
+        ctx->occ_frac = std::min(kOccFracMax, std::max(kOccFracMin, next));
+        ctx->occ_change_seq = ctx->occ_seq + 1u;           // the first frame that runs with it
+    };
+    // the share: pass 2 should stay well below pass 1 (a flat optimum: tools/occlusion_potential.py)
+    auto steer = [&]() {
+        if (ratio > 0.6f) set_share(ctx->occ_frac * 1.25f);
+        else if (ratio < 0.15f && ctx->occ_frac > kOccFracMin) set_share(ctx->occ_frac * 0.85f);
+    };
+    if (forced) {
+        if (fresh && !ctx->occ_pinned) steer();
+    } else {
+        // AUTO.  A bin pass 1 does not finish costs a second look; where a third of the bins never saturate whatever the share
+        // (a cloud seen from outside: its rim) and the cloud is small, the nine extra launches cost what the skipped splats save
+        // (BASELINE config 2: 5830 -> 5770 frames/s at best, serial 0.27 -> 0.33 ms).  So two passes are PROBED: four frames,
+        // then one pass again until their feedback is in (the probe must not cost a hundred slow frames because the host runs
+        // ahead); more than 30 % unfinished is a strike (the next probe takes a larger share), three strikes a pause that doubles
+        // every time; otherwise two passes stay on, steered, until three looks in a row say otherwise.
+        enum { OFF = 0, PROBE = 1, WAIT = 2, ON = 3 };
+        if (ctx->occ_state_auto == OFF) {
+            if (ctx->occ_off != 0u) { --ctx->occ_off; return no(); }
+            ctx->occ_state_auto = PROBE;
+            ctx->occ_probe_left = 4u;
+            ctx->occ_strikes = 0u;
+            set_share(0.25f);
+        }
+        if (ctx->occ_state_auto == WAIT) {
+            if (!fresh) return no();
             if (ufrac > 0.3f) {
-                if (!forced && ++ctx->occ_strikes >= 3u) {
-                    ctx->occ_strikes = 0u;
+                if (++ctx->occ_strikes >= 3u) {
+                    ctx->occ_state_auto = OFF;
                     ctx->occ_off = ctx->occ_backoff;
                     ctx->occ_backoff = std::min(ctx->occ_backoff * 2u, 16384u);
                     return no();
                 }
-                next = std::min(kOccFracMax, ctx->occ_frac * 1.5f);
+                set_share(ctx->occ_frac * 1.5f);
+                ctx->occ_state_auto = PROBE;
+                ctx->occ_probe_left = 4u;
+            } else {
+                ctx->occ_state_auto = ON;
+                ctx->occ_strikes = 0u;
+                ctx->occ_backoff = 1024u;
+                steer();
+            }
+        } else if (ctx->occ_state_auto == ON && fresh && !ctx->occ_pinned) {
+            if (ufrac > 0.3f) {
+                if (++ctx->occ_strikes >= 3u) {
+                    ctx->occ_state_auto = OFF;
+                    ctx->occ_off = ctx->occ_backoff;
+                    ctx->occ_backoff = std::min(ctx->occ_backoff * 2u, 16384u);
+                    return no();
+                }
+                set_share(ctx->occ_frac * 1.5f);
             } else {
                 ctx->occ_strikes = 0u;
-                if (ratio > 0.6f) next = std::min(kOccFracMax, ctx->occ_frac * 1.25f);
-                else if (ratio < 0.15f) next = std::max(kOccFracMin, ctx->occ_frac * 0.85f);
-            }
-            if (next != ctx->occ_frac) {
-                ctx->occ_frac = next;
-                ctx->occ_change_seq = ctx->occ_seq + 1u;       // the first frame that runs with it
-            } else if (ufrac > 0.3f) {
-                ctx->occ_change_seq = ctx->occ_seq + 1u;       // (the share is at its maximum: count the next strike on a new frame)
+                steer();
             }
         }
+        if (ctx->occ_state_auto == PROBE) {
+            if (ctx->occ_probe_left == 0u) {
+                ctx->occ_state_auto = WAIT;
+                return no();
+            }
+            --ctx->occ_probe_left;
+        }
+    }
+    if (buf_alloc(ctx, ctx->occ, 64) || buf_alloc(ctx, ctx->occ_mask, (size_t)kOccSatMax * 2 + 64) ||
+        buf_alloc(ctx, ctx->occ_fin, nbins * 16 + 64) || buf_alloc(ctx, ctx->occ_state, (size_t)fp.width * fp.height * 16 + 64) ||
+        buf_alloc(ctx, ctx->occ_live, ((size_t)ctx->N + 64) * 4) || buf_alloc(ctx, ctx->occ_boxdead, 2048 * 4 + 64) ||
+        buf_alloc(ctx, ctx->occ_unf, nbins * 4 + 64)) {
+        ctx->err.clear();                        // (no memory for the extra buffers: the frame runs in one pass)
+        return no();
     }
     ctx->occ_seq++;                              // this frame's number (never 0)
     if (ctx->occ_seq == 0u) ctx->occ_seq = 1u;
@@ -1828,7 +1870,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     if (crc) return crc;
     if (two_pass) {
         if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][8], s));
-        hipLaunchKernelGGL(occ_mask_kernel, dim3(1), dim3(kThreads), 0, s, (const uint32_t*)ctx->occ_fin.p, fp.tiles_x, fp.tiles_y,
+        hipLaunchKernelGGL(occ_mask_kernel, dim3(1), dim3(kOccMaskThreads), 0, s, (const uint32_t*)ctx->occ_fin.p, fp.tiles_x, fp.tiles_y,
                            (uint16_t*)ctx->occ_mask.p, occ, (const uint32_t*)d_Vsort, (uint32_t*)ctx->occ_unf.p);
         // spatially ordered cloud: whole boxes of 256 stored splats are dropped before any centre is fetched
         const uint32_t nboxes = (ctx->store && ctx->store->reordered && ctx->store->boxes.p) ? ctx->store->nboxes : 0u;

@@ -52,7 +52,8 @@ __global__ __launch_bounds__(64) void occ_plan_kernel(const uint32_t* __restrict
 
 // ONE workgroup: fin[bin * 4 + quadrant] (composite_kernel, pass 1) -> the summed-area table of the bins with a tile to resume
 // (built in LDS: a row prefix per thread, then a column prefix per thread), their number
-__global__ __launch_bounds__(kThreads) void occ_mask_kernel(const uint32_t* __restrict__ fin, int tiles_x, int tiles_y,
+constexpr int kOccMaskThreads = 1024;
+__global__ __launch_bounds__(kOccMaskThreads) void occ_mask_kernel(const uint32_t* __restrict__ fin, int tiles_x, int tiles_y,
                                                             uint16_t* __restrict__ sat, uint32_t* __restrict__ occ,
                                                             const uint32_t* __restrict__ d_V, uint32_t* __restrict__ unf_bins)
 {
@@ -62,9 +63,9 @@ __global__ __launch_bounds__(kThreads) void occ_mask_kernel(const uint32_t* __re
     __shared__ uint32_t s_cnt;
     const int stride = tiles_x + 1, nbins = tiles_x * tiles_y, nsat = stride * (tiles_y + 1);
     if (threadIdx.x == 0) s_cnt = 0u;
-    for (int i = threadIdx.x; i < nsat; i += kThreads) s_sat[i] = 0;
+    for (int i = threadIdx.x; i < nsat; i += kOccMaskThreads) s_sat[i] = 0;
     __syncthreads();
-    for (int bin = threadIdx.x; bin < nbins; bin += kThreads) {
+    for (int bin = threadIdx.x; bin < nbins; bin += kOccMaskThreads) {
         const uint4 f = *reinterpret_cast<const uint4*>(fin + (size_t)bin * 4);
         const bool unfinished = (f.x & f.y & f.z & f.w) != 0xFFFFFFFFu;      // a tile that is not final (composite_kernel, occ_pass 1)
         if (unfinished) {
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(kThreads) void occ_mask_kernel(const uint32_t* __re
         }
     }
     __syncthreads();
-    for (int row = 1 + (int)threadIdx.x; row <= tiles_y; row += kThreads) {
+    for (int row = 1 + (int)threadIdx.x; row <= tiles_y; row += kOccMaskThreads) {
         uint32_t run = 0;
         for (int c = 1; c <= tiles_x; ++c) {
             run += s_sat[row * stride + c];
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(kThreads) void occ_mask_kernel(const uint32_t* __re
         }
     }
     __syncthreads();
-    for (int c = 1 + (int)threadIdx.x; c <= tiles_x; c += kThreads) {
+    for (int c = 1 + (int)threadIdx.x; c <= tiles_x; c += kOccMaskThreads) {
         uint32_t run = 0;
         for (int row = 1; row <= tiles_y; ++row) {
             run += s_sat[row * stride + c];
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(kThreads) void occ_mask_kernel(const uint32_t* __re
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nsat; i += kThreads) sat[i] = s_sat[i];
+    for (int i = threadIdx.x; i < nsat; i += kOccMaskThreads) sat[i] = s_sat[i];
     if (threadIdx.x == 0) {
         occ[2] = s_cnt;
         occ[4] = s_cnt != 0u ? *d_V : 0u;

@@ -95,8 +95,10 @@ typedef struct msplat_config {
  * single pass would have consumed, in the same batches), whatever share of the splats goes into the first pass; that share is
  * steered from counts an earlier frame left in host-mapped memory, never waited for.
  * AUTO: clouds of >= 262 144 splats on the splat compositor (no emulated depth test / render-target rounding / points / two
- * views in one chain), after the context's first 8 frames, not while the tile probe is on.  A two-pass frame costs ~9 more
- * launches: it is a throughput feature (frames in flight, large clouds), neutral for a 1 M-splat frame rendered alone.
+ * views in one chain), after the context's first 8 frames, not while the tile probe is on.  A two-pass frame costs nine more
+ * launches, so AUTO probes (four frames, then one pass until their counts are in) and keeps two passes only where they pay:
+ * where more than 30 % of the bins never saturate (a 1 M-splat cloud seen from outside) it goes back to one pass and tries
+ * again after 1024 frames, then 2048, ...
  * After a two-pass Render, msplat_get_stats().pairs / drawn and the debug list getters describe the SECOND pass. */
 enum {
     MSPLAT_TWO_PASS_AUTO = 0,

@@ -1542,6 +1542,7 @@ static int sort_impl(msplat_ctx* ctx, const float cameraMat[16], const float pro
 // side only: reads what EARLIER frames of this context left in host-mapped memory (never waits); any answer gives the same
 // pixels.  Feedback of a two-pass frame: [4] pairs of pass 1, [8] pairs of pass 2, [5] unfinished bins.
 constexpr uint64_t kTwoPassMinSplats = 1u << 18;
+constexpr uint32_t kTwoPassMinVisibleSerial = 1500000u;
 constexpr int kProjGridTwoPass = 4096;       // one-wave workgroups of the grid-stride forms of project_kernel (9 fit a CU)
 constexpr float kOccFracMin = 1.0f / 256.0f, kOccFracMax = 0.75f;
 static bool occlusion_plan(msplat_ctx* ctx, const FrameParams& fp, bool stereo, float& frac)
@@ -1554,6 +1555,12 @@ static bool occlusion_plan(msplat_ctx* ctx, const FrameParams& fp, bool stereo, 
     if (fp.tiles_x * fp.tiles_y <= 0 || (fp.tiles_x + 1) * (fp.tiles_y + 1) > kOccSatMax) return no();      // (the table of unfinished bins)
     const bool forced = ctx->two_pass_mode == MSPLAT_TWO_PASS_ON;
     if (!forced && (ctx->N < kTwoPassMinSplats || ctx->frames_rendered <= 8)) return no();
+    // one frame at a time and few visible splats (a rank of a row-sharded frame, a 1 M-splat cloud): the nine extra launches
+    // are latency the skipped work does not buy back (rank 3 of 8 of config 4, V = 1 M: 0.33 -> 0.38 ms; with frames in flight
+    // the same rank gains 12 %)
+    if (!forced && ctx->cfg.frame_mode != MSPLAT_FRAMES_IN_FLIGHT && ctx->h_flags &&
+        __atomic_load_n(ctx->h_flags + 1, __ATOMIC_RELAXED) < kTwoPassMinVisibleSerial)
+        return no();
     const size_t nbins = (size_t)fp.tiles_x * fp.tiles_y;
 
     // Feedback of an earlier two-pass frame (host-mapped, never waited for): [4] pairs of pass 1, [8] pairs of pass 2, [5] bins

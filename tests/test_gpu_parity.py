@@ -1827,11 +1827,15 @@ def test_two_pass_with_bands_fp16_frames_in_flight_and_the_feedback_loop():
     # ... on for a large dense one after the context's first 8 frames (and off again for the probe / stats frames)
     big = scenes.synth_cloud(300000, 304, log_scale_mean=-2.9)
     a = make_renderer(big, two_pass=_capi.TWO_PASS_OFF)
-    c = make_renderer(big)
+    c = make_renderer(big, frame_mode=_capi.FRAMES_IN_FLIGHT)      # (a context that shares the GPU with other frames)
+    lat = make_renderer(big)                                       # one frame at a time, few visible splats: stays in one pass
     for k in range(24):
         cam, proj, vp, nf = scenes.default_view(W, H, z=3.0, yaw=0.07 * k)
-        a.Sort(cam, proj, vp, nf); c.Sort(cam, proj, vp, nf)
-        np.testing.assert_array_equal(a.Render(cam, proj, vp, nf), c.Render(cam, proj, vp, nf))
+        a.Sort(cam, proj, vp, nf); c.Sort(cam, proj, vp, nf); lat.Sort(cam, proj, vp, nf)
+        ref = a.Render(cam, proj, vp, nf)
+        np.testing.assert_array_equal(ref, c.Render(cam, proj, vp, nf))
+        np.testing.assert_array_equal(ref, lat.Render(cam, proj, vp, nf))
+    assert lat.two_pass_state()[0] == 0
     frames, share = c.two_pass_state()
     info = c.two_pass_info()
     assert frames >= 8 and info is not None and info["splats_pass1"] < info["visible"]

@@ -1844,3 +1844,14 @@ def test_two_pass_with_bands_fp16_frames_in_flight_and_the_feedback_loop():
     c.Sort(cam, proj, vp, nf)
     np.testing.assert_array_equal(a.Render(cam, proj, vp, nf), c.Render(cam, proj, vp, nf))
     assert c.two_pass_info() is None and c.stats()["pairs"] == a.stats()["pairs"]
+
+
+def test_two_pass_fuzz():
+    """tools/two_pass_fuzz.py, shortened: random clouds / cameras / viewports / band plans / targets / shares"""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "two_pass_fuzz.py"), "--cases", "40", "--seed", "3"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "0 mismatches" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

@@ -221,7 +221,7 @@ struct msplat_ctx {
     uint32_t occ_off = 0;                    // AUTO: frames left of a single-pass period after two passes did not pay
     uint32_t occ_strikes = 0, occ_backoff = 1024; // ... decided after three looks; the pause doubles every time
     int occ_state_auto = 0;                  // AUTO: 0 one pass, 1 probing (occ_probe_left frames), 2 waiting for the probe's feedback, 3 two passes
-    uint32_t occ_probe_left = 0;
+    uint32_t occ_probe_left = 0, occ_no_shrink = 0;
     bool occ_pinned = false;                 // msplat_debug_two_pass: the share is fixed
     bool last_render_two_pass = false;
     uint64_t frames_rendered = 0, frames_two_pass = 0;
@@ -1583,8 +1583,18 @@ static bool occlusion_plan(msplat_ctx* ctx, const FrameParams& fp, bool stereo, 
     };
     // the share: pass 2 should stay well below pass 1 (a flat optimum: tools/occlusion_potential.py)
     auto steer = [&]() {
-        if (ratio > 0.6f) set_share(ctx->occ_frac * 1.25f);
-        else if (ratio < 0.15f && ctx->occ_frac > kOccFracMin) set_share(ctx->occ_frac * 0.85f);
+        // (the step from "pass 2 has nothing to do" to "pass 2 does most of the work" can be one notch: after growing, the share
+        //  is not shrunk again for 32 looks)
+        if (ratio > 0.6f) {
+            set_share(ctx->occ_frac * 1.25f);
+            ctx->occ_no_shrink = 32u;
+        } else if (ctx->occ_no_shrink != 0u) {
+            --ctx->occ_no_shrink;
+        } else if (ratio < 0.02f && ctx->occ_frac > kOccFracMin) {
+            set_share(ctx->occ_frac * 0.75f);          // nothing left for pass 2: too much in pass 1
+        } else if (ratio < 0.15f && ctx->occ_frac > kOccFracMin) {
+            set_share(ctx->occ_frac * 0.85f);
+        }
     };
     if (forced) {
         if (fresh && !ctx->occ_pinned) steer();

@@ -366,4 +366,14 @@ __device__ __forceinline__ uint32_t live_box_at(const LiveBoxes& lb, const uint3
     return lb.list[lo * kBoxGroup + (vb - s_lpre[lo])];
 }
 
+// two-pass frames (msplat_occlusion.hip.h): first rank of pass 1 for V visible splats and a share of them in pass 1
+__device__ __forceinline__ uint32_t occ_cut(uint32_t V, float share)
+{
+    uint32_t r1 = (uint32_t)((float)V * share);
+    r1 = (r1 + 63u) & ~63u;
+    if (r1 < 64u) r1 = 64u;
+    const uint32_t cut = r1 >= V ? 0u : V - r1;
+    return cut & ~1023u;                      // whole chunks of the column pass (and waves of the projection) lie on one side of it
+}
+
 }  // namespace msplat

@@ -1690,9 +1690,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     float occ_frac = 0.0f;
     const bool two_pass = occlusion_plan(ctx, fp, stereo, occ_frac);
     uint32_t* occ = (uint32_t*)ctx->occ.p;
-    if (two_pass)
-        hipLaunchKernelGGL(occ_plan_kernel, dim3(1), dim3(64), 0, s, (const uint32_t*)d_Vsort, occ_frac, occ);
-    const uint32_t* d_cut = two_pass ? occ : nullptr;
+    uint32_t* d_cut = two_pass ? occ : nullptr;          // (project_kernel's first pass computes the cut and leaves it in occ[0])
     if (ctx->point_mode)
         hipLaunchKernelGGL(point_project_kernel, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
                            (const float4*)ctx->pos4.p, (const float4*)ctx->recs.p, fp, ctx->sprite_params,
@@ -1700,11 +1698,11 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     else if (ctx->full_sh)
         hipLaunchKernelGGL(project_kernel<true>, dim3(two_pass ? std::min(pgrid, kProjGridTwoPass) : pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_Vsort,
                            (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
-                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr, stereo ? d_V : nullptr, d_cut);
+                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr, stereo ? d_V : nullptr, d_cut, (const uint32_t*)nullptr, occ_frac);
     else
         hipLaunchKernelGGL(project_kernel<false>, dim3(two_pass ? std::min(pgrid, kProjGridTwoPass) : pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_Vsort,
                            (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
-                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr, stereo ? d_V : nullptr, d_cut);
+                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr, stereo ? d_V : nullptr, d_cut, (const uint32_t*)nullptr, occ_frac);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][3], s));
 
     // binning + compositor over the current rectangles: once per frame, twice for a two-pass frame
@@ -1904,11 +1902,11 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         if (ctx->full_sh)
             hipLaunchKernelGGL(project_kernel<true>, dim3(std::min(pgrid, kProjGridTwoPass)), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, (const uint32_t*)(occ + 1),
                                (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, (uint32_t*)nullptr,
-                               ctx->d_flags ? ctx->d_flags + 7 : (uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)ctx->occ_live.p);
+                               ctx->d_flags ? ctx->d_flags + 7 : (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)ctx->occ_live.p);
         else
             hipLaunchKernelGGL(project_kernel<false>, dim3(std::min(pgrid, kProjGridTwoPass)), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, (const uint32_t*)(occ + 1),
                                (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, (uint32_t*)nullptr,
-                               ctx->d_flags ? ctx->d_flags + 7 : (uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)ctx->occ_live.p);
+                               ctx->d_flags ? ctx->d_flags + 7 : (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)ctx->occ_live.p);
         if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][9], s));
         const bool timed1 = ctx->comp_kernel_timed;
         crc = chain(1, 2, 10, 11, 12);

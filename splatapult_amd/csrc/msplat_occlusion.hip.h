@@ -33,23 +33,9 @@ namespace msplat {
 // [0, col] (virtual rows in band mode, like the rectangles); row 0 and column 0 are zero.  uint16: at most kOccSatMax entries.
 constexpr int kOccSatMax = 24576;             // (tiles_x + 1) (tiles_y + 1): 4096 x 4096 pixels need 129 x 129
 
-// occ[0] = cut (first rank of pass 1, a multiple of 1024 = kBinChunk), occ[1] = splats behind the cut that pass the gate, occ[2] = unfinished bins,
-// occ[4] = ranks the second binning chain walks (occ_mask_kernel)
-__global__ __launch_bounds__(64) void occ_plan_kernel(const uint32_t* __restrict__ d_V, float frac, uint32_t* __restrict__ occ)
-{
-    if (threadIdx.x == 0) {
-        const uint32_t V = *d_V;
-        uint32_t r1 = (uint32_t)((float)V * frac);
-        r1 = (r1 + 63u) & ~63u;
-        if (r1 < 64u) r1 = 64u;
-        uint32_t cut = r1 >= V ? 0u : V - r1;
-        cut &= ~1023u;                        // whole chunks of the column pass (and waves of the projection) lie on one side of it
-        occ[0] = cut;
-        occ[1] = 0u;
-        occ[2] = 0u;
-    }
-}
-
+// occ[0] = cut (first rank of pass 1, a multiple of 1024 = kBinChunk), occ[1] = splats behind the cut that pass the gate, occ[2] =
+// unfinished bins, occ[4] = ranks the second binning chain walks (occ_mask_kernel).  The cut is a pure function of V and the
+// share, evaluated by project_kernel's first pass itself (its first workgroup also publishes it and clears occ[1], occ[2]).
 // ONE workgroup: fin[bin * 4 + quadrant] (composite_kernel, pass 1) -> the summed-area table of the bins with a tile to resume
 // (built in LDS: a row prefix per thread, then a column prefix per thread), their number
 constexpr int kOccMaskThreads = 1024;

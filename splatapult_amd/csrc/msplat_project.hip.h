@@ -237,11 +237,11 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
                                                                float4* __restrict__ out_rec,
                                                                uint32_t* __restrict__ out_rect,
                                                                uint32_t* __restrict__ out_zq, uint32_t* __restrict__ d_Veff = nullptr,
-                                                               const uint32_t* __restrict__ d_cut = nullptr,
-                                                               const uint32_t* __restrict__ rank_list = nullptr)
+                                                               uint32_t* __restrict__ d_cut = nullptr,
+                                                               const uint32_t* __restrict__ rank_list = nullptr, float occ_share = 0.0f)
 {
-    // Two-pass frame (msplat_occlusion.hip.h).  d_cut: pass 1 -- ranks below *d_cut (a multiple of 64) only get an empty
-    // rectangle, their records are not fetched.  rank_list: pass 2 -- the *d_V ranks to project are listed (any order); records
+    // Two-pass frame (msplat_occlusion.hip.h).  d_cut: pass 1 -- ranks below cut = occ_cut(V, occ_share) only get an empty
+    // rectangle, their records are not fetched; the cut is left in d_cut[0] (= occ[0]).  rank_list: pass 2 -- the *d_V ranks to project are listed (any order); records
     // and rectangles are stored by rank as always.
     // Records are 256 B (full SH) or 128 B (base) and line aligned.  The gather by sorted index is
     // done cooperatively: F4 consecutive lanes fetch one whole record (coalesced 256/128 B), the wave
@@ -270,7 +270,8 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
     }
     if (d_cut != nullptr) {
         // pass 1 of a two-pass frame: ranks [cut, V) are projected (grid-stride), the ranks behind the cut get empty rectangles
-        const uint32_t cut = *d_cut;
+        const uint32_t cut = occ_cut(V, occ_share);
+        if (blockIdx.x == 0 && lane == 0) { d_cut[0] = cut; d_cut[1] = 0u; d_cut[2] = 0u; }      // occ[0 .. 2] for the kernels that follow
         for (uint32_t i = blockIdx.x * kProjThreads + lane; i < cut; i += gridDim.x * kProjThreads) out_rect[i] = kRectEmpty;
         for (uint32_t r0 = cut + blockIdx.x * kProjThreads; r0 < V; r0 += gridDim.x * kProjThreads) {
             project_block<FULL_SH>(r0 + lane, r0 + lane, r0 + lane < V, false, lane, sorted_idx, recs, fp, out_rec, out_rect, out_zq, s_stage);

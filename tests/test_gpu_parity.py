@@ -1855,3 +1855,40 @@ def test_two_pass_fuzz():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "two_pass_fuzz.py"), "--cases", "40", "--seed", "3"], cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "0 mismatches" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_two_pass_with_a_pair_buffer_that_overflows():
+    """two-pass frames and the (splat, bin) pair capacity: the host-output Render grows the buffer and retries until the frame is
+    the single pass's frame; a device-output Render that overflowed in EITHER pass reports it on the next call and renders
+    correctly after the growth"""
+    import torch
+    from splatapult_amd import MsplatError, _capi
+    cloud = scenes.synth_cloud(12000, 123, log_scale_mean=-0.5, pos_sigma=1.0)      # ~10 M pairs at 1024 x 1024, capacity starts at 4 M
+    W = H = 1024
+    cam, proj, vp, nf = scenes.default_view(W, H, z=4.0)
+    want = make_renderer(cloud, two_pass=_capi.TWO_PASS_OFF)
+    want.Sort(cam, proj, vp, nf)
+    expect = want.Render(cam, proj, vp, nf)
+    for share in (0.05, 0.5, 1.0):
+        r = make_renderer(cloud, two_pass=_capi.TWO_PASS_ON)
+        r.two_pass_state(share)
+        r.Sort(cam, proj, vp, nf)
+        np.testing.assert_array_equal(r.Render(cam, proj, vp, nf), expect)       # host output: grows synchronously and retries
+        assert r.two_pass_state(share)[0] >= 1
+        dev = torch.device("cuda", 0)
+        fb = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+        r = make_renderer(cloud, two_pass=_capi.TWO_PASS_ON)
+        r.two_pass_state(share)
+        r.Sort(cam, proj, vp, nf)
+        r.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)
+        try:
+            r.synchronize()
+            overflowed = False
+        except MsplatError as e:
+            assert e.code == _capi.ERR_PAIR_OVERFLOW
+            overflowed = True
+        if overflowed:
+            r.Sort(cam, proj, vp, nf)
+            r.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)
+            r.synchronize()
+        np.testing.assert_array_equal(fb.cpu().numpy(), expect)

@@ -1846,6 +1846,32 @@ def test_two_pass_with_bands_fp16_frames_in_flight_and_the_feedback_loop():
     assert c.two_pass_info() is None and c.stats()["pairs"] == a.stats()["pairs"]
 
 
+def test_two_pass_nothing_visible_and_tiny_viewports():
+    """forced two-pass frames with no visible splat (camera looking away), one visible splat, a viewport smaller than a bin"""
+    from splatapult_amd import _capi
+    cloud = scenes.synth_cloud(5000, 311, log_scale_mean=-3.0)
+    for W, H, z, yaw in ((320, 200, -30.0, 0.0), (320, 200, 6.0, 0.0), (17, 9, 6.0, 0.3), (33, 31, 2.0, 1.0)):
+        a, b = _two_pass_pair(cloud)
+        b.two_pass_state(0.3)
+        cam, proj, vp, nf = scenes.default_view(W, H, z=z, yaw=yaw)
+        if z < 0:
+            cam = camera.pose((0.0, 0.0, 30.0))            # the cloud is behind the camera (it looks down -z from z = 30 ... away: flip below)
+            cam = np.array(cam, np.float32).reshape(4, 4).copy()
+            cam[2, :3] *= -1.0; cam[0, :3] *= -1.0         # rotate 180 degrees about y: now it looks away from the cloud
+        for _ in range(2):
+            a.Sort(cam, proj, vp, nf); b.Sort(cam, proj, vp, nf)
+            np.testing.assert_array_equal(a.Render(cam, proj, vp, nf), b.Render(cam, proj, vp, nf))
+        assert a.sort_count() == b.sort_count()
+        if z < 0:
+            assert a.sort_count() == 0
+    one = scenes.synth_cloud(1, 312, log_scale_mean=-2.0)
+    a, b = _two_pass_pair(one)
+    b.two_pass_state(1.0 / 256.0)
+    cam, proj, vp, nf = scenes.default_view(200, 120, z=5.0)
+    a.Sort(cam, proj, vp, nf); b.Sort(cam, proj, vp, nf)
+    np.testing.assert_array_equal(a.Render(cam, proj, vp, nf), b.Render(cam, proj, vp, nf))
+
+
 def test_two_pass_fuzz():
     """tools/two_pass_fuzz.py, shortened: random clouds / cameras / viewports / band plans / targets / shares"""
     import os

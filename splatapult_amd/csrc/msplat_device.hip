@@ -1706,7 +1706,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][3], s));
 
     // binning + compositor over the current rectangles: once per frame, twice for a two-pass frame
-    // (ev_bin / ev_c0 / ev_c1: the timing events of this chain; fin / binfin: see composite_kernel)
+    // (ev_bin / ev_c0 / ev_c1: the timing events of this chain; occ_pass: 0 one pass, 1 / 2 the passes of a two-pass frame)
     auto chain = [&](int keep_overflow, int occ_pass, int ev_bin, int ev_c0, int ev_c1) -> int {
     uint32_t* fin = occ_pass ? (uint32_t*)ctx->occ_fin.p : nullptr;
     float4* state = occ_pass ? (float4*)ctx->occ_state.p : nullptr;

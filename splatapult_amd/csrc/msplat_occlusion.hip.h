@@ -11,10 +11,10 @@
 //            of them is final; any other stops in front of its first incomplete batch and leaves its accumulators (r, g, b, T per
 //            pixel, fp32) and the number of entries it composited.
 //   gate     the unfinished bins form a summed-area table (any block of bins is tested with four reads).  A splat of pass 1
-//            keeps its rectangle only if it touches an unfinished
-//            bin; a splat behind the cut is tested with a conservative screen box from its centre and its footprint bound
-//            (pos4.w, the bound of the band-restricted cull) BEFORE its 256-byte record is fetched, and is projected only if
-//            that box touches one.
+//            keeps its rectangle only if it touches an unfinished bin; a splat behind the cut is tested BEFORE its 256-byte
+//            record is fetched -- first its bounding box of 256 stored splats (spatially ordered clouds), then a conservative
+//            screen box from its centre and its footprint bound (pos4.w, the bound of the band-restricted cull) -- and is
+//            projected only if that box touches one.
 //   pass 2   the surviving rectangles of ALL ranks are binned again: an unfinished bin gets its complete list (a splat that
 //            touches it passes the gate by construction), whose last entries are the ones pass 1 composited: its unfinished
 //            tiles RESUME behind them -- at a batch boundary of the single pass; finished tiles are skipped.
@@ -35,7 +35,9 @@ constexpr int kOccSatMax = 24576;             // (tiles_x + 1) (tiles_y + 1): 40
 
 // occ[0] = cut (first rank of pass 1, a multiple of 1024 = kBinChunk), occ[1] = splats behind the cut that pass the gate, occ[2] =
 // unfinished bins, occ[4] = ranks the second binning chain walks (occ_mask_kernel).  The cut is a pure function of V and the
-// share, evaluated by project_kernel's first pass itself (its first workgroup also publishes it and clears occ[1], occ[2]).
+// share (occ_cut, msplat_common.hip.h), evaluated by project_kernel's first pass itself (its first workgroup also publishes it
+// and clears occ[1], occ[2]).
+
 // ONE workgroup: fin[bin * 4 + quadrant] (composite_kernel, pass 1) -> the summed-area table of the bins with a tile to resume
 // (built in LDS: a row prefix per thread, then a column prefix per thread), their number
 constexpr int kOccMaskThreads = 1024;

@@ -241,14 +241,13 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
                                                                const uint32_t* __restrict__ rank_list = nullptr, float occ_share = 0.0f)
 {
     // Two-pass frame (msplat_occlusion.hip.h).  d_cut: pass 1 -- ranks below cut = occ_cut(V, occ_share) only get an empty
-    // rectangle, their records are not fetched; the cut is left in d_cut[0] (= occ[0]).  rank_list: pass 2 -- the *d_V ranks to project are listed (any order); records
-    // and rectangles are stored by rank as always.
+    // rectangle, their records are not fetched; the cut is left in d_cut[0] (= occ[0]).  rank_list: pass 2 -- the *d_V ranks to
+    // project are listed (any order); records and rectangles are stored by rank as always.
     // Records are 256 B (full SH) or 128 B (base) and line aligned.  The gather by sorted index is
-    // done cooperatively: F4 consecutive lanes fetch one whole record (coalesced 256/128 B), the wave
+    // done cooperatively (project_block): F4 consecutive lanes fetch one whole record (coalesced 256/128 B), the wave
     // stages 64 records in LDS, then every lane reads its own record back (stride 68/36 dwords keeps
     // the ds_read_b128 accesses conflict free).
     constexpr int F4 = FULL_SH ? 16 : 8;
-    constexpr int RPI = 64 / F4;              // records fetched per wave-wide load instruction
     constexpr int STRIDE = F4 * 4 + 4;        // dwords
     __shared__ __attribute__((aligned(16))) float s_stage[64 * STRIDE];
     const uint32_t V = *d_V;

@@ -40,6 +40,8 @@ def _check_contract(d, n):
         assert st["bytes"] > 0 and st["us"] > 0 and 0.0 < st["frac"] <= 1.0, (k, st)
     assert 0.0 < d["frame_moved_frac"] <= 1.0 and 0.0 < d["frame_moved_frac_serial"] <= 1.0
     assert "formula_frac" not in r and "frame_hbm_frac" not in d
+    tp = cfg["two_pass"]                                   # r4: what the latest two-pass frame did (None: the frames ran in one pass)
+    assert tp["mode"] in ("auto", "on", "off") and set(tp) == {"mode", "timed_region", "serial_frames"}
 
 
 def test_bench_single_gpu_json_contract():
@@ -88,3 +90,22 @@ def test_bench_peer_store_check_child_mode():
     assert p.returncode == 0, p.stderr[-2000:]
     d = _line(p.stdout)
     assert d["error"] is None and d["bit_exact"] is True and d["devices"] == [0] and d["poses"] == [5, 37]
+
+
+def test_bench_two_pass_workload_reports_what_the_passes_did():
+    """a 6 M-splat workload with two-pass frames forced on: the line says what pass 1 and pass 2 did, and no stage fraction exceeds 1"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "cfg3", "--two-pass", "on",
+                        "--no-cpu-baseline", "--steps", "6", "--warmup", "2", "--prewarm", "12", "--serial-frames", "16", "--profile-frames", "1"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    tp = d["config"]["two_pass"]
+    assert tp["mode"] == "on"
+    for part in ("timed_region", "serial_frames"):
+        t = tp[part]
+        assert t is not None and 0 < t["splats_pass1"] < t["visible"] and t["pairs_pass1"] > 0 and t["bins"] == 60 * 34
+        assert 0.0 < t["share_pass1"] <= 0.75
+    for k in ("sort", "project", "binning", "composite"):
+        st = d["roofline"]["stages"][k]
+        assert st["bytes"] > 0 and st["us"] > 0 and 0.0 < st["frac"] <= 1.0, (k, st)
+    assert 0.0 < d["frame_moved_frac"] <= 1.0

@@ -215,7 +215,7 @@ struct msplat_ctx {
     // two-pass frame with occlusion feedback (msplat_occlusion.hip.h)
     Buf occ, occ_mask, occ_fin, occ_state, occ_live, occ_boxdead, occ_unf;
     int two_pass_mode = MSPLAT_TWO_PASS_AUTO;
-    float occ_frac = 0.25f;                  // share of the visible splats that goes into pass 1
+    float occ_frac = 0.15f;                  // share of the visible splats that goes into pass 1 (0.15-0.3 is the optimum of the blobs, 0.02 of a camera inside a scene)
     uint32_t occ_streak = 0;                 // consecutive two-pass frames submitted (their feedback describes two-pass frames)
     uint32_t occ_seq = 0, occ_change_seq = 0;   // number of the latest two-pass frame; first frame that ran with the current share
     uint32_t occ_off = 0;                    // AUTO: frames left of a single-pass period after two passes did not pay
@@ -1611,7 +1611,7 @@ static bool occlusion_plan(msplat_ctx* ctx, const FrameParams& fp, bool stereo, 
             ctx->occ_state_auto = PROBE;
             ctx->occ_probe_left = 4u;
             ctx->occ_strikes = 0u;
-            set_share(0.25f);
+            set_share(0.15f);
         }
         if (ctx->occ_state_auto == WAIT) {
             if (!fresh) return no();

@@ -70,6 +70,12 @@ public:
     // frame in flight.
     void SetFramesInFlight(int depth) { framesInFlight = depth < 1 ? 1 : depth; }
 
+    // msplat_config.two_pass (before Init): MSPLAT_TWO_PASS_AUTO (default) / _ON / _OFF -- Render in two passes with occlusion
+    // feedback, the same pixels (include/msplat.h).  TwoPassInfo: what the current context's latest two-pass Render did
+    // (msplat_get_two_pass_info; out[0] == 0: it ran in one pass).
+    void SetTwoPass(int mode) { cfg.two_pass = mode; }
+    bool TwoPassInfo(uint64_t out[8]) const { return ctx != nullptr && msplat_get_two_pass_info(ctx, out) == MSPLAT_OK; }
+
     // splatrenderer.cpp:50-151.  false after logging on failure.  The cloud is copied to the device and
     // not retained; useRgcSortOverride is accepted and ignored (one HIP sort replaces both GL sorters).
     bool Init(std::shared_ptr<GaussianCloud> gaussianCloud, bool isFramebufferSRGBEnabledIn, bool useRgcSortOverrideIn)

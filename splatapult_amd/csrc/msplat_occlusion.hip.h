@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kThreads) void occ_box_kernel(const CullBox* __rest
 // stored by rank), otherwise its rectangle stays empty (project_kernel wrote it in pass 1).  The list is gathered in LDS and
 // appended with ONE global atomic per workgroup (same-address atomics are served one per ~10 ns: an atomic per wave made this
 // kernel 137 us at 1 M splats).
-constexpr int kOccGateItems = 16;
+constexpr int kOccGateItems = 8;          // (16: 168 VGPRs, the gate 8 us slower at 6 M splats; 4: no better)
 constexpr int kOccGateRanks = kThreads * kOccGateItems;
 __global__ __launch_bounds__(kThreads) void occ_gate_kernel(const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ d_V,
                                                             uint32_t* __restrict__ occ, const float4* __restrict__ pos4,

@@ -66,12 +66,56 @@ struct FrameParams {
     float view1[16], proj1[16], eye1[3];
 };
 
+// What the compositor needs of a frame (r5): eleven words instead of FrameParams' five matrices in its kernarg segment / SGPRs.
+struct CompParams {
+    int width, height, tiles_x;
+    int banded, band_first, band_block, band_stride;     // as in FrameParams
+    int rows_view;                                       // two views in one chain: bin rows of the first view
+    float t_eps;
+};
+__host__ inline CompParams comp_params(const FrameParams& fp)
+{
+    return CompParams{fp.width, fp.height, fp.tiles_x, fp.banded, fp.band_first, fp.band_block, fp.band_stride, fp.rows_view, fp.t_eps};
+}
+
+// What project_kernel needs of a frame (r5): one view's matrices and the raster geometry -- no mvp (the sort's), no second view.
+struct ProjParams {
+    float view[16], proj[16], eye[3];
+    float W, H, X0, Y0;
+    int width, height, tiles_y;
+    int banded, band_first, band_block, band_stride;
+    float band_inv_stride;
+    int srgb, depth_bits, rows_view;
+};
+struct ProjView1 { float view[16], proj[16], eye[3]; };   // the second view of a two-view chain (project_kernel<*, PROJ_TWO_VIEWS> only)
+struct ProjNoView1 { int unused; };
+__host__ inline ProjParams proj_params(const FrameParams& fp)
+{
+    ProjParams p;
+    for (int i = 0; i < 16; ++i) { p.view[i] = fp.view[i]; p.proj[i] = fp.proj[i]; }
+    for (int i = 0; i < 3; ++i) p.eye[i] = fp.eye[i];
+    p.W = fp.W; p.H = fp.H; p.X0 = fp.X0; p.Y0 = fp.Y0;
+    p.width = fp.width; p.height = fp.height; p.tiles_y = fp.tiles_y;
+    p.banded = fp.banded; p.band_first = fp.band_first; p.band_block = fp.band_block; p.band_stride = fp.band_stride;
+    p.band_inv_stride = fp.band_inv_stride;
+    p.srgb = fp.srgb; p.depth_bits = fp.depth_bits; p.rows_view = fp.rows_view;
+    return p;
+}
+__host__ inline ProjView1 proj_view1(const FrameParams& fp)
+{
+    ProjView1 v;
+    for (int i = 0; i < 16; ++i) { v.view[i] = fp.view1[i]; v.proj[i] = fp.proj1[i]; }
+    for (int i = 0; i < 3; ++i) v.eye[i] = fp.eye1[i];
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
 
 // band geometry (see FrameParams): real bin row of virtual row vy
-__host__ __device__ __forceinline__ int band_real_row(const FrameParams& fp, int vy)
+template <class P>
+__host__ __device__ __forceinline__ int band_real_row(const P& fp, int vy)
 {
     if (!fp.banded) return vy;
     const int k = vy / fp.band_block;
@@ -80,12 +124,14 @@ __host__ __device__ __forceinline__ int band_real_row(const FrameParams& fp, int
 // d / band_stride for 0 <= d < 65536 without an integer division (~30 instructions on this hardware, twice per splat in the
 // band-culled sort and in project_kernel): (d + 0.5) / s lies at least 0.5 / s away from every integer, far more than the
 // float error of the product
-__host__ __device__ __forceinline__ int band_quot(const FrameParams& fp, int d)
+template <class P>
+__host__ __device__ __forceinline__ int band_quot(const P& fp, int d)
 {
     return (int)(((float)d + 0.5f) * fp.band_inv_stride);
 }
 // virtual index of the first owned row >= t (>= tiles_y: there is none)
-__host__ __device__ __forceinline__ int band_first_owned_from(const FrameParams& fp, int t)
+template <class P>
+__host__ __device__ __forceinline__ int band_first_owned_from(const P& fp, int t)
 {
     if (!fp.banded) return t < 0 ? 0 : t;
     if (t <= fp.band_first) return 0;
@@ -93,7 +139,8 @@ __host__ __device__ __forceinline__ int band_first_owned_from(const FrameParams&
     return j < fp.band_block ? k * fp.band_block + j : (k + 1) * fp.band_block;
 }
 // virtual index of the last owned row <= t (-1: there is none; may be >= tiles_y: clamp)
-__host__ __device__ __forceinline__ int band_last_owned_upto(const FrameParams& fp, int t)
+template <class P>
+__host__ __device__ __forceinline__ int band_last_owned_upto(const P& fp, int t)
 {
     if (!fp.banded) return t;
     if (t < fp.band_first) return -1;

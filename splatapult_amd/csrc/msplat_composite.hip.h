@@ -101,23 +101,33 @@ constexpr int kCompOcc = 5;        // waves per SIMD the register allocation lea
 // tw = Ts w' = T w exactly as before (powers of two), colours accumulate unchanged and Ts -= 2^118 tw.  The bias costs 4 bits
 // of the exponent's absolute precision (|e - 118| ~ 2^7 instead of <= 2^3): a relative error of 3e-6 in w.  Only e == -8
 // exactly (w == 1/256, which the reference discards) is kept: a measure-zero threshold flip.
-template <bool F16>
+// Template parameters instead of run-time arguments (r5): F16 = RGBA16F target; OCC = 0 one pass, 1 / 2 the passes of a two-pass
+// frame; TWO_VIEWS = both eyes in one chain; PROBE = per-item counters.  The plain frame's instantiation <F16, 0, false, false>
+// carries none of the others' registers (r4 passed them at run time on top of the ~500-byte FrameParams: 81 VGPRs / 14 SGPR spills
+// against r3's 79 / 5) and takes the eleven words of CompParams instead of five 4x4 matrices.
+struct CompExtra {
+    void* out1;                  // TWO_VIEWS: the second view's target (bin rows >= rows_view belong to it)
+    uint32_t* fin;               // OCC != 0: per (bin, quadrant) 0xFFFFFFFF = final, else entries composited by pass 1
+    float4* state;               // OCC != 0: (r, g, b, 2^118 T) per pixel of the tiles pass 1 leaves unfinished
+    const uint32_t* d_nbins;     // OCC == 2: `order` lists *d_nbins bins -- the unfinished ones -- and the items are theirs alone
+    uint32_t* probe;             // PROBE: 8 words per work item
+};
+
+template <bool F16, int OCC, bool TWO_VIEWS, bool PROBE>
 __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const uint32_t* __restrict__ tile_start,
                                                                  const uint32_t* __restrict__ pairs,
                                                                  const float4* __restrict__ rec,
                                                                  void* __restrict__ out, size_t pitch_bytes,
-                                                                 FrameParams fp, uint32_t cap,
+                                                                 CompParams fp, uint32_t cap,
                                                                  const uint32_t* __restrict__ order,
                                                                  uint32_t* __restrict__ queue, uint32_t ntiles,
-                                                                 uint32_t* __restrict__ probe, int prio_levels,
-                                                                 void* __restrict__ out1 = nullptr,
-                                                                 uint32_t* __restrict__ fin = nullptr, int occ_pass = 0,
-                                                                 float4* __restrict__ state = nullptr,
-                                                                 const uint32_t* __restrict__ d_nbins = nullptr)
+                                                                 int prio_levels, CompExtra ex)
 {
-    // d_nbins (pass 2 of a two-pass frame): `order` lists *d_nbins bins -- the unfinished ones -- and the items are theirs alone
-    if (d_nbins != nullptr) ntiles = *d_nbins * 4u;
-    // out1: the second view's target (FrameParams.views == 2: bin rows >= rows_view belong to it)
+    constexpr int occ_pass = OCC;
+    uint32_t* __restrict__ const fin = ex.fin;
+    float4* __restrict__ const state = ex.state;
+    uint32_t* __restrict__ const probe = PROBE ? ex.probe : nullptr;
+    if (OCC == 2) ntiles = *ex.d_nbins * 4u;
     // Two-pass frame (msplat_occlusion.hip.h), occ_pass 1 / 2; fin[bin * 4 + quadrant] and state[y * width + x] = (r, g, b, 2^118 T)
     // carry a tile from one to the other.  Pass 1 walks WHOLE batches only: a tile whose strips are all saturated after one of
     // them is final (fin = 0xFFFFFFFF, pixels written); otherwise it stops in front of the first incomplete batch, leaves its
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
     const int quad = (int)quadrant;
     const int bvy = bin / fp.tiles_x;
     const int tx = (bin - bvy * fp.tiles_x) * 2 + (quad & 1);
-    const bool second = fp.views == 2 && bvy >= fp.rows_view;
+    const bool second = TWO_VIEWS && bvy >= fp.rows_view;
     const int ty = (second ? bvy - fp.rows_view : band_real_row(fp, bvy)) * 2 + (quad >> 1);
     if (tx * kTile >= fp.width || ty * kTile >= fp.height || (occ_pass == 2 && fin[bin * 4 + quad] == 0xFFFFFFFFu)) {
         // work item entirely outside the image, or (pass 2 of a two-pass frame) the tile was finished by pass 1
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
     cntA = min((uint32_t)kCompThreads, hiA - start);
     if (lane < (int)cntA) rankA = pairs[hiA - 1u - lane];
     hiA -= cntA;
-    const uint64_t probe_t0 = probe ? clock64() : 0ull;
+    const uint64_t probe_t0 = PROBE ? clock64() : 0ull;
     uint32_t probe_n = 0, probe_batches = 0;
     uint64_t probe_inner = 0;
     // pair words / records whose loads have been issued so far (the prefetch pipeline runs two / one batches ahead)
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
         ++probe_batches;
         probe_words += cntA;
         probe_recs += cnt;
-        const uint64_t probe_t1 = probe ? clock64() : 0ull;
+        const uint64_t probe_t1 = PROBE ? clock64() : 0ull;
         if (n != 0u) {
             float4 a = s_rec[0];          // c5, c0, r, c1
             float4 b = s_rec[1];          // g, c2, b, c3
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
                 a = na; b = nb; c4 = nc4;
             }
         }
-        if (probe) probe_inner += clock64() - probe_t1;
+        if (PROBE) probe_inner += clock64() - probe_t1;
         // strips whose 64 pixels are all saturated (or outside the image) are finished
         uint32_t na = 0;
 #pragma unroll
@@ -382,7 +392,7 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
     // (pass 1 of a two-pass frame) final, or to be resumed by pass 2?
     const bool carry = occ_pass == 1 && alive != 0u;
     if (occ_pass == 1 && lane == 0) fin[bin * 4 + quad] = carry ? consumed : 0xFFFFFFFFu;
-    if (probe != nullptr && lane == 0) {
+    if (PROBE && lane == 0) {
         probe[tile * 8 + 0] = (uint32_t)(clock64() - probe_t0);        // shader clocks, whole tile
         probe[tile * 8 + 1] = probe_n;          // splats composited (after culling / saturation)
         probe[tile * 8 + 2] = probe_batches;    // batches of 64 list entries staged
@@ -401,7 +411,7 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         if (inside[k] && !carry) {
-            char* row = (char*)(second ? out1 : out) + (size_t)(ybase + 4 * k) * pitch_bytes;
+            char* row = (char*)(second ? ex.out1 : out) + (size_t)(ybase + 4 * k) * pitch_bytes;
             if (F16) {
                 union { _Float16 h[4]; uint2 u; } pk;
                 pk.h[0] = (_Float16)cr[k >> 1][k & 1]; pk.h[1] = (_Float16)cg[k >> 1][k & 1]; pk.h[2] = (_Float16)cb[k >> 1][k & 1]; pk.h[3] = (_Float16)1.0f;

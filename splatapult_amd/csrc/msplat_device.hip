@@ -1695,14 +1695,28 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         hipLaunchKernelGGL(point_project_kernel, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
                            (const float4*)ctx->pos4.p, (const float4*)ctx->recs.p, fp, ctx->sprite_params,
                            (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr);
-    else if (ctx->full_sh)
-        hipLaunchKernelGGL(project_kernel<true>, dim3(two_pass ? std::min(pgrid, kProjGridTwoPass) : pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_Vsort,
-                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
-                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr, stereo ? d_V : nullptr, d_cut, (const uint32_t*)nullptr, occ_frac);
-    else
-        hipLaunchKernelGGL(project_kernel<false>, dim3(two_pass ? std::min(pgrid, kProjGridTwoPass) : pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_Vsort,
-                           (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p,
-                           ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr, stereo ? d_V : nullptr, d_cut, (const uint32_t*)nullptr, occ_frac);
+    else {
+        const ProjParams pp = proj_params(fp);
+        uint32_t* zq = ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr;
+#define MSPLAT_PROJECT(SH, MODE, GRID, DV, EX, V1)                                                                              \
+        hipLaunchKernelGGL((project_kernel<SH, MODE>), dim3(GRID), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, DV,  \
+                           (const float4*)ctx->recs.p, pp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, zq, EX, V1)
+        if (two_pass) {
+            const ProjExtra ex{nullptr, d_cut, nullptr, occ_frac};
+            const int grid = std::min(pgrid, kProjGridTwoPass);
+            if (ctx->full_sh) MSPLAT_PROJECT(true, PROJ_PASS1, grid, (const uint32_t*)d_Vsort, ex, ProjNoView1{0});
+            else MSPLAT_PROJECT(false, PROJ_PASS1, grid, (const uint32_t*)d_Vsort, ex, ProjNoView1{0});
+        } else if (stereo) {
+            const ProjExtra ex{d_V, nullptr, nullptr, 0.0f};
+            const ProjView1 v1 = proj_view1(fp);
+            if (ctx->full_sh) MSPLAT_PROJECT(true, PROJ_TWO_VIEWS, pgrid, (const uint32_t*)d_Vsort, ex, v1);
+            else MSPLAT_PROJECT(false, PROJ_TWO_VIEWS, pgrid, (const uint32_t*)d_Vsort, ex, v1);
+        } else {
+            const ProjExtra ex{nullptr, nullptr, nullptr, 0.0f};
+            if (ctx->full_sh) MSPLAT_PROJECT(true, PROJ_PLAIN, pgrid, (const uint32_t*)d_Vsort, ex, ProjNoView1{0});
+            else MSPLAT_PROJECT(false, PROJ_PLAIN, pgrid, (const uint32_t*)d_Vsort, ex, ProjNoView1{0});
+        }
+    }
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][3], s));
 
     // binning + compositor over the current rectangles: once per frame, twice for a two-pass frame
@@ -1868,12 +1882,25 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         // = 5.82 / 5.76 / 5.79 k frames/s, i.e. no effect there)
         const int prio_mode = ordered ? 1 : 0;
         const int grid = (int)std::min<uint32_t>(comp_items, comp_pool);
-        if (f16)
-            hipExtLaunchKernelGGL(composite_kernel<true>, dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
-                                  cap, ord, d_queue, comp_items, probe, occ_pass == 2 ? 0 : prio_mode, d_out1, fin, occ_pass, state, d_nbins);
-        else
-            hipExtLaunchKernelGGL(composite_kernel<false>, dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2, d_out, pitch, fp,
-                                  cap, ord, d_queue, comp_items, probe, occ_pass == 2 ? 0 : prio_mode, d_out1, fin, occ_pass, state, d_nbins);
+        const CompParams cp = comp_params(fp);
+        const CompExtra ex{d_out1, fin, state, d_nbins, probe};
+        const int prio = occ_pass == 2 ? 0 : prio_mode;
+#define MSPLAT_COMPOSITE(F16, OCC, TWO, PROBE)                                                                                     \
+        hipExtLaunchKernelGGL((composite_kernel<F16, OCC, TWO, PROBE>), dim3(grid), dim3(kCompThreads), 0, s, e0, e1, 0, ts, pb, r2,  \
+                              d_out, pitch, cp, cap, ord, d_queue, comp_items, prio, ex)
+#define MSPLAT_COMPOSITE_F(F16)                                                                                                    \
+        do {                                                                                                                       \
+            if (occ_pass == 1) MSPLAT_COMPOSITE(F16, 1, false, false);                                                             \
+            else if (occ_pass == 2) MSPLAT_COMPOSITE(F16, 2, false, false);                                                        \
+            else if (stereo && probe) MSPLAT_COMPOSITE(F16, 0, true, true);                                                        \
+            else if (stereo) MSPLAT_COMPOSITE(F16, 0, true, false);                                                                \
+            else if (probe) MSPLAT_COMPOSITE(F16, 0, false, true);                                                                 \
+            else MSPLAT_COMPOSITE(F16, 0, false, false);                                                                           \
+        } while (0)
+        // (occlusion_plan never chooses two passes for two views in one chain or while the probe is on)
+        if (f16) MSPLAT_COMPOSITE_F(true); else MSPLAT_COMPOSITE_F(false);
+#undef MSPLAT_COMPOSITE_F
+#undef MSPLAT_COMPOSITE
         ctx->comp_kernel_timed = timed;
     } else {
         ctx->comp_kernel_timed = false;
@@ -1899,14 +1926,15 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
                            (const uint16_t*)ctx->occ_mask.p, (uint32_t*)ctx->occ_live.p, ctx->d_flags, (const uint32_t*)d_D, ctx->occ_seq,
                            use_boxes ? (const uint32_t*)ctx->occ_boxdead.p : (const uint32_t*)nullptr, boxwords);
         // the listed ranks behind the cut (occ[1] of them)
-        if (ctx->full_sh)
-            hipLaunchKernelGGL(project_kernel<true>, dim3(std::min(pgrid, kProjGridTwoPass)), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, (const uint32_t*)(occ + 1),
-                               (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, (uint32_t*)nullptr,
-                               ctx->d_flags ? ctx->d_flags + 7 : (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)ctx->occ_live.p);
-        else
-            hipLaunchKernelGGL(project_kernel<false>, dim3(std::min(pgrid, kProjGridTwoPass)), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, (const uint32_t*)(occ + 1),
-                               (const float4*)ctx->recs.p, fp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, (uint32_t*)nullptr,
-                               ctx->d_flags ? ctx->d_flags + 7 : (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)ctx->occ_live.p);
+        {
+            const ProjParams pp = proj_params(fp);
+            uint32_t* zq = nullptr;
+            const ProjExtra ex{ctx->d_flags ? ctx->d_flags + 7 : (uint32_t*)nullptr, nullptr, (const uint32_t*)ctx->occ_live.p, 0.0f};
+            const int grid = std::min(pgrid, kProjGridTwoPass);
+            if (ctx->full_sh) MSPLAT_PROJECT(true, PROJ_LISTED, grid, (const uint32_t*)(occ + 1), ex, ProjNoView1{0});
+            else MSPLAT_PROJECT(false, PROJ_LISTED, grid, (const uint32_t*)(occ + 1), ex, ProjNoView1{0});
+        }
+#undef MSPLAT_PROJECT
         if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][9], s));
         const bool timed1 = ctx->comp_kernel_timed;
         crc = chain(1, 2, 10, 11, 12);

@@ -37,10 +37,12 @@ constexpr int kProjThreads = 64;          // one wave per workgroup: wave-privat
 
 // one wave-block of 64 ranks: cooperative gather of the records, then the vertex + geometry stage per lane (rank r, rank rl inside
 // its view; lanes with !valid take part in the gather only).  s_stage: 64 * STRIDE floats of wave-private LDS.
-template <bool FULL_SH>
-__device__ __forceinline__ void project_block(const uint32_t r, const uint32_t rl, const bool valid, const bool second, const int lane,
+// vm / pm / eye: the view's matrices (kernarg words: they stay in SGPRs); SECOND: the second view of a two-view chain.
+template <bool FULL_SH, bool SECOND>
+__device__ __forceinline__ void project_block(const uint32_t r, const uint32_t rl, const bool valid, const int lane,
                                               const uint32_t* __restrict__ sorted_idx, const float4* __restrict__ recs,
-                                              const FrameParams& fp, float4* __restrict__ out_rec, uint32_t* __restrict__ out_rect,
+                                              const ProjParams& fp, const float* vm, const float* pm, const float* eye,
+                                              float4* __restrict__ out_rec, uint32_t* __restrict__ out_rect,
                                               uint32_t* __restrict__ out_zq, float* s_stage)
 {
     constexpr int F4 = FULL_SH ? 16 : 8;
@@ -71,9 +73,6 @@ __device__ __forceinline__ void project_block(const uint32_t r, const uint32_t r
     }
     if (!valid) return;
     const float x = f[0], y = f[1], z = f[2], alpha = f[3];
-    const float* vm = second ? fp.view1 : fp.view;
-    const float* pm = second ? fp.proj1 : fp.proj;
-    const float* eye = second ? fp.eye1 : fp.eye;
 
     // t = viewMat * vec4(pos, 1)   -- same op order as the oracle (reject tests must not flip)
     float t[4];
@@ -207,7 +206,7 @@ __device__ __forceinline__ void project_block(const uint32_t r, const uint32_t r
                 ty0 = v0;
                 ty1 = v1;
             }
-            if (second) { ty0 += fp.rows_view; ty1 += fp.rows_view; }         // the second view's bins follow the first's
+            if (SECOND) { ty0 += fp.rows_view; ty1 += fp.rows_view; }         // the second view's bins follow the first's
             if (ty0 <= ty1) {
                 rect = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)tx1 << 16) | ((uint32_t)ty1 << 24);
             }
@@ -229,20 +228,34 @@ __device__ __forceinline__ void project_block(const uint32_t r, const uint32_t r
     if (out_zq != nullptr) out_zq[r] = quantise_depth(ndcz, fp.depth_bits);
 }
 
-template <bool FULL_SH>
+// MODE (r5: template parameters instead of r4's run-time arguments, which cost the plain frame 149 VGPRs / 36 SGPR spills against
+// r3's 98 / 0): PROJ_PLAIN one view, one pass; PROJ_PASS1 / PROJ_LISTED the two projections of a two-pass frame
+// (msplat_occlusion.hip.h); PROJ_TWO_VIEWS both eyes in one chain.
+// (plain ints, and the second view's type through a named trait: an unnamed enum or a conditional on MODE in the kernel's signature
+//  mangles differently in the host and the device compilation -- "Cannot find Symbol" at the first launch)
+constexpr int PROJ_PLAIN = 0, PROJ_PASS1 = 1, PROJ_LISTED = 2, PROJ_TWO_VIEWS = 3;
+template <int MODE> struct ProjSecondView { using type = ProjNoView1; };
+template <> struct ProjSecondView<3> { using type = ProjView1; };
+struct ProjExtra {
+    uint32_t* d_Veff;            // PROJ_TWO_VIEWS: ranks the binning walks (V1 + V); PROJ_LISTED: optional host-mapped count of listed ranks
+    uint32_t* d_cut;             // PROJ_PASS1: occ[0 .. 2]
+    const uint32_t* rank_list;   // PROJ_LISTED: the *d_V ranks to project (any order)
+    float occ_share;             // PROJ_PASS1: share of the visible splats in pass 1
+};
+
+template <bool FULL_SH, int MODE>
 __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* __restrict__ sorted_idx,
                                                                const uint32_t* __restrict__ d_V,
                                                                const float4* __restrict__ recs,
-                                                               FrameParams fp,
+                                                               ProjParams fp,
                                                                float4* __restrict__ out_rec,
                                                                uint32_t* __restrict__ out_rect,
-                                                               uint32_t* __restrict__ out_zq, uint32_t* __restrict__ d_Veff = nullptr,
-                                                               uint32_t* __restrict__ d_cut = nullptr,
-                                                               const uint32_t* __restrict__ rank_list = nullptr, float occ_share = 0.0f)
+                                                               uint32_t* __restrict__ out_zq, ProjExtra ex,
+                                                               typename ProjSecondView<MODE>::type v1)
 {
-    // Two-pass frame (msplat_occlusion.hip.h).  d_cut: pass 1 -- ranks below cut = occ_cut(V, occ_share) only get an empty
-    // rectangle, their records are not fetched; the cut is left in d_cut[0] (= occ[0]).  rank_list: pass 2 -- the *d_V ranks to
-    // project are listed (any order); records and rectangles are stored by rank as always.
+    // PROJ_PASS1: ranks below cut = occ_cut(V, occ_share) only get an empty rectangle, their records are not fetched; the cut is
+    // left in d_cut[0] (= occ[0]).  PROJ_LISTED: the *d_V ranks to project are listed (any order); records and rectangles are
+    // stored by rank as always.
     // Records are 256 B (full SH) or 128 B (base) and line aligned.  The gather by sorted index is
     // done cooperatively (project_block): F4 consecutive lanes fetch one whole record (coalesced 256/128 B), the wave
     // stages 64 records in LDS, then every lane reads its own record back (stride 68/36 dwords keeps
@@ -252,39 +265,46 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
     __shared__ __attribute__((aligned(16))) float s_stage[64 * STRIDE];
     const uint32_t V = *d_V;
     const int lane = threadIdx.x;
-    // two views in one chain (FrameParams.views == 2): ranks [0, V) are view 0, [V1, V1 + V) view 1; the gap gets empty rectangles
-    const uint32_t V1 = (V + 63u) & ~63u;
-    const uint32_t total = fp.views == 2 ? V1 + V : V;
-    if (d_Veff != nullptr && blockIdx.x == 0 && lane == 0) *d_Veff = total;       // what the binning passes walk
-    if (rank_list != nullptr) {
+    if constexpr (MODE == PROJ_LISTED) {
         // pass 2 of a two-pass frame: the listed ranks, grid-stride (the list is short: a grid sized for the cloud would be ~10^5
         // workgroups that find nothing -- 35 us at 6 M splats)
+        if (ex.d_Veff != nullptr && blockIdx.x == 0 && lane == 0) *ex.d_Veff = V;
         for (uint32_t s0 = blockIdx.x * kProjThreads; s0 < V; s0 += gridDim.x * kProjThreads) {
             const bool ok = s0 + lane < V;
-            const uint32_t rk = ok ? rank_list[s0 + lane] : 0u;
-            project_block<FULL_SH>(rk, rk, ok, false, lane, sorted_idx, recs, fp, out_rec, out_rect, out_zq, s_stage);
+            const uint32_t rk = ok ? ex.rank_list[s0 + lane] : 0u;
+            project_block<FULL_SH, false>(rk, rk, ok, lane, sorted_idx, recs, fp, fp.view, fp.proj, fp.eye, out_rec, out_rect, out_zq, s_stage);
             __syncthreads();              // s_stage is reused
         }
-        return;
-    }
-    if (d_cut != nullptr) {
+    } else if constexpr (MODE == PROJ_PASS1) {
         // pass 1 of a two-pass frame: ranks [cut, V) are projected (grid-stride), the ranks behind the cut get empty rectangles
-        const uint32_t cut = occ_cut(V, occ_share);
-        if (blockIdx.x == 0 && lane == 0) { d_cut[0] = cut; d_cut[1] = 0u; d_cut[2] = 0u; }      // occ[0 .. 2] for the kernels that follow
+        const uint32_t cut = occ_cut(V, ex.occ_share);
+        if (blockIdx.x == 0 && lane == 0) { ex.d_cut[0] = cut; ex.d_cut[1] = 0u; ex.d_cut[2] = 0u; }      // occ[0 .. 2] for the kernels that follow
         for (uint32_t i = blockIdx.x * kProjThreads + lane; i < cut; i += gridDim.x * kProjThreads) out_rect[i] = kRectEmpty;
         for (uint32_t r0 = cut + blockIdx.x * kProjThreads; r0 < V; r0 += gridDim.x * kProjThreads) {
-            project_block<FULL_SH>(r0 + lane, r0 + lane, r0 + lane < V, false, lane, sorted_idx, recs, fp, out_rec, out_rect, out_zq, s_stage);
+            project_block<FULL_SH, false>(r0 + lane, r0 + lane, r0 + lane < V, lane, sorted_idx, recs, fp, fp.view, fp.proj, fp.eye, out_rec, out_rect, out_zq, s_stage);
             __syncthreads();
         }
-        return;
+    } else if constexpr (MODE == PROJ_TWO_VIEWS) {
+        // ranks [0, V) are view 0, [V1, V1 + V) view 1 (V1 = V rounded up to 64: a wave never straddles the views); the gap gets
+        // empty rectangles
+        const uint32_t V1 = (V + 63u) & ~63u;
+        const uint32_t total = V1 + V;
+        if (blockIdx.x == 0 && lane == 0) *ex.d_Veff = total;       // what the binning passes walk
+        if (blockIdx.x * kProjThreads >= total) return;
+        const uint32_t r = blockIdx.x * kProjThreads + lane;
+        if (blockIdx.x * kProjThreads >= V1) {                        // wave-uniform
+            const uint32_t rl = r - V1;                               // rank inside the view
+            project_block<FULL_SH, true>(r, rl, rl < V, lane, sorted_idx, recs, fp, v1.view, v1.proj, v1.eye, out_rec, out_rect, out_zq, s_stage);
+        } else {
+            const bool valid = r < V;
+            if (!valid) out_rect[r] = kRectEmpty;                     // (the gap between the views, and nothing else)
+            project_block<FULL_SH, false>(r, r, valid, lane, sorted_idx, recs, fp, fp.view, fp.proj, fp.eye, out_rec, out_rect, out_zq, s_stage);
+        }
+    } else {
+        if (blockIdx.x * kProjThreads >= V) return;
+        const uint32_t r = blockIdx.x * kProjThreads + lane;
+        project_block<FULL_SH, false>(r, r, r < V, lane, sorted_idx, recs, fp, fp.view, fp.proj, fp.eye, out_rec, out_rect, out_zq, s_stage);
     }
-    if (blockIdx.x * kProjThreads >= total) return;
-    const uint32_t r = blockIdx.x * kProjThreads + lane;
-    const bool second = fp.views == 2 && blockIdx.x * kProjThreads >= V1;         // wave-uniform
-    const uint32_t rl = second ? r - V1 : r;                                       // rank inside the view
-    const bool valid = rl < V;
-    if (!valid && r < total) out_rect[r] = kRectEmpty;                             // (the gap between the views, and nothing else)
-    project_block<FULL_SH>(r, rl, valid, second, lane, sorted_idx, recs, fp, out_rec, out_rect, out_zq, s_stage);
 }
 
 __device__ __forceinline__ uint32_t rect_width(uint32_t rc)

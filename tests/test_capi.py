@@ -156,3 +156,29 @@ def test_frame_arguments_are_marshalled_through_one_buffer():
                 (cam, proj, [0, 0, 1], (0.1, 1.0)), (cam, proj, [0, 0, 1, 1], (0.1,)), (cam, proj, [0, 0, 1, 1], 3.0)):
         with pytest.raises(AssertionError):
             a.load(*bad)
+
+
+def test_every_kernel_the_host_registers_exists_in_the_device_code(tmp_path):
+    """The host half of libmsplat.so registers its kernels by mangled name; the first launch of a kernel whose name the device
+    compilation mangled differently aborts the process ("Cannot find Symbol", seen r5 with an unnamed enum in a kernel's
+    signature).  Checked without a GPU: every registered name has its kernel descriptor in the gfx950 code object."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not all(os.path.exists(os.path.join(llvm, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
+        pytest.skip("ROCm llvm tools not present")
+    lib = os.path.join(ROOT, "splatapult_amd", "lib", "libmsplat.so")
+    work = str(tmp_path)
+    shutil.copy(lib, os.path.join(work, "lib.so"))
+    fb, dev = os.path.join(work, "fb.bin"), os.path.join(work, "dev.elf")
+    subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fb, os.path.join(work, "lib.so")], check=True)
+    subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fb,
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + dev], check=True)
+    syms = subprocess.run([os.path.join(llvm, "llvm-readelf"), "-s", "-W", dev], check=True, capture_output=True, text=True).stdout
+    device = set(re.findall(r"(\S+)\.kd\b", syms))
+    ro = subprocess.run([os.path.join(llvm, "llvm-readelf"), "-p", ".rodata", os.path.join(work, "lib.so")], check=True,
+                        capture_output=True, text=True).stdout
+    host = set(re.findall(r"\]\s+(_ZN6msplat\S+)", ro))
+    assert len(host) > 40, len(host)                       # the registration strings were found at all
+    missing = sorted(h for h in host if h not in device)
+    assert not missing, missing

@@ -324,6 +324,13 @@ def measure(E, args, key, ply=None, primary=True):
     else:
         D_total = D
 
+    # ---- two-pass frames: are they THE frames?  (outside every timed region; only when the timed frames ran in two passes) ----
+    tp_check = None
+    if views == 1 and (tp_frames_flight > 0 or tp_serial is not None):
+        tp_check = two_pass_check(E, wl, init, cams_for, projs, vp, nf, W, Hpad, bpp, fdt,
+                                  tp_share_flight if tp_share_flight > 0.0 else 0.15,
+                                  (lay_kind, tiles_y, world, rank, lay_k) if world > 1 else None)
+
     # ---- N > 1: is rank 0's gathered frame THE frame?  (outside every timed region) ----
     gcheck = gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf, cloud, lay_kind, lay_k, primary) \
         if (world > 1 and gathers is not None) else None
@@ -448,6 +455,8 @@ def measure(E, args, key, ply=None, primary=True):
     }
     if gcheck is not None:
         out["gather_check"] = gcheck
+    if tp_check is not None:
+        out["two_pass_check"] = tp_check
     if world > 1 and gathers is not None:
         out["gather"] = {"p2p_ops_per_frame_rank0": (len(gathers[0].plan) * views) if rank == 0 else None,
                          "bytes_into_rank0_per_frame": None}
@@ -554,7 +563,7 @@ def main():
         sub = measure(E, args, key, primary=False)
         extra[key] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "gsplats_per_sec", "n_gpus", "rccl_ranks", "config",
                                           "timed_blocks", "serial", "stages_ms", "frame_moved_frac", "roofline", "gather",
-                                          "gather_check")
+                                          "gather_check", "two_pass_check")
                       if k in sub}
     if extra:
         out["also"] = extra
@@ -564,6 +573,13 @@ def main():
     if bad:
         out["value"] = None
         out["error"] = "gather_check failed for %s: rank 0's gathered frame differs from the unbanded render" % ", ".join(bad)
+    # a two-pass frame that is not bit-identical to the single pass voids the number as well
+    bad2 = [k for k, d in [(args.workload, out)] + list(extra.items())
+            if d.get("two_pass_check") is not None and not d["two_pass_check"]["bit_exact"]]
+    if bad2:
+        out["value"] = None
+        out["error"] = (out.get("error", "") + " two_pass_check failed for %s: a two-pass frame differs from the single pass" % ", ".join(bad2)).strip()
+        bad = bad + bad2
     if E.rank == 0:
         print(json.dumps(out))
     if E.world > 1:
@@ -637,6 +653,40 @@ def peer_store_check(args):
         out["error"] = "%s: %s" % (type(e).__name__, e)
     print(json.dumps(out))
     return 0
+
+
+def two_pass_check(E, wl, init, cams_for, projs, vp, nf, W, Hpad, bpp, fdt, share, band):
+    """Two fresh contexts -- two passes forced with the share the timed frames ended on, and one pass -- render orbit poses 5 and 37
+    (this rank's bin rows when the frame is row-sharded); the two-pass frames must equal the single-pass ones bit for bit
+    (one Render = one image however it is scheduled, src/splatrenderer.cpp:315-343)."""
+    import torch
+    from splatapult_amd import SplatRenderer, _capi
+    res = {"bit_exact": True, "poses": [5, 37], "share": float(share), "values_compared": 0, "values_different": 0, "two_pass_frames": 0}
+    rr = []
+    for mode in (_capi.TWO_PASS_OFF, _capi.TWO_PASS_ON):
+        x = SplatRenderer(device=E.local_rank, fb_format=wl["fb"], stream=E.stream.cuda_stream, frames_in_flight=1, two_pass=mode)
+        init(x)
+        if band is not None:
+            x.set_band_plan(band[0], band[1], band[2], band[3], block_rows=band[4], band_cull=True)
+        rr.append(x)
+    rr[1].two_pass_state(share)
+    fa = torch.zeros((Hpad, W, 4), dtype=fdt, device=E.dev)
+    fb = torch.zeros((Hpad, W, 4), dtype=fdt, device=E.dev)
+    for step in res["poses"]:
+        cam = cams_for(step)[0]
+        for x, f in ((rr[0], fa), (rr[1], fb)):
+            x.Sort(cam, projs[0], vp, nf)
+            x.Render(cam, projs[0], vp, nf, out_ptr=f.data_ptr(), pitch_bytes=W * bpp)
+            x.synchronize()
+        torch.cuda.synchronize(E.dev)
+        diff = int((fa != fb).sum().item())
+        res["values_compared"] += fa.numel()
+        res["values_different"] += diff
+    res["two_pass_frames"] = int(rr[1].two_pass_state(share)[0])
+    res["bit_exact"] = res["values_different"] == 0 and res["two_pass_frames"] == len(res["poses"])
+    for x in rr:
+        x.close()
+    return res
 
 
 def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf, cloud, lay_kind, lay_k, primary):

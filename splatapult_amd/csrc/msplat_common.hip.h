@@ -15,6 +15,14 @@
 namespace msplat {
 
 constexpr int kThreads = 256;            // 4 wave64 per workgroup
+// Wave issue priorities (s_setprio; SIMD arbitration is priority first, then age).  With frames in flight the waves of different
+// frames' kernels share SIMDs: the short, latency-bound sort / binning kernels run at 3, the HBM-bound projection at 2 and the
+// VALU-bound compositor at 1 (its heaviest items) or 0, so a chain kernel's few instructions between two memory waits are issued
+// ahead of the compositor's arithmetic instead of queueing behind it.  Measured r5 (tools/gpu_r5_d.sh, eight combinations,
+// driver protocol, same box): config 2 5741 -> 6028 frames/s (6208 -> 6352 in 500-frame blocks), config 5 2890 -> 3036,
+// 6 M / 1080p 2313 -> 2349, 6 M / 4096^2 1312 -> 1338, scene-like 5217 -> 5328; one frame at a time: unchanged.
+constexpr int kChainPrio = 3, kProjPrio = 2, kCompPrioMax = 1;
+#define MSPLAT_CHAIN_ENTER() __builtin_amdgcn_s_setprio(msplat::kChainPrio)
 // keys per thread per chunk of the sort passes: 8 (2048-key chunks) up to 2 M splats -- 4 measured no faster (r1), 16 slower
 // at 1 M (245 workgroups for 256 CUs: sort 76 -> 91 us) -- and 16 (4096-key chunks) beyond: digit runs twice as long make
 // the scattered write-out cheaper (6 M splats: sort 234 -> 212 us, r2)
@@ -207,7 +215,10 @@ __host__ __device__ inline float footprint_bound(const float* S, float alpha)
     }
     if (!(lmax <= tr)) lmax = tr;                       // NaN / negative-eigenvalue junk: fall back to the trace (also a bound for PSD)
     if (!(lmax >= 0.0)) lmax = 0.0;
-    return (float)((double)rho2 * lmax * (1.0 + 1e-5));
+    // never 0 for a splat that can be drawn: a zero (or underflowing) covariance still has the 0.3-pixel low-pass footprint, and
+    // "bound == 0" means exactly "alpha <= 1/256" to the band cull and the two-pass gate
+    const float bnd = (float)((double)rho2 * lmax * (1.0 + 1e-5));
+    return bnd > 1.17549435e-38f ? bnd : 1.17549435e-38f;
 }
 
 // Milder form: only GROUPS of g consecutive chunks share an XCD (workgroups p and p + 8 of every block of 8 g, which are

@@ -190,9 +190,8 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
     if (prio_levels == 1) {
         const uint32_t band = max(ntiles >> 3, 1u);                    // an eighth of the items per priority step
         const uint32_t lvl = qpos / band;
-        if (lvl == 0u) __builtin_amdgcn_s_setprio(3);
-        else if (lvl == 1u) __builtin_amdgcn_s_setprio(2);
-        else if (lvl <= 3u) __builtin_amdgcn_s_setprio(1);
+        // (r5: one step only, kCompPrioMax = 1 -- the levels above it belong to the other frames' short kernels, msplat_common.hip.h)
+        if (lvl <= 3u) __builtin_amdgcn_s_setprio(kCompPrioMax);
         else __builtin_amdgcn_s_setprio(0);
     }
     const int lane = threadIdx.x;

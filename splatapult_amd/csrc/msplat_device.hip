@@ -77,6 +77,10 @@ struct AsyncWorker {
     bool busy = false, quit = false;
     int err_code = 0;
     std::string err_msg;
+    // a queued call found that an EARLIER device-output frame overflowed the pair buffer (its own work was done): kept until
+    // the next msplat_synchronize / msplat_stream_wait hands it to the caller (it used to be dropped)
+    bool warn = false;
+    std::string warn_msg;
 
     void run()
     {
@@ -221,7 +225,7 @@ struct msplat_ctx {
     uint32_t occ_off = 0;                    // AUTO: frames left of a single-pass period after two passes did not pay
     uint32_t occ_strikes = 0, occ_backoff = 1024; // ... decided after three looks; the pause doubles every time
     int occ_state_auto = 0;                  // AUTO: 0 one pass, 1 probing (occ_probe_left frames), 2 waiting for the probe's feedback, 3 two passes
-    uint32_t occ_probe_left = 0, occ_no_shrink = 0;
+    uint32_t occ_probe_left = 0, occ_no_shrink = 0, occ_wait_frames = 0;
     bool occ_pinned = false;                 // msplat_debug_two_pass: the share is fixed
     bool last_render_two_pass = false;
     uint64_t frames_rendered = 0, frames_two_pass = 0;
@@ -536,6 +540,17 @@ static int poll_async_overflow(msplat_ctx* ctx, std::string& msg)
     return MSPLAT_ERR_PAIR_OVERFLOW;
 }
 
+// the overflow warning a queued call left behind (async_submit), once
+static bool take_async_warning(msplat_ctx* ctx, std::string& msg)
+{
+    if (!ctx->worker) return false;
+    std::lock_guard<std::mutex> lk(ctx->worker->mu);
+    if (!ctx->worker->warn) return false;
+    ctx->worker->warn = false;
+    msg = ctx->worker->warn_msg;
+    return true;
+}
+
 int msplat_synchronize(msplat_ctx* ctx)
 {
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
@@ -554,6 +569,7 @@ int msplat_synchronize(msplat_ctx* ctx)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     std::string msg;
     if (poll_async_overflow(ctx, msg) != MSPLAT_OK) return fail(ctx, MSPLAT_ERR_PAIR_OVERFLOW, "%s", msg.c_str());
+    if (take_async_warning(ctx, msg)) return fail(ctx, MSPLAT_ERR_PAIR_OVERFLOW_EARLIER, "%s", msg.c_str());
     return MSPLAT_OK;
 }
 
@@ -638,10 +654,16 @@ int msplat_stream_wait(msplat_ctx* ctx, void* stream)
     drain_async(ctx);
     if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if ((hipStream_t)stream == ctx->stream) return MSPLAT_OK;
+    if ((hipStream_t)stream == ctx->stream) {
+        std::string msg;
+        if (take_async_warning(ctx, msg)) return fail(ctx, MSPLAT_ERR_PAIR_OVERFLOW_EARLIER, "%s", msg.c_str());
+        return MSPLAT_OK;
+    }
     if (!ctx->join_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventRecord(ctx->join_ev, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->join_ev, 0));
+    std::string msg;
+    if (take_async_warning(ctx, msg)) return fail(ctx, MSPLAT_ERR_PAIR_OVERFLOW_EARLIER, "%s", msg.c_str());
     return MSPLAT_OK;
 }
 
@@ -1341,11 +1363,16 @@ struct FrameArgs {            // the caller's four arrays, copied: a queued call
     }
 };
 
-// result of a queued call: the first real failure is kept for msplat_synchronize (MSPLAT_ERR_PAIR_OVERFLOW_EARLIER is about a
-// past frame and already handled -- the buffer has grown)
+// result of a queued call: the first real failure is kept for msplat_synchronize; MSPLAT_ERR_PAIR_OVERFLOW_EARLIER (a past frame
+// was composited from truncated lists; the buffer has grown since) is kept as a warning for the next msplat_synchronize /
+// msplat_stream_wait, which return it once
 static int note_async_result(msplat_ctx* ctx, int rc)
 {
-    if (rc != MSPLAT_OK && rc != MSPLAT_ERR_PAIR_OVERFLOW_EARLIER) {
+    if (rc == MSPLAT_ERR_PAIR_OVERFLOW_EARLIER) {
+        std::lock_guard<std::mutex> lk(ctx->worker->mu);
+        ctx->worker->warn = true;
+        ctx->worker->warn_msg = ctx->err;
+    } else if (rc != MSPLAT_OK) {
         std::lock_guard<std::mutex> lk(ctx->worker->mu);
         if (ctx->worker->err_code == 0) { ctx->worker->err_code = rc; ctx->worker->err_msg = ctx->err; }
     }
@@ -1361,7 +1388,10 @@ int msplat_sort(msplat_ctx* ctx, const float cameraMat[16], const float projMat[
 {
     if (ctx && ctx->worker && g_on_worker_of != ctx) {
         FrameArgs a;
-        if (!a.load(cameraMat, projMat, viewport, nearFar)) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL matrix/viewport argument");
+        if (!a.load(cameraMat, projMat, viewport, nearFar)) {
+            ctx->worker->drain();           // (ctx->err is the worker's while it runs)
+            return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL matrix/viewport argument");
+        }
         ctx->worker->post([ctx, a] { return note_async_result(ctx, sort_impl(ctx, a.cam, a.proj, a.vp, a.nf)); });
         return MSPLAT_OK;
     }
@@ -1614,7 +1644,17 @@ static bool occlusion_plan(msplat_ctx* ctx, const FrameParams& fp, bool stereo, 
             set_share(0.15f);
         }
         if (ctx->occ_state_auto == WAIT) {
-            if (!fresh) return no();
+            if (!fresh) {
+                // feedback that never becomes fresh (the probe frames binned nothing: the camera looked away from the cloud):
+                // back to one pass with the usual pause instead of waiting for ever
+                if (++ctx->occ_wait_frames > 256u) {
+                    ctx->occ_wait_frames = 0u;
+                    ctx->occ_state_auto = OFF;
+                    ctx->occ_off = ctx->occ_backoff;
+                }
+                return no();
+            }
+            ctx->occ_wait_frames = 0u;
             if (ufrac > 0.3f) {
                 if (++ctx->occ_strikes >= 3u) {
                     ctx->occ_state_auto = OFF;
@@ -1648,6 +1688,7 @@ static bool occlusion_plan(msplat_ctx* ctx, const FrameParams& fp, bool stereo, 
         if (ctx->occ_state_auto == PROBE) {
             if (ctx->occ_probe_left == 0u) {
                 ctx->occ_state_auto = WAIT;
+                ctx->occ_wait_frames = 0u;
                 return no();
             }
             --ctx->occ_probe_left;
@@ -1667,8 +1708,15 @@ static bool occlusion_plan(msplat_ctx* ctx, const FrameParams& fp, bool stereo, 
     return true;
 }
 
+// One Render's decision (occlusion_plan), taken ONCE per Render: the retries of a host-output frame whose pair buffer overflowed
+// re-issue the chain with the same plan (every retry used to advance the controller).
+struct RenderPlan {
+    bool decided = false, two_pass = false;
+    float frac = 0.0f;
+};
+
 static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, size_t pitch, bool async_overflow_flag,
-                         void* d_out1 = nullptr)
+                         void* d_out1 = nullptr, RenderPlan* plan = nullptr)
 {
     hipStream_t s = ctx->stream;
     const bool stereo = fp.views == 2;          // two views in one chain: ranks [0, V) and [V1, V1 + V), bin rows stacked
@@ -1687,8 +1735,14 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     const int pgrid = std::max(1u, div_up(N, kProjThreads));
     // Two-pass frame with occlusion feedback (msplat_occlusion.hip.h): the nearest R1 splats first, then only what the bins
     // they did not saturate still need.  Same pixels; chosen per frame (occlusion_plan).
-    float occ_frac = 0.0f;
-    const bool two_pass = occlusion_plan(ctx, fp, stereo, occ_frac);
+    RenderPlan local_plan;
+    if (!plan) plan = &local_plan;
+    if (!plan->decided) {
+        plan->two_pass = occlusion_plan(ctx, fp, stereo, plan->frac);
+        plan->decided = true;
+    }
+    const float occ_frac = plan->frac;
+    const bool two_pass = plan->two_pass;
     uint32_t* occ = (uint32_t*)ctx->occ.p;
     uint32_t* d_cut = two_pass ? occ : nullptr;          // (project_kernel's first pass computes the cut and leaves it in occ[0])
     if (ctx->point_mode)
@@ -1963,7 +2017,10 @@ int msplat_render(msplat_ctx* ctx, const float cameraMat[16], const float projMa
     if (ctx && ctx->worker && g_on_worker_of != ctx) {
         if (out_is_device && rgba) {
             FrameArgs a;
-            if (!a.load(cameraMat, projMat, viewport, nearFar)) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL matrix/viewport argument");
+            if (!a.load(cameraMat, projMat, viewport, nearFar)) {
+                ctx->worker->drain();
+                return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL matrix/viewport argument");
+            }
             ctx->worker->post([ctx, a, rgba, pitch_bytes] {
                 return note_async_result(ctx, render_impl(ctx, a.cam, a.proj, a.vp, a.nf, rgba, pitch_bytes, 1));
             });
@@ -2008,8 +2065,9 @@ static int render_impl(msplat_ctx* ctx, const float cameraMat[16], const float p
     }
     // host output: render into an internal device framebuffer, copy back, grow the pair buffer on overflow
     if ((rc = buf_alloc(ctx, ctx->fb, tight * fp.height))) return rc;
+    RenderPlan plan;
     for (int attempt = 0; attempt < 6; ++attempt) {
-        rc = launch_render(ctx, fp, ctx->fb.p, tight, false);
+        rc = launch_render(ctx, fp, ctx->fb.p, tight, false, nullptr, &plan);
         if (rc) return rc;
         uint32_t cnt[4];
         HIP_TRY(ctx, hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
@@ -2080,8 +2138,10 @@ int msplat_render_stereo(msplat_ctx* ctx, const float cameraMat0[16], const floa
     if (ctx && ctx->worker && g_on_worker_of != ctx) {
         if (out_is_device && rgba0 && rgba1) {
             FrameArgs a, b;
-            if (!a.load(cameraMat0, projMat0, viewport, nearFar) || !b.load(cameraMat1, projMat1, viewport, nearFar))
+            if (!a.load(cameraMat0, projMat0, viewport, nearFar) || !b.load(cameraMat1, projMat1, viewport, nearFar)) {
+                ctx->worker->drain();
                 return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL matrix/viewport argument");
+            }
             ctx->worker->post([ctx, a, b, rgba0, rgba1, pitch_bytes] {
                 return note_async_result(ctx, render_stereo_impl(ctx, a.cam, a.proj, b.cam, b.proj, a.vp, a.nf, rgba0, rgba1, pitch_bytes, 1));
             });

@@ -230,13 +230,18 @@ public:
     {
         if (group && msplat_group_synchronize(group) != MSPLAT_OK)
             std::fprintf(stderr, "[msplat][E] Synchronize: %s\n", msplat_group_last_error(group));
-        for (msplat_ctx* h : ctxs)
-            if (msplat_synchronize(h) != MSPLAT_OK) std::fprintf(stderr, "[msplat][E] Synchronize: %s\n", msplat_last_error(h));
+        for (msplat_ctx* h : ctxs) {
+            // (MSPLAT_ERR_PAIR_OVERFLOW_EARLIER: a queued call of an async_submit context found an earlier frame's overflow)
+            const int rc = msplat_synchronize(h);
+            if (rc != MSPLAT_OK) std::fprintf(stderr, "[msplat][%c] Synchronize: %s\n", Level(rc), msplat_last_error(h));
+        }
     }
     // device-side join: `stream` (hipStream_t) waits for the frame issued last (the latest Sort's context)
     void WaitOnStream(void* stream)
     {
-        if (ctx) msplat_stream_wait(ctx, stream);
+        if (!ctx) return;
+        const int rc = msplat_stream_wait(ctx, stream);
+        if (rc != MSPLAT_OK) std::fprintf(stderr, "[msplat][%c] WaitOnStream: %s\n", Level(rc), msplat_last_error(ctx));
     }
 
     // reverse join: the context the NEXT Sort will use waits for `event` (hipEvent_t), e.g. recorded after the

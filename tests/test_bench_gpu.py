@@ -109,3 +109,6 @@ def test_bench_two_pass_workload_reports_what_the_passes_did():
         st = d["roofline"]["stages"][k]
         assert st["bytes"] > 0 and st["us"] > 0 and 0.0 < st["frac"] <= 1.0, (k, st)
     assert 0.0 < d["frame_moved_frac"] <= 1.0
+    tc = d["two_pass_check"]               # r5: two fresh contexts, two passes (the share the timed frames ended on) against one pass
+    assert tc["bit_exact"] is True and tc["values_different"] == 0 and tc["values_compared"] >= 2 * 1920 * 1080 * 4
+    assert tc["poses"] == [5, 37] and tc["two_pass_frames"] == 2 and 0.0 < tc["share"] <= 0.75

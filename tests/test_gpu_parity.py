@@ -891,6 +891,30 @@ def test_device_output_pair_overflow_is_reported_on_the_next_call():
     with pytest.raises(MsplatError):                        # host output with a fixed capacity fails at once
         r.Render(cam, proj, vp, nf)
 
+    # (d) async_submit (the default with frames in flight): the worker thread's Sort finds the earlier frame's
+    # overflow, grows the buffer and does its work; the warning is kept and handed out by the next synchronize / stream wait, once
+    r = make_renderer(cloud, frames_in_flight=2, async_submit=True)
+    for k in range(2):                                      # both contexts: frame, then a wait so that the count has landed
+        r.Sort(cam, proj, vp, nf)
+        r.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)
+    with pytest.raises(MsplatError) as e:                   # synchronize itself sees the overflow of context 0's frame
+        r.synchronize()
+    assert e.value.code == _capi.ERR_PAIR_OVERFLOW
+    r2 = make_renderer(cloud, frames_in_flight=1, async_submit=True)
+    r2.Sort(cam, proj, vp, nf)
+    r2.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)
+    r2.wait_on_stream(None)
+    torch.cuda.synchronize()                                # the truncated frame is done, nobody has looked at the flag yet
+    r2.Sort(cam, proj, vp, nf)                              # queued: returns OK; the worker gets MSPLAT_ERR_PAIR_OVERFLOW_EARLIER
+    r2.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)
+    with pytest.warns(_capi.EarlierFrameOverflow, match="earlier device-output render"):
+        r2.synchronize()
+    np.testing.assert_array_equal(fb.cpu().numpy(), expect)  # the frame after the growth is complete
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        r2.synchronize()                                    # reported once
+
 
 def test_render_before_sort_and_bad_viewport_errors():
     from splatapult_amd import MsplatError
@@ -997,6 +1021,42 @@ def test_full_size_config2_whole_frame_at_rotated_orbit_poses(cloud_1m, step):
     _check_window(r, img, aos, W, H, cam, proj, nf, 0, H)
 
 
+def _check_two_pass_at_full_size(init, cam, proj, vp, nf, single, window=None):
+    """the two-pass frames behind the 6 M-splat bench numbers, at BASELINE size, against the single-pass frame
+    (itself checked against the oracle windows) bit for bit: forced with a pinned share, forced with the share left to the feedback
+    loop after 12 warm frames, and AUTO (what bench.py runs) after 16.  `init(**kw)` makes an initialised renderer;
+    `window(img)` repeats an oracle-window check on the two-pass image.  One Render = one image, however it is scheduled
+    (src/splatrenderer.cpp:315-343)."""
+    import torch
+    from splatapult_amd import _capi
+    W, H = int(vp[2]), int(vp[3])
+    Hpad = (H + bin_px() - 1) // bin_px() * bin_px()
+    scratch = torch.zeros((Hpad, W, 4), dtype=torch.float32, device=torch.device("cuda", 0))
+    for mode, share, warm in ((_capi.TWO_PASS_ON, 0.15, 0), (_capi.TWO_PASS_ON, 0.0, 12), (_capi.TWO_PASS_AUTO, 0.0, 16)):
+        b = init(two_pass=mode)
+        if share > 0.0:
+            b.two_pass_state(share)
+        for k in range(warm):
+            b.Sort(cam, proj, vp, nf)
+            b.Render(cam, proj, vp, nf, out_ptr=scratch.data_ptr(), pitch_bytes=W * 16)
+            b.synchronize()                     # the frame's feedback has landed before the next plan is made
+        b.Sort(cam, proj, vp, nf)
+        img = b.Render(cam, proj, vp, nf)
+        info = b.two_pass_info()
+        frames, now = b.two_pass_state(share)
+        print("two-pass at full size: mode %d share %.3f -> %.3f, two-pass frames %d, latest %s" % (mode, share, now, frames, info))
+        if mode == _capi.TWO_PASS_ON:
+            assert info is not None and info["splats_pass1"] > 0 and frames == warm + 1
+            assert info["splats_pass1"] + info["splats_pass2"] < info["visible"]       # work really was skipped
+        else:
+            assert frames > 0                   # AUTO engaged (probe frames at least): these are the frames bench.py times
+        np.testing.assert_array_equal(img, single)
+        if window is not None and share > 0.0:
+            window(img)
+        assert b.verify_order() == (0, 0)
+        b.close()
+
+
 def test_full_size_config3_6m_1080p(cloud_6m):
     """BASELINE configs[2] (synthetic stand-in for the 6 M-splat Inria scene), 1920x1080 fp32: exact keys and
     permutation, ordered bin lists, 256-row oracle window"""
@@ -1013,6 +1073,8 @@ def test_full_size_config3_6m_1080p(cloud_6m):
     assert np.isfinite(img).all() and (img[..., 3] == 1).all()
     _check_window(r, img, aos, W, H, cam, proj, nf, 412, 668)
     _check_window(r, img, aos, W, H, cam, proj, nf, 1056, 1080)      # the ragged top bin row (1080 = 33.75 bins)
+    _check_two_pass_at_full_size(lambda **kw: make_renderer(cloud_6m, **kw), cam, proj, vp, nf, img,
+                                 window=lambda im: _check_window(r, im, aos, W, H, cam, proj, nf, 412, 668))
 
 
 def test_full_size_config4_6m_4096_and_8_bands(cloud_6m):
@@ -1030,6 +1092,8 @@ def test_full_size_config4_6m_4096_and_8_bands(cloud_6m):
     aos = cloud_6m.as_array()
     _check_window(r, full, aos, W, H, cam, proj, nf, 1984, 2112)
     _check_window(r, full, aos, W, H, cam, proj, nf, 4064, 4096)     # the top bin row
+    _check_two_pass_at_full_size(lambda **kw: make_renderer(cloud_6m, **kw), cam, proj, vp, nf, full,
+                                 window=lambda im: _check_window(r, im, aos, W, H, cam, proj, nf, 1984, 2112))
     from splatapult_amd import _capi
     G = 8
     part = np.zeros_like(full)
@@ -1452,6 +1516,14 @@ def test_scene_like_6m_file_replay_matches_the_oracle(tmp_path):
         assert st["pairs"] > 5 * st["drawn"]                      # big footprints: many bins per splat
         assert np.isfinite(img).all() and (img[..., 3] == 1).all()
         _check_window(r, img, aos, W, H, cam, proj, nf, y0, y1)
+
+        def init(**kw):
+            b = SplatRenderer(device=0, **kw)
+            assert b.InitFromPly(ply, True, False), b.last_error()
+            return b
+        if k == 0:
+            _check_two_pass_at_full_size(init, cam, proj, vp, nf, img,
+                                         window=lambda im: _check_window(r, im, aos, W, H, cam, proj, nf, y0, y1))
 
 
 def test_heavy_chunks_of_the_column_pass_are_split_without_changing_anything():

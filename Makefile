@@ -5,7 +5,7 @@ LIB = splatapult_amd/lib/libmsplat.so
 SRC = splatapult_amd/csrc/msplat_device.hip splatapult_amd/csrc/msplat_group.hip splatapult_amd/host/gaussian_scene.cpp splatapult_amd/host/scene_config.cpp \
       splatapult_amd/host/point_scene.cpp
 HDR = $(wildcard splatapult_amd/csrc/*.hip.h) splatapult_amd/host/gaussian_scene.hpp splatapult_amd/host/scene_config.hpp \
-      splatapult_amd/host/point_scene.hpp include/msplat.h
+      splatapult_amd/host/point_scene.hpp include/msplat.h include/msplat_debug.h
 
 all: $(LIB) examples
 
@@ -26,7 +26,7 @@ oracle:
 # tests/sanitize/host_sanitize_driver.cpp stubs the device entry points and replays the golden files + hostile inputs.
 SAN = build/host_sanitize
 HOSTSRC = splatapult_amd/host/gaussian_scene.cpp splatapult_amd/host/scene_config.cpp splatapult_amd/host/point_scene.cpp
-sanitize: $(HOSTSRC) tests/sanitize/host_sanitize_driver.cpp include/msplat.h
+sanitize: $(HOSTSRC) tests/sanitize/host_sanitize_driver.cpp include/msplat.h include/msplat_debug.h
 	mkdir -p build build/sanitize_scratch
 	$(CXX) -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined -I. \
 	    $(HOSTSRC) tests/sanitize/host_sanitize_driver.cpp -o $(SAN)

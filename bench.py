@@ -634,20 +634,46 @@ def peer_store_check(args):
             raise RuntimeError(ref.last_error() or g.last_error())
         out["peer_store_ranks"] = [i for i in range(g.size) if g.peer_store(i)]
         a, b = torch.zeros((H, W, 4), dtype=tdt, device=dev), torch.zeros((H, W, 4), dtype=tdt, device=dev)
-        ok = True
-        for step in out["poses"]:
-            c = camera.orbit(wl["cam_z"], 2.0 * math.pi * step / 64.0)
-            cams = [c] if views == 1 else [camera.translate_local(c, dx=-0.032), camera.translate_local(c, dx=+0.032)]
-            ref.Sort(cams[0], projs[0], vp, nf)
-            g.Sort(cams[0], projs[0], vp, nf)
-            for v in range(views):
-                a.zero_(); b.zero_()
-                torch.cuda.synchronize(dev)
-                ref.Render(cams[v], projs[v], vp, nf, out_ptr=a.data_ptr(), pitch_bytes=W * bpp)
-                g.Render(cams[v], projs[v], vp, nf, out_ptr=b.data_ptr(), pitch_bytes=W * bpp)
-                ref.synchronize(); g.synchronize()
-                ok = ok and bool((a.view(bits) == b.view(bits)).all().item())
-        out["bit_exact"] = ok
+
+        def compare():
+            ok = True
+            for step in out["poses"]:
+                c = camera.orbit(wl["cam_z"], 2.0 * math.pi * step / 64.0)
+                cams = [c] if views == 1 else [camera.translate_local(c, dx=-0.032), camera.translate_local(c, dx=+0.032)]
+                ref.Sort(cams[0], projs[0], vp, nf)
+                g.Sort(cams[0], projs[0], vp, nf)
+                for v in range(views):
+                    a.zero_(); b.zero_()
+                    torch.cuda.synchronize(dev)
+                    ref.Render(cams[v], projs[v], vp, nf, out_ptr=a.data_ptr(), pitch_bytes=W * bpp)
+                    g.Render(cams[v], projs[v], vp, nf, out_ptr=b.data_ptr(), pitch_bytes=W * bpp)
+                    ref.synchronize(); g.synchronize()
+                    ok = ok and bool((a.view(bits) == b.view(bits)).all().item())
+            return ok
+
+        def frames_ms(n=12):
+            c = camera.orbit(wl["cam_z"], 0.5)
+            for k in range(n + 4):
+                if k == 4:
+                    g.synchronize(); torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                g.Sort(c, projs[0], vp, nf)
+                g.Render(c, projs[0], vp, nf, out_ptr=b.data_ptr(), pitch_bytes=W * bpp)
+            g.synchronize(); torch.cuda.synchronize(dev)
+            return 1e3 * (time.perf_counter() - t0) / n
+
+        out["bit_exact"] = compare()                       # the default exchange: peer stores where the mapping exists
+        out["exchanges"] = {g.exchange(): {"bit_exact": out["bit_exact"], "ms_per_frame": frames_ms()}}
+        # r5: the same rows over RCCL (ncclCommInitAll + grouped ncclSend / ncclRecv behind msplat_group_render) and as plain copies
+        for name in ("rccl", "copy"):
+            if G < 2:
+                break
+            try:
+                g.set_exchange(name)
+                ok = compare()
+                out["exchanges"][name] = {"bit_exact": ok, "ms_per_frame": frames_ms(), "used": g.exchange()}
+            except Exception as e:
+                out["exchanges"][name] = {"bit_exact": None, "error": "%s: %s" % (type(e).__name__, e)}
         g.close(); ref.close()
     except Exception as e:
         out["error"] = "%s: %s" % (type(e).__name__, e)
@@ -734,6 +760,69 @@ def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf,
                 res["values_different"] += ne
                 if ne:
                     res["max_abs_diff"] = max(res["max_abs_diff"], float((a.float() - b.float()).abs().max().item()))
+    # what the exchange costs each rank (r5): frames whose gather is bracketed by events on the gathering stream -- rank 0's
+    # interval is the arrival of every foreign run, the others' their sends; reported per rank so that a first multi-GPU run
+    # shows whether the rows or the kernels bound the frame
+    try:
+        n_t = 6
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_t)]
+        state_g = {"k": 0}
+        from splatapult_amd import dist as _sd
+        orig_call = _sd.BandGather.__call__
+
+        def timed_call(self, fb):
+            k = state_g["k"]
+            if k < n_t:
+                evs[k][0].record(stream)
+            out_ = orig_call(self, fb)
+            if k < n_t:
+                evs[k][1].record(stream)
+            state_g["k"] = k + 1
+            return out_
+        _sd.BandGather.__call__ = timed_call
+        try:
+            for k in range(n_t // max(1, views)):
+                frame(100 + k, rs, rs_sets)
+                host_barrier()
+        finally:
+            _sd.BandGather.__call__ = orig_call
+        torch.cuda.synchronize(dev)
+        mine = float(np.median([a.elapsed_time(b) for a, b in evs[:state_g["k"]]])) if state_g["k"] else None
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine, group=E.cpu_group)
+        res["exchange_ms_per_gather_per_rank"] = per_rank
+        res["exchange_call"] = "torch.distributed.batch_isend_irecv = ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd, one run of rows per op" \
+            if dist.get_backend() == "nccl" else "gloo stand-in (host staging)"
+    except Exception as e:
+        res["exchange_ms_per_gather_per_rank"] = "%s: %s" % (type(e).__name__, e)
+    # opt-in (MSPLAT_BENCH_CABI_EXCHANGE=1, RCCL only): the same gather through the C ABI -- msplat_band_exchange with a communicator
+    # of this bench's own (ncclCommInitRank; collective, so it is not on by default on hardware nobody has run it on)
+    if os.environ.get("MSPLAT_BENCH_CABI_EXCHANGE") == "1" and dist.get_backend() == "nccl" and not E.one_dev and views == 1:
+        cab = {"bit_exact": None, "error": None}
+        try:
+            from splatapult_amd.dist import CAbiBandGather, RcclComm
+            comm = RcclComm(rank, world, E.local_rank)
+            from splatapult_amd import _capi as _cp
+            TILE = _cp.lib().msplat_tile_size()
+            tiles_y = rs_sets[0][0].shape[0] // TILE
+            cg = CAbiBandGather(rs, comm, tiles_y, W, rs_sets[0][0].dtype, rank, world, tile=TILE, layout=lay_kind, block_rows=lay_k)
+            cams = cams_for(poses[0])
+            rs_sets[0][0].zero_()
+            host_barrier()
+            rs.Sort(cams[0], projs[0], vp, nf)
+            rs.Render(cams[0], projs[0], vp, nf, out_ptr=rs_sets[0][0].data_ptr(), pitch_bytes=W * bpp)
+            cg(rs_sets[0][0])
+            rs.synchronize()
+            host_barrier()
+            if rank == 0:
+                ref.Sort(cams[0], projs[0], vp, nf)
+                ref.Render(cams[0], projs[0], vp, nf, out_ptr=ref_fbs[0].data_ptr(), pitch_bytes=W * bpp)
+                torch.cuda.synchronize(dev)
+                cab["bit_exact"] = bool((rs_sets[0][0][:H].view(bits) == ref_fbs[0][:H].view(bits)).all().item())
+            comm.close()
+        except Exception as e:
+            cab["error"] = "%s: %s" % (type(e).__name__, e)
+        res["c_abi_exchange"] = cab
     # the other exchange form: one process, one context per device, peer stores into device 0's framebuffer.  Run in a CHILD
     # process (bench.py --peer-store-check): a fault on that path must not take the bench line with it
     if rank == 0 and primary and not E.one_dev and torch.cuda.device_count() >= world and not args.ply:
@@ -744,7 +833,7 @@ def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf,
                    "--layout", "%s:%d" % (lay_kind, lay_k) if lay_kind == "block" else lay_kind]
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")
                    and not k.startswith("TORCHELASTIC")}
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
             lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
             if p.returncode == 0 and lines:
                 ps = json.loads(lines[-1])

@@ -65,7 +65,7 @@ class Timings(C.Structure):
                 ("binning", C.c_float), ("composite", C.c_float), ("reserved", C.c_float * 3)]
 
 
-# every symbol include/msplat.h declares: (name, restype, argtypes)
+# every symbol include/msplat.h and include/msplat_debug.h declare: (name, restype, argtypes)
 _F16 = C.POINTER(C.c_float)
 _U32P = C.POINTER(C.c_uint32)
 SYMBOLS = [
@@ -97,6 +97,11 @@ SYMBOLS = [
     ("msplat_group_sort", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16]),
     ("msplat_group_render", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16, C.c_void_p, C.c_uint64, C.c_int]),
     ("msplat_group_synchronize", C.c_int, [C.c_void_p]),
+    ("msplat_group_set_exchange", C.c_int, [C.c_void_p, C.c_int32]),
+    ("msplat_group_get_exchange", C.c_int, [C.c_void_p]),
+    ("msplat_band_exchange", C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32]),
+    ("msplat_debug_band_exchange_loopback", C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_uint64,
+                                                                                                C.c_int32, C.c_int32]),
     ("msplat_sort", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16]),
     ("msplat_render", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16, C.c_void_p, C.c_uint64, C.c_int]),
     ("msplat_render_stereo", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16, _F16, _F16, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/msplat.h"
+#include "../../include/msplat_debug.h"
 
 using namespace msplat;
 

@@ -7,9 +7,15 @@
 // msplat_sort / msplat_render.  The only exchange step is the row gather, and it is zero-copy where the hardware allows:
 // device i's compositor stores its rows STRAIGHT into device 0's framebuffer through the peer mapping
 // (hipDeviceEnablePeerAccess: every band travels over its own direct xGMI link, 7 links into device 0 concurrently, no
-// ring), else its rows are staged locally and moved with one hipMemcpy2DAsync per run of consecutive rows.  No RCCL
-// communicator is needed inside one process; bench.py's one-process-per-GPU form (torch.distributed over RCCL) remains for
-// the driver's launcher.
+// ring), else its rows are staged locally and moved with one hipMemcpy2DAsync per run of consecutive rows.
+//
+// r5: the same gather over RCCL (the north star's "RCCL over xGMI only for the final row gather"), for both process shapes:
+//   msplat_band_exchange       one process per GPU (the caller owns the ncclComm_t, e.g. made with ncclCommInitRank): rank `root`
+//                              posts one ncclRecv per run of foreign bin rows straight into its framebuffer, the owners ncclSend
+//                              their runs from where the compositor left them -- one ncclGroupStart/End, no pack / staging;
+//   MSPLAT_EXCHANGE_RCCL       this file's one-process group with communicators from ncclCommInitAll.
+// librccl is resolved with dlopen at the first use (the copy already in the process, e.g. PyTorch's, else /opt/rocm's): the
+// library has no link-time dependency on it and loads on a box without RCCL.
 //
 // Host side: launching ~12 kernels on each of 8 devices from one thread costs more host time than the frame lasts on the
 // GPUs, so every device beyond the first has a worker thread that issues its context's calls; the caller's thread drives
@@ -17,6 +23,7 @@
 // stream is made to wait for the others' streams, so "synchronise device 0's stream" = "the frame is complete").
 // Uses only the public C ABI of the single-device library plus HIP runtime calls.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -32,6 +39,7 @@
 #include <vector>
 
 #include "../../include/msplat.h"
+#include "../../include/msplat_debug.h"
 
 namespace {
 
@@ -75,13 +83,83 @@ struct Worker {
     }
 };
 
+
+// ---- RCCL, resolved at run time --------------------------------------------------------------------------------------------
+// (signatures: /opt/rocm/include/rccl/rccl.h:187-260,700-722,923-933; ncclUint8 = 1, ncclSuccess = 0)
+struct Rccl {
+    void* lib = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;             // why it is not available
+    bool ok() const { return lib != nullptr; }
+};
+
+const Rccl& rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        std::vector<std::string> names;
+        if (const char* e = getenv("MSPLAT_RCCL_LIB")) names.push_back(e);
+        void* h = nullptr;
+        // the copy the process already uses (its communicators belong to THAT copy), then the system's
+        for (const char* n : {"librccl.so.1", "librccl.so"})
+            if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        for (const std::string& n : names)
+            if (!h) h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+        for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!h) { x.why = std::string("librccl not found (") + (dlerror() ? dlerror() : "?") + "); set MSPLAT_RCCL_LIB"; return x; }
+        bool all = true;
+        auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) { all = false; x.why = std::string("librccl lacks ") + n; } return p; };
+        x.GroupStart = (int (*)())sym("ncclGroupStart");
+        x.GroupEnd = (int (*)())sym("ncclGroupEnd");
+        x.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
+        x.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
+        x.CommInitAll = (int (*)(void**, int, const int*))sym("ncclCommInitAll");
+        x.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+        x.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+        if (all) x.lib = h;
+        return x;
+    }();
+    return r;
+}
+constexpr int kNcclUint8 = 1;
+
+// the runs of consecutive bin rows rank `rank` of `world` owns under a standard layout, as pixel rows [y0, y0 + nrows) of an
+// image of H rows: f(y0, nrows).  (Runs end at block boundaries; contiguous bands are one run.)
+template <class F>
+int for_each_run(int32_t kind, int32_t block_rows, int32_t world, int32_t rank, int H, F&& f)
+{
+    const int T = msplat_tile_size(), rows_full = (H + T - 1) / T;
+    int32_t first, count, block, stride;
+    const int pr = msplat_band_plan(kind, rows_full, world, rank, block_rows, &first, &count, &block, &stride);
+    if (pr) return pr;
+    for (int v = 0; v < count;) {
+        const int k = v / block, row = first + k * stride + (v - k * block);
+        int run = std::min(block - (v - k * block), count - v);          // the rest of this block
+        // (stride == block: the next block follows immediately -- contiguous bands arrive here as count rows in one block)
+        const int y0 = row * T, nrows = std::min(run * T, H - y0);
+        v += run;
+        if (nrows <= 0) break;
+        const int rc = f(y0, nrows);
+        if (rc) return rc;
+    }
+    return MSPLAT_OK;
+}
+
 }  // namespace
 
 struct msplat_group {
     std::vector<int> devices;
     std::vector<msplat_ctx*> ctx;
     std::vector<std::unique_ptr<Worker>> workers;      // [i - 1] drives ctx[i]
-    std::vector<bool> peer_store;                      // ctx[i] may store into device 0's memory directly
+    std::vector<bool> peer_store;                      // ctx[i] stores into device 0's memory directly (the exchange in use)
+    std::vector<bool> peer_ok;                         // ... and whether the peer mapping exists at all
     std::vector<void*> stage;                          // per-rank staging framebuffer when it may not
     std::vector<size_t> stage_bytes;
     int fb_format = MSPLAT_FB_RGBA32F;
@@ -89,6 +167,9 @@ struct msplat_group {
     bool band_cull = false;
     int planned_rows = -1;                             // rows_full the contexts' layouts were set for
     hipEvent_t order_ev = nullptr;                     // "everything queued on context 0's stream so far" (msplat_group_render)
+    int exchange = MSPLAT_EXCHANGE_PEER_STORE;         // what msplat_group_render is asked to use; last_exchange: what it used
+    int last_exchange = MSPLAT_EXCHANGE_PEER_STORE;
+    std::vector<void*> comms;                          // MSPLAT_EXCHANGE_RCCL: one ncclComm_t per device (ncclCommInitAll)
     std::string err;
     std::vector<std::string> rank_err;                 // [i]: text of a failure on rank i's worker thread that is not the
                                                        // context's own (HIP calls of the staged exchange); merged by for_all
@@ -232,16 +313,56 @@ int msplat_group_create(msplat_group** out, const int32_t* devices, uint32_t n, 
         (void)hipGetLastError();
         g->peer_store[i] = ok;
     }
-    if (getenv("MSPLAT_GROUP_EXCHANGE") && std::string(getenv("MSPLAT_GROUP_EXCHANGE")) == "copy")
-        for (uint32_t i = 1; i < n; ++i) g->peer_store[i] = false;       // force the staged form (comparison / debugging)
+    g->peer_ok = g->peer_store;
     for (uint32_t i = 1; i < n; ++i) {
         g->workers.emplace_back(new Worker);
         Worker* w = g->workers.back().get();
         w->th = std::thread([w] { w->run(); });
     }
+    if (const char* e = getenv("MSPLAT_GROUP_EXCHANGE")) {
+        const std::string x = e;
+        const int want = x == "rccl" ? MSPLAT_EXCHANGE_RCCL : (x == "copy" ? MSPLAT_EXCHANGE_COPY : MSPLAT_EXCHANGE_PEER_STORE);
+        const int rc = msplat_group_set_exchange(g, want);
+        if (rc) {                       // asked for in the environment and not available: say so instead of silently doing something else
+            gfail(nullptr, rc, "msplat_group_create: MSPLAT_GROUP_EXCHANGE=%s: %s", e, g->err.c_str());
+            msplat_group_destroy(g);
+            return rc;
+        }
+    }
     *out = g;
     return MSPLAT_OK;
 }
+
+int msplat_group_set_exchange(msplat_group* g, int32_t exchange)
+{
+    if (!g) return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "group is NULL");
+    const uint32_t n = (uint32_t)g->ctx.size();
+    if (exchange == MSPLAT_EXCHANGE_PEER_STORE || exchange == MSPLAT_EXCHANGE_COPY) {
+        for (uint32_t i = 1; i < n; ++i) g->peer_store[i] = exchange == MSPLAT_EXCHANGE_PEER_STORE && g->peer_ok[i];
+        g->exchange = exchange;
+        return MSPLAT_OK;
+    }
+    if (exchange != MSPLAT_EXCHANGE_RCCL) return gfail(g, MSPLAT_ERR_INVALID_ARG, "msplat_group_set_exchange: unknown exchange %d", exchange);
+    if (n == 1) { g->exchange = exchange; return MSPLAT_OK; }          // one device: there is nothing to exchange
+    const Rccl& R = rccl();
+    if (!R.ok()) return gfail(g, MSPLAT_ERR_UNSUPPORTED, "msplat_group_set_exchange: %s", R.why.c_str());
+    if (g->comms.empty()) {
+        // one communicator per device of this process (rccl.h:236).  RCCL refuses a device that is listed twice.
+        std::vector<void*> comms(n, nullptr);
+        const int rc = R.CommInitAll(comms.data(), (int)n, g->devices.data());
+        if (rc != 0) {
+            (void)hipGetLastError();
+            return gfail(g, MSPLAT_ERR_UNSUPPORTED, "msplat_group_set_exchange: ncclCommInitAll over %u devices failed: %s", n,
+                         R.GetErrorString(rc));
+        }
+        g->comms = comms;
+    }
+    for (uint32_t i = 1; i < n; ++i) g->peer_store[i] = false;          // rows are rendered locally and sent
+    g->exchange = exchange;
+    return MSPLAT_OK;
+}
+
+int msplat_group_get_exchange(const msplat_group* g) { return g ? g->last_exchange : -1; }
 
 void msplat_group_destroy(msplat_group* g)
 {
@@ -250,8 +371,11 @@ void msplat_group_destroy(msplat_group* g)
         { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; w->cv.notify_all(); }
         if (w->th.joinable()) w->th.join();
     }
-    for (size_t i = 0; i < g->ctx.size(); ++i) {
+    for (size_t i = 0; i < g->ctx.size(); ++i)
         if (g->ctx[i]) (void)msplat_synchronize(g->ctx[i]);
+    for (void* c : g->comms)
+        if (c && rccl().ok()) (void)rccl().CommDestroy(c);
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
         if (i < g->stage.size() && g->stage[i]) { (void)hipSetDevice(g->devices[i]); (void)hipFree(g->stage[i]); }
         msplat_destroy(g->ctx[i]);
     }
@@ -322,7 +446,7 @@ int msplat_group_render(msplat_group* g, const float cameraMat[16], const float 
     int rc = plan_rows(g, viewport);
     if (rc) return rc;
     const uint32_t n = (uint32_t)g->ctx.size();
-    const int W = (int)viewport[2], H = (int)viewport[3], T = msplat_tile_size();
+    const int W = (int)viewport[2], H = (int)viewport[3];
     const size_t bpp = g->fb_format == MSPLAT_FB_RGBA16F ? 8 : 16;
     const size_t tight = (size_t)W * bpp;
     if (pitch_bytes == 0) pitch_bytes = tight;
@@ -339,6 +463,50 @@ int msplat_group_render(msplat_group* g, const float cameraMat[16], const float 
     if (n > 1) {
         if (hipSetDevice(g->devices[0]) != hipSuccess || hipEventRecord(g->order_ev, (hipStream_t)stream0) != hipSuccess)
             return gfail(g, MSPLAT_ERR_HIP, "msplat_group_render: cannot record the ordering event on device %d", g->devices[0]);
+    }
+    const bool use_rccl = n > 1 && g->exchange == MSPLAT_EXCHANGE_RCCL && !g->comms.empty();
+    g->last_exchange = n == 1 ? g->exchange : (use_rccl ? MSPLAT_EXCHANGE_RCCL : MSPLAT_EXCHANGE_COPY);
+    for (uint32_t i = 1; i < n && !use_rccl; ++i)
+        if (g->peer_store[i]) g->last_exchange = MSPLAT_EXCHANGE_PEER_STORE;
+    if (use_rccl) {
+        // every rank renders its rows into an image of its own with the target's pitch (a run of rows is then one contiguous
+        // range on both sides); the caller's thread then issues ALL sends and receives as one group: rank i's sends on its
+        // stream behind its compositor, device 0's receives on context 0's stream -- synchronising that stream = frame complete
+        rc = for_all(g, [&](uint32_t i) -> int {
+            msplat_ctx* c = g->ctx[i];
+            if (i == 0) return msplat_render(c, cameraMat, projMat, viewport, nearFar, rgba, pitch_bytes, 1);
+            const int j = msplat_wait_event(c, g->order_ev);
+            if (j) return j;
+            if (hipSetDevice(g->devices[i]) != hipSuccess) return rfail(g, i, MSPLAT_ERR_HIP, "hipSetDevice(%d) failed", g->devices[i]);
+            const size_t need = (size_t)pitch_bytes * (size_t)H;
+            if (g->stage_bytes[i] < need) {
+                (void)msplat_synchronize(c);
+                if (g->stage[i]) (void)hipFree(g->stage[i]);
+                g->stage[i] = nullptr;
+                g->stage_bytes[i] = 0;
+                if (hipMalloc(&g->stage[i], need) != hipSuccess) return rfail(g, i, MSPLAT_ERR_HIP, "staging framebuffer: out of device memory");
+                g->stage_bytes[i] = need;
+            }
+            return msplat_render(c, cameraMat, projMat, viewport, nearFar, g->stage[i], pitch_bytes, 1);
+        });
+        if (rc && rc != MSPLAT_ERR_PAIR_OVERFLOW_EARLIER) return rc;
+        const Rccl& R = rccl();
+        int nrc = R.GroupStart();
+        for (uint32_t i = 1; i < n && nrc == 0; ++i) {
+            hipStream_t si = (hipStream_t)msplat_get_stream(g->ctx[i]);
+            const int prc = for_each_run(g->kind, g->block_rows, (int32_t)n, (int32_t)i, H, [&](int y0, int nrows) -> int {
+                const size_t off = (size_t)y0 * pitch_bytes, bytes = (size_t)(nrows - 1) * pitch_bytes + tight;
+                int e = R.Send((const char*)g->stage[i] + off, bytes, kNcclUint8, 0, g->comms[i], si);
+                if (e == 0) e = R.Recv((char*)rgba + off, bytes, kNcclUint8, (int)i, g->comms[0], (hipStream_t)stream0);
+                if (e != 0) nrc = e;
+                return e != 0 ? MSPLAT_ERR_HIP : MSPLAT_OK;
+            });
+            if (prc && nrc == 0) { (void)R.GroupEnd(); return gfail(g, prc, "msplat_group_render: %s", msplat_last_error(nullptr)); }
+        }
+        const int erc = R.GroupEnd();
+        if (nrc == 0) nrc = erc;
+        if (nrc != 0) return gfail(g, MSPLAT_ERR_HIP, "msplat_group_render: RCCL row exchange failed: %s", R.GetErrorString(nrc));
+        return rc;
     }
     rc = for_all(g, [&](uint32_t i) -> int {
         msplat_ctx* c = g->ctx[i];
@@ -363,25 +531,83 @@ int msplat_group_render(msplat_group* g, const float cameraMat[16], const float 
         }
         int r = msplat_render(c, cameraMat, projMat, viewport, nearFar, g->stage[i], tight, 1);
         if (r && r != MSPLAT_ERR_PAIR_OVERFLOW_EARLIER) return r;
-        int32_t first, count, block, stride;
-        const int rows_full = (H + T - 1) / T;
-        int pr = msplat_band_plan(g->kind, rows_full, (int32_t)n, (int32_t)i, g->block_rows, &first, &count, &block, &stride);
-        if (pr) return rfail(g, i, pr, "%s", msplat_last_error(nullptr));
         hipStream_t s = (hipStream_t)msplat_get_stream(c);
-        for (int v = 0; v < count;) {
-            const int k = v / block, row = first + k * stride + (v - k * block);
-            const int run = std::min(block - (v - k * block), count - v);          // the rest of this block
-            const int y0 = row * T, nrows = std::min(run * T, H - y0);
-            v += run;
-            if (nrows <= 0) break;
+        const int pr = for_each_run(g->kind, g->block_rows, (int32_t)n, (int32_t)i, H, [&](int y0, int nrows) -> int {
             if (hipMemcpy2DAsync((char*)rgba + (size_t)y0 * pitch_bytes, pitch_bytes, (const char*)g->stage[i] + (size_t)y0 * tight,
                                  tight, tight, (size_t)nrows, hipMemcpyDeviceToDevice, s) != hipSuccess)
                 return rfail(g, i, MSPLAT_ERR_HIP, "hipMemcpy2DAsync (device %d -> %d) failed", g->devices[i], g->devices[0]);
-        }
+            return MSPLAT_OK;
+        });
+        if (pr) { if (g->rank_err[i].empty()) rfail(g, i, pr, "%s", msplat_last_error(nullptr)); return pr; }
         const int j = msplat_stream_wait(c, stream0);
         return j ? j : r;
     });
     return rc;
+}
+
+// ---- the exchange for one process per GPU --------------------------------------------------------------------------------------
+static int band_exchange_impl(msplat_ctx* ctx, void* comm, int32_t rank, int32_t world, int32_t root, int32_t kind, int32_t block_rows,
+                              const void* src, void* dst, uint64_t pitch_bytes, int32_t width, int32_t height, bool loopback)
+{
+    if (!ctx) return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_exchange: ctx is NULL");
+    if (world < 1 || rank < 0 || rank >= world || root < 0 || root >= world)
+        return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_exchange: rank %d / root %d of %d", rank, root, world);
+    if (world == 1 && !loopback) return MSPLAT_OK;                     // the whole image is this rank's
+    if (!comm || !src || !dst || width < 1 || height < 1)
+        return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_exchange: NULL communicator / framebuffer or empty image");
+    // (8 = the smaller pixel, RGBA16F: the pitch must hold a row of either format)
+    if (pitch_bytes < (uint64_t)width * 8u) return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_exchange: pitch %llu too small for width %d",
+                                                         (unsigned long long)pitch_bytes, width);
+    const Rccl& R = rccl();
+    if (!R.ok()) return gfail(nullptr, MSPLAT_ERR_UNSUPPORTED, "msplat_band_exchange: %s", R.why.c_str());
+    hipStream_t s = (hipStream_t)msplat_get_stream(ctx);               // (waits for the context's worker thread to have issued the frame)
+    // a run travels as whole pitch rows (the framebuffer holds `height` rows of pitch_bytes; both sides count the same bytes)
+    auto bytes_of = [&](int, int nrows) { return (size_t)nrows * (size_t)pitch_bytes; };
+    int nrc = R.GroupStart();
+    if (nrc != 0) return gfail(nullptr, MSPLAT_ERR_HIP, "msplat_band_exchange: ncclGroupStart: %s", R.GetErrorString(nrc));
+    int prc = MSPLAT_OK;
+    if (loopback) {
+        // (tests, one rank: this rank plays owner and root at once -- its runs travel from src to dst through ncclSend / ncclRecv to itself)
+        prc = for_each_run(kind, block_rows, world, rank, height, [&](int y0, int nrows) -> int {
+            const size_t off = (size_t)y0 * pitch_bytes;
+            int e = R.Send((const char*)src + off, bytes_of(y0, nrows), kNcclUint8, 0, comm, s);
+            if (e == 0) e = R.Recv((char*)dst + off, bytes_of(y0, nrows), kNcclUint8, 0, comm, s);
+            if (e != 0) nrc = e;
+            return e != 0 ? MSPLAT_ERR_HIP : MSPLAT_OK;
+        });
+    } else if (rank == root) {
+        for (int32_t r = 0; r < world && prc == MSPLAT_OK; ++r) {
+            if (r == root) continue;
+            prc = for_each_run(kind, block_rows, world, r, height, [&](int y0, int nrows) -> int {
+                const int e = R.Recv((char*)dst + (size_t)y0 * pitch_bytes, bytes_of(y0, nrows), kNcclUint8, r, comm, s);
+                if (e != 0) nrc = e;
+                return e != 0 ? MSPLAT_ERR_HIP : MSPLAT_OK;
+            });
+        }
+    } else {
+        prc = for_each_run(kind, block_rows, world, rank, height, [&](int y0, int nrows) -> int {
+            const int e = R.Send((const char*)src + (size_t)y0 * pitch_bytes, bytes_of(y0, nrows), kNcclUint8, root, comm, s);
+            if (e != 0) nrc = e;
+            return e != 0 ? MSPLAT_ERR_HIP : MSPLAT_OK;
+        });
+    }
+    const int erc = R.GroupEnd();
+    if (nrc == 0) nrc = erc;
+    if (nrc != 0) return gfail(nullptr, MSPLAT_ERR_HIP, "msplat_band_exchange: RCCL: %s", R.GetErrorString(nrc));
+    if (prc) return gfail(nullptr, prc, "msplat_band_exchange: %s", msplat_last_error(nullptr));
+    return MSPLAT_OK;
+}
+
+int msplat_band_exchange(msplat_ctx* ctx, void* comm, int32_t rank, int32_t world, int32_t root, int32_t kind, int32_t block_rows,
+                         void* rgba, uint64_t pitch_bytes, int32_t width, int32_t height)
+{
+    return band_exchange_impl(ctx, comm, rank, world, root, kind, block_rows, rgba, rgba, pitch_bytes, width, height, false);
+}
+
+int msplat_debug_band_exchange_loopback(msplat_ctx* ctx, void* comm, int32_t kind, int32_t block_rows, int32_t world, int32_t rank,
+                                        const void* src, void* dst, uint64_t pitch_bytes, int32_t width, int32_t height)
+{
+    return band_exchange_impl(ctx, comm, rank, world, 0, kind, block_rows, src, dst, pitch_bytes, width, height, true);
 }
 
 int msplat_group_synchronize(msplat_group* g)

@@ -81,3 +81,90 @@ class BandGather:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         return fb if self.rank == self.dst else None
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The same gather behind the C ABI (r5): msplat_band_exchange(ctx, ncclComm_t, ...) -- what a C++ host with one process per GPU
+# calls (include/msplat.h).  Python only has to own a communicator: RcclComm makes one with ncclGetUniqueId / ncclCommInitRank
+# through ctypes on the librccl the process already uses (the id travels over the torch.distributed group that exists anyway).
+# ------------------------------------------------------------------------------------------------------------------------------
+import ctypes as _C
+import os as _os
+
+
+def loaded_rccl_path():
+    """the librccl mapped into this process (PyTorch's bundled copy once torch is imported), else the system's"""
+    try:
+        for ln in open("/proc/self/maps"):
+            p = ln.rsplit(" ", 1)[-1].strip()
+            if "librccl" in _os.path.basename(p):
+                return p
+    except OSError:
+        pass
+    for p in ("/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"):
+        if _os.path.exists(p):
+            return p
+    return None
+
+
+class _UniqueId(_C.Structure):
+    _fields_ = [("internal", _C.c_char * 128)]      # NCCL_UNIQUE_ID_BYTES (rccl.h:40-43)
+
+
+class RcclComm:
+    """an ncclComm_t of this process's rank (rccl.h:187-260): `handle` is what msplat_band_exchange takes.
+    world == 1 needs no process group; otherwise the unique id is broadcast from rank 0 over torch.distributed."""
+
+    def __init__(self, rank=0, world=1, device=0):
+        path = loaded_rccl_path()
+        if path is None:
+            raise RuntimeError("librccl not found")
+        _os.environ.setdefault("MSPLAT_RCCL_LIB", path)       # libmsplat resolves the same copy (communicators belong to one copy)
+        self._lib = L = _C.CDLL(path)
+        L.ncclGetErrorString.restype = _C.c_char_p
+        L.ncclGetUniqueId.argtypes = [_C.POINTER(_UniqueId)]
+        L.ncclCommInitRank.argtypes = [_C.POINTER(_C.c_void_p), _C.c_int, _UniqueId, _C.c_int]
+        L.ncclCommDestroy.argtypes = [_C.c_void_p]
+        import torch
+        torch.cuda.set_device(device)
+        uid = _UniqueId()
+        if rank == 0:
+            self._ok(L.ncclGetUniqueId(_C.byref(uid)), "ncclGetUniqueId")
+        if world > 1:
+            box = [bytes(uid)] if rank == 0 else [None]          # the raw 128 bytes (uid.internal would stop at a NUL)
+            dist.broadcast_object_list(box, src=0)
+            _C.memmove(_C.byref(uid), box[0], 128)
+        self.handle = _C.c_void_p()
+        self._ok(L.ncclCommInitRank(_C.byref(self.handle), world, uid, rank), "ncclCommInitRank")
+        self.rank, self.world, self.path = rank, world, path
+
+    def _ok(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s: %s" % (what, self._lib.ncclGetErrorString(rc).decode()))
+
+    def close(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self._lib.ncclCommDestroy(h)
+
+    def __del__(self):
+        self.close()
+
+
+_KIND = {"contiguous": 0, "interleaved": 1, "block": 2}
+
+
+class CAbiBandGather:
+    """BandGather's job through msplat_band_exchange: one ncclGroupStart/End of ncclSend / ncclRecv issued by libmsplat on the
+    renderer's stream.  Same plan (runs of consecutive bin rows, straight into rank dst's framebuffer)."""
+
+    def __init__(self, renderer, comm, tiles_y, width, dtype, rank, world, dst=0, tile=32, layout="interleaved", block_rows=1):
+        self.r, self.comm, self.rank, self.world, self.dst = renderer, comm, rank, world, dst
+        self.kind, self.block_rows = _KIND[layout], int(block_rows)
+        self.W, self.H = width, tiles_y * tile
+        self.pitch = width * (8 if str(dtype).endswith("float16") else 16)
+
+    def __call__(self, fb):
+        self.r.band_exchange(self.comm.handle, self.rank, self.world, self.dst, self.kind, self.block_rows, fb.data_ptr(),
+                             self.pitch, self.W, self.H)
+        return fb if self.rank == self.dst else None

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/msplat.h"
+#include "../../include/msplat_debug.h"
 #include "gaussian_scene.hpp"
 #include "point_scene.hpp"
 
@@ -60,6 +61,40 @@ public:
         groupKind = bandKind;
         groupBlockRows = blockRows;
         groupBandCull = bandCull;
+    }
+
+    // optional, before Init, with ConfigureDevices: how the other devices' rows reach devices[0]'s render target --
+    // MSPLAT_EXCHANGE_PEER_STORE (default: their compositors store through the peer mapping), MSPLAT_EXCHANGE_RCCL (grouped
+    // ncclSend / ncclRecv over communicators from ncclCommInitAll) or MSPLAT_EXCHANGE_COPY.  Not available (RCCL missing, a
+    // device listed twice): logged, the group keeps its previous exchange.
+    void SetGroupExchange(int exchange) { groupExchange = exchange; }
+
+    // One process per GPU (the other multi-GPU shape): this process renders the bin rows of rank `rank` of `world`
+    // (msplat_band_plan's layouts) and, after Render into a device target, ExchangeBands() gathers every rank's rows into rank
+    // `root`'s target with ONE group of ncclSend / ncclRecv on the context's stream (msplat_band_exchange; `comm` = the host's
+    // ncclComm_t).  Call SetBandPlan after Init.
+    bool SetBandPlan(int rank, int world, int rowsFull, int bandKind = MSPLAT_BANDS_CONTIGUOUS, int blockRows = 1, bool bandCull = false)
+    {
+        int32_t first = 0, count = 0, block = 1, stride = 1;
+        if (msplat_band_plan(bandKind, rowsFull, world, rank, blockRows, &first, &count, &block, &stride) != MSPLAT_OK) {
+            std::fprintf(stderr, "[msplat][E] SetBandPlan: %s\n", msplat_last_error(nullptr));
+            return false;
+        }
+        bandRank = rank; bandWorld = world; bandKindSet = bandKind; bandBlockRows = blockRows;
+        for (msplat_ctx* h : ctxs)
+            if (msplat_set_band_layout(h, first, count, block, stride) != MSPLAT_OK || msplat_set_band_cull(h, bandCull ? 1 : 0) != MSPLAT_OK) {
+                std::fprintf(stderr, "[msplat][E] SetBandPlan: %s\n", msplat_last_error(h));
+                return false;
+            }
+        return true;
+    }
+    bool ExchangeBands(void* comm, int root, int width, int height)
+    {
+        if (!ctx || !targetIsDevice || !target) return false;
+        const uint64_t pitch = targetPitch ? targetPitch : (uint64_t)width * (cfg.fb_format == MSPLAT_FB_RGBA16F ? 8u : 16u);
+        const int rc = msplat_band_exchange(ctx, comm, bandRank, bandWorld, root, bandKindSet, bandBlockRows, target, pitch, width, height);
+        if (rc != MSPLAT_OK) std::fprintf(stderr, "[msplat][E] ExchangeBands: %s\n", msplat_group_last_error(nullptr));
+        return rc == MSPLAT_OK;
     }
 
     // optional, before Init: number of frames in flight (default 1).  With depth > 1 every Sort moves on to
@@ -269,6 +304,8 @@ protected:
         }
         msplat_group_set_layout(group, groupKind, groupBlockRows);
         msplat_group_set_band_cull(group, groupBandCull ? 1 : 0);
+        if (groupExchange != MSPLAT_EXCHANGE_PEER_STORE && msplat_group_set_exchange(group, groupExchange) != MSPLAT_OK)
+            std::fprintf(stderr, "[msplat][W] SetGroupExchange: %s\n", msplat_group_last_error(group));
         msplat_attr_offsets off{};
         off.pos_with_alpha = (uint32_t)cloud.GetPosWithAlphaAttrib().offset;
         off.r_sh0 = (uint32_t)cloud.GetR_SH0Attrib().offset;
@@ -308,6 +345,8 @@ protected:
     std::vector<int> groupDevices;
     int groupKind = MSPLAT_BANDS_CONTIGUOUS, groupBlockRows = 1;
     bool groupBandCull = false;
+    int groupExchange = MSPLAT_EXCHANGE_PEER_STORE;
+    int bandRank = 0, bandWorld = 1, bandKindSet = MSPLAT_BANDS_CONTIGUOUS, bandBlockRows = 1;
 
     std::vector<msplat_ctx*> ctxs;       // one per frame in flight; ctxs[0] owns the cloud
     msplat_ctx* ctx = nullptr;           // == ctxs[cur]

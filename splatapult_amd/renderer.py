@@ -256,6 +256,19 @@ class SplatRenderer:
         default stream) waits for the frame issued last"""
         _capi.check(self._ctx, self._lib.msplat_stream_wait(self._ctx, C.c_void_p(stream or 0)))
 
+    def band_exchange(self, comm, rank, world, root, kind, block_rows, fb_ptr, pitch_bytes, width, height, loopback_src=None):
+        """msplat_band_exchange on the current context's stream (comm = ncclComm_t handle, e.g. dist.RcclComm().handle): rank
+        `root` receives every other rank's runs of bin rows straight into its framebuffer, the owners send theirs.
+        loopback_src: one-rank test form (msplat_debug_band_exchange_loopback): this rank's runs travel from loopback_src to fb_ptr"""
+        if loopback_src is not None:
+            rc = self._lib.msplat_debug_band_exchange_loopback(self._ctx, comm, kind, block_rows, world, rank, C.c_void_p(loopback_src),
+                                                               C.c_void_p(fb_ptr), pitch_bytes, width, height)
+        else:
+            rc = self._lib.msplat_band_exchange(self._ctx, comm, rank, world, root, kind, block_rows, C.c_void_p(fb_ptr), pitch_bytes,
+                                                width, height)
+        if rc != _capi.OK:
+            raise _capi.MsplatError(rc, self._lib.msplat_group_last_error(None).decode())
+
     def next_frame_wait_event(self, event):
         """the context the NEXT Sort will use waits for `event` (hipEvent_t handle, e.g. torch.cuda.Event
         .cuda_event recorded after the consumer of the framebuffer that frame is going to overwrite)"""
@@ -504,3 +517,14 @@ class SplatRendererGroup:
 
     def synchronize(self):
         self._check(self._lib.msplat_group_synchronize(self._g))
+
+    EXCHANGES = ("peer_store", "rccl", "copy")      # MSPLAT_EXCHANGE_*
+
+    def set_exchange(self, name):
+        """how the other devices' rows reach devices[0]'s framebuffer: "peer_store" (default), "rccl" (ncclSend / ncclRecv over
+        communicators from ncclCommInitAll) or "copy" (hipMemcpy2DAsync per run)"""
+        self._check(self._lib.msplat_group_set_exchange(self._g, self.EXCHANGES.index(name)))
+
+    def exchange(self):
+        """the exchange the latest device-output Render used"""
+        return self.EXCHANGES[self._lib.msplat_group_get_exchange(self._g)]

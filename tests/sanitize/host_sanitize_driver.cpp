@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/msplat.h"
+#include "../../include/msplat_debug.h"
 
 static int g_fail = 0;
 static uint64_t g_stub_bytes = 0;

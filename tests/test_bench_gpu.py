@@ -78,6 +78,9 @@ def test_bench_two_ranks_one_device_control_flow():
     gc = d["gather_check"]                                 # rank 0's gathered frame == the unbanded single-context frame
     assert gc["bit_exact"] is True and gc["values_different"] == 0 and gc["values_compared"] >= 2 * 1920 * 1080 * 4
     assert gc["poses"] == [5, 37] and gc["exchange"] == "gloo"
+    per = gc["exchange_ms_per_gather_per_rank"]            # r5: what the row exchange costs each rank (events on the gathering stream)
+    assert isinstance(per, list) and len(per) == 2 and all(x is not None and x >= 0.0 for x in per), per
+    assert "gloo" in gc["exchange_call"] and "c_abi_exchange" not in gc
     assert "over 2 ranks" in d["config"]["sharding"] and "layout" in d["config"]["sharding"]
     assert d["gather"]["bytes_into_rank0_per_frame"] > 0
 
@@ -90,6 +93,8 @@ def test_bench_peer_store_check_child_mode():
     assert p.returncode == 0, p.stderr[-2000:]
     d = _line(p.stdout)
     assert d["error"] is None and d["bit_exact"] is True and d["devices"] == [0] and d["poses"] == [5, 37]
+    ex = d["exchanges"]                                    # r5: every exchange form the group has, compared and timed (one device: one entry)
+    assert list(ex) == ["peer_store"] and ex["peer_store"]["bit_exact"] is True and ex["peer_store"]["ms_per_frame"] > 0
 
 
 def test_bench_two_pass_workload_reports_what_the_passes_did():

@@ -11,10 +11,20 @@ from splatapult_amd import SplatRenderer, _capi
 from tests.conftest import ROOT, has_gpu
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "msplat.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(msplat_[a-z0-9_]+)\s*\(", src)))
+def declared_symbols(headers=("msplat.h", "msplat_debug.h")):
+    names = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(msplat_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
+
+
+def test_the_integrator_header_stays_small_and_free_of_debug_entry_points():
+    """msplat.h is what a maintainer binding Sort / Render reads; taps and probes live in msplat_debug.h"""
+    lines = open(os.path.join(ROOT, "include", "msplat.h")).read().splitlines()
+    assert len(lines) <= 300, len(lines)
+    assert not [n for n in declared_symbols(("msplat.h",)) if n.startswith("msplat_debug_") or "probe" in n]
 
 
 def test_library_exports_every_declared_symbol():
@@ -28,7 +38,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_signatures_are_plain_c_no_framework_types():
-    src = open(os.path.join(ROOT, "include", "msplat.h")).read()
+    src = open(os.path.join(ROOT, "include", "msplat.h")).read() + open(os.path.join(ROOT, "include", "msplat_debug.h")).read()
     code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     assert "torch" not in code and "std::" not in code and "glm" not in code and "hipStream" not in code
     assert 'extern "C"' in code

@@ -1419,7 +1419,7 @@ def _hip_device_count():
         return 0
 
 
-@pytest.mark.parametrize("exchange", ["peer", "copy"])
+@pytest.mark.parametrize("exchange", ["peer", "copy", "rccl"])
 def test_device_group_over_distinct_devices(exchange, monkeypatch):
     """msplat_group over REAL distinct GPUs (skipped on a one-GPU box): the peer mapping towards device 0 and the
     cross-device stream waits, the per-device kernel attributes (the three-pass sort's dynamic LDS on devices 1..), both exchange
@@ -1430,8 +1430,8 @@ def test_device_group_over_distinct_devices(exchange, monkeypatch):
     ndev = min(_hip_device_count(), torch.cuda.device_count())
     if ndev < 2:
         pytest.skip("needs two GPUs (found %d)" % ndev)
-    if exchange == "copy":
-        monkeypatch.setenv("MSPLAT_GROUP_EXCHANGE", "copy")
+    if exchange != "peer":
+        monkeypatch.setenv("MSPLAT_GROUP_EXCHANGE", exchange)            # rccl: ncclSend / ncclRecv over ncclCommInitAll's communicators
     devices = list(range(min(ndev, 4)))
     cloud = scenes.synth_cloud(300000, 56, log_scale_mean=-3.6)          # large enough for the spatial storage order (AUTO)
     W, H = 1280, 720
@@ -1459,7 +1459,67 @@ def test_device_group_over_distinct_devices(exchange, monkeypatch):
     torch.cuda.synchronize()
     for k in range(len(cams)):
         np.testing.assert_array_equal(keep[k].cpu().numpy(), refs[k])
+    assert g.exchange() == {"peer": "peer_store", "copy": "copy", "rccl": "rccl"}[exchange]
     g.close()
+
+
+def test_band_exchange_through_rccl_on_one_rank_and_the_group_switch():
+    """the row gather over RCCL behind the C ABI.  A one-GPU box cannot hold two ranks (RCCL refuses a device
+    twice), so the real calls are exercised on a ONE-rank communicator: the runs of bin rows that rank g of 8 owns travel through
+    ncclSend / ncclRecv to the rank itself, from one framebuffer into another (msplat_debug_band_exchange_loopback: the same run
+    enumeration and the same group of calls as msplat_band_exchange) -- every layout, both pixel sizes; world == 1 is a no-op;
+    the one-process group accepts the switch where it can (one device) and refuses it with a message where RCCL cannot (a device
+    listed twice), staying on its previous exchange."""
+    import torch
+    from splatapult_amd import MsplatError, SplatRendererGroup, _capi
+    from splatapult_amd.dist import RcclComm, owned_rows
+    comm = RcclComm(0, 1, 0)
+    r = make_renderer(scenes.synth_cloud(2000, 5))
+    T = bin_px()
+    dev = torch.device("cuda", 0)
+    for W, H, dtype, bpp in ((640, 360, torch.float32, 16), (517, 293, torch.float16, 8)):
+        tiles_y = (H + T - 1) // T
+        Hpad = tiles_y * T
+        src = torch.randn((Hpad, W, 4), dtype=torch.float32, device=dev).to(dtype)
+        for kind, name, k in ((_capi.BANDS_CONTIGUOUS, "contiguous", 1), (_capi.BANDS_INTERLEAVED, "interleaved", 1),
+                              (_capi.BANDS_BLOCK_INTERLEAVED, "block", 2)):
+            for g in (0, 3, 7):
+                dst = torch.zeros_like(src)
+                r.band_exchange(comm.handle, g, 8, 0, kind, k, dst.data_ptr(), W * bpp, W, Hpad, loopback_src=src.data_ptr())
+                r.synchronize()
+                torch.cuda.synchronize()
+                want = torch.zeros_like(src)
+                rows = np.isin(np.arange(Hpad) // T, owned_rows(name, tiles_y, 8, g, k))
+                want[torch.from_numpy(rows).to(dev)] = src[torch.from_numpy(rows).to(dev)]
+                assert torch.equal(dst, want), (name, g, W, H)
+    # world == 1: the whole image is this rank's, nothing to exchange (no communicator needed)
+    r.band_exchange(None, 0, 1, 0, _capi.BANDS_CONTIGUOUS, 1, 0, 0, 0, 0)
+    with pytest.raises(MsplatError):
+        r.band_exchange(None, 0, 2, 0, _capi.BANDS_CONTIGUOUS, 1, src.data_ptr(), W * bpp, W, Hpad)      # no communicator
+    comm.close()
+    # the one-process group
+    cloud = scenes.synth_cloud(20000, 77, log_scale_mean=-3.2)
+    W, H = 640, 360
+    cam, proj, vp, nf = scenes.default_view(W, H)
+    one = make_renderer(cloud)
+    one.Sort(cam, proj, vp, nf)
+    ref = one.Render(cam, proj, vp, nf)
+    g1 = SplatRendererGroup([0])
+    assert g1.Init(cloud), g1.last_error()
+    g1.set_exchange("rccl")                                    # one device: accepted, nothing to exchange
+    g2 = SplatRendererGroup([0, 0], layout="interleaved")
+    assert g2.Init(cloud), g2.last_error()
+    with pytest.raises(MsplatError) as e:
+        g2.set_exchange("rccl")                                # RCCL refuses a device listed twice
+    assert e.value.code == _capi.ERR_UNSUPPORTED and "ncclCommInitAll" in str(e.value)
+    fb = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    for g in (g1, g2):
+        g.Sort(cam, proj, vp, nf)
+        fb.zero_()
+        g.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)
+        g.synchronize()
+        np.testing.assert_array_equal(fb.cpu().numpy(), ref)
+        g.close()
 
 
 def test_device_group_errors():

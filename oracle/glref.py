@@ -39,16 +39,33 @@ def init(full_sh, srgb=False):
     return _lib.glref_gl_version().decode()
 
 
-def presort(aos, mvp, near_far):
+def presort(aos, mvp, near_far, raw=False):
     """SplatRenderer::Sort's pre-sort on the reference's compute shader: (keys, indices) of the visible splats, ordered by index
-    (the shader hands out slots with an atomic counter: its own order is not deterministic)"""
+    (the shader hands out slots with an atomic counter: its own order is not deterministic); raw: in the shader's slot order --
+    what the reference's sorter is fed"""
     n = aos.shape[0]
     pos4 = np.ascontiguousarray(np.c_[aos[:, :3], np.ones(n, np.float32)], np.float32)     # posVec, splatrenderer.cpp:106-111
     keys, idx, cnt = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32), C.c_uint32()
     if _lib.glref_presort(_f(pos4), n, _f(mvp), _f(near_far), _u(keys), _u(idx), C.byref(cnt)) != 0:
         raise RuntimeError("glref_presort: " + _lib.glref_last_error().decode())
+    if raw:
+        return keys[:cnt.value].copy(), idx[:cnt.value].copy()
     o = np.argsort(idx[:cnt.value], kind="stable")
     return keys[:cnt.value][o].copy(), idx[:cnt.value][o].copy()
+
+
+RGC_HPP = os.path.join(os.path.dirname(SHADER_DIR.rstrip("/")), "src", "radix_sort.hpp")
+
+
+def rgc_sort(keys, values):
+    """the reference's fallback sorter (rgc::radix_sort::sorter::sort, src/radix_sort.hpp:340-485) on its own compute shaders -- the
+    string literals of that header, read where it lies: (sorted keys, values carried along), uint32"""
+    k = np.ascontiguousarray(keys, np.uint32).copy()
+    v = np.ascontiguousarray(values, np.uint32).copy()
+    assert k.shape == v.shape and k.ndim == 1
+    if _lib.glref_rgc_sort(RGC_HPP.encode(), _u(k), _u(v), k.shape[0]) != 0:
+        raise RuntimeError("glref_rgc_sort: " + _lib.glref_last_error().decode())
+    return k, v
 
 
 def render(aos, sorted_idx, view_mat, proj_mat, viewport, near_far, eye, target="fp32", depth_bits=0):

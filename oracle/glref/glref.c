@@ -18,6 +18,7 @@
 #include <GL/internal/dri_interface.h>
 #include <GL/glcorearb.h>
 #include <dlfcn.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -486,4 +487,171 @@ int glref_points_render(const float* points, uint32_t n, const uint32_t* sorted_
     pglDeleteBuffers(1, &vbo);
     pglDeleteBuffers(1, &ebo);
     return e == GL_NO_ERROR ? 0 : fail("GL error 0x%x in glref_points_render", e);
+}
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * The reference's fallback sorter, rgc::radix_sort::sorter (src/radix_sort.hpp: the path SplatRenderer::Sort takes where
+ * KHR_shader_subgroup is missing, splatrenderer.cpp:86,223-264 -- llvmpipe is such a GL).  Its three compute shaders are C string
+ * literals inside that header (radix_sort.hpp:122-124); they are READ from the file where it lies at run time (nothing is copied),
+ * unescaped, prefixed with "#version 460" like __rgc_shader_injector_load_src does (:93-103), and driven with the buffers,
+ * uniforms and dispatch sequence of sorter::sort (:340-485): eight 4-bit passes of count -> Blelloch scan of the per-block
+ * counts (up-sweep, clear last, down-sweep) -> reorder, ping-ponging between the caller's buffers and scratch.
+ * keys / vals (n each) are sorted in place.
+ * ------------------------------------------------------------------------------------------------------------------------------ */
+static GLuint g_rgc[3];            /* count, local offsets, reorder */
+
+/* the next string literal assigned to a variable whose name starts with `prefix`, unescaped (malloc'd); *cursor advances */
+static char* next_literal(const char** cursor, const char* prefix)
+{
+    const char* p = strstr(*cursor, prefix);
+    if (!p) return NULL;
+    p = strchr(p, '"');
+    if (!p) return NULL;
+    ++p;
+    size_t cap = 1 << 16, len = 0;
+    char* out = (char*)malloc(cap);
+    while (*p && *p != '"') {
+        char c = *p++;
+        if (c == '\\' && *p) {
+            const char e = *p++;
+            c = e == 'n' ? '\n' : e == 't' ? '\t' : e == 'r' ? '\r' : e == '0' ? '\0' : e;      /* \" \\ \' map to themselves */
+        }
+        if (len + 2 > cap) { cap *= 2; out = (char*)realloc(out, cap); }
+        out[len++] = c;
+    }
+    out[len] = 0;
+    *cursor = *p ? p + 1 : p;
+    return out;
+}
+
+static GLuint compute_program_from_source(const char* body, const char* what)
+{
+    const size_t n = strlen(body) + 32;
+    char* src = (char*)malloc(n);
+    snprintf(src, n, "#version 460\n%s", body);                         /* radix_sort.hpp:93-103 (non-Android) */
+    GLuint sh = pglCreateShader(GL_COMPUTE_SHADER);
+    const char* srcs[1] = {src};
+    pglShaderSource(sh, 1, srcs, NULL);
+    pglCompileShader(sh);
+    GLint ok = 0;
+    pglGetShaderiv(sh, GL_COMPILE_STATUS, &ok);
+    free(src);
+    if (!ok) {
+        char log[3000];
+        pglGetShaderInfoLog(sh, sizeof(log), NULL, log);
+        fail("compile rgc %s shader: %s", what, log);
+        return 0;
+    }
+    return link_program(sh, 0, 0);
+}
+
+static int rgc_load(const char* hpp_path)
+{
+    if (g_rgc[0]) return 0;
+    FILE* f = fopen(hpp_path, "rb");
+    if (!f) return fail("cannot open %s", hpp_path);
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    char* text = (char*)malloc((size_t)sz + 1);
+    if (fread(text, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(text); return fail("short read of %s", hpp_path); }
+    text[sz] = 0;
+    fclose(f);
+    const char* cur = text;
+    char* lit;
+    /* which literal is which program follows from the interface it declares (sorter::sorter attaches them by hash, :300-330) */
+    while ((lit = next_literal(&cur, "__rgc_shader_injector_shader_src_")) != NULL) {
+        int slot = -1;
+        if (strstr(lit, "layout(local_size_x")) {
+            if (strstr(lit, "b_tot_count_buf")) slot = 0;
+            else if (strstr(lit, "u_op")) slot = 1;
+            else if (strstr(lit, "b_out_keys")) slot = 2;
+        }
+        if (slot >= 0 && !g_rgc[slot]) {
+            g_rgc[slot] = compute_program_from_source(lit, slot == 0 ? "count" : slot == 1 ? "local offsets" : "reorder");
+            if (!g_rgc[slot]) { free(lit); free(text); return -1; }
+        }
+        free(lit);
+    }
+    free(text);
+    if (!g_rgc[0] || !g_rgc[1] || !g_rgc[2]) return fail("%s: the sorter's three shader literals were not found", hpp_path);
+    return 0;
+}
+
+int glref_rgc_sort(const char* hpp_path, uint32_t* keys, uint32_t* vals, uint32_t n)
+{
+    if (!g_ready) return fail("glref_init has not run");
+    if (rgc_load(hpp_path)) return -1;
+    if (n <= 1) return 0;                                                        /* sorter::sort, :342-344 */
+    const uint32_t T = 64, I = 4, RADIX = 16;                                    /* RGC_RADIX_SORT_* (:80-84) */
+    const uint32_t blocks = (uint32_t)ceilf((float)n / (float)(T * I));          /* calc_thread_blocks_num (:261-264) */
+    const uint32_t blocks2 = (uint32_t)exp2(ceil(log2((double)blocks)));         /* round_to_power_of_2 (:266-270) */
+    const size_t off_bytes = (size_t)blocks2 * RADIX * 4;
+    uint32_t* zeros = (uint32_t*)calloc(off_bytes / 4 + RADIX, 4);
+    GLuint b[6];                       /* keys, values, key scratch, value scratch, local offsets, global counts (resize_internal_buf, :272-300) */
+    pglGenBuffers(6, b);
+    for (int k = 0; k < 4; ++k) {
+        pglBindBuffer(GL_SHADER_STORAGE_BUFFER, b[k]);
+        pglBufferData(GL_SHADER_STORAGE_BUFFER, (GLsizeiptr)n * 4, k == 0 ? (const void*)keys : k == 1 ? (const void*)vals : NULL, GL_DYNAMIC_COPY);
+    }
+    const GLuint kb[2] = {b[0], b[2]}, vb[2] = {b[1], b[3]};
+    const GLuint wg_scan = (GLuint)ceilf((float)blocks2 / (float)(T * I));
+    const int depth = (int)log2((double)blocks2);
+    for (uint32_t pass = 0; pass < 32 / 4; ++pass) {                            /* RGC_RADIX_SORT_BITSET_COUNT passes (:360) */
+        /* initial clearing (:366-384) */
+        pglBindBuffer(GL_SHADER_STORAGE_BUFFER, b[5]);
+        pglBufferData(GL_SHADER_STORAGE_BUFFER, RADIX * 4, zeros, GL_DYNAMIC_COPY);
+        pglBindBuffer(GL_SHADER_STORAGE_BUFFER, b[4]);
+        pglBufferData(GL_SHADER_STORAGE_BUFFER, (GLsizeiptr)off_bytes, zeros, GL_DYNAMIC_COPY);
+        /* counting (:390-404) */
+        pglUseProgram(g_rgc[0]);
+        pglBindBufferBase(GL_SHADER_STORAGE_BUFFER, 0, kb[pass % 2]);
+        pglBindBufferBase(GL_SHADER_STORAGE_BUFFER, 1, b[4]);
+        pglBindBufferBase(GL_SHADER_STORAGE_BUFFER, 2, b[5]);
+        pglUniform1ui(pglGetUniformLocation(g_rgc[0], "u_arr_len"), n);
+        pglUniform1ui(pglGetUniformLocation(g_rgc[0], "u_bitset_idx"), pass);
+        pglDispatchCompute(blocks, 1, 1);
+        pglMemoryBarrier(GL_SHADER_STORAGE_BARRIER_BIT);
+        /* block-wide exclusive scan per radix (:410-452): up-sweep, clear last, down-sweep */
+        pglUseProgram(g_rgc[1]);
+        pglBindBufferBase(GL_SHADER_STORAGE_BUFFER, 0, b[4]);
+        const GLint l_len = pglGetUniformLocation(g_rgc[1], "u_arr_len"), l_op = pglGetUniformLocation(g_rgc[1], "u_op"),
+                    l_depth = pglGetUniformLocation(g_rgc[1], "u_depth");
+        for (int d = 0; d < depth; ++d) {
+            pglUniform1ui(l_len, blocks2); pglUniform1ui(l_op, 0); pglUniform1ui(l_depth, (GLuint)d);
+            pglDispatchCompute(wg_scan, 1, 1);
+            pglMemoryBarrier(GL_SHADER_STORAGE_BARRIER_BIT);
+        }
+        pglUniform1ui(l_len, blocks2); pglUniform1ui(l_op, 1);
+        pglDispatchCompute(wg_scan, 1, 1);
+        pglMemoryBarrier(GL_SHADER_STORAGE_BARRIER_BIT);
+        for (int d = depth - 1; d >= 0; --d) {
+            pglUniform1ui(l_len, blocks2); pglUniform1ui(l_op, 2); pglUniform1ui(l_depth, (GLuint)d);
+            pglDispatchCompute(wg_scan, 1, 1);
+            pglMemoryBarrier(GL_SHADER_STORAGE_BARRIER_BIT);
+        }
+        /* reordering (:458-480) */
+        pglUseProgram(g_rgc[2]);
+        pglBindBufferBase(GL_SHADER_STORAGE_BUFFER, 0, kb[pass % 2]);
+        pglBindBufferBase(GL_SHADER_STORAGE_BUFFER, 1, kb[(pass + 1) % 2]);
+        pglBindBufferBase(GL_SHADER_STORAGE_BUFFER, 2, vb[pass % 2]);
+        pglBindBufferBase(GL_SHADER_STORAGE_BUFFER, 3, vb[(pass + 1) % 2]);
+        pglBindBufferBase(GL_SHADER_STORAGE_BUFFER, 4, b[4]);
+        pglBindBufferBase(GL_SHADER_STORAGE_BUFFER, 5, b[5]);
+        pglUniform1ui(pglGetUniformLocation(g_rgc[2], "u_write_values"), 1u);
+        pglUniform1ui(pglGetUniformLocation(g_rgc[2], "u_arr_len"), n);
+        pglUniform1ui(pglGetUniformLocation(g_rgc[2], "u_bitset_idx"), pass);
+        pglDispatchCompute(blocks, 1, 1);
+        pglMemoryBarrier(GL_SHADER_STORAGE_BARRIER_BIT);
+    }
+    pglFinish();
+    /* eight passes: the result is back in the caller's buffers */
+    pglBindBuffer(GL_SHADER_STORAGE_BUFFER, b[0]);
+    pglGetBufferSubData(GL_SHADER_STORAGE_BUFFER, 0, (GLsizeiptr)n * 4, keys);
+    pglBindBuffer(GL_SHADER_STORAGE_BUFFER, b[1]);
+    pglGetBufferSubData(GL_SHADER_STORAGE_BUFFER, 0, (GLsizeiptr)n * 4, vals);
+    pglDeleteBuffers(6, b);
+    free(zeros);
+    const GLenum e = pglGetError();
+    return e == GL_NO_ERROR ? 0 : fail("GL error 0x%x in glref_rgc_sort", e);
 }

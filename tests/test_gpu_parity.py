@@ -1278,6 +1278,30 @@ def test_gpu_ingest_matches_host_import(tmp_path, n, full_sh):
     check_image(img, refimg)
 
 
+def test_gpu_ingest_covariance_by_rodrigues_rotation(tmp_path):
+    """VERDICT r4 item 7c on the device: ingest_kernel's R S S^T R^T for random non-normalised quaternions against the property
+    Sigma = sum_i s_i^2 (R e_i)(R e_i)^T with R e_i from Rodrigues' formula in float64 (tests/test_host.py) -- no shared formula"""
+    from splatapult_amd import synthetic
+    from tests.test_host import _covariance_by_rodrigues
+    rng = np.random.default_rng(78)
+    n = 5000
+    a = synthetic.generate(n, seed=6, full_sh=True)
+    a["rot"] = (rng.normal(size=(n, 4)) * rng.uniform(0.2, 5.0, size=(n, 1))).astype(np.float32)
+    a["rot"][:4] = np.array([[0, 1, 0, 0], [1, 1, 0, 0], [1, 1, 1, 1], [-1, 2, -3, 4]], np.float32)
+    a["log_scale"] = rng.uniform(-9.0, 0.5, size=(n, 3)).astype(np.float32)
+    path = str(tmp_path / "q.ply")
+    synthetic.write_ply(path, a)
+    r = SplatRenderer()
+    assert r.InitFromPly(path, importFullSH=True), r.last_error()
+    dev = r.download_cloud(True)
+    got = dev[:, 16:25].reshape(n, 3, 3).transpose(0, 2, 1).astype(np.float64)
+    want = _covariance_by_rodrigues(a["rot"], a["log_scale"])
+    scale = np.abs(want).max(axis=(1, 2), keepdims=True)
+    err = (np.abs(got - want) / scale).max()
+    print("ingest_kernel covariance vs Rodrigues construction: worst error %.3g of the splat's largest entry" % err)
+    assert err < 6e-6
+
+
 def test_gpu_ingest_test_ply_and_errors(golden_dir, tmp_path):
     import os
     r = SplatRenderer()

@@ -257,3 +257,46 @@ def test_host_library_is_clean_under_asan_ubsan(tmp_path):
     tail = (p.stdout + p.stderr)[-3000:]
     assert p.returncode == 0, tail
     assert "0 failed expectation(s)" in p.stdout and "ERROR: AddressSanitizer" not in tail and "runtime error" not in tail
+
+
+def _covariance_by_rodrigues(rot, log_scale):
+    """Sigma = sum_i s_i^2 (R e_i)(R e_i)^T with R e_i from Rodrigues' rotation formula about the quaternion's axis, in float64 --
+    no quaternion-to-matrix closed form, no matrix products: independent of the restatements of glm's mat3_cast it checks"""
+    q = np.asarray(rot, np.float64)
+    q = q / np.linalg.norm(q, axis=1, keepdims=True)                 # glm::normalize (gaussiancloud.cpp:88-89); rot = (w, x, y, z)
+    w, v = q[:, 0], q[:, 1:]
+    sin_half = np.linalg.norm(v, axis=1)
+    angle = 2.0 * np.arctan2(sin_half, w)
+    axis = v / np.maximum(sin_half, 1e-300)[:, None]
+    s2 = np.exp(np.asarray(log_scale, np.float64)) ** 2              # scale = exp(log_scale) (gaussiancloud.cpp:254-361)
+    sigma = np.zeros((q.shape[0], 3, 3))
+    for i in range(3):
+        e = np.zeros((q.shape[0], 3)); e[:, i] = 1.0
+        c, s = np.cos(angle)[:, None], np.sin(angle)[:, None]
+        re = e * c + np.cross(axis, e) * s + axis * (axis * e).sum(1, keepdims=True) * (1.0 - c)
+        sigma += s2[:, i, None, None] * re[:, :, None] * re[:, None, :]
+    return sigma
+
+
+def test_covariance_of_random_quaternions_by_rodrigues_rotation():
+    """VERDICT r4 item 7c: GaussianCloud::ImportPly's load math (a-2: R S S^T R^T from a quaternion and log-scales,
+    gaussiancloud.cpp:86-94,349) checked by a PROPERTY that does not share the restatement's formulas: rotate the basis vectors
+    about the quaternion's axis (Rodrigues) and sum s_i^2 (R e_i)(R e_i)^T.  Random non-identity, non-normalised quaternions,
+    anisotropic scales over four decades; msplat_cloud_from_attributes must agree to fp32 rounding of the largest entry."""
+    from tests import scenes
+    rng = np.random.default_rng(77)
+    n = 4000
+    a = synthetic.generate(n, seed=5, full_sh=False)
+    a["rot"] = (rng.normal(size=(n, 4)) * rng.uniform(0.2, 5.0, size=(n, 1))).astype(np.float32)      # not unit length
+    a["rot"][:8] = np.array([[0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1], [1, 1, 0, 0], [1, 0, 1, 0], [1, 0, 0, 1],
+                             [1, 1, 1, 1], [-1, 2, -3, 4]], np.float32)                                # half turns, 90 and 120 degrees
+    a["log_scale"] = rng.uniform(-9.0, 0.5, size=(n, 3)).astype(np.float32)
+    cloud = scenes.cloud_from_attrs(a, full_sh=False)
+    aos = cloud.as_array()
+    got = aos[:, 16:25].reshape(n, 3, 3).transpose(0, 2, 1).astype(np.float64)      # stored column-major: [col][row]
+    want = _covariance_by_rodrigues(a["rot"], a["log_scale"])
+    scale = np.abs(want).max(axis=(1, 2), keepdims=True)
+    err = (np.abs(got - want) / scale).max()
+    print("covariance vs Rodrigues construction: worst error %.3g of the splat's largest entry" % err)
+    assert err < 4e-6                                                # a few fp32 roundings of a product of three matrices
+    np.testing.assert_allclose(got, got.transpose(0, 2, 1), rtol=0, atol=float(scale.max()) * 1e-6)   # symmetric

@@ -6,6 +6,8 @@ src/app.cpp:144-164 and the uniforms / vertex layout of src/splatrenderer.cpp.  
 restatement every GPU parity test is measured against) to that execution:
   keys, visible set ......... exact
   framebuffer ............... SURVEY 8c: max |diff| <= 5e-3, mean <= 1e-4, >= 99.9 % of values within 1e-4, alpha == 1
+  draw order ................ the reference's fallback sorter (src/radix_sort.hpp's compute shaders, run the same way): keys exact,
+                              indices equal to the oracle's up to the order inside runs of equal keys (r5)
 Runs where the reference checkout and Mesa's software rasteriser exist (the build container; `-m "not gpu"`); the GPU box compares
 the HIP path with the committed outputs of these very calls (tests/golden/glref_*.npz, tests/test_gpu_reference_shaders.py)."""
 import os
@@ -30,16 +32,36 @@ def _gl_context():
         pytest.skip("no OpenGL 4.6 context from Mesa's software rasteriser here: %s" % e)
 
 
+def check_reference_sorter(raw_k, raw_i, sk, si):
+    """r5 (VERDICT r4 item 7a): the reference's OWN sorter on the shader's keys -- rgc::radix_sort (src/radix_sort.hpp:340-485,
+    the path SplatRenderer::Sort takes on a GL without KHR_shader_subgroup such as this one, splatrenderer.cpp:86,223-264), its
+    three compute shaders read from that header and run on llvmpipe.  Its output IS the reference's draw order: the keys must be
+    the oracle's sorted keys bit for bit, the indices the oracle's up to the order inside runs of equal keys (the oracle breaks
+    ties by ascending index; the reference by the slot order of an atomic counter), and the sorter must be stable with
+    respect to its input -- the contract "stable ascending 32-bit" the HIP sort is tested against."""
+    rk, ri = glref.rgc_sort(raw_k, raw_i)
+    np.testing.assert_array_equal(rk, sk)
+    stable = np.argsort(raw_k, kind="stable")
+    np.testing.assert_array_equal(ri, raw_i[stable])                    # ties keep the order they came in
+    # the same index SET inside every run of equal keys: sorting each run by index gives the oracle's order
+    run = np.cumsum(np.r_[0, (rk[1:] != rk[:-1]).astype(np.int64)]) if rk.shape[0] else np.zeros(0, np.int64)
+    np.testing.assert_array_equal(ri[np.lexsort((ri, run))], si)
+    return ri
+
+
 def check_against_shaders(aos, full_sh, cam, proj, W, H, nf=scenes.NF, srgb=False, render_cam=None, render_proj=None):
     version = glref.init(full_sh, srgb)
     assert "llvmpipe" in version and "4.6" in version
     vp = [0, 0, W, H]
     mvp = orc.mat4_mul(proj, orc.mat4_inverse(cam))                     # splatrenderer.cpp:161,175
-    gk, gi = glref.presort(aos, mvp, nf)
+    raw_k, raw_i = glref.presort(aos, mvp, nf, raw=True)                # in the slot order of the shader's atomic counter
+    o = np.argsort(raw_i, kind="stable")
+    gk, gi = raw_k[o], raw_i[o]
     ok, oi = orc.presort(aos, mvp, nf[1])
     np.testing.assert_array_equal(gi, oi)                               # the visible set of the reference's cull
     np.testing.assert_array_equal(gk, ok)                               # ... and its 32-bit depth keys, bit for bit
     sk, si = orc.sort(ok, oi)                                           # draw order: ascending key (ties: the reference's are undefined)
+    check_reference_sorter(raw_k, raw_i, sk, si)
     rcam = cam if render_cam is None else render_cam
     rproj = proj if render_proj is None else render_proj
     eye = np.asarray(rcam, np.float32).reshape(16)[12:15].copy()        # splatrenderer.cpp:328
@@ -287,3 +309,41 @@ def test_point_sprite_levels_and_the_level_of_detail_of_llvmpipe():
             # (every level is made from the level above, so a step of difference there carries over: two steps in the sRGB encoding)
             assert dl <= (2e-6 if l == 0 else (2.0 if srgb else 1.0) / 255.0 + 1e-5), (srgb, l, dl)
             w = max(1, w // 2)
+
+
+def test_what_an_unpinned_glm_inverse_could_move():
+    """VERDICT r4 item 7b.  The shaders receive `mvp = projMat * inverse(cameraMat)` from the host (splatrenderer.cpp:161,175), computed
+    by glm -- an unpinned dependency this repo restates (orc.mat4_inverse / mat4_mul = glm's cofactor inverse and column-major
+    product in fp32).  How much could another correct implementation of those two functions move the keys?  The reference's
+    presort shader is run twice on rotated, translated cameras: with the restated fp32 product and with the product evaluated in
+    fp64 and rounded once.  Bound asserted: every key within 64 units of 2^-32 far (the two matrices differ in the last bits
+    only), the visible sets equal but for splats within that distance of a cull plane, fewer than 1 % of neighbouring ranks
+    swapped.  What the HIP path is pinned to is the restated product: both sides of every parity test get the same mvp."""
+    glref.init(True)
+    cloud = scenes.synth_cloud(60000, 71, log_scale_mean=-3.0)
+    aos = cloud.as_array()
+    worst = dict(dkey=0, dset=0, swapped=0.0, dmvp=0.0)
+    for angle, radius, height, dx in ((0.37, 7.0, 0.3, 0.2), (2.1, 5.0, -1.2, -0.4), (4.0, 9.0, 2.0, 0.0), (5.5, 3.0, 0.7, 0.5)):
+        cam = camera.translate_local(camera.orbit(radius, angle, height), dx=dx)      # rotated, off-axis: no zero in the matrix
+        proj = camera.perspective(camera.FOVY, 16.0 / 9.0)
+        mvp32 = orc.mat4_mul(proj, orc.mat4_inverse(cam))
+        c64 = np.asarray(cam, np.float64).reshape(4, 4).T                   # column-major float[16] -> row-major matrix
+        p64 = np.asarray(proj, np.float64).reshape(4, 4).T
+        mvp64 = (p64 @ np.linalg.inv(c64)).T.reshape(16).astype(np.float32)
+        worst["dmvp"] = max(worst["dmvp"], float(np.abs(mvp64 - np.asarray(mvp32, np.float32).reshape(16)).max()))
+        ka, ia = glref.presort(aos, mvp32, scenes.NF)
+        kb, ib = glref.presort(aos, mvp64, scenes.NF)
+        both = np.intersect1d(ia, ib)
+        assert both.shape[0] > 20000
+        worst["dset"] = max(worst["dset"], int(ia.shape[0] + ib.shape[0] - 2 * both.shape[0]))
+        da = dict(zip(ia.tolist(), ka.tolist()))
+        db = dict(zip(ib.tolist(), kb.tolist()))
+        dk = max(abs(da[i] - db[i]) for i in both.tolist())
+        worst["dkey"] = max(worst["dkey"], int(dk))
+        _, sa = orc.sort(ka, ia)
+        _, sb = orc.sort(kb, ib)
+        if sa.shape == sb.shape:
+            worst["swapped"] = max(worst["swapped"], float((sa != sb).mean()))
+    print("fp64-rounded mvp against the restated glm product: max |d mvp| %(dmvp).3g, max |d key| %(dkey)d, visible sets differ by "
+          "%(dset)d splats, ranks that differ %(swapped).5f" % worst)
+    assert worst["dkey"] <= 64 and worst["dset"] <= 4 and worst["swapped"] < 0.01, worst

@@ -1716,73 +1716,86 @@ struct RenderPlan {
     float frac = 0.0f;
 };
 
-static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, size_t pitch, bool async_overflow_flag,
-                         void* d_out1 = nullptr, RenderPlan* plan = nullptr)
-{
-    hipStream_t s = ctx->stream;
-    const bool stereo = fp.views == 2;          // two views in one chain: ranks [0, V) and [V1, V1 + V), bin rows stacked
-    // (rank-indexed launches cover the cloud; with two views 2 N + 64 ranks)
-    const uint32_t N = stereo ? (uint32_t)(2 * ctx->N + 64) : (uint32_t)ctx->N;
-    uint32_t* counters = (uint32_t*)ctx->counters.p;
-    uint32_t *d_Vsort = counters + 0, *d_D = counters + 1, *d_overflow = counters + 2, *d_queue = (uint32_t*)ctx->queue.p;
-    uint32_t* d_Vframe = stereo ? counters + 9 : d_Vsort;  // ranks the binning walks (written by project_kernel for two views)
-    uint32_t* d_V = d_Vframe;
-    const int ntiles = fp.tiles_x * fp.tiles_y;
-    const uint32_t cap = (uint32_t)ctx->pair_cap;
+// ---- one Render = a chain of launches on the context's stream.  r5: one function per stage and one per kind of chain, instead of
+// r4's single 260-line launch_render with a lambda inside.  What the stages share: -------------------------------
+struct RenderChain {
+    msplat_ctx* ctx;
+    const FrameParams& fp;
+    hipStream_t s;
+    bool stereo;                 // two views in one chain: ranks [0, V) and [V1, V1 + V), bin rows stacked
+    uint32_t N;                  // rank-indexed launches cover this many ranks (the cloud; 2 N + 64 with two views)
+    uint32_t *d_Vsort, *d_D, *d_overflow, *d_queue;
+    uint32_t* d_Vframe;          // ranks the binning walks (written by project_kernel for two views)
+    uint32_t* occ;               // two-pass frames: cut / counters (msplat_occlusion.hip.h)
+    int ntiles;
+    uint32_t cap;
+    bool timed;
+    int tset, pgrid;
+    void *d_out, *d_out1;
+    size_t pitch;
+    bool async_overflow_flag;
+    // the compositor's schedule, decided where the bins are ordered (issue_binning) and used by issue_compositor
+    bool ordered = true;
+    uint32_t comp_items = 0, comp_pool = 0;
+};
 
-    const bool timed = ctx->ev_ok && (ctx->render_calls++ % ctx->timing_stride) == 0;
-    const int tset = (int)(ctx->render_sets % msplat_ctx::kEvSets);
-    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][2], s));
-    const int pgrid = std::max(1u, div_up(N, kProjThreads));
-    // Two-pass frame with occlusion feedback (msplat_occlusion.hip.h): the nearest R1 splats first, then only what the bins
-    // they did not saturate still need.  Same pixels; chosen per frame (occlusion_plan).
-    RenderPlan local_plan;
-    if (!plan) plan = &local_plan;
-    if (!plan->decided) {
-        plan->two_pass = occlusion_plan(ctx, fp, stereo, plan->frac);
-        plan->decided = true;
-    }
-    const float occ_frac = plan->frac;
-    const bool two_pass = plan->two_pass;
-    uint32_t* occ = (uint32_t*)ctx->occ.p;
-    uint32_t* d_cut = two_pass ? occ : nullptr;          // (project_kernel's first pass computes the cut and leaves it in occ[0])
-    if (ctx->point_mode)
-        hipLaunchKernelGGL(point_project_kernel, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, d_V,
+// vertex + geometry stage.  mode: PROJ_PLAIN / PROJ_TWO_VIEWS (chosen from the chain), PROJ_PASS1 or PROJ_LISTED (two-pass frames)
+static void issue_projection(RenderChain& rc, int mode, float occ_frac)
+{
+    msplat_ctx* ctx = rc.ctx;
+    const FrameParams& fp = rc.fp;
+    hipStream_t s = rc.s;
+    uint32_t *d_Vsort = rc.d_Vsort, *occ = rc.occ;
+    const int pgrid = rc.pgrid;
+    if (ctx->point_mode) {
+        hipLaunchKernelGGL(point_project_kernel, dim3(pgrid), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, rc.d_Vframe,
                            (const float4*)ctx->pos4.p, (const float4*)ctx->recs.p, fp, ctx->sprite_params,
                            (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr);
-    else {
-        const ProjParams pp = proj_params(fp);
-        uint32_t* zq = ctx->depth_bits ? (uint32_t*)ctx->zq.p : nullptr;
-#define MSPLAT_PROJECT(SH, MODE, GRID, DV, EX, V1)                                                                              \
-        hipLaunchKernelGGL((project_kernel<SH, MODE>), dim3(GRID), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, DV,  \
-                           (const float4*)ctx->recs.p, pp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, zq, EX, V1)
-        if (two_pass) {
-            const ProjExtra ex{nullptr, d_cut, nullptr, occ_frac};
-            const int grid = std::min(pgrid, kProjGridTwoPass);
-            if (ctx->full_sh) MSPLAT_PROJECT(true, PROJ_PASS1, grid, (const uint32_t*)d_Vsort, ex, ProjNoView1{0});
-            else MSPLAT_PROJECT(false, PROJ_PASS1, grid, (const uint32_t*)d_Vsort, ex, ProjNoView1{0});
-        } else if (stereo) {
-            const ProjExtra ex{d_V, nullptr, nullptr, 0.0f};
-            const ProjView1 v1 = proj_view1(fp);
-            if (ctx->full_sh) MSPLAT_PROJECT(true, PROJ_TWO_VIEWS, pgrid, (const uint32_t*)d_Vsort, ex, v1);
-            else MSPLAT_PROJECT(false, PROJ_TWO_VIEWS, pgrid, (const uint32_t*)d_Vsort, ex, v1);
-        } else {
-            const ProjExtra ex{nullptr, nullptr, nullptr, 0.0f};
-            if (ctx->full_sh) MSPLAT_PROJECT(true, PROJ_PLAIN, pgrid, (const uint32_t*)d_Vsort, ex, ProjNoView1{0});
-            else MSPLAT_PROJECT(false, PROJ_PLAIN, pgrid, (const uint32_t*)d_Vsort, ex, ProjNoView1{0});
-        }
+        return;
     }
-    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][3], s));
+    const ProjParams pp = proj_params(fp);
+    uint32_t* zq = (mode != PROJ_LISTED && ctx->depth_bits) ? (uint32_t*)ctx->zq.p : nullptr;
+#define MSPLAT_PROJECT(SH, MODE, GRID, DV, EX, V1)                                                                          \
+    hipLaunchKernelGGL((project_kernel<SH, MODE>), dim3(GRID), dim3(kProjThreads), 0, s, (const uint32_t*)ctx->valA.p, DV,  \
+                       (const float4*)ctx->recs.p, pp, (float4*)ctx->rec2d.p, (uint32_t*)ctx->rect.p, zq, EX, V1)
+    if (mode == PROJ_PASS1) {
+        // (project_kernel's first pass computes the cut and leaves it in occ[0])
+        const ProjExtra ex{nullptr, occ, nullptr, occ_frac};
+        const int grid = std::min(pgrid, kProjGridTwoPass);
+        if (ctx->full_sh) MSPLAT_PROJECT(true, PROJ_PASS1, grid, (const uint32_t*)d_Vsort, ex, ProjNoView1{0});
+        else MSPLAT_PROJECT(false, PROJ_PASS1, grid, (const uint32_t*)d_Vsort, ex, ProjNoView1{0});
+    } else if (mode == PROJ_LISTED) {
+        // the listed ranks behind the cut (occ[1] of them)
+        const ProjExtra ex{ctx->d_flags ? ctx->d_flags + 7 : (uint32_t*)nullptr, nullptr, (const uint32_t*)ctx->occ_live.p, 0.0f};
+        const int grid = std::min(pgrid, kProjGridTwoPass);
+        if (ctx->full_sh) MSPLAT_PROJECT(true, PROJ_LISTED, grid, (const uint32_t*)(occ + 1), ex, ProjNoView1{0});
+        else MSPLAT_PROJECT(false, PROJ_LISTED, grid, (const uint32_t*)(occ + 1), ex, ProjNoView1{0});
+    } else if (rc.stereo) {
+        const ProjExtra ex{rc.d_Vframe, nullptr, nullptr, 0.0f};
+        const ProjView1 v1 = proj_view1(fp);
+        if (ctx->full_sh) MSPLAT_PROJECT(true, PROJ_TWO_VIEWS, pgrid, (const uint32_t*)d_Vsort, ex, v1);
+        else MSPLAT_PROJECT(false, PROJ_TWO_VIEWS, pgrid, (const uint32_t*)d_Vsort, ex, v1);
+    } else {
+        const ProjExtra ex{nullptr, nullptr, nullptr, 0.0f};
+        if (ctx->full_sh) MSPLAT_PROJECT(true, PROJ_PLAIN, pgrid, (const uint32_t*)d_Vsort, ex, ProjNoView1{0});
+        else MSPLAT_PROJECT(false, PROJ_PLAIN, pgrid, (const uint32_t*)d_Vsort, ex, ProjNoView1{0});
+    }
+#undef MSPLAT_PROJECT
+}
 
-    // binning + compositor over the current rectangles: once per frame, twice for a two-pass frame
-    // (ev_bin / ev_c0 / ev_c1: the timing events of this chain; occ_pass: 0 one pass, 1 / 2 the passes of a two-pass frame)
-    auto chain = [&](int keep_overflow, int occ_pass, int ev_bin, int ev_c0, int ev_c1) -> int {
-    uint32_t* fin = occ_pass ? (uint32_t*)ctx->occ_fin.p : nullptr;
-    float4* state = occ_pass ? (float4*)ctx->occ_state.p : nullptr;
-    // second chain of a two-pass frame: the binning walks occ[4] ranks (V, or 0 when pass 1 left no bin unfinished), the
-    // compositor the listed unfinished bins
+// bin lists over the current rectangles: column pass (bin1_*), row pass (radix_*<MODE_PAIR>), list offsets + work order.
+// occ_pass: 0 one pass, 1 / 2 the passes of a two-pass frame; keep_overflow: second chain of a two-pass frame
+static void issue_binning(RenderChain& rc, int keep_overflow, int occ_pass)
+{
+    msplat_ctx* ctx = rc.ctx;
+    const FrameParams& fp = rc.fp;
+    hipStream_t s = rc.s;
+    const uint32_t N = rc.N, cap = rc.cap;
+    const bool stereo = rc.stereo, async_overflow_flag = rc.async_overflow_flag;
+    const int ntiles = rc.ntiles;
+    uint32_t *d_Vsort = rc.d_Vsort, *d_D = rc.d_D, *d_overflow = rc.d_overflow, *d_queue = rc.d_queue, *occ = rc.occ, *d_Vframe = rc.d_Vframe;
+    // second chain of a two-pass frame: the binning walks occ[4] ranks (V, or 0 when pass 1 left no bin unfinished)
     uint32_t* d_V = occ_pass == 2 ? occ + 4 : d_Vframe;
-    const uint32_t* d_nbins = occ_pass == 2 ? occ + 2 : nullptr;
     const uint32_t* d_first = occ_pass == 1 ? occ : nullptr;      // pass 1 bins the ranks from the cut on
 
     // pass 1: stable partition by tile column, enumerated from the rank-ordered rectangles
@@ -1885,7 +1898,27 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
             hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)ctx->tile_start.p, ntiles,
                                (uint32_t*)ctx->tile_order.p, d_queue);
     }
-    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][ev_bin], s));
+    rc.ordered = ordered;
+    rc.comp_items = comp_items;
+    rc.comp_pool = comp_pool;
+}
+
+// fragment stage + blend over the bin lists: the splat compositor (front to back), the draw-order compositor of the emulations,
+// or the sprite compositor.  ev_c0 / ev_c1: the timing set's slots for the kernel's dispatch begin / end
+static int issue_compositor(RenderChain& rc, int occ_pass, int ev_c0, int ev_c1)
+{
+    msplat_ctx* ctx = rc.ctx;
+    const FrameParams& fp = rc.fp;
+    hipStream_t s = rc.s;
+    const uint32_t cap = rc.cap, comp_items = rc.comp_items, comp_pool = rc.comp_pool;
+    const bool stereo = rc.stereo, timed = rc.timed, ordered = rc.ordered;
+    const int ntiles = rc.ntiles, tset = rc.tset;
+    uint32_t *d_queue = rc.d_queue, *occ = rc.occ;
+    void *d_out = rc.d_out, *d_out1 = rc.d_out1;
+    const size_t pitch = rc.pitch;
+    uint32_t* fin = occ_pass ? (uint32_t*)ctx->occ_fin.p : nullptr;
+    float4* state = occ_pass ? (float4*)ctx->occ_state.p : nullptr;
+    const uint32_t* d_nbins = occ_pass == 2 ? occ + 2 : nullptr;      // second chain of a two-pass frame: the listed unfinished bins
 
     // persistent compositor: a fixed pool of waves pulls (bin, quadrant) items; never more waves than items
     const int cgrid = std::min(ntiles * 4, ctx->comp_waves);     // work items = (bin, quadrant) (the draw-order compositors)
@@ -1961,38 +1994,72 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         ctx->comp_kernel_timed = false;
     }
     return MSPLAT_OK;
-    };      // chain
+}
 
-    int crc = chain(0, two_pass ? 1 : 0, 4, 6, 7);
+// between the passes of a two-pass frame: the map of unfinished bins, dead boxes, the gate over the ranks behind the cut
+static void issue_occlusion_gate(RenderChain& rc)
+{
+    msplat_ctx* ctx = rc.ctx;
+    const FrameParams& fp = rc.fp;
+    hipStream_t s = rc.s;
+    const uint32_t N = rc.N;
+    uint32_t *d_Vsort = rc.d_Vsort, *d_D = rc.d_D, *occ = rc.occ;
+    hipLaunchKernelGGL(occ_mask_kernel, dim3(1), dim3(kOccMaskThreads), 0, s, (const uint32_t*)ctx->occ_fin.p, fp.tiles_x, fp.tiles_y,
+                       (uint16_t*)ctx->occ_mask.p, occ, (const uint32_t*)d_Vsort, (uint32_t*)ctx->occ_unf.p);
+    // spatially ordered cloud: whole boxes of 256 stored splats are dropped before any centre is fetched
+    const uint32_t nboxes = (ctx->store && ctx->store->reordered && ctx->store->boxes.p) ? ctx->store->nboxes : 0u;
+    const uint32_t boxwords = ((nboxes + (uint32_t)kThreads - 1u) / (uint32_t)kThreads) * ((uint32_t)kThreads / 32u);
+    const bool use_boxes = nboxes != 0u && boxwords <= 2048u && ctx->occ_boxdead.p != nullptr;
+    if (use_boxes)
+        hipLaunchKernelGGL(occ_box_kernel, dim3(div_up(nboxes, kThreads)), dim3(kThreads), 0, s, (const CullBox*)ctx->store->boxes.p,
+                           nboxes, fp, (const uint16_t*)ctx->occ_mask.p, (uint32_t*)ctx->occ_boxdead.p);
+    hipLaunchKernelGGL(occ_gate_kernel, dim3(std::max(1u, div_up(N, kOccGateRanks))), dim3(kThreads), 0, s, (const uint32_t*)ctx->valA.p,
+                       (const uint32_t*)d_Vsort, occ, (const float4*)ctx->pos4.p, (uint32_t*)ctx->rect.p, fp,
+                       (const uint16_t*)ctx->occ_mask.p, (uint32_t*)ctx->occ_live.p, ctx->d_flags, (const uint32_t*)d_D, ctx->occ_seq,
+                       use_boxes ? (const uint32_t*)ctx->occ_boxdead.p : (const uint32_t*)nullptr, boxwords);
+}
+
+static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, size_t pitch, bool async_overflow_flag,
+                         void* d_out1 = nullptr, RenderPlan* plan = nullptr)
+{
+    hipStream_t s = ctx->stream;
+    const bool stereo = fp.views == 2;
+    uint32_t* counters = (uint32_t*)ctx->counters.p;
+    const uint32_t N = stereo ? (uint32_t)(2 * ctx->N + 64) : (uint32_t)ctx->N;
+    RenderChain rc{ctx, fp, s, stereo, N, counters + 0, counters + 1, counters + 2, (uint32_t*)ctx->queue.p,
+                   stereo ? counters + 9 : counters + 0, (uint32_t*)ctx->occ.p, fp.tiles_x * fp.tiles_y, (uint32_t)ctx->pair_cap,
+                   false, 0, (int)std::max(1u, div_up(N, kProjThreads)), d_out, d_out1, pitch, async_overflow_flag};
+    const bool timed = rc.timed = ctx->ev_ok && (ctx->render_calls++ % ctx->timing_stride) == 0;
+    const int tset = rc.tset = (int)(ctx->render_sets % msplat_ctx::kEvSets);
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][2], s));
+    // Two-pass frame with occlusion feedback (msplat_occlusion.hip.h): the nearest R1 splats first, then only what the bins
+    // they did not saturate still need.  Same pixels; chosen once per Render (occlusion_plan).
+    RenderPlan local_plan;
+    if (!plan) plan = &local_plan;
+    if (!plan->decided) {
+        plan->two_pass = occlusion_plan(ctx, fp, stereo, plan->frac);
+        plan->decided = true;
+    }
+    const bool two_pass = plan->two_pass;
+    rc.occ = (uint32_t*)ctx->occ.p;              // (allocated by occlusion_plan with a context's first two-pass frame)
+
+    // ---- the plain chain (also: both eyes in one chain, points, the emulations), or pass 1 of a two-pass frame ----
+    issue_projection(rc, two_pass ? PROJ_PASS1 : PROJ_PLAIN, plan->frac);
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][3], s));
+    issue_binning(rc, 0, two_pass ? 1 : 0);
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][4], s));
+    int crc = issue_compositor(rc, two_pass ? 1 : 0, 6, 7);
     if (crc) return crc;
     if (two_pass) {
+        // ---- pass 2: gate, the listed ranks, the bins pass 1 left unfinished ----
         if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][8], s));
-        hipLaunchKernelGGL(occ_mask_kernel, dim3(1), dim3(kOccMaskThreads), 0, s, (const uint32_t*)ctx->occ_fin.p, fp.tiles_x, fp.tiles_y,
-                           (uint16_t*)ctx->occ_mask.p, occ, (const uint32_t*)d_Vsort, (uint32_t*)ctx->occ_unf.p);
-        // spatially ordered cloud: whole boxes of 256 stored splats are dropped before any centre is fetched
-        const uint32_t nboxes = (ctx->store && ctx->store->reordered && ctx->store->boxes.p) ? ctx->store->nboxes : 0u;
-        const uint32_t boxwords = ((nboxes + (uint32_t)kThreads - 1u) / (uint32_t)kThreads) * ((uint32_t)kThreads / 32u);
-        const bool use_boxes = nboxes != 0u && boxwords <= 2048u && ctx->occ_boxdead.p != nullptr;
-        if (use_boxes)
-            hipLaunchKernelGGL(occ_box_kernel, dim3(div_up(nboxes, kThreads)), dim3(kThreads), 0, s, (const CullBox*)ctx->store->boxes.p,
-                               nboxes, fp, (const uint16_t*)ctx->occ_mask.p, (uint32_t*)ctx->occ_boxdead.p);
-        hipLaunchKernelGGL(occ_gate_kernel, dim3(std::max(1u, div_up(N, kOccGateRanks))), dim3(kThreads), 0, s, (const uint32_t*)ctx->valA.p,
-                           (const uint32_t*)d_Vsort, occ, (const float4*)ctx->pos4.p, (uint32_t*)ctx->rect.p, fp,
-                           (const uint16_t*)ctx->occ_mask.p, (uint32_t*)ctx->occ_live.p, ctx->d_flags, (const uint32_t*)d_D, ctx->occ_seq,
-                           use_boxes ? (const uint32_t*)ctx->occ_boxdead.p : (const uint32_t*)nullptr, boxwords);
-        // the listed ranks behind the cut (occ[1] of them)
-        {
-            const ProjParams pp = proj_params(fp);
-            uint32_t* zq = nullptr;
-            const ProjExtra ex{ctx->d_flags ? ctx->d_flags + 7 : (uint32_t*)nullptr, nullptr, (const uint32_t*)ctx->occ_live.p, 0.0f};
-            const int grid = std::min(pgrid, kProjGridTwoPass);
-            if (ctx->full_sh) MSPLAT_PROJECT(true, PROJ_LISTED, grid, (const uint32_t*)(occ + 1), ex, ProjNoView1{0});
-            else MSPLAT_PROJECT(false, PROJ_LISTED, grid, (const uint32_t*)(occ + 1), ex, ProjNoView1{0});
-        }
-#undef MSPLAT_PROJECT
+        issue_occlusion_gate(rc);
+        issue_projection(rc, PROJ_LISTED, 0.0f);
         if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][9], s));
         const bool timed1 = ctx->comp_kernel_timed;
-        crc = chain(1, 2, 10, 11, 12);
+        issue_binning(rc, 1, 2);
+        if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][10], s));
+        crc = issue_compositor(rc, 2, 11, 12);
         if (crc) return crc;
         ctx->comp_kernel_timed = ctx->comp_kernel_timed && timed1;
         ctx->frames_two_pass++;

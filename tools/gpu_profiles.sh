@@ -6,7 +6,7 @@
 cd ${GRAFT_REPO_ROOT:-.}
 R=$(pwd)
 export TMPDIR=/tmp
-T=${1:-r04}
+T=${1:-r05}
 mkdir -p gpurun_out
 ( time timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -rsP ) > gpurun_out/${T}_gpu_tests.log 2>&1
 grep -E "passed|failed|SKIPPED|check_image:" gpurun_out/${T}_gpu_tests.log | head -20
@@ -17,7 +17,7 @@ timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${T}_cfg2_bench_s
 timeout 600 python bench.py --frames-in-flight 1 --no-cpu-baseline > gpurun_out/${T}_cfg2_bench_serial.json 2> gpurun_out/${T}_cfg2_bench_serial.err
 prof() {  # name, bench args
   name=$1; shift
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_prof_$name -o run --output-format csv -- python $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/${T}_prof_$name.log 2>&1)
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_prof_$name -o run --output-format csv -- python $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/${T}_prof_$name.log 2>&1)   # (a rocprofv3 whose child aborts can hang for ever: r5 lost 25 GPU-minutes to one)
   f=$(find gpurun_out/${T}_prof_$name -name run_kernel_stats.csv | head -1)
   cp $f gpurun_out/${T}_${name}_kernel_stats.csv
   grep -h "^{" gpurun_out/${T}_prof_$name.log > gpurun_out/${T}_${name}_bench_under_rocprof.json
@@ -42,7 +42,7 @@ for wl in cfg2 cfg4; do
   timeout 1200 python tools/band_table.py --workload $wl --fif 4 --block 20 --worlds 2,4,8 --layouts auto,contiguous --out gpurun_out/${T}_${wl}_bands_fif4.json > gpurun_out/${T}_${wl}_bands_fif4.log 2>&1
   grep -E "^single|^G =" gpurun_out/${T}_${wl}_bands_fif4.log
 done
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_prof_rank3 -o run --output-format csv -- python $R/tools/band_rank_profile.py cfg4 8 3 block 8 100 > $R/gpurun_out/${T}_prof_rank3.log 2>&1)
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_prof_rank3 -o run --output-format csv -- python $R/tools/band_rank_profile.py cfg4 8 3 block 8 100 > $R/gpurun_out/${T}_prof_rank3.log 2>&1)
 cp $(find gpurun_out/${T}_prof_rank3 -name run_kernel_stats.csv | head -1) gpurun_out/${T}_cfg4_rank3_of_8_kernel_stats.csv; rm -rf gpurun_out/${T}_prof_rank3
 for wl in cfg2 cfg4; do
   bash tools/pmc_traffic.sh ${T}_$wl $wl

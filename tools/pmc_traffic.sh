@@ -10,7 +10,7 @@ TAG=$1
 WL=${2:-cfg2}
 mkdir -p $R/gpurun_out/pmc_$TAG
 for C in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/pmc_$TAG/$C -o run --output-format csv -- \
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/pmc_$TAG/$C -o run --output-format csv -- \
      python $R/bench.py --workload $WL --frames-in-flight 1 --steps 8 --warmup 2 --prewarm 8 --serial-frames 8 --no-cpu-baseline --profile-frames 1 --timing-stride 0 > $R/gpurun_out/pmc_$TAG/$C.log 2>&1)
 done
 python - <<PY

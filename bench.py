@@ -357,14 +357,20 @@ def measure(E, args, key, ply=None, primary=True):
     # (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE in their own passes, gfx950 x2 correction on FETCH_SIZE);
     # the committed summary is only quoted for the workload it was measured on
     traffic, tsrc = None, None
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, key))
         if world == 1 and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                kname = "msplat::composite_kernel<%s" % ("true" if wl["fb"] == "fp16" else "false")
-                kname = [k for k in tj if k.startswith(kname)][0]          # template arguments follow the target format
-                traffic = tj[kname]["hbm_bytes_per_launch_corrected"]
+                # template arguments (r5): <RGBA16F target, pass of a two-pass frame (0 = one pass), two views in one chain, probe>
+                f16 = "true" if wl["fb"] == "fp16" else "false"
+                if rnd < "r05":
+                    names = [[k for k in tj if k.startswith("msplat::composite_kernel<%s" % f16)][0]]
+                elif tp_serial:
+                    names = ["msplat::composite_kernel<%s, %d, false, false>" % (f16, q) for q in (1, 2)]      # both launches of the frame
+                else:
+                    names = ["msplat::composite_kernel<%s, 0, %s, false>" % (f16, "true" if stereo_batch else "false")]
+                traffic = sum(tj[k]["hbm_bytes_per_launch_corrected"] for k in names)
                 tsrc = "profiles/%s (rocprofv3 --pmc of bench.py --frames-in-flight 1, bytes per launch)" % os.path.basename(tpath)
                 break
             except (KeyError, ValueError, IndexError):

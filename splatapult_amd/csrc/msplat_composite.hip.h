@@ -88,7 +88,8 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
 // ------------------------------------------------------------------------------------------
 
 constexpr int kCompThreads = 64;   // one wave per 16x16 tile, 4 pixels (one per 16x4 strip) per lane
-constexpr int kCompOcc = 5;        // waves per SIMD the register allocation leaves room for (76 VGPRs; 6+ measured slower)
+constexpr int kCompOcc = 5;        // occupancy bound handed to the compiler (<= 102 VGPRs); the kernel needs 76, so 6 waves fit a SIMD (tools/kres.sh).
+                                   // A bound of 6+ was measured slower (r3: the allocator then squeezes the inner loop), DESIGN.md 4
 
 // Work item = (bin, quadrant): one wave composites one 16x16 tile of a 32x32 bin.  The kernel is VALU bound: 21.5 VALU
 // instructions per record in the inner loop (12 packed, 4 v_exp_f32, 3 scalar FMAs: ~147 pipe cycles) and ~70 per staged

@@ -490,6 +490,11 @@ int msplat_group_render(msplat_group* g, const float cameraMat[16], const float 
             return msplat_render(c, cameraMat, projMat, viewport, nearFar, g->stage[i], pitch_bytes, 1);
         });
         if (rc && rc != MSPLAT_ERR_PAIR_OVERFLOW_EARLIER) return rc;
+        // (contexts created with async_submit: every rank's worker has issued its render before the sends are queued behind it)
+        for (uint32_t i = 0; i < n; ++i) {
+            const int w = msplat_stream_wait(g->ctx[i], msplat_get_stream(g->ctx[i]));
+            if (w != MSPLAT_OK && w != MSPLAT_ERR_PAIR_OVERFLOW_EARLIER) return gfail(g, w, "msplat_group_render: %s", msplat_last_error(g->ctx[i]));
+        }
         const Rccl& R = rccl();
         int nrc = R.GroupStart();
         for (uint32_t i = 1; i < n && nrc == 0; ++i) {
@@ -560,7 +565,11 @@ static int band_exchange_impl(msplat_ctx* ctx, void* comm, int32_t rank, int32_t
                                                          (unsigned long long)pitch_bytes, width);
     const Rccl& R = rccl();
     if (!R.ok()) return gfail(nullptr, MSPLAT_ERR_UNSUPPORTED, "msplat_band_exchange: %s", R.why.c_str());
-    hipStream_t s = (hipStream_t)msplat_get_stream(ctx);               // (waits for the context's worker thread to have issued the frame)
+    hipStream_t s = (hipStream_t)msplat_get_stream(ctx);
+    // an async_submit context: its worker thread must have ISSUED the frame before the exchange is queued behind it (a wait on the
+    // context's own stream is just that; it may also hand over a queued call's overflow warning, which is passed on at the end)
+    const int wrc = msplat_stream_wait(ctx, s);
+    if (wrc != MSPLAT_OK && wrc != MSPLAT_ERR_PAIR_OVERFLOW_EARLIER) return gfail(nullptr, wrc, "msplat_band_exchange: %s", msplat_last_error(ctx));
     // a run travels as whole pitch rows (the framebuffer holds `height` rows of pitch_bytes; both sides count the same bytes)
     auto bytes_of = [&](int, int nrows) { return (size_t)nrows * (size_t)pitch_bytes; };
     int nrc = R.GroupStart();
@@ -595,6 +604,7 @@ static int band_exchange_impl(msplat_ctx* ctx, void* comm, int32_t rank, int32_t
     if (nrc == 0) nrc = erc;
     if (nrc != 0) return gfail(nullptr, MSPLAT_ERR_HIP, "msplat_band_exchange: RCCL: %s", R.GetErrorString(nrc));
     if (prc) return gfail(nullptr, prc, "msplat_band_exchange: %s", msplat_last_error(nullptr));
+    if (wrc != MSPLAT_OK) return gfail(nullptr, wrc, "%s", msplat_last_error(ctx));
     return MSPLAT_OK;
 }
 

@@ -1516,6 +1516,25 @@ def test_band_exchange_through_rccl_on_one_rank_and_the_group_switch():
                 rows = np.isin(np.arange(Hpad) // T, owned_rows(name, tiles_y, 8, g, k))
                 want[torch.from_numpy(rows).to(dev)] = src[torch.from_numpy(rows).to(dev)]
                 assert torch.equal(dst, want), (name, g, W, H)
+    # ordering behind a frame whose launches a worker thread issues (async_submit): the exchange waits for them to be ISSUED
+    cloud_a = scenes.synth_cloud(30000, 91, log_scale_mean=-3.0)
+    Wa, Ha = 640, 352
+    cam, proj, vp, nf = scenes.default_view(Wa, Ha)
+    ra = make_renderer(cloud_a, frames_in_flight=1, async_submit=True)
+    ref_img = make_renderer(cloud_a)
+    ref_img.Sort(cam, proj, vp, nf)
+    want_img = ref_img.Render(cam, proj, vp, nf)
+    fa = torch.zeros((Ha, Wa, 4), dtype=torch.float32, device=dev)
+    fb2 = torch.zeros_like(fa)
+    for _ in range(3):
+        ra.Sort(cam, proj, vp, nf)
+        fa.zero_(); fb2.zero_()
+        torch.cuda.synchronize()
+        ra.Render(cam, proj, vp, nf, out_ptr=fa.data_ptr(), pitch_bytes=Wa * 16)       # queued: returns at once
+        ra.band_exchange(comm.handle, 0, 1, 0, _capi.BANDS_CONTIGUOUS, 1, fb2.data_ptr(), Wa * 16, Wa, Ha, loopback_src=fa.data_ptr())
+        ra.synchronize()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(fb2.cpu().numpy(), want_img)       # the whole frame (rank 0 of 1 owns every row) arrived
     # world == 1: the whole image is this rank's, nothing to exchange (no communicator needed)
     r.band_exchange(None, 0, 1, 0, _capi.BANDS_CONTIGUOUS, 1, 0, 0, 0, 0)
     with pytest.raises(MsplatError):

@@ -2093,3 +2093,112 @@ def test_two_pass_with_a_pair_buffer_that_overflows():
             r.Render(cam, proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)
             r.synchronize()
         np.testing.assert_array_equal(fb.cpu().numpy(), expect)
+
+
+def test_every_combination_of_scheduling_modes_gives_the_same_pixels():
+    """the modes were tested in pairs, not as a lattice.  Target format x row bands x two-pass frames x
+    frames in flight x (one view | both eyes in one chain): 32 combinations of one small dense scene, every one against the plain
+    fp32 context's two views -- bit for bit (fp16 targets: the fp32 frame rounded once to fp16, which is what the compositor
+    stores).  Combinations the library schedules differently (two passes are not used for two views in one chain; banded
+    contexts render two views one after the other) are in the product on purpose: the CALLER'S pixels must not depend on that."""
+    import itertools
+    import torch
+    from splatapult_amd import _capi
+    cloud = scenes.synth_cloud(60000, 611, log_scale_mean=-2.9)
+    W, H = 640, 352                                          # 11 bin rows exactly: device targets need no padding
+    T = bin_px()
+    tiles_y = H // T
+    cam0 = camera.pose((0.1, -0.05, 5.5), 0.1, 0.03)
+    cams = [camera.translate_local(cam0, dx=-0.032), camera.translate_local(cam0, dx=+0.032)]
+    projs = [camera.create_projection(-1.0, 0.8, 0.95, -0.95), camera.create_projection(-0.8, 1.0, 0.95, -0.95)]
+    vp, nf = [0, 0, W, H], scenes.NF
+    plain = make_renderer(cloud)
+    plain.Sort(cams[0], projs[0], vp, nf)                    # one sort with the first eye (app.cpp:603-607)
+    ref = [plain.Render(cams[v], projs[v], vp, nf) for v in range(2)]
+    assert all((im[..., :3] != 0).any() for im in ref)
+    dev = torch.device("cuda", 0)
+    combos = 0
+    for fmt, bands, two_pass, fif, stereo in itertools.product(("fp32", "fp16"), (1, 3), (False, True), (1, 3), (False, True)):
+        tdt, bpp, ndt = (torch.float16, 8, np.float16) if fmt == "fp16" else (torch.float32, 16, np.float32)
+        r = make_renderer(cloud, fb_format=fmt, frames_in_flight=fif, two_pass=_capi.TWO_PASS_ON if two_pass else _capi.TWO_PASS_OFF)
+        if two_pass:
+            r.two_pass_state(0.2)
+        got = [np.zeros((H, W, 4), ndt) for _ in range(2)]
+        fbs = [torch.zeros((H, W, 4), dtype=tdt, device=dev) for _ in range(2)]
+        for rep in range(2 if fif > 1 else 1):               # frames in flight: a second round lands on other contexts
+            for g in range(bands):
+                lay = None
+                if bands > 1:
+                    lay = r.set_band_plan("block", tiles_y, bands, g, block_rows=2, band_cull=False)
+                r.Sort(cams[0], projs[0], vp, nf)
+                for t in fbs:
+                    t.zero_()
+                torch.cuda.synchronize()
+                if stereo:
+                    r.RenderStereo(cams, projs, vp, nf, out_ptrs=[t.data_ptr() for t in fbs], pitch_bytes=W * bpp)
+                else:
+                    for v in range(2):
+                        r.Render(cams[v], projs[v], vp, nf, out_ptr=fbs[v].data_ptr(), pitch_bytes=W * bpp)
+                r.synchronize()
+                torch.cuda.synchronize()
+                rows = np.ones(H, bool) if lay is None else np.isin(np.arange(H) // T, _capi.band_rows(*lay, rows_full=tiles_y))
+                for v in range(2):
+                    got[v][rows] = fbs[v].cpu().numpy()[rows]
+            for v in range(2):
+                want = ref[v] if fmt == "fp32" else ref[v].astype(np.float16)
+                np.testing.assert_array_equal(got[v], want, err_msg="target %s, %d band(s), two_pass %s, %d in flight, stereo %s, view %d"
+                                              % (fmt, bands, two_pass, fif, stereo, v))
+        r.close()
+        combos += 1
+    assert combos == 32
+
+
+def test_every_combination_of_the_render_target_emulations_gives_the_same_pixels():
+    """the other half of the lattice: emulated depth buffer (0 / 24 bits) x render-target rounding (none / RGBA8 / RGBA16F) x row
+    bands x frames in flight, the second eye drawn in the first eye's order (where the depth test matters): every combination
+    against the same emulation on a plain context.  The draw-order compositor takes over whenever one of the two is set; two-pass
+    frames requested on such a context run in one pass."""
+    import itertools
+    import torch
+    from splatapult_amd import _capi
+    cloud = scenes.synth_cloud(25000, 612, log_scale_mean=-2.9)
+    W, H = 480, 288
+    T = bin_px()
+    tiles_y = H // T
+    cam0 = camera.pose((0.0, 0.0, 5.5), 0.05, 0.0)
+    cams = [camera.translate_local(cam0, dx=-0.032), camera.translate_local(cam0, dx=+0.032)]
+    proj = camera.perspective(camera.FOVY, W / H)
+    vp, nf = [0, 0, W, H], scenes.NF
+    dev = torch.device("cuda", 0)
+    combos = 0
+    for depth_bits, rop in itertools.product((0, 24), (None, "rgba8", "fp16")):
+        if depth_bits == 0 and rop is None:
+            continue                                         # the plain compositor: the test above
+        plain = make_renderer(cloud)
+        plain.set_depth_test(depth_bits)
+        plain.set_target_emulation(rop)
+        plain.Sort(cams[0], proj, vp, nf)
+        ref = plain.Render(cams[1], proj, vp, nf)            # the second eye in the first eye's order
+        for bands, fif in itertools.product((1, 3), (1, 3)):
+            r = make_renderer(cloud, frames_in_flight=fif, two_pass=_capi.TWO_PASS_ON)
+            r.set_depth_test(depth_bits)
+            r.set_target_emulation(rop)
+            fb = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+            got = np.zeros((H, W, 4), np.float32)
+            for rep in range(2 if fif > 1 else 1):
+                for g in range(bands):
+                    lay = r.set_band_plan("interleaved", tiles_y, bands, g) if bands > 1 else None
+                    r.Sort(cams[0], proj, vp, nf)
+                    fb.zero_()
+                    torch.cuda.synchronize()
+                    r.Render(cams[1], proj, vp, nf, out_ptr=fb.data_ptr(), pitch_bytes=W * 16)
+                    r.synchronize()
+                    torch.cuda.synchronize()
+                    rows = np.ones(H, bool) if lay is None else np.isin(np.arange(H) // T, _capi.band_rows(*lay, rows_full=tiles_y))
+                    got[rows] = fb.cpu().numpy()[rows]
+                np.testing.assert_array_equal(got, ref, err_msg="depth %d, rop %s, %d band(s), %d in flight" % (depth_bits, rop, bands, fif))
+            assert r.two_pass_state()[0] == 0               # the draw-order compositor never runs in two passes
+            r.close()
+            combos += 1
+        plain.close()
+    assert combos == 20

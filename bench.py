@@ -811,7 +811,10 @@ def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf,
             from splatapult_amd import _capi as _cp
             TILE = _cp.lib().msplat_tile_size()
             tiles_y = rs_sets[0][0].shape[0] // TILE
-            cg = CAbiBandGather(rs, comm, tiles_y, W, rs_sets[0][0].dtype, rank, world, tile=TILE, layout=lay_kind, block_rows=lay_k)
+            wire16 = os.environ.get("MSPLAT_BENCH_WIRE_FP16") == "1" and wl["fb"] != "fp16"
+            cab["wire_fp16"] = wire16
+            cg = CAbiBandGather(rs, comm, tiles_y, W, rs_sets[0][0].dtype, rank, world, tile=TILE, layout=lay_kind, block_rows=lay_k,
+                                wire_fp16=wire16)
             cams = cams_for(poses[0])
             rs_sets[0][0].zero_()
             host_barrier()
@@ -825,6 +828,7 @@ def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf,
                 ref.Render(cams[0], projs[0], vp, nf, out_ptr=ref_fbs[0].data_ptr(), pitch_bytes=W * bpp)
                 torch.cuda.synchronize(dev)
                 cab["bit_exact"] = bool((rs_sets[0][0][:H].view(bits) == ref_fbs[0][:H].view(bits)).all().item())
+                cab["max_abs_diff"] = float((rs_sets[0][0][:H].float() - ref_fbs[0][:H].float()).abs().max().item())      # fp16 wire: <= 2^-11 |value|
             comm.close()
         except Exception as e:
             cab["error"] = "%s: %s" % (type(e).__name__, e)

@@ -184,9 +184,12 @@ int msplat_set_band_cull(msplat_ctx* ctx, int enable);
  * receive per run of foreign rows straight into its framebuffer, the owners send their runs from where the compositor left
  * them, all in ONE ncclGroupStart/End, on the context's stream.  `comm` = the caller's ncclComm_t (librccl is loaded at the
  * first call: no link-time dependency), `kind` / `block_rows` = the layout every rank set with msplat_band_plan.  `rgba` =
- * device memory of `height` rows of pitch_bytes (runs travel as whole pitch rows).  world == 1: nothing to do. */
+ * device memory of `height` rows of pitch_bytes (runs travel as whole pitch rows).  world == 1: nothing to do.
+ * flags: MSPLAT_EXCHANGE_WIRE_FP16 (RGBA32F targets only): rows cross the link as RGBA16F -- half the bytes; the gathered rows
+ * then differ from the owners' by one fp16 rounding, |d| <= 2^-11 |value| (values beyond 65504 become inf), root's own rows not. */
+enum { MSPLAT_EXCHANGE_WIRE_FP16 = 1 };
 int msplat_band_exchange(msplat_ctx* ctx, void* comm, int32_t rank, int32_t world, int32_t root, int32_t kind, int32_t block_rows,
-                         void* rgba, uint64_t pitch_bytes, int32_t width, int32_t height);
+                         void* rgba, uint64_t pitch_bytes, int32_t width, int32_t height, int32_t flags);
 
 /* ---- several GPUs, ONE process: the reference's shape, a single-threaded host calling Sort / Render (app.cpp:1067-1068).
  * One context per listed device, replicated cloud, bin rows partitioned (default MSPLAT_BANDS_CONTIGUOUS).  The only exchange

@@ -58,7 +58,7 @@ int msplat_get_composite_work(msplat_ctx* ctx, msplat_composite_work* out);
 /* ---- msplat_band_exchange on ONE rank (tests on a one-GPU box): the runs of bin rows that rank `rank` of `world` owns travel
  * from src to dst through ncclSend / ncclRecv to the calling rank itself (`comm` = a 1-rank communicator) ---- */
 int msplat_debug_band_exchange_loopback(msplat_ctx* ctx, void* comm, int32_t kind, int32_t block_rows, int32_t world, int32_t rank,
-                                        const void* src, void* dst, uint64_t pitch_bytes, int32_t width, int32_t height);
+                                        const void* src, void* dst, uint64_t pitch_bytes, int32_t width, int32_t height, int32_t flags);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@ FRAMES_AUTO, FRAMES_SERIAL, FRAMES_IN_FLIGHT = 0, 1, 2
 SPATIAL_AUTO, SPATIAL_ON, SPATIAL_OFF = 0, 1, 2
 TWO_PASS_AUTO, TWO_PASS_ON, TWO_PASS_OFF = 0, 1, 2          # msplat_config.two_pass
 BANDS_CONTIGUOUS, BANDS_INTERLEAVED, BANDS_BLOCK_INTERLEAVED = 0, 1, 2
+EXCHANGE_WIRE_FP16 = 1              # msplat_band_exchange flags
 BAND_KINDS = {"contiguous": BANDS_CONTIGUOUS, "interleaved": BANDS_INTERLEAVED, "block": BANDS_BLOCK_INTERLEAVED}
 
 
@@ -99,9 +100,9 @@ SYMBOLS = [
     ("msplat_group_synchronize", C.c_int, [C.c_void_p]),
     ("msplat_group_set_exchange", C.c_int, [C.c_void_p, C.c_int32]),
     ("msplat_group_get_exchange", C.c_int, [C.c_void_p]),
-    ("msplat_band_exchange", C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32]),
+    ("msplat_band_exchange", C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32]),
     ("msplat_debug_band_exchange_loopback", C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_uint64,
-                                                                                                C.c_int32, C.c_int32]),
+                                                                                                C.c_int32, C.c_int32, C.c_int32]),
     ("msplat_sort", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16]),
     ("msplat_render", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16, C.c_void_p, C.c_uint64, C.c_int]),
     ("msplat_render_stereo", C.c_int, [C.c_void_p, _F16, _F16, _F16, _F16, _F16, _F16, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),

@@ -152,6 +152,31 @@ int for_each_run(int32_t kind, int32_t block_rows, int32_t world, int32_t rank, 
     return MSPLAT_OK;
 }
 
+// ---- fp16 on the wire (MSPLAT_EXCHANGE_WIRE_FP16): the rows of an RGBA32F target travel as RGBA16F ---------------------------------
+// One thread per pixel of a run: float4 <-> four halves (round to nearest even).  `rows` pitch rows of `width` pixels; the packed side
+// is tight (width * 8 bytes per row).
+__global__ __launch_bounds__(256) void pack_rows_f16(const char* __restrict__ src, size_t pitch, int width, int rows, uint2* __restrict__ dst)
+{
+    const size_t n = (size_t)width * rows;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t y = i / (size_t)width, x = i - y * (size_t)width;
+        const float4 v = reinterpret_cast<const float4*>(src + y * pitch)[x];
+        union { _Float16 h[4]; uint2 u; } pk;
+        pk.h[0] = (_Float16)v.x; pk.h[1] = (_Float16)v.y; pk.h[2] = (_Float16)v.z; pk.h[3] = (_Float16)v.w;
+        dst[i] = pk.u;
+    }
+}
+__global__ __launch_bounds__(256) void unpack_rows_f16(const uint2* __restrict__ src, char* __restrict__ dst, size_t pitch, int width, int rows)
+{
+    const size_t n = (size_t)width * rows;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t y = i / (size_t)width, x = i - y * (size_t)width;
+        union { _Float16 h[4]; uint2 u; } pk;
+        pk.u = src[i];
+        reinterpret_cast<float4*>(dst + y * pitch)[x] = make_float4((float)pk.h[0], (float)pk.h[1], (float)pk.h[2], (float)pk.h[3]);
+    }
+}
+
 }  // namespace
 
 struct msplat_group {
@@ -552,7 +577,7 @@ int msplat_group_render(msplat_group* g, const float cameraMat[16], const float 
 
 // ---- the exchange for one process per GPU --------------------------------------------------------------------------------------
 static int band_exchange_impl(msplat_ctx* ctx, void* comm, int32_t rank, int32_t world, int32_t root, int32_t kind, int32_t block_rows,
-                              const void* src, void* dst, uint64_t pitch_bytes, int32_t width, int32_t height, bool loopback)
+                              const void* src, void* dst, uint64_t pitch_bytes, int32_t width, int32_t height, int32_t flags, bool loopback)
 {
     if (!ctx) return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_exchange: ctx is NULL");
     if (world < 1 || rank < 0 || rank >= world || root < 0 || root >= world)
@@ -560,9 +585,11 @@ static int band_exchange_impl(msplat_ctx* ctx, void* comm, int32_t rank, int32_t
     if (world == 1 && !loopback) return MSPLAT_OK;                     // the whole image is this rank's
     if (!comm || !src || !dst || width < 1 || height < 1)
         return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_exchange: NULL communicator / framebuffer or empty image");
-    // (8 = the smaller pixel, RGBA16F: the pitch must hold a row of either format)
-    if (pitch_bytes < (uint64_t)width * 8u) return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_exchange: pitch %llu too small for width %d",
-                                                         (unsigned long long)pitch_bytes, width);
+    const bool wire16 = (flags & MSPLAT_EXCHANGE_WIRE_FP16) != 0;
+    // (8 = the smaller pixel, RGBA16F: the pitch must hold a row of either format; fp16 on the wire is for RGBA32F targets)
+    if (pitch_bytes < (uint64_t)width * (wire16 ? 16u : 8u) || (wire16 && pitch_bytes % 16u != 0))
+        return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_exchange: pitch %llu too small / misaligned for width %d%s",
+                     (unsigned long long)pitch_bytes, width, wire16 ? " (MSPLAT_EXCHANGE_WIRE_FP16 needs an RGBA32F target)" : "");
     const Rccl& R = rccl();
     if (!R.ok()) return gfail(nullptr, MSPLAT_ERR_UNSUPPORTED, "msplat_band_exchange: %s", R.why.c_str());
     hipStream_t s = (hipStream_t)msplat_get_stream(ctx);
@@ -570,54 +597,82 @@ static int band_exchange_impl(msplat_ctx* ctx, void* comm, int32_t rank, int32_t
     // context's own stream is just that; it may also hand over a queued call's overflow warning, which is passed on at the end)
     const int wrc = msplat_stream_wait(ctx, s);
     if (wrc != MSPLAT_OK && wrc != MSPLAT_ERR_PAIR_OVERFLOW_EARLIER) return gfail(nullptr, wrc, "msplat_band_exchange: %s", msplat_last_error(ctx));
-    // a run travels as whole pitch rows (the framebuffer holds `height` rows of pitch_bytes; both sides count the same bytes)
-    auto bytes_of = [&](int, int nrows) { return (size_t)nrows * (size_t)pitch_bytes; };
-    int nrc = R.GroupStart();
-    if (nrc != 0) return gfail(nullptr, MSPLAT_ERR_HIP, "msplat_band_exchange: ncclGroupStart: %s", R.GetErrorString(nrc));
+
+    // the runs this call sends and the runs it receives: (peer, first pixel row, rows)
+    struct Run { int peer, y0, nrows; };
+    std::vector<Run> sends, recvs;
     int prc = MSPLAT_OK;
     if (loopback) {
         // (tests, one rank: this rank plays owner and root at once -- its runs travel from src to dst through ncclSend / ncclRecv to itself)
         prc = for_each_run(kind, block_rows, world, rank, height, [&](int y0, int nrows) -> int {
-            const size_t off = (size_t)y0 * pitch_bytes;
-            int e = R.Send((const char*)src + off, bytes_of(y0, nrows), kNcclUint8, 0, comm, s);
-            if (e == 0) e = R.Recv((char*)dst + off, bytes_of(y0, nrows), kNcclUint8, 0, comm, s);
-            if (e != 0) nrc = e;
-            return e != 0 ? MSPLAT_ERR_HIP : MSPLAT_OK;
-        });
+            sends.push_back(Run{0, y0, nrows}); recvs.push_back(Run{0, y0, nrows}); return MSPLAT_OK; });
     } else if (rank == root) {
-        for (int32_t r = 0; r < world && prc == MSPLAT_OK; ++r) {
-            if (r == root) continue;
-            prc = for_each_run(kind, block_rows, world, r, height, [&](int y0, int nrows) -> int {
-                const int e = R.Recv((char*)dst + (size_t)y0 * pitch_bytes, bytes_of(y0, nrows), kNcclUint8, r, comm, s);
-                if (e != 0) nrc = e;
-                return e != 0 ? MSPLAT_ERR_HIP : MSPLAT_OK;
-            });
-        }
+        for (int32_t r = 0; r < world && prc == MSPLAT_OK; ++r)
+            if (r != root) prc = for_each_run(kind, block_rows, world, r, height, [&](int y0, int nrows) -> int { recvs.push_back(Run{r, y0, nrows}); return MSPLAT_OK; });
     } else {
-        prc = for_each_run(kind, block_rows, world, rank, height, [&](int y0, int nrows) -> int {
-            const int e = R.Send((const char*)src + (size_t)y0 * pitch_bytes, bytes_of(y0, nrows), kNcclUint8, root, comm, s);
-            if (e != 0) nrc = e;
-            return e != 0 ? MSPLAT_ERR_HIP : MSPLAT_OK;
-        });
+        prc = for_each_run(kind, block_rows, world, rank, height, [&](int y0, int nrows) -> int { sends.push_back(Run{root, y0, nrows}); return MSPLAT_OK; });
     }
-    const int erc = R.GroupEnd();
-    if (nrc == 0) nrc = erc;
-    if (nrc != 0) return gfail(nullptr, MSPLAT_ERR_HIP, "msplat_band_exchange: RCCL: %s", R.GetErrorString(nrc));
     if (prc) return gfail(nullptr, prc, "msplat_band_exchange: %s", msplat_last_error(nullptr));
+
+    // fp16 on the wire: a run is packed into (and received into) stream-ordered scratch; half the bytes cross the link
+    char* scratch = nullptr;
+    std::vector<size_t> soff(sends.size()), roff(recvs.size());
+    if (wire16) {
+        size_t total = 0;
+        for (size_t i = 0; i < sends.size(); ++i) { soff[i] = total; total += (size_t)sends[i].nrows * width * 8; }
+        for (size_t i = 0; i < recvs.size(); ++i) { roff[i] = total; total += (size_t)recvs[i].nrows * width * 8; }
+        if (total != 0 && hipMallocAsync((void**)&scratch, total, s) != hipSuccess) {
+            (void)hipGetLastError();
+            return gfail(nullptr, MSPLAT_ERR_HIP, "msplat_band_exchange: no memory for %zu bytes of fp16 rows", total);
+        }
+        for (size_t i = 0; i < sends.size(); ++i) {
+            const size_t px = (size_t)sends[i].nrows * width;
+            hipLaunchKernelGGL(pack_rows_f16, dim3((unsigned)std::min<size_t>((px + 255) / 256, 4096)), dim3(256), 0, s,
+                               (const char*)src + (size_t)sends[i].y0 * pitch_bytes, (size_t)pitch_bytes, width, sends[i].nrows,
+                               (uint2*)(scratch + soff[i]));
+        }
+    }
+    // a run travels as whole pitch rows (the framebuffer holds `height` rows of pitch_bytes; both sides count the same bytes),
+    // or as tight fp16 rows
+    int nrc = R.GroupStart();
+    if (nrc == 0) {
+        for (size_t i = 0; i < sends.size() && nrc == 0; ++i)
+            nrc = wire16 ? R.Send(scratch + soff[i], (size_t)sends[i].nrows * width * 8, kNcclUint8, sends[i].peer, comm, s)
+                         : R.Send((const char*)src + (size_t)sends[i].y0 * pitch_bytes, (size_t)sends[i].nrows * pitch_bytes, kNcclUint8,
+                                  sends[i].peer, comm, s);
+        for (size_t i = 0; i < recvs.size() && nrc == 0; ++i)
+            nrc = wire16 ? R.Recv(scratch + roff[i], (size_t)recvs[i].nrows * width * 8, kNcclUint8, recvs[i].peer, comm, s)
+                         : R.Recv((char*)dst + (size_t)recvs[i].y0 * pitch_bytes, (size_t)recvs[i].nrows * pitch_bytes, kNcclUint8,
+                                  recvs[i].peer, comm, s);
+        const int erc = R.GroupEnd();
+        if (nrc == 0) nrc = erc;
+    }
+    if (wire16) {
+        if (nrc == 0)
+            for (size_t i = 0; i < recvs.size(); ++i) {
+                const size_t px = (size_t)recvs[i].nrows * width;
+                hipLaunchKernelGGL(unpack_rows_f16, dim3((unsigned)std::min<size_t>((px + 255) / 256, 4096)), dim3(256), 0, s,
+                                   (const uint2*)(scratch + roff[i]), (char*)dst + (size_t)recvs[i].y0 * pitch_bytes, (size_t)pitch_bytes,
+                                   width, recvs[i].nrows);
+            }
+        if (scratch) (void)hipFreeAsync(scratch, s);
+        if (hipGetLastError() != hipSuccess) return gfail(nullptr, MSPLAT_ERR_HIP, "msplat_band_exchange: a pack / unpack launch failed");
+    }
+    if (nrc != 0) return gfail(nullptr, MSPLAT_ERR_HIP, "msplat_band_exchange: RCCL: %s", R.GetErrorString(nrc));
     if (wrc != MSPLAT_OK) return gfail(nullptr, wrc, "%s", msplat_last_error(ctx));
     return MSPLAT_OK;
 }
 
 int msplat_band_exchange(msplat_ctx* ctx, void* comm, int32_t rank, int32_t world, int32_t root, int32_t kind, int32_t block_rows,
-                         void* rgba, uint64_t pitch_bytes, int32_t width, int32_t height)
+                         void* rgba, uint64_t pitch_bytes, int32_t width, int32_t height, int32_t flags)
 {
-    return band_exchange_impl(ctx, comm, rank, world, root, kind, block_rows, rgba, rgba, pitch_bytes, width, height, false);
+    return band_exchange_impl(ctx, comm, rank, world, root, kind, block_rows, rgba, rgba, pitch_bytes, width, height, flags, false);
 }
 
 int msplat_debug_band_exchange_loopback(msplat_ctx* ctx, void* comm, int32_t kind, int32_t block_rows, int32_t world, int32_t rank,
-                                        const void* src, void* dst, uint64_t pitch_bytes, int32_t width, int32_t height)
+                                        const void* src, void* dst, uint64_t pitch_bytes, int32_t width, int32_t height, int32_t flags)
 {
-    return band_exchange_impl(ctx, comm, rank, world, 0, kind, block_rows, src, dst, pitch_bytes, width, height, true);
+    return band_exchange_impl(ctx, comm, rank, world, 0, kind, block_rows, src, dst, pitch_bytes, width, height, flags, true);
 }
 
 int msplat_group_synchronize(msplat_group* g)

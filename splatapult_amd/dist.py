@@ -158,13 +158,15 @@ class CAbiBandGather:
     """BandGather's job through msplat_band_exchange: one ncclGroupStart/End of ncclSend / ncclRecv issued by libmsplat on the
     renderer's stream.  Same plan (runs of consecutive bin rows, straight into rank dst's framebuffer)."""
 
-    def __init__(self, renderer, comm, tiles_y, width, dtype, rank, world, dst=0, tile=32, layout="interleaved", block_rows=1):
+    def __init__(self, renderer, comm, tiles_y, width, dtype, rank, world, dst=0, tile=32, layout="interleaved", block_rows=1,
+                 wire_fp16=False):
         self.r, self.comm, self.rank, self.world, self.dst = renderer, comm, rank, world, dst
         self.kind, self.block_rows = _KIND[layout], int(block_rows)
         self.W, self.H = width, tiles_y * tile
         self.pitch = width * (8 if str(dtype).endswith("float16") else 16)
+        self.wire_fp16 = bool(wire_fp16) and not str(dtype).endswith("float16")       # fp32 targets: RGBA16F on the wire
 
     def __call__(self, fb):
         self.r.band_exchange(self.comm.handle, self.rank, self.world, self.dst, self.kind, self.block_rows, fb.data_ptr(),
-                             self.pitch, self.W, self.H)
+                             self.pitch, self.W, self.H, wire_fp16=self.wire_fp16)
         return fb if self.rank == self.dst else None

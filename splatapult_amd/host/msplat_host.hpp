@@ -88,11 +88,11 @@ public:
             }
         return true;
     }
-    bool ExchangeBands(void* comm, int root, int width, int height)
+    bool ExchangeBands(void* comm, int root, int width, int height, int flags = 0)        // flags: MSPLAT_EXCHANGE_WIRE_FP16
     {
         if (!ctx || !targetIsDevice || !target) return false;
         const uint64_t pitch = targetPitch ? targetPitch : (uint64_t)width * (cfg.fb_format == MSPLAT_FB_RGBA16F ? 8u : 16u);
-        const int rc = msplat_band_exchange(ctx, comm, bandRank, bandWorld, root, bandKindSet, bandBlockRows, target, pitch, width, height);
+        const int rc = msplat_band_exchange(ctx, comm, bandRank, bandWorld, root, bandKindSet, bandBlockRows, target, pitch, width, height, flags);
         if (rc != MSPLAT_OK) std::fprintf(stderr, "[msplat][E] ExchangeBands: %s\n", msplat_group_last_error(nullptr));
         return rc == MSPLAT_OK;
     }

@@ -256,16 +256,19 @@ class SplatRenderer:
         default stream) waits for the frame issued last"""
         _capi.check(self._ctx, self._lib.msplat_stream_wait(self._ctx, C.c_void_p(stream or 0)))
 
-    def band_exchange(self, comm, rank, world, root, kind, block_rows, fb_ptr, pitch_bytes, width, height, loopback_src=None):
+    def band_exchange(self, comm, rank, world, root, kind, block_rows, fb_ptr, pitch_bytes, width, height, loopback_src=None,
+                      wire_fp16=False):
         """msplat_band_exchange on the current context's stream (comm = ncclComm_t handle, e.g. dist.RcclComm().handle): rank
         `root` receives every other rank's runs of bin rows straight into its framebuffer, the owners send theirs.
-        loopback_src: one-rank test form (msplat_debug_band_exchange_loopback): this rank's runs travel from loopback_src to fb_ptr"""
+        loopback_src: one-rank test form (msplat_debug_band_exchange_loopback): this rank's runs travel from loopback_src to fb_ptr;
+        wire_fp16 (RGBA32F targets): the rows cross the link as RGBA16F (MSPLAT_EXCHANGE_WIRE_FP16)"""
+        flags = _capi.EXCHANGE_WIRE_FP16 if wire_fp16 else 0
         if loopback_src is not None:
             rc = self._lib.msplat_debug_band_exchange_loopback(self._ctx, comm, kind, block_rows, world, rank, C.c_void_p(loopback_src),
-                                                               C.c_void_p(fb_ptr), pitch_bytes, width, height)
+                                                               C.c_void_p(fb_ptr), pitch_bytes, width, height, flags)
         else:
             rc = self._lib.msplat_band_exchange(self._ctx, comm, rank, world, root, kind, block_rows, C.c_void_p(fb_ptr), pitch_bytes,
-                                                width, height)
+                                                width, height, flags)
         if rc != _capi.OK:
             raise _capi.MsplatError(rc, self._lib.msplat_group_last_error(None).decode())
 

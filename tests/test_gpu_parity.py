@@ -1516,6 +1516,25 @@ def test_band_exchange_through_rccl_on_one_rank_and_the_group_switch():
                 rows = np.isin(np.arange(Hpad) // T, owned_rows(name, tiles_y, 8, g, k))
                 want[torch.from_numpy(rows).to(dev)] = src[torch.from_numpy(rows).to(dev)]
                 assert torch.equal(dst, want), (name, g, W, H)
+    # fp16 on the wire (MSPLAT_EXCHANGE_WIRE_FP16, fp32 targets): the rows arrive rounded once to fp16 -- |d| <= 2^-11 |value| --
+    # packed and unpacked by the library around the same ncclSend / ncclRecv; an fp16-sized pitch is refused
+    W, H = 640, 360
+    tiles_y = (H + T - 1) // T
+    Hpad = tiles_y * T
+    src = torch.randn((Hpad, W, 4), dtype=torch.float32, device=dev) * 3.0
+    for kind, name, k in ((_capi.BANDS_CONTIGUOUS, "contiguous", 1), (_capi.BANDS_BLOCK_INTERLEAVED, "block", 2)):
+        for g in (0, 5):
+            dst = torch.zeros_like(src)
+            r.band_exchange(comm.handle, g, 8, 0, kind, k, dst.data_ptr(), W * 16, W, Hpad, loopback_src=src.data_ptr(), wire_fp16=True)
+            r.synchronize()
+            torch.cuda.synchronize()
+            rows = torch.from_numpy(np.isin(np.arange(Hpad) // T, owned_rows(name, tiles_y, 8, g, k))).to(dev)
+            want = torch.zeros_like(src)
+            want[rows] = src[rows].half().float()
+            assert torch.equal(dst, want), (name, g)
+            assert float((dst[rows] - src[rows]).abs().max()) <= 2.0 ** -11 * float(src.abs().max())
+    with pytest.raises(MsplatError):
+        r.band_exchange(comm.handle, 0, 8, 0, _capi.BANDS_CONTIGUOUS, 1, dst.data_ptr(), W * 8, W, Hpad, loopback_src=src.data_ptr(), wire_fp16=True)
     # ordering behind a frame whose launches a worker thread issues (async_submit): the exchange waits for them to be ISSUED
     cloud_a = scenes.synth_cloud(30000, 91, log_scale_mean=-3.0)
     Wa, Ha = 640, 352

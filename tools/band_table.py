@@ -195,6 +195,8 @@ def main_fif(args):
                 "ranks": ranks, "max_rank_block_ms": slow["block_ms"], "predicted_frames_per_sec": fps,
                 "predicted_frames_per_sec_with_modelled_gather": fps_g, "modelled_gather_ms_per_frame": gather_ms,
                 "speedup_vs_single_gpu": fps_g / whole["frames_per_sec"], "scaling_efficiency": fps_g / whole["frames_per_sec"] / G,
+                # r5: the same with the rows of an fp32 target on the wire as fp16 (msplat_band_exchange, MSPLAT_EXCHANGE_WIRE_FP16)
+                "predicted_frames_per_sec_with_fp16_wire": (min(fps, 2e3 / gather_ms) if (gather_ms > 0 and bpp == 16) else fps_g),
                 "max_V_frac": max(x["V"] for x in ranks) / max(1, whole["V"])}
             L = out["worlds"][str(G)][lay]
             print("G = %d  %-12s slowest rank %.0f frames/s (ranks %s)  gather %.3f ms  -> %.0f frames/s = x%.2f (efficiency %.2f)" % (

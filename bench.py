@@ -71,6 +71,9 @@ WORKLOADS = {
     "cfg3s": dict(n=6_000_000, seed=0x5CE11E, scene=True, W=1920, H=1080, cam_z=0.0, fb="fp32", views=1,
                   desc="6M scene-like synthetic splats (surfaces, log-scale sigma 1.2, 1% background, camera inside), SH3, "
                        "1920x1080 fp32, PLY + cameras.json replay (BASELINE configs[2] stand-in)"),
+    # experiment (r6): BASELINE configs[1] drawn as two views of one Sort -- what a chain shared by two frames' renders buys
+    "cfg2v2": dict(n=1_000_000, seed=0x5EED1234, pos_sigma=1.5, W=1920, H=1080, cam_z=7.0, fb="fp32", views=2,
+                   desc="1M synthetic Gaussians, SH3, two 1920x1080 fp32 views of one sort (experiment)"),
     "tiny": dict(n=20_000, seed=7, pos_sigma=1.5, W=640, H=360, cam_z=7.0, fb="fp32", views=1,
                  desc="20k synthetic Gaussians, 640x360 (debug)"),
     "tinys": dict(n=60_000, seed=0x5CE11E, scene=True, W=640, H=360, cam_z=0.0, fb="fp32", views=1,
@@ -164,6 +167,8 @@ def measure(E, args, key, ply=None, primary=True):
     vp, nf = [0, 0, W, H], [camera.Z_NEAR, camera.Z_FAR]
     if views == 1:
         projs = [camera.perspective(camera.FOVY, W / H)]
+    elif key == "cfg2v2":
+        projs = [camera.perspective(camera.FOVY, W / H)] * 2
     else:   # BASELINE config 5: asymmetric XR frusta (util.cpp:420-480)
         projs = [camera.create_projection(-1.0, 0.8, 0.95, -0.95), camera.create_projection(-0.8, 1.0, 0.95, -0.95)]
 

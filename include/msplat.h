@@ -43,7 +43,7 @@ enum { MSPLAT_TWO_PASS_AUTO = 0, MSPLAT_TWO_PASS_ON = 1, MSPLAT_TWO_PASS_OFF = 2
 enum { MSPLAT_SPATIAL_AUTO = 0, MSPLAT_SPATIAL_ON = 1, MSPLAT_SPATIAL_OFF = 2 };     /* msplat_config.spatial_order */
 enum { MSPLAT_FRAMES_AUTO = 0, MSPLAT_FRAMES_SERIAL = 1, MSPLAT_FRAMES_IN_FLIGHT = 2 }; /* msplat_config.frame_mode */
 enum { MSPLAT_RANK_AUTO = 0, MSPLAT_RANK_BALLOT = 1 };                               /* msplat_config.rank_mode */
-enum { MSPLAT_BANDS_CONTIGUOUS = 0, MSPLAT_BANDS_INTERLEAVED = 1, MSPLAT_BANDS_BLOCK_INTERLEAVED = 2 };
+enum { MSPLAT_BANDS_CONTIGUOUS = 0, MSPLAT_BANDS_INTERLEAVED = 1, MSPLAT_BANDS_BLOCK_INTERLEAVED = 2, MSPLAT_BANDS_ROOT_WEIGHTED = 3 };
 
 typedef struct msplat_ctx msplat_ctx;
 typedef struct msplat_cloud msplat_cloud;
@@ -167,6 +167,7 @@ int msplat_attach_cloud(msplat_ctx* ctx, msplat_ctx* owner);        /* `ctx` ren
 int msplat_stream_wait(msplat_ctx* ctx, void* stream);              /* `stream` (hipStream_t) waits for the context's work so far */
 int msplat_wait_event(msplat_ctx* ctx, void* event);                /* the context's stream waits for `event` (hipEvent_t) */
 void* msplat_get_stream(msplat_ctx* ctx);                           /* the hipStream_t the context launches on */
+int msplat_get_fb_format(const msplat_ctx* ctx);                    /* MSPLAT_FB_* the context was created with (-1: NULL) */
 
 /* ---- rows of the screen on several GPUs (no reference counterpart).  The context owns blocks of `block`
  * consecutive bin rows (msplat_tile_size() pixels; row 0 = GL bottom) starting at first_row, first_row + stride, ..., at most
@@ -177,6 +178,13 @@ int msplat_set_band_layout(msplat_ctx* ctx, int32_t first_row, int32_t row_count
 /* the standard layouts (MSPLAT_BANDS_*) for rank `rank` of `world` over rows_full bin rows; host arithmetic only */
 int msplat_band_plan(int32_t kind, int32_t rows_full, int32_t world, int32_t rank, int32_t block_rows, int32_t* first_row,
                      int32_t* row_count, int32_t* block, int32_t* stride);
+/* MSPLAT_BANDS_ROOT_WEIGHTED (r6): contiguous bands, rank 0 -- the gather's root, which sends nothing -- weighted `block_rows`
+ * PERCENT of another rank (100 = equal bands).  msplat_band_root_weight picks the percentage from a linear cost model (a rank
+ * with r rows computes fixed_ms + ms_per_row r; every other rank also moves r row_bytes over its own link, overlapped with the next
+ * frame's compute or not); msplat_band_plan_weighted is the general form: rows proportional to weights[], bounds_out[world + 1]. */
+int msplat_band_plan_weighted(int32_t rows_full, int32_t world, const float* weights, int32_t* bounds_out);
+int msplat_band_root_weight(int32_t rows_full, int32_t world, double fixed_ms, double ms_per_row, double row_bytes, double link_gbps,
+                            int overlap);
 /* msplat_sort also drops splats whose footprint bound cannot reach an owned row (mono rendering: every render then uses
  * its sort's camera; msplat_sort_count and the sorted list describe the band only) */
 int msplat_set_band_cull(msplat_ctx* ctx, int enable);
@@ -184,7 +192,8 @@ int msplat_set_band_cull(msplat_ctx* ctx, int enable);
  * receive per run of foreign rows straight into its framebuffer, the owners send their runs from where the compositor left
  * them, all in ONE ncclGroupStart/End, on the context's stream.  `comm` = the caller's ncclComm_t (librccl is loaded at the
  * first call: no link-time dependency), `kind` / `block_rows` = the layout every rank set with msplat_band_plan.  `rgba` =
- * device memory of `height` rows of pitch_bytes (runs travel as whole pitch rows).  world == 1: nothing to do.
+ * device memory of `height` rows of pitch_bytes, pixels of the context's fb_format (a run is ONE message when the rows are
+ * tight, pitch == width x pixel size; else it travels row by row in the same group: a window of a wider surface keeps its neighbours).  world == 1: nothing to do.
  * flags: MSPLAT_EXCHANGE_WIRE_FP16 (RGBA32F targets only): rows cross the link as RGBA16F -- half the bytes; the gathered rows
  * then differ from the owners' by one fp16 rounding, |d| <= 2^-11 |value| (values beyond 65504 become inf), root's own rows not. */
 enum { MSPLAT_EXCHANGE_WIRE_FP16 = 1 };

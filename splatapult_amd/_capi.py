@@ -17,9 +17,11 @@ RANK_AUTO, RANK_BALLOT = 0, 1
 FRAMES_AUTO, FRAMES_SERIAL, FRAMES_IN_FLIGHT = 0, 1, 2
 SPATIAL_AUTO, SPATIAL_ON, SPATIAL_OFF = 0, 1, 2
 TWO_PASS_AUTO, TWO_PASS_ON, TWO_PASS_OFF = 0, 1, 2          # msplat_config.two_pass
-BANDS_CONTIGUOUS, BANDS_INTERLEAVED, BANDS_BLOCK_INTERLEAVED = 0, 1, 2
+BANDS_CONTIGUOUS, BANDS_INTERLEAVED, BANDS_BLOCK_INTERLEAVED, BANDS_ROOT_WEIGHTED = 0, 1, 2, 3
 EXCHANGE_WIRE_FP16 = 1              # msplat_band_exchange flags
-BAND_KINDS = {"contiguous": BANDS_CONTIGUOUS, "interleaved": BANDS_INTERLEAVED, "block": BANDS_BLOCK_INTERLEAVED}
+# "weighted": contiguous bands, rank 0 (the gather's root) weighted block_rows PERCENT of another rank (msplat.h)
+BAND_KINDS = {"contiguous": BANDS_CONTIGUOUS, "interleaved": BANDS_INTERLEAVED, "block": BANDS_BLOCK_INTERLEAVED,
+              "weighted": BANDS_ROOT_WEIGHTED}
 
 
 class MsplatError(RuntimeError):
@@ -83,7 +85,10 @@ SYMBOLS = [
     ("msplat_set_band_cull", C.c_int, [C.c_void_p, C.c_int]),
     ("msplat_set_band_layout", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     ("msplat_band_plan", C.c_int, [C.c_int32] * 5 + [C.POINTER(C.c_int32)] * 4),
+    ("msplat_band_plan_weighted", C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    ("msplat_band_root_weight", C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]),
     ("msplat_get_stream", C.c_void_p, [C.c_void_p]),
+    ("msplat_get_fb_format", C.c_int, [C.c_void_p]),
     ("msplat_group_create", C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(Config)]),
     ("msplat_group_destroy", None, [C.c_void_p]),
     ("msplat_group_last_error", C.c_char_p, [C.c_void_p]),
@@ -209,6 +214,20 @@ def band_plan(kind, rows_full, world, rank, block_rows=1):
                                 *[C.byref(o) for o in out])
     check(None, rc)
     return tuple(o.value for o in out)
+
+
+def band_plan_weighted(rows_full, weights):
+    """bounds[world + 1] of contiguous bands with row counts proportional to `weights` (msplat_band_plan_weighted)"""
+    w = (C.c_float * len(weights))(*[float(x) for x in weights])
+    out = (C.c_int32 * (len(weights) + 1))()
+    check(None, lib().msplat_band_plan_weighted(rows_full, len(weights), w, out))
+    return list(out)
+
+
+def band_root_weight(rows_full, world, fixed_ms, ms_per_row, row_bytes, link_gbps=153.0, overlap=True):
+    """root weight (percent) for the "weighted" layout from the linear cost model of msplat_band_root_weight"""
+    return int(lib().msplat_band_root_weight(rows_full, world, float(fixed_ms), float(ms_per_row), float(row_bytes), float(link_gbps),
+                                             1 if overlap else 0))
 
 
 def band_rows(first, count, block, stride, rows_full=None):

@@ -648,6 +648,8 @@ int msplat_attach_cloud(msplat_ctx* ctx, msplat_ctx* owner)
 
 void* msplat_get_stream(msplat_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+int msplat_get_fb_format(const msplat_ctx* ctx) { return ctx ? ctx->cfg.fb_format : -1; }
+
 // Makes `stream` (a hipStream_t, NULL = the legacy default stream) wait for everything enqueued so far on
 // the context's stream, without blocking the host.
 int msplat_stream_wait(msplat_ctx* ctx, void* stream)
@@ -1216,6 +1218,71 @@ int msplat_set_band(msplat_ctx* ctx, int32_t row_mod, int32_t row_rem)
     return msplat_set_band_layout(ctx, row_rem, 0, 1, row_mod);       // rows t with t % row_mod == row_rem
 }
 
+// Contiguous bands whose row counts are proportional to weights[rank] (r6).  Why: rank 0 is the root of the row gather and sends
+// nothing, every other rank's band has to cross its xGMI link -- with equal bands a 2-GPU frame of BASELINE
+// configs[3] is bound by the one link (0.88 ms for 134 MB) and slower than one GPU.  Largest-remainder rounding; while rows last
+// every rank with a positive weight owns at least one.  bounds_out[i] .. bounds_out[i + 1] = the bin rows of rank i.
+int msplat_band_plan_weighted(int32_t rows_full, int32_t world, const float* weights, int32_t* bounds_out)
+{
+    if (!weights || !bounds_out || rows_full < 0 || world < 1)
+        return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_plan_weighted: need weights, bounds_out, rows_full >= 0, world >= 1");
+    double sum = 0.0;
+    for (int i = 0; i < world; ++i) {
+        if (!(weights[i] >= 0.0f) || !std::isfinite(weights[i]))
+            return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_plan_weighted: weight %d is negative or not finite", i);
+        sum += weights[i];
+    }
+    if (!(sum > 0.0)) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_plan_weighted: all weights are zero");
+    std::vector<int32_t> rows((size_t)world, 0);
+    std::vector<double> frac((size_t)world, 0.0);
+    int64_t given = 0;
+    for (int i = 0; i < world; ++i) {
+        const double x = (double)rows_full * weights[i] / sum;
+        rows[(size_t)i] = (int32_t)std::floor(x);
+        frac[(size_t)i] = x - std::floor(x);
+        given += rows[(size_t)i];
+    }
+    for (int64_t left = rows_full - given; left > 0; --left) {        // the largest remainders get the rows the floors left over
+        int best = 0;
+        for (int i = 1; i < world; ++i)
+            if (frac[(size_t)i] > frac[(size_t)best]) best = i;
+        rows[(size_t)best]++;
+        frac[(size_t)best] = -1.0;
+    }
+    for (int i = 0; i < world; ++i) {          // nobody with a positive weight stays empty while a larger band can spare a row
+        if (rows[(size_t)i] != 0 || !(weights[i] > 0.0f)) continue;
+        int big = 0;
+        for (int j = 1; j < world; ++j)
+            if (rows[(size_t)j] > rows[(size_t)big]) big = j;
+        if (rows[(size_t)big] >= 2) { rows[(size_t)big]--; rows[(size_t)i] = 1; }
+    }
+    bounds_out[0] = 0;
+    for (int i = 0; i < world; ++i) bounds_out[i + 1] = bounds_out[i] + rows[(size_t)i];
+    return MSPLAT_OK;
+}
+
+// Root weight (percent, >= 1) for MSPLAT_BANDS_ROOT_WEIGHTED from a linear cost model: a rank that owns r bin rows computes for
+// fixed_ms + ms_per_row * r; a rank other than the root also moves r * row_bytes over its own link of link_gbps GB/s -- at the
+// same time as it computes the next frame (overlap != 0: its cost is the larger of the two) or after it (their sum).  Returns
+// the percentage that minimises the slowest rank (searched over the row counts; host arithmetic).
+int msplat_band_root_weight(int32_t rows_full, int32_t world, double fixed_ms, double ms_per_row, double row_bytes, double link_gbps,
+                            int overlap)
+{
+    if (world < 2 || rows_full < world || !(ms_per_row >= 0.0) || !(link_gbps > 0.0)) return 100;
+    const double link_ms_per_row = row_bytes / (link_gbps * 1e6);
+    double best_t = 1e300;
+    int best_r = rows_full / world;
+    for (int r = 1; r * (world - 1) < rows_full; ++r) {             // r rows for every other rank, the rest for the root
+        const int root_rows = rows_full - r * (world - 1);
+        const double comp = fixed_ms + ms_per_row * r, link = link_ms_per_row * r;
+        const double other = overlap ? std::max(comp, link) : comp + link;
+        const double t = std::max(other, fixed_ms + ms_per_row * root_rows);
+        if (t < best_t) { best_t = t; best_r = r; }
+    }
+    const int root_rows = rows_full - best_r * (world - 1);
+    return std::max(1, (int)std::lround(100.0 * (double)root_rows / (double)best_r));
+}
+
 // The standard partitions of `rows_full` bin rows over `world` ranks: pure arithmetic, no context needed.
 int msplat_band_plan(int32_t kind, int32_t rows_full, int32_t world, int32_t rank, int32_t block_rows, int32_t* first_row,
                      int32_t* row_count, int32_t* block, int32_t* stride)
@@ -1228,8 +1295,19 @@ int msplat_band_plan(int32_t kind, int32_t rows_full, int32_t world, int32_t ran
         const int d = R - first, k = d / str, j = d - k * str;
         return k * blk + std::min(j, blk);
     };
-    if (kind == MSPLAT_BANDS_CONTIGUOUS) {
-        const int a = (int)(((int64_t)rows_full * rank) / world), b = (int)(((int64_t)rows_full * (rank + 1)) / world);
+    if (kind == MSPLAT_BANDS_CONTIGUOUS || kind == MSPLAT_BANDS_ROOT_WEIGHTED) {
+        int a = (int)(((int64_t)rows_full * rank) / world), b = (int)(((int64_t)rows_full * (rank + 1)) / world);
+        if (kind == MSPLAT_BANDS_ROOT_WEIGHTED) {
+            // contiguous bands, rank 0 -- the root of the row gather, which sends nothing -- weighted block_rows percent of another rank
+            if (block_rows < 1 || world > 4096)
+                return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_plan: root weight (block_rows, percent) must be >= 1");
+            std::vector<float> w((size_t)world, 100.0f);        // (whole numbers: the Python restatement arrives at the same floats)
+            std::vector<int32_t> bounds((size_t)world + 1);
+            w[0] = (float)block_rows;
+            const int rc = msplat_band_plan_weighted(rows_full, world, w.data(), bounds.data());
+            if (rc) return rc;
+            a = bounds[(size_t)rank]; b = bounds[(size_t)rank + 1];
+        }
         // (row_count == 0 means "no limit" to msplat_set_band_layout: an empty band starts past the last row instead)
         *first_row = b > a ? a : rows_full; *row_count = b - a; *block = std::max(1, b - a);
         *stride = std::max(1, std::max(rows_full, b - a));
@@ -2029,18 +2107,22 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
     RenderChain rc{ctx, fp, s, stereo, N, counters + 0, counters + 1, counters + 2, (uint32_t*)ctx->queue.p,
                    stereo ? counters + 9 : counters + 0, (uint32_t*)ctx->occ.p, fp.tiles_x * fp.tiles_y, (uint32_t)ctx->pair_cap,
                    false, 0, (int)std::max(1u, div_up(N, kProjThreads)), d_out, d_out1, pitch, async_overflow_flag};
-    const bool timed = rc.timed = ctx->ev_ok && (ctx->render_calls++ % ctx->timing_stride) == 0;
-    const int tset = rc.tset = (int)(ctx->render_sets % msplat_ctx::kEvSets);
-    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][2], s));
     // Two-pass frame with occlusion feedback (msplat_occlusion.hip.h): the nearest R1 splats first, then only what the bins
-    // they did not saturate still need.  Same pixels; chosen once per Render (occlusion_plan).
+    // they did not saturate still need.  Same pixels; chosen once per Render (occlusion_plan).  The retries of a host-output
+    // frame whose pair buffer overflowed reuse the plan AND count as the same Render: the sampling counter, the two-pass
+    // statistics and the feedback's frame number advance once.
     RenderPlan local_plan;
     if (!plan) plan = &local_plan;
-    if (!plan->decided) {
+    const bool first_attempt = !plan->decided;
+    if (first_attempt) {
         plan->two_pass = occlusion_plan(ctx, fp, stereo, plan->frac);
         plan->decided = true;
+        ctx->render_calls++;
     }
     const bool two_pass = plan->two_pass;
+    const bool timed = rc.timed = ctx->ev_ok && ((ctx->render_calls - 1) % ctx->timing_stride) == 0;
+    const int tset = rc.tset = (int)(ctx->render_sets % msplat_ctx::kEvSets);
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][2], s));
     rc.occ = (uint32_t*)ctx->occ.p;              // (allocated by occlusion_plan with a context's first two-pass frame)
 
     // ---- the plain chain (also: both eyes in one chain, points, the emulations), or pass 1 of a two-pass frame ----
@@ -2062,7 +2144,7 @@ static int launch_render(msplat_ctx* ctx, const FrameParams& fp, void* d_out, si
         crc = issue_compositor(rc, 2, 11, 12);
         if (crc) return crc;
         ctx->comp_kernel_timed = ctx->comp_kernel_timed && timed1;
-        ctx->frames_two_pass++;
+        if (first_attempt) ctx->frames_two_pass++;
     }
     ctx->last_render_two_pass = two_pass;
     if (timed) {

@@ -107,13 +107,20 @@ const Rccl& rccl()
         if (const char* e = getenv("MSPLAT_RCCL_LIB")) names.push_back(e);
         void* h = nullptr;
         // the copy the process already uses (its communicators belong to THAT copy), then the system's
-        for (const char* n : {"librccl.so.1", "librccl.so"})
-            if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        // (MSPLAT_RCCL_LIB, when set, is the only candidate: a wrong path is reported, not papered over)
+        if (names.empty())
+            for (const char* n : {"librccl.so.1", "librccl.so"})
+                if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
         for (const std::string& n : names)
             if (!h) h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
-        for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (!h) { x.why = std::string("librccl not found (") + (dlerror() ? dlerror() : "?") + "); set MSPLAT_RCCL_LIB"; return x; }
+        if (names.empty())
+            for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            const char* de = dlerror();          // (ONE call: dlerror() clears the error it returns -- ADVICE r5)
+            x.why = std::string("librccl not found (") + (de ? de : "?") + "); set MSPLAT_RCCL_LIB";
+            return x;
+        }
         bool all = true;
         auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) { all = false; x.why = std::string("librccl lacks ") + n; } return p; };
         x.GroupStart = (int (*)())sym("ncclGroupStart");
@@ -346,7 +353,15 @@ int msplat_group_create(msplat_group** out, const int32_t* devices, uint32_t n, 
     }
     if (const char* e = getenv("MSPLAT_GROUP_EXCHANGE")) {
         const std::string x = e;
-        const int want = x == "rccl" ? MSPLAT_EXCHANGE_RCCL : (x == "copy" ? MSPLAT_EXCHANGE_COPY : MSPLAT_EXCHANGE_PEER_STORE);
+        int want = -1;
+        if (x == "rccl") want = MSPLAT_EXCHANGE_RCCL;
+        else if (x == "copy") want = MSPLAT_EXCHANGE_COPY;
+        else if (x == "peer" || x == "peer_store") want = MSPLAT_EXCHANGE_PEER_STORE;
+        if (want < 0) {                 // a typo ("nccl") must not silently select the default
+            gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_group_create: MSPLAT_GROUP_EXCHANGE=%s: expected peer | peer_store | rccl | copy", e);
+            msplat_group_destroy(g);
+            return MSPLAT_ERR_INVALID_ARG;
+        }
         const int rc = msplat_group_set_exchange(g, want);
         if (rc) {                       // asked for in the environment and not available: say so instead of silently doing something else
             gfail(nullptr, rc, "msplat_group_create: MSPLAT_GROUP_EXCHANGE=%s: %s", e, g->err.c_str());
@@ -436,10 +451,11 @@ int msplat_group_upload_ply(msplat_group* g, const char* path, int import_full_s
 int msplat_group_set_layout(msplat_group* g, int32_t kind, int32_t block_rows)
 {
     if (!g) return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "group is NULL");
-    if (kind != MSPLAT_BANDS_CONTIGUOUS && kind != MSPLAT_BANDS_INTERLEAVED && kind != MSPLAT_BANDS_BLOCK_INTERLEAVED)
+    if (kind != MSPLAT_BANDS_CONTIGUOUS && kind != MSPLAT_BANDS_INTERLEAVED && kind != MSPLAT_BANDS_BLOCK_INTERLEAVED &&
+        kind != MSPLAT_BANDS_ROOT_WEIGHTED)
         return gfail(g, MSPLAT_ERR_INVALID_ARG, "msplat_group_set_layout: unknown kind %d", kind);
-    if (kind == MSPLAT_BANDS_BLOCK_INTERLEAVED && block_rows < 1)
-        return gfail(g, MSPLAT_ERR_INVALID_ARG, "msplat_group_set_layout: block_rows must be >= 1");
+    if ((kind == MSPLAT_BANDS_BLOCK_INTERLEAVED || kind == MSPLAT_BANDS_ROOT_WEIGHTED) && block_rows < 1)
+        return gfail(g, MSPLAT_ERR_INVALID_ARG, "msplat_group_set_layout: block_rows (rows per block / root weight in percent) must be >= 1");
     g->kind = kind;
     g->block_rows = std::max(1, block_rows);
     g->planned_rows = -1;
@@ -586,10 +602,14 @@ static int band_exchange_impl(msplat_ctx* ctx, void* comm, int32_t rank, int32_t
     if (!comm || !src || !dst || width < 1 || height < 1)
         return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_exchange: NULL communicator / framebuffer or empty image");
     const bool wire16 = (flags & MSPLAT_EXCHANGE_WIRE_FP16) != 0;
-    // (8 = the smaller pixel, RGBA16F: the pitch must hold a row of either format; fp16 on the wire is for RGBA32F targets)
-    if (pitch_bytes < (uint64_t)width * (wire16 ? 16u : 8u) || (wire16 && pitch_bytes % 16u != 0))
-        return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_exchange: pitch %llu too small / misaligned for width %d%s",
-                     (unsigned long long)pitch_bytes, width, wire16 ? " (MSPLAT_EXCHANGE_WIRE_FP16 needs an RGBA32F target)" : "");
+    // the pixel size is the CONTEXT's target format (it used to be inferred from the pitch)
+    const size_t bpp = msplat_get_fb_format(ctx) == MSPLAT_FB_RGBA16F ? 8u : 16u;
+    const size_t tight = (size_t)width * bpp;
+    if (wire16 && bpp != 16u)
+        return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_exchange: MSPLAT_EXCHANGE_WIRE_FP16 needs an RGBA32F target");
+    if (pitch_bytes < tight || pitch_bytes % bpp != 0)
+        return gfail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_exchange: pitch %llu too small / misaligned for width %d of %zu-byte pixels",
+                     (unsigned long long)pitch_bytes, width, bpp);
     const Rccl& R = rccl();
     if (!R.ok()) return gfail(nullptr, MSPLAT_ERR_UNSUPPORTED, "msplat_band_exchange: %s", R.why.c_str());
     hipStream_t s = (hipStream_t)msplat_get_stream(ctx);
@@ -632,18 +652,28 @@ static int band_exchange_impl(msplat_ctx* ctx, void* comm, int32_t rank, int32_t
                                (uint2*)(scratch + soff[i]));
         }
     }
-    // a run travels as whole pitch rows (the framebuffer holds `height` rows of pitch_bytes; both sides count the same bytes),
-    // or as tight fp16 rows
+    // a run travels as ONE message when the rows are tight (pitch == width x pixel size: the usual case), else row by row inside
+    // the same group: nothing outside the target's own pixels is read or written -- a target that is a window of a wider
+    // surface keeps its neighbours, and the last row need not be followed by a full pitch; or as tight fp16 rows
+    const bool tight_rows = (size_t)pitch_bytes == tight;
+    auto post = [&](bool send, const Run& r, size_t scratch_off) -> int {
+        if (wire16)
+            return send ? R.Send(scratch + scratch_off, (size_t)r.nrows * width * 8, kNcclUint8, r.peer, comm, s)
+                        : R.Recv(scratch + scratch_off, (size_t)r.nrows * width * 8, kNcclUint8, r.peer, comm, s);
+        const int ops = tight_rows ? 1 : r.nrows;
+        const size_t bytes = tight_rows ? (size_t)r.nrows * tight : tight;
+        for (int k = 0; k < ops; ++k) {
+            const size_t off = (size_t)(r.y0 + k) * (size_t)pitch_bytes;
+            const int e = send ? R.Send((const char*)src + off, bytes, kNcclUint8, r.peer, comm, s)
+                               : R.Recv((char*)dst + off, bytes, kNcclUint8, r.peer, comm, s);
+            if (e != 0) return e;
+        }
+        return 0;
+    };
     int nrc = R.GroupStart();
     if (nrc == 0) {
-        for (size_t i = 0; i < sends.size() && nrc == 0; ++i)
-            nrc = wire16 ? R.Send(scratch + soff[i], (size_t)sends[i].nrows * width * 8, kNcclUint8, sends[i].peer, comm, s)
-                         : R.Send((const char*)src + (size_t)sends[i].y0 * pitch_bytes, (size_t)sends[i].nrows * pitch_bytes, kNcclUint8,
-                                  sends[i].peer, comm, s);
-        for (size_t i = 0; i < recvs.size() && nrc == 0; ++i)
-            nrc = wire16 ? R.Recv(scratch + roff[i], (size_t)recvs[i].nrows * width * 8, kNcclUint8, recvs[i].peer, comm, s)
-                         : R.Recv((char*)dst + (size_t)recvs[i].y0 * pitch_bytes, (size_t)recvs[i].nrows * pitch_bytes, kNcclUint8,
-                                  recvs[i].peer, comm, s);
+        for (size_t i = 0; i < sends.size() && nrc == 0; ++i) nrc = post(true, sends[i], wire16 ? soff[i] : 0);
+        for (size_t i = 0; i < recvs.size() && nrc == 0; ++i) nrc = post(false, recvs[i], wire16 ? roff[i] : 0);
         const int erc = R.GroupEnd();
         if (nrc == 0) nrc = erc;
     }

@@ -23,9 +23,33 @@ def owned_rows(kind, tiles_y, world, rank, block_rows=1):
     that the gather plan needs no library call): ascending list"""
     if kind == "contiguous":
         return list(range((tiles_y * rank) // world, (tiles_y * (rank + 1)) // world))
+    if kind == "weighted":         # contiguous bands, rank 0 weighted block_rows percent of another rank (MSPLAT_BANDS_ROOT_WEIGHTED)
+        b = weighted_bounds(tiles_y, [float(int(block_rows))] + [100.0] * (world - 1))
+        return list(range(b[rank], b[rank + 1]))
     k = 1 if kind == "interleaved" else int(block_rows)
     assert kind in ("interleaved", "block") and k >= 1
     return [t for t in range(tiles_y) if (t // k) % world == rank]
+
+
+def weighted_bounds(tiles_y, weights):
+    """msplat_band_plan_weighted restated (largest remainders; nobody with a positive weight stays empty while a larger band can
+    spare a row): bounds[i] .. bounds[i + 1] = the bin rows of rank i.  float32 weights like the C ABI's"""
+    import numpy as np
+    w = np.asarray(weights, np.float32).astype(np.float64)
+    x = tiles_y * w / w.sum()
+    rows = np.floor(x).astype(np.int64)
+    frac = x - np.floor(x)
+    for _ in range(int(tiles_y - rows.sum())):
+        i = int(np.argmax(frac))               # (first of equals, like the library)
+        rows[i] += 1
+        frac[i] = -1.0
+    for i in range(len(w)):
+        if rows[i] == 0 and w[i] > 0:
+            j = int(np.argmax(rows))
+            if rows[j] >= 2:
+                rows[j] -= 1
+                rows[i] = 1
+    return [0] + [int(v) for v in np.cumsum(rows)]
 
 
 def row_runs(rows):
@@ -151,7 +175,7 @@ class RcclComm:
         self.close()
 
 
-_KIND = {"contiguous": 0, "interleaved": 1, "block": 2}
+_KIND = {"contiguous": 0, "interleaved": 1, "block": 2, "weighted": 3}
 
 
 class CAbiBandGather:

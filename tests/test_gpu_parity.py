@@ -15,6 +15,8 @@ Tolerances, stated once:
   alpha channel ............................................ == 1 exactly
   fp16 framebuffer ......................................... vs fp32 oracle: 2e-3 + 1 fp16 ulp
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -23,6 +25,7 @@ from splatapult_amd import SplatRenderer, camera
 from tests import scenes
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 KK = -0.5 * 1.4426950408889634
 
@@ -1499,23 +1502,40 @@ def test_band_exchange_through_rccl_on_one_rank_and_the_group_switch():
     from splatapult_amd.dist import RcclComm, owned_rows
     comm = RcclComm(0, 1, 0)
     r = make_renderer(scenes.synth_cloud(2000, 5))
+    r16 = make_renderer(scenes.synth_cloud(2000, 5), fb_format="fp16")      # the pixel size is the context's target format (r6)
     T = bin_px()
     dev = torch.device("cuda", 0)
-    for W, H, dtype, bpp in ((640, 360, torch.float32, 16), (517, 293, torch.float16, 8)):
+    for rr, W, H, dtype, bpp in ((r, 640, 360, torch.float32, 16), (r16, 517, 293, torch.float16, 8)):
         tiles_y = (H + T - 1) // T
         Hpad = tiles_y * T
         src = torch.randn((Hpad, W, 4), dtype=torch.float32, device=dev).to(dtype)
         for kind, name, k in ((_capi.BANDS_CONTIGUOUS, "contiguous", 1), (_capi.BANDS_INTERLEAVED, "interleaved", 1),
-                              (_capi.BANDS_BLOCK_INTERLEAVED, "block", 2)):
+                              (_capi.BANDS_BLOCK_INTERLEAVED, "block", 2), (_capi.BANDS_ROOT_WEIGHTED, "weighted", 300)):
             for g in (0, 3, 7):
                 dst = torch.zeros_like(src)
-                r.band_exchange(comm.handle, g, 8, 0, kind, k, dst.data_ptr(), W * bpp, W, Hpad, loopback_src=src.data_ptr())
-                r.synchronize()
+                rr.band_exchange(comm.handle, g, 8, 0, kind, k, dst.data_ptr(), W * bpp, W, Hpad, loopback_src=src.data_ptr())
+                rr.synchronize()
                 torch.cuda.synchronize()
                 want = torch.zeros_like(src)
                 rows = np.isin(np.arange(Hpad) // T, owned_rows(name, tiles_y, 8, g, k))
                 want[torch.from_numpy(rows).to(dev)] = src[torch.from_numpy(rows).to(dev)]
                 assert torch.equal(dst, want), (name, g, W, H)
+    with pytest.raises(MsplatError):         # an fp16-sized pitch on an RGBA32F context: refused, not reinterpreted
+        r.band_exchange(comm.handle, 0, 8, 0, _capi.BANDS_CONTIGUOUS, 1, dst.data_ptr(), 517 * 8, 517, Hpad, loopback_src=src.data_ptr())
+    # a target that is a WINDOW of a wider surface (pitch > width x 16): the run travels row by row, the surface's other pixels
+    # keep their values on both sides and nothing behind the last row's last pixel is touched
+    Ws, Ww, Hh = 640, 500, 96
+    surf_src = torch.randn((Hh, Ws, 4), dtype=torch.float32, device=dev)
+    surf_dst = torch.full((Hh, Ws, 4), -7.0, dtype=torch.float32, device=dev)
+    for g in (0, 1):
+        surf_dst.fill_(-7.0)
+        r.band_exchange(comm.handle, g, 2, 0, _capi.BANDS_ROOT_WEIGHTED, 200, surf_dst.data_ptr(), Ws * 16, Ww, Hh, loopback_src=surf_src.data_ptr())
+        r.synchronize()
+        torch.cuda.synchronize()
+        rows = torch.from_numpy(np.isin(np.arange(Hh) // T, owned_rows("weighted", Hh // T, 2, g, 200))).to(dev)
+        want = torch.full_like(surf_dst, -7.0)
+        want[rows, :Ww] = surf_src[rows, :Ww]
+        assert torch.equal(surf_dst, want), g
     # fp16 on the wire (MSPLAT_EXCHANGE_WIRE_FP16, fp32 targets): the rows arrive rounded once to fp16 -- |d| <= 2^-11 |value| --
     # packed and unpacked by the library around the same ncclSend / ncclRecv; an fp16-sized pitch is refused
     W, H = 640, 360
@@ -1582,6 +1602,59 @@ def test_band_exchange_through_rccl_on_one_rank_and_the_group_switch():
         g.synchronize()
         np.testing.assert_array_equal(fb.cpu().numpy(), ref)
         g.close()
+
+
+def test_exchange_without_librccl_is_refused_not_a_crash():
+    """with no loadable librccl the RCCL entry points return MSPLAT_ERR_UNSUPPORTED with the loader's message (the
+    first version called dlerror() twice and crashed on the NULL the second call returns); a mistyped MSPLAT_GROUP_EXCHANGE is
+    refused instead of silently selecting the default.  Child processes: the library resolves librccl once per process"""
+    import subprocess
+    import sys
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import torch
+from splatapult_amd import SplatRenderer, SplatRendererGroup, MsplatError, _capi
+import numpy as np
+r = SplatRenderer(device=0)
+assert r.Init(np.zeros((8, 61), np.float32), False, False)
+fb = torch.zeros((64, 64, 4), dtype=torch.float32, device="cuda")
+import ctypes as C
+try:
+    r.band_exchange(C.c_void_p(1234), 1, 2, 0, _capi.BANDS_CONTIGUOUS, 1, fb.data_ptr(), 64 * 16, 64, 64)
+    print("NO ERROR")
+except MsplatError as e:
+    print("CODE", e.code, str(e))
+g = SplatRendererGroup([0, 0])
+assert g.Init(np.zeros((8, 61), np.float32))
+try:
+    g.set_exchange("rccl")
+    print("NO ERROR")
+except MsplatError as e:
+    print("CODE", e.code, str(e))
+""" % ROOT
+    env = dict(os.environ, MSPLAT_RCCL_LIB="/nonexistent/librccl_not_here.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-800:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("CODE")]
+    assert len(lines) == 2 and all(("CODE %d" % _capi_mod().ERR_UNSUPPORTED) in ln and "librccl not found" in ln for ln in lines), out.stdout
+    code2 = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from splatapult_amd import SplatRendererGroup
+g = SplatRendererGroup([0, 0])
+ok = g.Init(np.zeros((8, 61), np.float32))
+print("INIT", ok, g.last_error())
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code2], env=dict(os.environ, MSPLAT_GROUP_EXCHANGE="nccl"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-800:]
+    assert "INIT False" in out.stdout and "MSPLAT_GROUP_EXCHANGE=nccl" in out.stdout, out.stdout
+
+
+def _capi_mod():
+    from splatapult_amd import _capi
+    return _capi
 
 
 def test_device_group_errors():

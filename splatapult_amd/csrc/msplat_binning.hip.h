@@ -33,6 +33,7 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
                                                          int keep_overflow = 0, const uint32_t* __restrict__ d_first = nullptr)
 {
     MSPLAT_CHAIN_ENTER();
+    MSPLAT_STAMP(KID_BIN1_UP);
     // d_first (pass 1 of a two-pass frame): the chunks start at rank *d_first (a multiple of BIN_CHUNK): the ranks below it have
     // empty rectangles and are not walked
     // keep_overflow: second binning chain of a two-pass frame -- the first chain's overflow verdict stays
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && BIN_CHUNK == kBinChunk) ?
                                                            const uint32_t* __restrict__ d_first = nullptr)
 {
     MSPLAT_CHAIN_ENTER();
+    MSPLAT_STAMP(KID_BIN1_DOWN);
     // d_first: see bin1_upsweep
     // host_D2 (host-mapped): second binning chain of a two-pass frame -- its pair count, for the host's choice of the next share
     // d_V_report: the Sort's own V for the host-mapped hint (with two views in one chain d_V counts the ranks of both)
@@ -360,6 +362,7 @@ __global__ __launch_bounds__(kThreads) void tile_start_kernel(const uint32_t* __
                                                               uint32_t* __restrict__ queue_reset)
 {
     MSPLAT_CHAIN_ENTER();
+    MSPLAT_STAMP(KID_TILE_START);
     // (the compositors' work queue starts empty every frame; tile_order_kernel does it when it runs)
     if (queue_reset != nullptr && blockIdx.x == 0 && threadIdx.x < kQueueShards) queue_reset[threadIdx.x * kQueueStride] = 0u;
     __shared__ uint32_t s_row[kThreads + 1];

@@ -47,6 +47,47 @@ constexpr uint32_t kRankMask = 0x00FFFFFFu;
 
 enum { MODE_KEYS = 0, MODE_CULL = 1, MODE_PAIR = 2 };
 
+// Workgroup residency stamps (r6; DIAGNOSTIC builds only: -DMSPLAT_STAMPS, tools/stamp_timeline.py).  rocprofv3 serialises dispatches
+// while it collects counters and this box has no PC sampling, so what frames IN FLIGHT do to each other was unknown.  With stamps
+// every workgroup of the frame's kernels leaves {kernel id, block, HW_ID, XCC_ID, start, end} (s_memrealtime: 100 MHz) in a hashed
+// table -- plain stores, no atomics, nothing returns to the wave -- while a device flag is on.  The product build compiles the
+// macro to nothing.
+#ifdef MSPLAT_STAMPS
+struct StampRec { uint32_t kid, blk, hwid, xcc; unsigned long long t0, t1; };
+__device__ StampRec* g_stamp_buf = nullptr;
+__device__ uint32_t g_stamp_mask = 0u;           // table size - 1 while stamping is on, else 0
+struct StampScope {
+    unsigned long long t0;
+    uint32_t kid, mask;
+    __device__ __forceinline__ explicit StampScope(uint32_t k) : t0(0ull), kid(k), mask(0u)
+    {
+        if (threadIdx.x == 0) {
+            mask = __builtin_nontemporal_load(&g_stamp_mask);
+            if (mask) t0 = wall_clock64();
+        }
+    }
+    __device__ __forceinline__ ~StampScope()
+    {
+        if (threadIdx.x == 0 && mask) {
+            StampRec r;
+            r.kid = kid; r.blk = blockIdx.x;
+            r.hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
+            r.xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);        // HW_REG_XCC_ID
+            r.t0 = t0; r.t1 = wall_clock64();
+            uint32_t h = (uint32_t)t0 * 2654435761u ^ (blockIdx.x * 40503u) ^ (kid << 26) ^ (r.hwid * 97u) ^ (r.xcc << 13);
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            g_stamp_buf[h & mask] = r;
+        }
+    }
+};
+#define MSPLAT_STAMP(KID) msplat::StampScope stamp_scope_((uint32_t)(KID))
+#else
+#define MSPLAT_STAMP(KID)
+#endif
+// kernel ids of the stamps (tools/stamp_timeline.py names them)
+enum { KID_WS_UP_CULL = 1, KID_WS_DOWN_CULL = 2, KID_WS_UP = 3, KID_WS_DOWN = 4, KID_PROJECT = 5, KID_BIN1_UP = 6, KID_BIN1_DOWN = 7,
+       KID_ROW_UP = 8, KID_ROW_DOWN = 9, KID_TILE_START = 10, KID_COMPOSITE = 11, KID_BOX_CULL = 12, KID_RADIX_UP = 13, KID_RADIX_DOWN = 14 };
+
 // Per-frame constants, passed by value (lives in SGPRs / kernarg segment).
 struct FrameParams {
     float mvp[16];     // projMat * inverse(cameraMat)            (splatrenderer.cpp:161,175)

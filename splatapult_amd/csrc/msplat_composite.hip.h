@@ -125,6 +125,7 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
                                                                  int prio_levels, CompExtra ex)
 {
     constexpr int occ_pass = OCC;
+    MSPLAT_STAMP(KID_COMPOSITE);
     uint32_t* __restrict__ const fin = ex.fin;
     float4* __restrict__ const state = ex.state;
     uint32_t* __restrict__ const probe = PROBE ? ex.probe : nullptr;

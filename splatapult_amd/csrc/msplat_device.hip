@@ -650,6 +650,34 @@ void* msplat_get_stream(msplat_ctx* ctx) { return ctx ? (void*)ctx->stream : nul
 
 int msplat_get_fb_format(const msplat_ctx* ctx) { return ctx ? ctx->cfg.fb_format : -1; }
 
+#ifdef MSPLAT_STAMPS
+// diagnostic build only (msplat_common.hip.h, MSPLAT_STAMP): switch the workgroup stamps of the current device on / off, read the
+// table (and clear it).  enable != 0 allocates 2^log2_slots records of 32 bytes at the first call.
+static msplat::StampRec* g_stamps_dev = nullptr;
+static uint32_t g_stamps_slots = 0;
+int msplat_debug_stamps(int enable, uint32_t log2_slots)
+{
+    if (enable && !g_stamps_dev) {
+        g_stamps_slots = 1u << std::min(26u, std::max(10u, log2_slots));
+        if (hipMalloc((void**)&g_stamps_dev, (size_t)g_stamps_slots * sizeof(msplat::StampRec)) != hipSuccess) return MSPLAT_ERR_HIP;
+        if (hipMemset(g_stamps_dev, 0, (size_t)g_stamps_slots * sizeof(msplat::StampRec)) != hipSuccess) return MSPLAT_ERR_HIP;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(msplat::g_stamp_buf), &g_stamps_dev, sizeof(g_stamps_dev)) != hipSuccess) return MSPLAT_ERR_HIP;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return MSPLAT_ERR_HIP;
+    const uint32_t mask = (enable && g_stamps_dev) ? g_stamps_slots - 1u : 0u;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(msplat::g_stamp_mask), &mask, sizeof(mask)) != hipSuccess) return MSPLAT_ERR_HIP;
+    return hipDeviceSynchronize() == hipSuccess ? (int)g_stamps_slots : MSPLAT_ERR_HIP;
+}
+int msplat_debug_stamps_read(void* dst, uint64_t bytes)
+{
+    if (!g_stamps_dev || !dst) return MSPLAT_ERR_INVALID_ARG;
+    const size_t n = std::min<size_t>(bytes, (size_t)g_stamps_slots * sizeof(msplat::StampRec));
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(dst, g_stamps_dev, n, hipMemcpyDeviceToHost) != hipSuccess) return MSPLAT_ERR_HIP;
+    if (hipMemset(g_stamps_dev, 0, (size_t)g_stamps_slots * sizeof(msplat::StampRec)) != hipSuccess) return MSPLAT_ERR_HIP;
+    return MSPLAT_OK;
+}
+#endif
+
 // Makes `stream` (a hipStream_t, NULL = the legacy default stream) wait for everything enqueued so far on
 // the context's stream, without blocking the host.
 int msplat_stream_wait(msplat_ctx* ctx, void* stream)

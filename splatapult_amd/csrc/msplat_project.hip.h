@@ -261,6 +261,7 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
     // stages 64 records in LDS, then every lane reads its own record back (stride 68/36 dwords keeps
     // the ds_read_b128 accesses conflict free).
     __builtin_amdgcn_s_setprio(kProjPrio);
+    MSPLAT_STAMP(KID_PROJECT);
     constexpr int F4 = FULL_SH ? 16 : 8;
     constexpr int STRIDE = F4 * 4 + 4;        // dwords
     __shared__ __attribute__((aligned(16))) float s_stage[64 * STRIDE];

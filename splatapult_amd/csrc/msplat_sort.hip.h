@@ -100,6 +100,7 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
                                                           LiveBoxes lb = LiveBoxes{nullptr, nullptr, 0u, 0u})
 {
     MSPLAT_CHAIN_ENTER();
+    MSPLAT_STAMP(MODE == MODE_PAIR ? KID_ROW_UP : KID_RADIX_UP);
     // MODE_CULL with lb.list != nullptr: pass 0 over the listed live boxes only (virtual positions), see ws_upsweep / box_live
     // MODE_PAIR with bincnt != nullptr (r3): the input is ordered by (column, rank) and carries the row in its top byte, so
     // counting the words per (row, column) here gives every bin's list length before the partition has run: the
@@ -467,6 +468,7 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE != MODE_PAIR && SORT
                                                             LiveBoxes lb = LiveBoxes{nullptr, nullptr, 0u, 0u})
 {
     MSPLAT_CHAIN_ENTER();
+    MSPLAT_STAMP(MODE == MODE_PAIR ? KID_ROW_DOWN : KID_RADIX_DOWN);
     // lb.list != nullptr (MODE_CULL): pass 0 over the listed live boxes only (virtual positions), see ws_upsweep
     // gsum != nullptr: scan-free path -- hist holds raw per-chunk counts, prefixes come from the group tables;
     // otherwise hist holds exclusive prefixes and totals the digit totals (radix_scan*).
@@ -823,6 +825,7 @@ __global__ __launch_bounds__(THREADS) void ws_upsweep(const uint32_t* __restrict
                                                       FrameParams fp, LiveBoxes lb = LiveBoxes{nullptr, nullptr, 0u, 0u})
 {
     MSPLAT_CHAIN_ENTER();
+    MSPLAT_STAMP(CULL ? KID_WS_UP_CULL : KID_WS_UP);
     // lb.list != nullptr (CULL, spatially ordered cloud, box_cull_kernel has run): the pass walks the LISTED boxes only.  A chunk
     // is BPC consecutive live boxes; element e of chunk c is splat box[c * BPC + e / kBoxSplats] * kBoxSplats + e % kBoxSplats;
     // raw_keys / vmask / the histogram rows are indexed by the VIRTUAL position c * CHUNK + e, which is dense.
@@ -945,6 +948,7 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
     uint32_t* __restrict__ vals_out, uint32_t* __restrict__ d_count_out, int xcd_map, LiveBoxes lb = LiveBoxes{nullptr, nullptr, 0u, 0u})
 {
     MSPLAT_CHAIN_ENTER();
+    MSPLAT_STAMP(CULL ? KID_WS_DOWN_CULL : KID_WS_DOWN);
     // lb.list != nullptr (CULL): pass 0 over the listed boxes only, see ws_upsweep -- keys_in / vmask are indexed by virtual
     // position, the value written is the splat's STORAGE index.
     // xcd_map: workgroup b runs on XCD b % 8; chunk = xcd_contiguous(b) gives every XCD a contiguous range of chunks, so

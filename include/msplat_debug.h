@@ -38,7 +38,7 @@ int msplat_debug_two_pass(msplat_ctx* ctx, float share, uint64_t* two_pass_frame
 int msplat_get_two_pass_info(msplat_ctx* ctx, uint64_t out[8]);
 
 /* ---- compositor probe (bench statistics): per (bin, quadrant) work item 8 words {shader clocks, records composited, batches
- * staged, inner-loop clocks, pair words fetched, records fetched, bin-list length, ran}.  Off by default (a few clock reads per
+ * staged, inner-loop clocks, pair words fetched, records fetched, bin-list length, 1 + evaluations with w > 0}.  Off by default (a few clock reads per
  * batch; a probed context renders in one pass); MSPLAT_TILE_PROBE=1 turns it on at msplat_create ---- */
 typedef struct msplat_composite_work {     /* sums over the work items of the latest render */
     uint64_t work_items;          /* 16x16 tiles composited */
@@ -49,6 +49,8 @@ typedef struct msplat_composite_work {     /* sums over the work items of the la
     uint64_t pixel_evals;         /* (pixel, splat) evaluations = 256 per composited record */
     uint64_t batches;             /* 64-entry batches staged */
     uint64_t clocks_sum, clocks_max, inner_clocks_sum;   /* shader clocks per work item (probe overhead included) */
+    uint64_t useful_evals;        /* r6: evaluations whose weight survived the discard (w > 1/256): the rest of pixel_evals is the price
+                                     of evaluating a whole 16x16 tile per record (splat_frag.glsl:37-40 runs per covered fragment) */
 } msplat_composite_work;
 int msplat_set_tile_probe(msplat_ctx* ctx, int enable);
 /* (the record size is in the name: a caller built for the 4-word records of the first release fails to link) */

@@ -60,7 +60,7 @@ class Stats(C.Structure):
 class CompositeWork(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("work_items", "list_entries", "pair_words_fetched", "records_fetched", "records_composited",
-                 "pixel_evals", "batches", "clocks_sum", "clocks_max", "inner_clocks_sum")]
+                 "pixel_evals", "batches", "clocks_sum", "clocks_max", "inner_clocks_sum", "useful_evals")]
 
 
 class Timings(C.Structure):
@@ -183,7 +183,14 @@ def lib():
                 "(there is no CPU fallback)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
-            fn = getattr(L, name)
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                # another build of the ABI loaded for an A/B (MSPLAT_LIB_PATH: e.g. an earlier round's tree) may predate an entry
+                # point -- it then fails at its first use; the in-tree library must export everything
+                if os.environ.get("MSPLAT_LIB_PATH"):
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _LIB = L

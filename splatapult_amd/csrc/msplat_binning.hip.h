@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kThreads) void bin1_upsweep(const uint32_t* __restr
 // (5 waves per SIMD = 5 workgroups per CU, as in r2: the r3 additions had pushed the kernel to 106 VGPRs = 4, which cost
 //  the frames-in-flight mode throughput)
 template <bool ATOMIC_RANK, int BIN_CHUNK>
-__global__ __launch_bounds__(kThreads, (ATOMIC_RANK && BIN_CHUNK == kBinChunk) ? 5 : 2) void bin1_downsweep(const uint32_t* __restrict__ rect,
+__global__ __launch_bounds__(kThreads, (ATOMIC_RANK && BIN_CHUNK == kBinChunk) ? 4 : 2) void bin1_downsweep(const uint32_t* __restrict__ rect,
                                                            const uint32_t* __restrict__ d_V,
                                                            const uint32_t* __restrict__ hist, uint32_t hist_stride,
                                                            const uint32_t* __restrict__ totals,

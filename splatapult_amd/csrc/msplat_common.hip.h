@@ -275,6 +275,9 @@ __device__ __forceinline__ uint32_t xcd_grouped(uint32_t b, uint32_t n, uint32_t
 
 // presort_compute.glsl:38-55.  Operation order identical to oracle/msplat_oracle.c (orc_cull_key)
 // so that keys and the visible set are bit-exact.
+// BAND = false (r6): an instantiation for frames WITHOUT the band-restricted cull (every single-GPU frame) -- the branch below
+// keeps ~25 uniform values live (view rows, proj[5], the layout), which is what pushed pass 0's upsweep over the SGPR file.
+template <bool BAND = true>
 __device__ __forceinline__ bool cull_key(const float4 p, const FrameParams& fp, uint32_t& key)
 {
     const float* m = fp.mvp;
@@ -286,7 +289,7 @@ __device__ __forceinline__ bool cull_key(const float4 p, const FrameParams& fp, 
     float yy = __fdiv_rn(py, depth);
     const float CLIP = 1.5f;
     if (depth > 0.0f && xx < CLIP && xx > -CLIP && yy < CLIP && yy > -CLIP) {
-        if (fp.band_cull) {
+        if (BAND && fp.band_cull) {
             // Band-restricted cull (never active on a single GPU, where the reference's cull
             // must be reproduced exactly).  Conservative bound on the footprint's y half-extent:
             //   ey^2 = rho^2 (M1 Sigma M1^T + 0.3) <= |J1|^2 |W|^2 * (rho^2 lambda_max(Sigma)) + 0.3 rho^2_max,

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
     if (lane < (int)cntA) rankA = pairs[hiA - 1u - lane];
     hiA -= cntA;
     const uint64_t probe_t0 = PROBE ? clock64() : 0ull;
-    uint32_t probe_n = 0, probe_batches = 0;
+    uint32_t probe_n = 0, probe_batches = 0, probe_useful = 0;      // probe_useful: (pixel, record) evaluations with w > 0
     uint64_t probe_inner = 0;
     // pair words / records whose loads have been issued so far (the prefetch pipeline runs two / one batches ahead)
     uint32_t probe_words = min(end - start, 2u * (uint32_t)kCompThreads), probe_recs = cnt;
@@ -371,6 +371,7 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
                     v2f w;           // discard by underflow (see the kernel's header)
                     w.x = __builtin_amdgcn_exp2f(e.x);
                     w.y = __builtin_amdgcn_exp2f(e.y);
+                    if (PROBE) probe_useful += (w.x > 0.0f ? 1u : 0u) + (w.y > 0.0f ? 1u : 0u);      // per lane; summed over the wave at the end
                     const v2f tw = T[h] * w;
                     cr[h] = __builtin_elementwise_fma(tw, vr, cr[h]);
                     cg[h] = __builtin_elementwise_fma(tw, vg, cg[h]);
@@ -393,6 +394,10 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
     // (pass 1 of a two-pass frame) final, or to be resumed by pass 2?
     const bool carry = occ_pass == 1 && alive != 0u;
     if (occ_pass == 1 && lane == 0) fin[bin * 4 + quad] = carry ? consumed : 0xFFFFFFFFu;
+    if (PROBE) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) probe_useful += (uint32_t)__shfl_xor((int)probe_useful, d, 64);
+    }
     if (PROBE && lane == 0) {
         probe[tile * 8 + 0] = (uint32_t)(clock64() - probe_t0);        // shader clocks, whole tile
         probe[tile * 8 + 1] = probe_n;          // splats composited (after culling / saturation)
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(kCompThreads, kCompOcc) void composite_kernel(const
         probe[tile * 8 + 4] = probe_words;      // 4-byte pair words loaded
         probe[tile * 8 + 5] = probe_recs;       // 48-byte projected records loaded
         probe[tile * 8 + 6] = end - start;      // length of the bin list
-        probe[tile * 8 + 7] = 1u;               // work item ran
+        probe[tile * 8 + 7] = 1u + probe_useful;      // != 0: the work item ran; - 1 = evaluations whose weight survived the discard (w > 0)
     }
     if (carry) {
 #pragma unroll

@@ -1560,7 +1560,6 @@ static int sort_impl(msplat_ctx* ctx, const float cameraMat[16], const float pro
         uint32_t items = lb.list != nullptr ? 8u : items0;
         int wgrid = grid_for(div_up(N, ctx->ws_threads * items));
         const uint32_t* dV = d_V;
-        const int wsx = 1;          // XCD-contiguous chunk ranges in the downsweeps
 #define MSPLAT_WS_T(KERNEL, CULLF, LDS, T, ...)                                                                          \
     do {                                                                                                                \
         if (items == 16u) hipLaunchKernelGGL((KERNEL<CULLF, 16, T>), dim3(wgrid), dim3(T), LDS(16, T), s, __VA_ARGS__); \
@@ -1581,21 +1580,25 @@ static int sort_impl(msplat_ctx* ctx, const float cameraMat[16], const float pro
             hipLaunchKernelGGL((ws_upsweep<CULLF, 4, 2 * kWsThreads>), dim3(wgrid), dim3(2 * kWsThreads), 0, s, __VA_ARGS__); \
         else MSPLAT_WS(ws_upsweep, CULLF, MSPLAT_NO_LDS, __VA_ARGS__);                                                    \
     } while (0)
-        MSPLAT_WS_UP(true, (const uint32_t*)nullptr, pos, kB, vm, (const uint32_t*)nullptr, N, N, 0, mk_cur,
-                  mk_next, whist, gt(0), gsh, gt(-1), gw, fp, lb);
+        if (fp.band_cull)
+            MSPLAT_WS_UP(2, (const uint32_t*)nullptr, pos, kB, vm, (const uint32_t*)nullptr, N, N, 0, mk_cur,
+                      mk_next, whist, gt(0), gsh, gt(-1), gw, fp, lb);
+        else
+            MSPLAT_WS_UP(1, (const uint32_t*)nullptr, pos, kB, vm, (const uint32_t*)nullptr, N, N, 0, mk_cur,
+                      mk_next, whist, gt(0), gsh, gt(-1), gw, fp, lb);
         MSPLAT_WS(ws_downsweep, true, ws_downsweep_lds, (const uint32_t*)kB, (const uint32_t*)nullptr, (const unsigned long long*)vm,
                   (const uint32_t*)nullptr, N, N, 0, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(0), gsh, kA, vA,
-                  d_V, wsx, lb);
+                  d_V, lb);
         items = items12;
         wgrid = grid_for(div_up(N, ctx->ws_threads * items));
-        MSPLAT_WS_UP(false, (const uint32_t*)kA, (const float4*)nullptr, (uint32_t*)nullptr,
+        MSPLAT_WS_UP(0, (const uint32_t*)kA, (const float4*)nullptr, (uint32_t*)nullptr,
                   (unsigned long long*)nullptr, dV, 0u, N, 1, mk_cur, mk_next, whist, gt(1), gsh, gt(0), gw, fp);
         MSPLAT_WS(ws_downsweep, false, ws_downsweep_lds, (const uint32_t*)kA, (const uint32_t*)vA, (const unsigned long long*)nullptr, dV,
-                  0u, N, 1, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(1), gsh, kB, vB, (uint32_t*)nullptr, wsx);
-        MSPLAT_WS_UP(false, (const uint32_t*)kB, (const float4*)nullptr, (uint32_t*)nullptr,
+                  0u, N, 1, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(1), gsh, kB, vB, (uint32_t*)nullptr);
+        MSPLAT_WS_UP(0, (const uint32_t*)kB, (const float4*)nullptr, (uint32_t*)nullptr,
                   (unsigned long long*)nullptr, dV, 0u, N, 2, mk_cur, mk_next, whist, gt(2), gsh, gt(1), gw, fp);
         MSPLAT_WS(ws_downsweep, false, ws_downsweep_lds, (const uint32_t*)kB, (const uint32_t*)vB, (const unsigned long long*)nullptr, dV,
-                  0u, N, 2, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(2), gsh, kA, vA, (uint32_t*)nullptr, wsx);
+                  0u, N, 2, (const uint32_t*)mk_cur, (const uint32_t*)whist, (const uint32_t*)gt(2), gsh, kA, vA, (uint32_t*)nullptr);
 #undef MSPLAT_NO_LDS
 #undef MSPLAT_WS
 #undef MSPLAT_WS_T
@@ -1621,30 +1624,38 @@ static int sort_impl(msplat_ctx* ctx, const float cameraMat[16], const float pro
     const bool fused = ctx->scan_free && div_up(N, chunk) <= kFusedMaxChunks;
     auto gacc = [&](int pass) { return fused ? (uint32_t*)ctx->gsumS[pass & 1].p : nullptr; };
     auto gzero = [&](int pass) { return (uint32_t*)ctx->gsumS[(pass + 1) & 1].p; };      // always: keeps both tables clean
-#define MSPLAT_UPSWEEP(MODE, ...)                                                                                       \
+#define MSPLAT_UPSWEEP_B(MODE, BAND, ...)                                                                               \
     do {                                                                                                                \
-        if (large) hipLaunchKernelGGL((radix_upsweep<MODE, kSortItemsLarge>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__); \
-        else hipLaunchKernelGGL((radix_upsweep<MODE, kSortItems>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__);            \
+        if (large) hipLaunchKernelGGL((radix_upsweep<MODE, kSortItemsLarge, BAND>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((radix_upsweep<MODE, kSortItems, BAND>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__);            \
     } while (0)
-#define MSPLAT_DOWNSWEEP(MODE, ...)                                                                                              \
+#define MSPLAT_DOWNSWEEP_B(MODE, BAND, ...)                                                                                      \
     do {                                                                                                                         \
         if (large) {                                                                                                             \
-            if (ctx->atomic_rank) hipLaunchKernelGGL((radix_downsweep<MODE, true, true, kSortItemsLarge>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__); \
-            else hipLaunchKernelGGL((radix_downsweep<MODE, true, false, kSortItemsLarge>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__);                 \
+            if (ctx->atomic_rank) hipLaunchKernelGGL((radix_downsweep<MODE, true, true, kSortItemsLarge, BAND>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__); \
+            else hipLaunchKernelGGL((radix_downsweep<MODE, true, false, kSortItemsLarge, BAND>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__);                 \
         } else {                                                                                                                 \
-            if (ctx->atomic_rank) hipLaunchKernelGGL((radix_downsweep<MODE, true, true, kSortItems>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__);      \
-            else hipLaunchKernelGGL((radix_downsweep<MODE, true, false, kSortItems>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__);                      \
+            if (ctx->atomic_rank) hipLaunchKernelGGL((radix_downsweep<MODE, true, true, kSortItems, BAND>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__);      \
+            else hipLaunchKernelGGL((radix_downsweep<MODE, true, false, kSortItems, BAND>), dim3(grid), dim3(kThreads), 0, s, __VA_ARGS__);                      \
         }                                                                                                                        \
     } while (0)
+#define MSPLAT_UPSWEEP(MODE, ...) MSPLAT_UPSWEEP_B(MODE, true, __VA_ARGS__)
+#define MSPLAT_DOWNSWEEP(MODE, ...) MSPLAT_DOWNSWEEP_B(MODE, true, __VA_ARGS__)
     // pass 0: cull + key fused into the first radix pass (presort_compute.glsl + byte 0 of the sort)
     const LiveBoxes lb = list_live_boxes(ctx, fp, ctx->h_flags ? __atomic_load_n(ctx->h_flags + 1, __ATOMIC_RELAXED) : 0u);
-    MSPLAT_UPSWEEP(MODE_CULL, (const uint32_t*)nullptr, pos, (const uint32_t*)nullptr, N, N, 0, hist, ctx->hist_stride, gacc(0),
-                   gzero(0), ctx->gsumS_rows, fp, (const uint32_t*)nullptr, (uint32_t*)nullptr, ctx->gsupS, lb);
-    if (!fused) launch_scan(s, ctx->N <= (2u << 20), hist, ctx->hist_stride, nullptr, N, N, chunk, totals);
-    MSPLAT_DOWNSWEEP(MODE_CULL, (const uint32_t*)nullptr, (const uint32_t*)nullptr, pos, (const uint32_t*)nullptr, N, N, 0,
-                     (const uint32_t*)hist, ctx->hist_stride, (const uint32_t*)totals, kB, vB, d_V, (const uint32_t*)nullptr,
-                     (const uint32_t*)gacc(0), (uint32_t*)nullptr, fp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                     (uint32_t*)nullptr, 0, 0, ctx->gsupS, lb);
+    // (r6: frames without the band-restricted cull -- every single-GPU frame -- run instantiations that leave its code out)
+#define MSPLAT_PASS0(BAND)                                                                                                              \
+    do {                                                                                                                                \
+        MSPLAT_UPSWEEP_B(MODE_CULL, BAND, (const uint32_t*)nullptr, pos, (const uint32_t*)nullptr, N, N, 0, hist, ctx->hist_stride, gacc(0), \
+                         gzero(0), ctx->gsumS_rows, fp, (const uint32_t*)nullptr, (uint32_t*)nullptr, ctx->gsupS, lb);                 \
+        if (!fused) launch_scan(s, ctx->N <= (2u << 20), hist, ctx->hist_stride, nullptr, N, N, chunk, totals);                       \
+        MSPLAT_DOWNSWEEP_B(MODE_CULL, BAND, (const uint32_t*)nullptr, (const uint32_t*)nullptr, pos, (const uint32_t*)nullptr, N, N, 0, \
+                           (const uint32_t*)hist, ctx->hist_stride, (const uint32_t*)totals, kB, vB, d_V, (const uint32_t*)nullptr,    \
+                           (const uint32_t*)gacc(0), (uint32_t*)nullptr, fp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, \
+                           (uint32_t*)nullptr, 0, 0, ctx->gsupS, lb);                                                                  \
+    } while (0)
+    if (fp.band_cull) MSPLAT_PASS0(true); else MSPLAT_PASS0(false);
+#undef MSPLAT_PASS0
     // passes 1..3 on the V survivors (V stays on the device; splatrenderer.cpp:195-204's readback is gone)
     for (int pass = 1; pass < 4; ++pass) {
         uint32_t* kin = (pass & 1) ? kB : kA;
@@ -1662,6 +1673,8 @@ static int sort_impl(msplat_ctx* ctx, const float cameraMat[16], const float pro
     }
 #undef MSPLAT_UPSWEEP
 #undef MSPLAT_DOWNSWEEP
+#undef MSPLAT_UPSWEEP_B
+#undef MSPLAT_DOWNSWEEP_B
     if (timed) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev[tset][1], s));
         ctx->sort_sets++;
@@ -2665,6 +2678,7 @@ int msplat_get_composite_work(msplat_ctx* ctx, msplat_composite_work* out)
         out->pair_words_fetched += p[4];
         out->records_fetched += p[5];
         out->list_entries += p[6];
+        out->useful_evals += (uint64_t)(p[7] - 1u);
     }
     return MSPLAT_OK;
 }

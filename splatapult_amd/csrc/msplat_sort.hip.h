@@ -86,7 +86,8 @@ constexpr int kGroupShift = 5;
 // supergroups of 1024 chunks (first attempt) put a 10 us chain on every address and cost the two binning upsweeps 30 us.
 constexpr int kSuperShift = 7;
 
-template <int MODE, int SORT_ITEMS = kSortItems>
+// (BAND = false: MODE_CULL for frames without the band-restricted cull, see cull_key)
+template <int MODE, int SORT_ITEMS = kSortItems, bool BAND = true>
 __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __restrict__ keys,
                                                           const float4* __restrict__ pos,
                                                           const uint32_t* __restrict__ d_n, uint32_t n_static,
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(kThreads) void radix_upsweep(const uint32_t* __rest
                     bool in;
                     (void)locate(base + r * kThreads + threadIdx.x, in);
                     uint32_t key;
-                    if (in && cull_key(pp[r], fp, key)) atomicAdd(&s_hist[digit_of<MODE>(key, shift)], 1u);
+                    if (in && cull_key<BAND>(pp[r], fp, key)) atomicAdd(&s_hist[digit_of<MODE>(key, shift)], 1u);
                 }
             } else {
                 // unconditional (clamped) loads first: under `if (i < n)` the compiler waits for every load before it
@@ -445,8 +446,9 @@ __device__ __forceinline__ void tile_table_role(uint32_t* __restrict__ bincnt, i
     }
 }
 
-template <int MODE, bool HAS_VALUES, bool ATOMIC_RANK, int SORT_ITEMS = kSortItems>
-__global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE != MODE_PAIR && SORT_ITEMS == kSortItems) ? 5 : 2) void radix_downsweep(const uint32_t* __restrict__ keys_in,
+template <int MODE, bool HAS_VALUES, bool ATOMIC_RANK, int SORT_ITEMS = kSortItems, bool BAND = true>
+__global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE == MODE_KEYS && SORT_ITEMS == kSortItems) ? 5
+                                       : (ATOMIC_RANK && MODE == MODE_CULL && SORT_ITEMS == kSortItems) ? 4 : 2) void radix_downsweep(const uint32_t* __restrict__ keys_in,
                                                             const uint32_t* __restrict__ vals_in,
                                                             const float4* __restrict__ pos,
                                                             const uint32_t* __restrict__ d_n, uint32_t n_static,
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE != MODE_PAIR && SORT
             if (MODE == MODE_CULL) {
                 bool in;
                 const uint32_t st = locate(i, in);
-                valid[r] = in && cull_key(pp[r % kPosBatch], fp, key[r]);
+                valid[r] = in && cull_key<BAND>(pp[r % kPosBatch], fp, key[r]);
                 val[r] = st;
             } else if (valid[r]) {
                 {
@@ -590,7 +592,8 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE != MODE_PAIR && SORT
                 // wave's DS instructions in program order (verified at context creation by
                 // lds_atomic_order_probe; if the probe ever fails the ballot path below is used), so the
                 // returned value IS the stable local rank: 1 LDS op instead of ~45 VALU ops per key.
-                lrank[r] = 0;
+                // (r6: validity then lives in lrank: ITEMS lane masks kept in SGPR pairs across the phases were what spilled)
+                lrank[r] = 0xFFFFFFFFu;
                 if (valid[r]) lrank[r] = atomicAdd(&s_cnt[w][d], 1u);
             } else {
                 uint64_t m = __ballot(valid[r]);
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE != MODE_PAIR && SORT
         }
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
-            if (valid[r]) {
+            if (ATOMIC_RANK ? lrank[r] != 0xFFFFFFFFu : valid[r]) {
                 const uint32_t d = digit_of<MODE>(key[r], shift);
                 const uint32_t p = s_cnt[w][d] + lrank[r];
                 uint32_t kout = key[r];
@@ -811,7 +814,8 @@ __device__ __forceinline__ void ws_row_sum(const uint32_t* __restrict__ rows0, u
 
 // CULL: pass 0.  keys are computed from the positions (presort_compute.glsl:38-55 via cull_key), written to raw_keys
 // together with one visibility bit per splat (vmask: one uint64 per 64 splats), and their minimum goes to *minkey_cur.
-template <bool CULL, int ITEMS, int THREADS = kWsThreads>
+// (CULL: 0 = keys of an earlier pass, 1 = pass 0 with the presort cull, 2 = the same with the band-restricted cull of a multi-GPU rank)
+template <int CULL, int ITEMS, int THREADS = kWsThreads>
 __global__ __launch_bounds__(THREADS) void ws_upsweep(const uint32_t* __restrict__ keys_in,
                                                       const float4* __restrict__ pos,
                                                       uint32_t* __restrict__ raw_keys,
@@ -893,7 +897,7 @@ __global__ __launch_bounds__(THREADS) void ws_upsweep(const uint32_t* __restrict
             if (CULL) {
                 bool in;
                 (void)locate(i, in);
-                if (in) ok = cull_key(pp[r], fp, key);
+                if (in) ok = cull_key<CULL == 2>(pp[r], fp, key);
             } else if (i < n) {
                 key = kk[r];
                 ok = true;
@@ -945,13 +949,13 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, const unsigned long long* __restrict__ vmask,
     const uint32_t* __restrict__ d_n, uint32_t n_static, uint32_t n_cap, int pass, const uint32_t* __restrict__ minkey_cur,
     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ gsum, int gshift, uint32_t* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out, uint32_t* __restrict__ d_count_out, int xcd_map, LiveBoxes lb = LiveBoxes{nullptr, nullptr, 0u, 0u})
+    uint32_t* __restrict__ vals_out, uint32_t* __restrict__ d_count_out, LiveBoxes lb = LiveBoxes{nullptr, nullptr, 0u, 0u})
 {
     MSPLAT_CHAIN_ENTER();
     MSPLAT_STAMP(CULL ? KID_WS_DOWN_CULL : KID_WS_DOWN);
     // lb.list != nullptr (CULL): pass 0 over the listed boxes only, see ws_upsweep -- keys_in / vmask are indexed by virtual
     // position, the value written is the splat's STORAGE index.
-    // xcd_map: workgroup b runs on XCD b % 8; chunk = xcd_contiguous(b) gives every XCD a contiguous range of chunks, so
+    // workgroup b runs on XCD b % 8; chunk = xcd_contiguous(b) gives every XCD a contiguous range of chunks, so
     // the digit runs that neighbouring chunks write next to each other meet in ONE L2 instead of being written to HBM
     // as partial lines by several (the per-XCD L2s are not coherent; every one writes back its own bytes of a shared line)
     constexpr int CHUNK = THREADS * ITEMS;
@@ -968,7 +972,7 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
     __shared__ uint32_t s_lpre[CULL ? 257 : 1], s_box[CULL ? BPC : 1];
     const bool compact = CULL && lb.list != nullptr;
 
-    uint32_t n = d_n ? *d_n : n_static;
+    uint32_t n = CULL ? n_static : *d_n;         // (pass 0 walks the cloud, the later passes the visible count left on the device)
     if (n > n_cap) n = n_cap;
     if (compact) {
         live_prefix<WAVES>(lb, s_lpre, s_tmp);
@@ -1002,7 +1006,7 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
     }
 
     for (uint32_t cidx = blockIdx.x; cidx < nchunks; cidx += gridDim.x) {
-        const uint32_t chunk = (xcd_map && (gridDim.x >= nchunks || (gridDim.x & 7u) == 0u)) ? xcd_contiguous(cidx, nchunks) : cidx;
+        const uint32_t chunk = (gridDim.x >= nchunks || (gridDim.x & 7u) == 0u) ? xcd_contiguous(cidx, nchunks) : cidx;
         if (compact && t < BPC) s_box[t] = live_box_at(lb, s_lpre, chunk * BPC + (uint32_t)t);      // (barriers follow before its use)
         // this chunk's exclusive prefix per digit: the group rows before its group + the chunk rows before it in the group
         const uint32_t g = chunk >> gshift;
@@ -1013,7 +1017,7 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
         __syncthreads();
 
         uint32_t key[ITEMS], val[ITEMS], lrank[ITEMS];
-        bool valid[ITEMS];
+        constexpr uint32_t kNoRank = 0xFFFFFFFFu;               // lrank of a position that holds no (visible) key
         // wave w owns the contiguous sub-chunk [w * 64 * ITEMS, (w + 1) * 64 * ITEMS): keeps the sort stable
         const uint32_t base = chunk * CHUNK + (uint32_t)w * (64 * ITEMS);
         // unconditional (clamped) loads, all in flight together (see ws_upsweep); n >= 1 inside this loop
@@ -1025,27 +1029,25 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
             if (CULL) vm[r] = vmask[min(base + r * 64, n - 1u) >> 6];          // wave-uniform address
             else val[r] = vals_in[ic];
         }
+        uint32_t* wcnt = s_cnt + (uint32_t)w * half;
+        // (r6: validity lives in lrank -- ITEMS lane masks in SGPR pairs across three phases were what spilled 13-30 SGPRs)
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const uint32_t i = base + r * 64 + lane;
-            valid[r] = i < n;
+            bool ok = i < n;
             if (CULL) {
-                valid[r] = valid[r] && ((vm[r] >> lane) & 1ull);
+                ok = ok && ((vm[r] >> lane) & 1ull);
                 val[r] = i;
                 if (compact) {                        // virtual position -> storage index (a row of 64 lies in one box)
                     const uint32_t e = i - chunk * CHUNK;
                     val[r] = s_box[e / kBoxSplats] * kBoxSplats + (e % kBoxSplats);
                 }
             }
-        }
-        uint32_t* wcnt = s_cnt + (uint32_t)w * half;
-#pragma unroll
-        for (int r = 0; r < ITEMS; ++r) {
             // ds_add_rtn_u32 serves the lanes of one wave instruction in ascending lane order and a wave's DS instructions
             // in program order (lds_atomic_order_probe), so the returned half-word IS the stable rank inside the wave
             const uint32_t d = (key[r] >> shift) & dmask, sh = (d & 1u) << 4;
-            lrank[r] = 0u;
-            if (valid[r]) lrank[r] = (atomicAdd(&wcnt[d >> 1], 1u << sh) >> sh) & 0xFFFFu;
+            lrank[r] = kNoRank;
+            if (ok) lrank[r] = (atomicAdd(&wcnt[d >> 1], 1u << sh) >> sh) & 0xFFFFu;
         }
         __syncthreads();
         // per digit: counts of the waves -> chunk-local exclusive positions -> per-wave bases (16 bit: < CHUNK <= 8192)
@@ -1058,9 +1060,10 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
             //  x 4 digits would be 64 registers)
             uint32_t tot[4] = {0u, 0u, 0u, 0u};
             if (own) {
+                const uint32_t* pc = s_cnt + 2u * qd;         // (a running pointer: WAVES scalar products k * half cost SGPRs)
 #pragma unroll
-                for (int k = 0; k < WAVES; ++k) {
-                    const uint2 x = *reinterpret_cast<const uint2*>(s_cnt + (uint32_t)k * half + 2u * qd);
+                for (int k = 0; k < WAVES; ++k, pc += half) {
+                    const uint2 x = *reinterpret_cast<const uint2*>(pc);
                     tot[0] += x.x & 0xFFFFu; tot[1] += x.x >> 16; tot[2] += x.y & 0xFFFFu; tot[3] += x.y >> 16;
                 }
             }
@@ -1073,9 +1076,10 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
                 const uint32_t pr[4] = {pre[kq].x, pre[kq].y, pre[kq].z, pre[kq].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) s_gd[4u * qd + j] = gbase[kq][j] + pr[j] - run[j];
+                uint32_t* ps = s_cnt + 2u * qd;
 #pragma unroll
-                for (int k = 0; k < WAVES; ++k) {
-                    uint2* slot = reinterpret_cast<uint2*>(s_cnt + (uint32_t)k * half + 2u * qd);
+                for (int k = 0; k < WAVES; ++k, ps += half) {
+                    uint2* slot = reinterpret_cast<uint2*>(ps);
                     const uint2 c = *slot;
                     uint2 x;
                     x.x = run[0] | (run[1] << 16);
@@ -1090,7 +1094,7 @@ __global__ __launch_bounds__(THREADS, ITEMS == 8 ? 4 : 2) void ws_downsweep(
         // p + s_gd[digit], so neighbouring threads write neighbouring words of a digit run
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
-            if (valid[r]) {
+            if (lrank[r] != kNoRank) {
                 const uint32_t d = (key[r] >> shift) & dmask, sh = (d & 1u) << 4;
                 const uint32_t p = ((wcnt[d >> 1] >> sh) & 0xFFFFu) + lrank[r];
                 s_keys[p] = key[r];

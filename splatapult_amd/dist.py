@@ -139,7 +139,7 @@ class RcclComm:
     """an ncclComm_t of this process's rank (rccl.h:187-260): `handle` is what msplat_band_exchange takes.
     world == 1 needs no process group; otherwise the unique id is broadcast from rank 0 over torch.distributed."""
 
-    def __init__(self, rank=0, world=1, device=0):
+    def __init__(self, rank=0, world=1, device=0, group=None):
         path = loaded_rccl_path()
         if path is None:
             raise RuntimeError("librccl not found")
@@ -156,7 +156,7 @@ class RcclComm:
             self._ok(L.ncclGetUniqueId(_C.byref(uid)), "ncclGetUniqueId")
         if world > 1:
             box = [bytes(uid)] if rank == 0 else [None]          # the raw 128 bytes (uid.internal would stop at a NUL)
-            dist.broadcast_object_list(box, src=0)
+            dist.broadcast_object_list(box, src=0, group=group)       # (group: e.g. a gloo side group; None = the default group)
             _C.memmove(_C.byref(uid), box[0], 128)
         self.handle = _C.c_void_p()
         self._ok(L.ncclCommInitRank(_C.byref(self.handle), world, uid, rank), "ncclCommInitRank")

@@ -40,6 +40,12 @@ def _check_contract(d, n):
         assert st["bytes"] > 0 and st["us"] > 0 and 0.0 < st["frac"] <= 1.0, (k, st)
     assert 0.0 < d["frame_moved_frac"] <= 1.0 and 0.0 < d["frame_moved_frac_serial"] <= 1.0
     assert "formula_frac" not in r and "frame_hbm_frac" not in d
+    # r6: the VALU view reports ACHIEVED flops (14.5 executed per evaluation) beside the nominal 20, and the share of the
+    # evaluations whose weight survives the discard; the timed phase is long enough to be seen from outside
+    v = r["valu"]
+    assert 0.0 < v["frac_of_fp32_vector_peak"] < v["frac_of_fp32_vector_peak_nominal_20_flop"] < 1.0 and v["flop_per_eval_executed"] == 14.5
+    assert 0.05 < v["useful_eval_frac"] < 1.0
+    assert d["timed_seconds"] >= 1.5 and d["timed_blocks"] >= 2 and d["block_ms"]["min"] <= d["block_ms"]["median"] <= d["block_ms"]["max"]
     tp = cfg["two_pass"]                                   # r4: what the latest two-pass frame did (None: the frames ran in one pass)
     assert tp["mode"] in ("auto", "on", "off") and set(tp) == {"mode", "timed_region", "serial_frames"}
 
@@ -83,6 +89,20 @@ def test_bench_two_ranks_one_device_control_flow():
     assert "gloo" in gc["exchange_call"] and "c_abi_exchange" not in gc
     assert "over 2 ranks" in d["config"]["sharding"] and "layout" in d["config"]["sharding"]
     assert d["gather"]["bytes_into_rank0_per_frame"] > 0
+    # r6: --layout auto calibrates msplat_band_root_weight's cost model on rank 0 and says what it found; the timed frames' exchange
+    # is named (torch's gather here: the C-ABI exchange needs RCCL, i.e. one device per rank)
+    lm = d["config"]["layout_model"]
+    assert lm["root_weight_percent"] >= 1 and lm["ms_per_bin_row"] > 0 and lm["row_bytes"] == 32 * 1920 * 16
+    assert "torch.distributed" in d["config"]["exchange"]
+    # the weighted contiguous bands through the same control flow: rank 0 owns 2.5x the rows of rank 1, gathered bit-exactly
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--no-cpu-baseline", "--also", "", "--layout", "weighted:250"] + QUICK,
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    d = _line(p.stdout)
+    assert d["gather_check"]["bit_exact"] is True and "weighted:250" in d["config"]["sharding"]
+    assert d["gather"]["bytes_into_rank0_per_frame"] == 10 * 32 * 1920 * 16          # 34 bin rows: 24 for rank 0, 10 for rank 1
 
 
 def test_bench_peer_store_check_child_mode():

@@ -989,6 +989,41 @@ def _check_window(r, img, aos, W, H, cam, proj, nf, y0, y1, render_cam=None, ren
     return ref
 
 
+def _check_whole_frame(r, img, aos, W, H, cam, proj, nf, render_cam=None, render_proj=None, fp16=False):
+    """EVERY pixel of a full-size frame (the oracle windows leave > 75 % of configs 3 / 4 / 5 to properties).
+    Checker: oracle/msplat_cpu_tiled.c -- the tiled front-to-back CPU renderer that tests/test_oracle.py holds against the literal
+    oracle -- fed the cloud in the renderer's storage order, SURVEY 8c's tolerance.  A value beyond 5e-3 (2e-3 + 1 ulp for fp16)
+    must be explained by the LITERAL oracle's threshold-flip budget for its row (orc_composite_flip over just those rows)."""
+    import os
+    import time
+    aos_s, _ = storage_aos(r, aos)
+    t0 = time.time()
+    ref = orc.render_frame_tiled(aos_s, True, cam, proj, [0, 0, W, H], nf, render_cam=render_cam, render_proj=render_proj,
+                                 nthreads=max(8, min(64, os.cpu_count() or 16)))
+    want = ref["image"]
+    assert ref["V"] == r.sort_count()
+    d = np.abs(img[..., :3].astype(np.float64) - want[..., :3].astype(np.float64))
+    lim = (2e-3 + np.abs(want[..., :3]) * 2.0 ** -10) if fp16 else np.full(d.shape, TIGHT)
+    tol = lim if fp16 else 1e-4
+    within = float((d <= tol).mean())
+    print("_check_whole_frame %dx%d: %.2f M values, max |diff| %.3g, mean %.3g, %.5f within tolerance, checker %.1f s"
+          % (W, H, d.size / 1e6, d.max(), d.mean(), within, time.time() - t0))
+    assert within >= 0.999 and d.mean() <= 1e-4, (within, d.mean())
+    assert (img[..., 3] == 1).all() and np.isfinite(img.astype(np.float32)).all()
+    over = (d > lim).any(axis=-1)
+    if over.any():
+        rows = np.unique(np.nonzero(over)[0])
+        assert len(rows) <= 64, "%d rows hold values beyond the bound (max %.3g)" % (len(rows), d.max())
+        lit = orc.render_frame(aos_s, True, cam, proj, [0, 0, W, H], nf, render_cam=render_cam, render_proj=render_proj, nthreads=32,
+                               want_image=False, want_splats=True)
+        for y in rows:
+            win, bud = orc.composite_flip(lit["splats"], W, H, nthreads=8, row0=int(y), row1=int(y) + 1)
+            dl = np.abs(img[y, :, :3].astype(np.float64) - win[y, :, :3])
+            ll = (2e-3 + np.abs(win[y, :, :3]) * 2.0 ** -10) if fp16 else TIGHT
+            assert (dl <= ll + bud[y][:, None]).all(), "row %d: max excess %.3g over the literal oracle's flip budget" % (y, (dl - ll - bud[y][:, None]).max())
+        print("_check_whole_frame: %d pixel(s) in %d row(s) beyond the bound, all inside the literal oracle's threshold-flip budget" % (over.sum(), len(rows)))
+
+
 def test_full_size_config2_sort_and_properties(cloud_1m):
     n, W, H = 1_000_000, 1920, 1080
     cloud = cloud_1m
@@ -1076,6 +1111,7 @@ def test_full_size_config3_6m_1080p(cloud_6m):
     assert np.isfinite(img).all() and (img[..., 3] == 1).all()
     _check_window(r, img, aos, W, H, cam, proj, nf, 412, 668)
     _check_window(r, img, aos, W, H, cam, proj, nf, 1056, 1080)      # the ragged top bin row (1080 = 33.75 bins)
+    _check_whole_frame(r, img, aos, W, H, cam, proj, nf)              # r6: every pixel
     _check_two_pass_at_full_size(lambda **kw: make_renderer(cloud_6m, **kw), cam, proj, vp, nf, img,
                                  window=lambda im: _check_window(r, im, aos, W, H, cam, proj, nf, 412, 668))
 
@@ -1095,6 +1131,7 @@ def test_full_size_config4_6m_4096_and_8_bands(cloud_6m):
     aos = cloud_6m.as_array()
     _check_window(r, full, aos, W, H, cam, proj, nf, 1984, 2112)
     _check_window(r, full, aos, W, H, cam, proj, nf, 4064, 4096)     # the top bin row
+    _check_whole_frame(r, full, aos, W, H, cam, proj, nf)             # r6: every one of the 16.8 M pixels
     _check_two_pass_at_full_size(lambda **kw: make_renderer(cloud_6m, **kw), cam, proj, vp, nf, full,
                                  window=lambda im: _check_window(r, im, aos, W, H, cam, proj, nf, 1984, 2112))
     from splatapult_amd import _capi
@@ -1133,6 +1170,7 @@ def test_full_size_config5_stereo_fp16(cloud_1m):
         _check_tile_lists_ascending(r)
         _check_window(r, img, aos, W, H, eyes[0], projs[0], nf, 992, 1248, render_cam=eyes[e], render_proj=projs[e], fp16=True)
         _check_window(r, img, aos, W, H, eyes[0], projs[0], nf, 2208, 2240, render_cam=eyes[e], render_proj=projs[e], fp16=True)
+        _check_whole_frame(r, img, aos, W, H, eyes[0], projs[0], nf, render_cam=eyes[e], render_proj=projs[e], fp16=True)     # r6: every pixel of both eyes
 
 
 def test_large_cloud_uses_the_wide_scan_path():

@@ -175,6 +175,18 @@ def main_fif(args):
         for lay in args.layouts.split(","):
             if lay == "auto":
                 lay = "block:%d" % max(1, R // (2 * G))
+            if lay == "weighted":
+                # r6: contiguous bands, rank 0 (the gather's root: sends nothing) weighted by the linear cost model of
+                # msplat_band_root_weight, calibrated on THIS GPU: a rank with r rows takes fixed + per_row r ms per frame (from
+                # the whole frame and one equal band in the middle of the image); the others also move r rows over their link
+                r.set_band_layout((R - R // G) // 2, R // G, R // G, max(R, 1), band_cull=True)
+                part = measure()
+                per_row = max(1e-6, (whole["ms_per_frame"] - part["ms_per_frame"]) / max(1, R - R // G))
+                fixed = max(0.0, part["ms_per_frame"] - per_row * (R // G))
+                pct = _capi.band_root_weight(R, G, fixed, per_row, T * W * bpp, XGMI_LINK / 1e9, True)
+                print("G = %d  weighted: calibration fixed %.4f ms + %.5f ms per bin row, %.0f KB per row over the link -> root weight %d %%" % (
+                    G, fixed, per_row, T * W * bpp / 1024.0, pct))
+                lay = "weighted:%d" % pct
             kind, k = (lay.split(":")[0], int(lay.split(":")[1])) if ":" in lay else (lay, 1)
             if kind == "block" and k == 1:
                 kind = "interleaved"

@@ -4,7 +4,7 @@ CXX ?= g++
 LIB = splatapult_amd/lib/libmsplat.so
 SRC = splatapult_amd/csrc/msplat_device.hip splatapult_amd/csrc/msplat_group.hip splatapult_amd/host/gaussian_scene.cpp splatapult_amd/host/scene_config.cpp \
       splatapult_amd/host/point_scene.cpp
-HDR = $(wildcard splatapult_amd/csrc/*.hip.h) splatapult_amd/host/gaussian_scene.hpp splatapult_amd/host/scene_config.hpp \
+HDR = $(wildcard splatapult_amd/csrc/*.hip.h) $(wildcard splatapult_amd/csrc/*.hip.inc) splatapult_amd/host/gaussian_scene.hpp splatapult_amd/host/scene_config.hpp \
       splatapult_amd/host/point_scene.hpp include/msplat.h include/msplat_debug.h
 
 all: $(LIB) examples

@@ -87,7 +87,7 @@ FLOP_PER_EVAL = 20.0     # ~20 flop + 1 transcendental per (pixel,
 # = 58 flop, and 4 v_exp_f32): 14.5 flop + 1 transcendental
 FLOP_PER_EVAL_EXECUTED = 14.5
 MIN_TIMED_SECONDS = 2.0  # r6: the timed GPU phase lasts long enough for an outside observer (the driver's SMI sampler) to see it
-MAX_BLOCKS = 1200
+MAX_BLOCKS = 4000
 
 
 class Env:

@@ -145,7 +145,7 @@ struct msplat_ctx {
     // table per pass, one visibility bit per splat, the visible set's minimum key per frame parity (counters[10..11])
     Buf wsHist, wsGsum[3], vmask;
     Buf live_list, live_cnt;    // live bounding boxes of the latest Sort that ran box_cull_kernel (spatially ordered clouds)
-    int spatial_mode = 0;       // msplat_config.spatial_order / MSPLAT_SPATIAL_ORDER: 0 auto, 1 always, 2 never
+    int spatial_mode = 0;       // msplat_config.spatial_order: 0 auto, 1 always, 2 never
     bool last_sort_listed = false;   // the latest Sort's pass 0 walked the listed boxes only
     FrameParams last_sort_fp{};
     uint32_t ws_items = 8, ws_gshift = 4, ws_gsum_words = 0;
@@ -157,7 +157,7 @@ struct msplat_ctx {
     bool tables_dirty = false;  // a launch failed: clear every self-cleaning table before the next frame
     // per-bin pair counts taken by the row pass's upsweep (r3): list offsets + work order without tile_start_kernel
     Buf bincnt;
-    bool bin_counts = true;     // MSPLAT_TILE_TABLE=search (and contexts with frames in flight): tile_start_kernel / tile_order_kernel
+    bool bin_counts = true;     // contexts with frames in flight: tile_start_kernel / tile_order_kernel (measured r3 / r5: the better form there)
     // (XCD-contiguous chunk ranges: on for the sort's downsweeps -- 6 M splats 196 -> 185 us, no change at 1 M -- and the row
     //  pass's downsweep -- 6 M / 4096^2 binning 347 -> 327 us: a column's chunks write adjacent runs of every row --, off for the
     //  column pass's downsweep, where they were measured slower: 453 -> 509 us.  Fixed since r4.)
@@ -189,7 +189,7 @@ struct msplat_ctx {
     Buf hist2;      // uint32[256 * hist2_stride]
     uint32_t hist2_stride = 0;
     Buf fb;         // internal framebuffer for host-output renders
-    Buf probe;      // uint32[8 * work items] compositor probe (msplat_set_tile_probe / MSPLAT_TILE_PROBE=1)
+    Buf probe;      // uint32[8 * work items] compositor probe (msplat_set_tile_probe)
     bool probe_on = false;
     // device-output renders never synchronise: a pair-buffer overflow is left in host-mapped memory by the
     // binning kernel and picked up by the next call on the context (poll_async_overflow)
@@ -233,7 +233,7 @@ struct msplat_ctx {
 
     std::unique_ptr<AsyncWorker> worker;     // msplat_config.async_submit
     bool atomic_rank = true;    // LDS atomics hand out ranks in lane order (probed at create)
-    int comp_waves = 8192;      // compositor grid (persistent waves; measured best of 2k..8k); MSPLAT_COMP_WAVES overrides
+    int comp_waves = 8192;      // compositor grid (persistent waves; measured best of 2k..8k); msplat_config.compositor_waves overrides
     bool comp_waves_auto = true;   // nobody chose a pool size: up to 20 k work items every item gets its own wave (r2: a wave
                                    // that pulls a second item pays an atomic + two dependent loads; 17.6 k items: -8 %)
     uint64_t device_bytes = 0;
@@ -390,11 +390,6 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
     if (rc == MSPLAT_OK) rc = buf_alloc(ctx, ctx->tile_order, 2 * 65536 * sizeof(uint32_t));
 
     if (c.compositor_waves > 0) { ctx->comp_waves = std::max(64, (int)c.compositor_waves); ctx->comp_waves_auto = false; }
-    if (getenv("MSPLAT_COMP_WAVES")) { ctx->comp_waves = std::max(64, atoi(getenv("MSPLAT_COMP_WAVES"))); ctx->comp_waves_auto = false; }
-    if (rc == MSPLAT_OK && getenv("MSPLAT_TILE_PROBE") != nullptr) {
-        rc = buf_alloc(ctx, ctx->probe, kProbeBytes);
-        ctx->probe_on = rc == MSPLAT_OK;
-    }
     if (rc == MSPLAT_OK) {
         if (hipHostMalloc((void**)&ctx->h_flags, 64, hipHostMallocMapped) != hipSuccess ||
             hipHostGetDevicePointer((void**)&ctx->d_flags, ctx->h_flags, 0) != hipSuccess)
@@ -415,7 +410,7 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         if (hipMemcpyAsync(&hbad, bad, sizeof(hbad), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess)
             rc = fail(ctx, MSPLAT_ERR_HIP, "LDS atomic order probe failed to run");
-        ctx->atomic_rank = (hbad == 0) && c.rank_mode != MSPLAT_RANK_BALLOT && getenv("MSPLAT_BALLOT_RANK") == nullptr;
+        ctx->atomic_rank = (hbad == 0) && c.rank_mode != MSPLAT_RANK_BALLOT;
         ctx->scan_free = getenv("MSPLAT_SCAN_KERNELS") == nullptr;
         // frames in flight: kernels that co-schedule well (msplat.h); AUTO and any stale padding value = one frame at a time
         ctx->wide_sort = true;
@@ -423,9 +418,7 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         ctx->bin_counts = c.frame_mode != MSPLAT_FRAMES_IN_FLIGHT;
         if (const char* sk = getenv("MSPLAT_SORT")) ctx->wide_sort = std::string(sk) != "lsd8";
         if (!ctx->atomic_rank) ctx->wide_sort = false;       // the wide kernels rank with lane-ordered LDS atomics only
-        if (const char* tk = getenv("MSPLAT_TILE_TABLE")) ctx->bin_counts = std::string(tk) != "search";
         ctx->spatial_mode = c.spatial_order;
-        if (const char* so = getenv("MSPLAT_SPATIAL_ORDER")) ctx->spatial_mode = atoi(so) != 0 ? MSPLAT_SPATIAL_ON : MSPLAT_SPATIAL_OFF;
         if (ctx->wide_sort) {
             // ws_downsweep needs 72 / 104 KB of dynamic LDS with 512 threads (40 / 56 KB with 256).  The attribute belongs to
             // the function ON A DEVICE (a kernel object per device): it is requested once per device, with that device current
@@ -650,33 +643,6 @@ void* msplat_get_stream(msplat_ctx* ctx) { return ctx ? (void*)ctx->stream : nul
 
 int msplat_get_fb_format(const msplat_ctx* ctx) { return ctx ? ctx->cfg.fb_format : -1; }
 
-#ifdef MSPLAT_STAMPS
-// diagnostic build only (msplat_common.hip.h, MSPLAT_STAMP): switch the workgroup stamps of the current device on / off, read the
-// table (and clear it).  enable != 0 allocates 2^log2_slots records of 32 bytes at the first call.
-static msplat::StampRec* g_stamps_dev = nullptr;
-static uint32_t g_stamps_slots = 0;
-int msplat_debug_stamps(int enable, uint32_t log2_slots)
-{
-    if (enable && !g_stamps_dev) {
-        g_stamps_slots = 1u << std::min(26u, std::max(10u, log2_slots));
-        if (hipMalloc((void**)&g_stamps_dev, (size_t)g_stamps_slots * sizeof(msplat::StampRec)) != hipSuccess) return MSPLAT_ERR_HIP;
-        if (hipMemset(g_stamps_dev, 0, (size_t)g_stamps_slots * sizeof(msplat::StampRec)) != hipSuccess) return MSPLAT_ERR_HIP;
-        if (hipMemcpyToSymbol(HIP_SYMBOL(msplat::g_stamp_buf), &g_stamps_dev, sizeof(g_stamps_dev)) != hipSuccess) return MSPLAT_ERR_HIP;
-    }
-    if (hipDeviceSynchronize() != hipSuccess) return MSPLAT_ERR_HIP;
-    const uint32_t mask = (enable && g_stamps_dev) ? g_stamps_slots - 1u : 0u;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(msplat::g_stamp_mask), &mask, sizeof(mask)) != hipSuccess) return MSPLAT_ERR_HIP;
-    return hipDeviceSynchronize() == hipSuccess ? (int)g_stamps_slots : MSPLAT_ERR_HIP;
-}
-int msplat_debug_stamps_read(void* dst, uint64_t bytes)
-{
-    if (!g_stamps_dev || !dst) return MSPLAT_ERR_INVALID_ARG;
-    const size_t n = std::min<size_t>(bytes, (size_t)g_stamps_slots * sizeof(msplat::StampRec));
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(dst, g_stamps_dev, n, hipMemcpyDeviceToHost) != hipSuccess) return MSPLAT_ERR_HIP;
-    if (hipMemset(g_stamps_dev, 0, (size_t)g_stamps_slots * sizeof(msplat::StampRec)) != hipSuccess) return MSPLAT_ERR_HIP;
-    return MSPLAT_OK;
-}
-#endif
 
 // Makes `stream` (a hipStream_t, NULL = the legacy default stream) wait for everything enqueued so far on
 // the context's stream, without blocking the host.
@@ -709,649 +675,9 @@ int msplat_wait_event(msplat_ctx* ctx, void* event)
     return MSPLAT_OK;
 }
 
-// group table for `nchunks` chunk rows, zero-filled (the stream is idle whenever buffers are (re)allocated)
-static int alloc_group_table(msplat_ctx* ctx, Buf& b, uint32_t& rows, uint64_t nchunks, uint32_t& sup)
-{
-    sup = (uint32_t)((nchunks >> kSuperShift) + 2);                      // supergroup rows first, then the group rows
-    rows = (uint32_t)(sup + (nchunks >> kGroupShift) + 2);
-    int rc = buf_alloc(ctx, b, (size_t)rows * 256 * sizeof(uint32_t));
-    if (rc) return rc;
-    rows = (uint32_t)(b.bytes / (256 * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMemsetAsync(b.p, 0, b.bytes, ctx->stream));
-    return MSPLAT_OK;
-}
+#include "msplat_upload.hip.inc"
 
-static int ensure_pair_capacity(msplat_ctx* ctx, uint64_t cap)
-{
-    if (cap > 0x7FFFFFFFull) cap = 0x7FFFFFFFull;
-    if (ctx->pair_cap >= cap && ctx->pairsA.p) return MSPLAT_OK;
-    int rc = buf_alloc(ctx, ctx->pairsA, cap * sizeof(uint32_t));
-    if (rc) return rc;
-    rc = buf_alloc(ctx, ctx->pairsB, cap * sizeof(uint32_t));
-    if (rc) return rc;
-    ctx->hist2_stride = div_up(cap, kPairChunk);
-    rc = buf_alloc(ctx, ctx->hist2, (size_t)256 * ctx->hist2_stride * sizeof(uint32_t));
-    if (rc) return rc;
-    rc = alloc_group_table(ctx, ctx->gsumB2, ctx->gsumB2_rows, ctx->hist2_stride, ctx->gsupB2);
-    if (rc) return rc;
-    ctx->pair_cap = cap;
-    return MSPLAT_OK;
-}
-
-// (re)allocates every per-cloud device buffer for n splats; leaves the context without a cloud.
-// `share` != null: use that store's cloud instead of allocating one (msplat_attach_cloud).
-static int prepare_cloud_buffers(msplat_ctx* ctx, uint64_t n, bool full_sh, const std::shared_ptr<CloudStore>& share)
-{
-    if (n > (1ull << 24))
-        return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "%llu splats > 2^24 (rank field is 24 bit)", (unsigned long long)n);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->has_cloud = false;
-    ctx->has_sort = false;
-    ctx->has_render = false;
-    ctx->N = n;
-    ctx->full_sh = full_sh;
-    const int F4 = ctx->point_mode ? 1 : (ctx->full_sh ? 16 : 8);
-    const size_t alloc_n = std::max<uint64_t>(n, 1);
-    int rc;
-    if (share) {
-        if (ctx->store && ctx->store != share && ctx->store.use_count() == 1)
-            ctx->device_bytes -= ctx->store->pos4.bytes + ctx->store->recs.bytes;
-        ctx->store = share;
-    } else {
-        const size_t need_pos = alloc_n * 16, need_rec = alloc_n * F4 * 16;
-        const bool reuse = ctx->store && ctx->store.use_count() == 1 && ctx->store->pos4.bytes >= need_pos &&
-                           ctx->store->recs.bytes >= need_rec;
-        if (!reuse) {
-            if (ctx->store && ctx->store.use_count() == 1)
-                ctx->device_bytes -= ctx->store->pos4.bytes + ctx->store->recs.bytes;
-            ctx->pos4 = Buf{};
-            ctx->recs = Buf{};
-            ctx->store.reset();
-            auto st = std::make_shared<CloudStore>();
-            st->device = ctx->device;
-            HIP_TRY(ctx, hipMalloc(&st->pos4.p, need_pos));
-            st->pos4.bytes = need_pos;
-            HIP_TRY(ctx, hipMalloc(&st->recs.p, need_rec));
-            st->recs.bytes = need_rec;
-            ctx->device_bytes += need_pos + need_rec;
-            ctx->store = st;
-        }
-        // a fresh upload starts in upload order (spatial_reorder runs once the cloud is on the device)
-        ctx->store->reordered = false;
-        ctx->store->order_host.clear();
-        if (ctx->store->boxes.p) { (void)hipFree(ctx->store->boxes.p); ctx->store->boxes = Buf{}; }
-        ctx->store->nboxes = 0;
-    }
-    ctx->pos4 = ctx->store->pos4;
-    ctx->recs = ctx->store->recs;
-    if ((rc = buf_alloc(ctx, ctx->keyA, alloc_n * 4))) return rc;
-    if ((rc = buf_alloc(ctx, ctx->keyB, alloc_n * 4))) return rc;
-    if ((rc = buf_alloc(ctx, ctx->valA, alloc_n * 4))) return rc;
-    if ((rc = buf_alloc(ctx, ctx->valB, alloc_n * 4))) return rc;
-    ctx->hist_stride = std::max(1u, div_up(n, kSortChunk));
-    if ((rc = buf_alloc(ctx, ctx->hist, (size_t)256 * ctx->hist_stride * 4))) return rc;
-    uint32_t rows_s0 = 0;
-    if ((rc = alloc_group_table(ctx, ctx->gsumS[0], rows_s0, ctx->hist_stride, ctx->gsupS))) return rc;
-    if ((rc = alloc_group_table(ctx, ctx->gsumS[1], ctx->gsumS_rows, ctx->hist_stride, ctx->gsupS))) return rc;
-    ctx->gsumS_rows = std::min(ctx->gsumS_rows, rows_s0);
-    // frames in flight (256-thread form): three passes up to 2 M splats, the four 8-bit passes beyond -- measured r3 with 4
-    // frames in flight: 1 M 6045 vs 5880 frames/s, 6 M 1497 vs 1616 (tools/archive/gpu_round3_ab5.sh)
-    ctx->wide_sort = ctx->wide_sort_cfg && (ctx->ws_threads == (uint32_t)kWsThreads || n <= (2u << 20) || ctx->ws_forced);
-    if (ctx->wide_sort) {
-        // 4096-key chunks up to 2 M splats, 8192 beyond; groups of 16 chunk rows while
-        // there are at most 512 rows, else of 32 (a downsweep sums <= nchunks / G + G - 1 rows)
-        ctx->ws_items = n > (2u << 20) ? 16u : 8u;
-        // (the tables are sized for 8 keys per thread: passes 1 and 2 drop to that when few splats survive the cull, below)
-        const uint32_t nch = std::max(1u, div_up(n, (uint64_t)ctx->ws_threads * 8u));
-        ctx->ws_gshift = nch <= 512u ? 4u : 5u;
-        if ((rc = buf_alloc(ctx, ctx->wsHist, (size_t)nch * kWsMaxBins * 4))) return rc;
-        const size_t gwords = (size_t)((nch >> ctx->ws_gshift) + 2) * kWsMaxBins;
-        for (auto& g : ctx->wsGsum) {
-            if ((rc = buf_alloc(ctx, g, gwords * 4))) return rc;
-            HIP_TRY(ctx, hipMemsetAsync(g.p, 0, g.bytes, ctx->stream));
-        }
-        ctx->ws_gsum_words = (uint32_t)gwords;
-        if ((rc = buf_alloc(ctx, ctx->vmask, (size_t)div_up(alloc_n, 64) * 8 + 64))) return rc;
-    }
-    if ((rc = buf_alloc(ctx, ctx->live_list, ((size_t)div_up(div_up(alloc_n, kBoxSplats), kBoxGroup) * kBoxGroup + 16) * 4))) return rc;
-    if ((rc = buf_alloc(ctx, ctx->live_cnt, 256 * 4))) return rc;
-    ctx->rank_cap = alloc_n;
-    if ((rc = buf_alloc(ctx, ctx->rec2d, alloc_n * 48))) return rc;
-    if ((rc = buf_alloc(ctx, ctx->rect, alloc_n * 4))) return rc;
-    if (ctx->depth_bits != 0 && (rc = buf_alloc(ctx, ctx->zq, alloc_n * 4))) return rc;
-    // (column pass: 1024-rank chunks; 2048 measured r3 at 6 M: binning 183 -> 191 us at 1080p, 459 -> 453 us at 4096^2)
-    if ((rc = buf_alloc(ctx, ctx->heavy, (size_t)2 * (1 + kHeavyCap) * 4))) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->heavy.p, 0, ctx->heavy.bytes, ctx->stream));
-    if ((rc = buf_alloc(ctx, ctx->heavy_flag, (size_t)div_up(alloc_n, kBinChunk) + 64))) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->heavy_flag.p, 0, ctx->heavy_flag.bytes, ctx->stream));
-    ctx->hist1_stride = std::max(1u, div_up(n, kBinChunk));
-    if ((rc = buf_alloc(ctx, ctx->hist1, (size_t)256 * ctx->hist1_stride * 4))) return rc;
-    if ((rc = alloc_group_table(ctx, ctx->gsumB1, ctx->gsumB1_rows, ctx->hist1_stride, ctx->gsupB1))) return rc;
-    uint64_t cap = ctx->cfg.pair_capacity ? ctx->cfg.pair_capacity
-                                          : std::max<uint64_t>(1ull << 22, std::min<uint64_t>(32 * n, 1ull << 30));
-    return ensure_pair_capacity(ctx, cap);
-}
-
-static void launch_scan(hipStream_t s, bool small, uint32_t* hist, uint32_t hist_stride, const uint32_t* d_n,
-                        uint32_t n_static, uint32_t n_cap, uint32_t chunk, uint32_t* totals);
-
-// Spatial storage order (r4, msplat_common.hip.h: box_live).  Called at the end of an upload, the cloud being on the device in
-// UPLOAD order: Morton codes of the positions, a stable sort of (code, upload index) with the library's own 8-bit radix passes,
-// the cloud gathered into that order, one bounding box per kBoxSplats slots.  From then on slot j holds upload index
-// order_host[j]; everything that reports splat numbers (msplat_get_sorted_indices, msplat_download_cloud) maps back.
-// Draw order = ascending key, ties in ascending STORAGE slot: for a cloud that is not reordered that is the upload index.
-// Out of device memory for the second copy: the cloud simply stays in upload order.
-static int spatial_reorder(msplat_ctx* ctx)
-{
-    const uint64_t n64 = ctx->N;
-    const bool want = !ctx->point_mode && n64 > 1 &&
-                      (ctx->spatial_mode == MSPLAT_SPATIAL_ON || (ctx->spatial_mode == MSPLAT_SPATIAL_AUTO && n64 >= kSpatialMinSplats));
-    if (!want) return MSPLAT_OK;
-    CloudStore& st = *ctx->store;
-    hipStream_t s = ctx->stream;
-    const uint32_t N = (uint32_t)n64;
-    const int F4 = ctx->full_sh ? 16 : 8;
-    const size_t need_pos = (size_t)N * 16, need_rec = (size_t)N * F4 * 16;
-    void *npos = nullptr, *nrec = nullptr;
-    if (hipMalloc(&npos, need_pos) != hipSuccess || hipMalloc(&nrec, need_rec) != hipSuccess) {
-        (void)hipGetLastError();
-        if (npos) (void)hipFree(npos);
-        return MSPLAT_OK;
-    }
-    double* acc = (double*)ctx->totals1.p;          // 1 KB, idle outside a render
-    uint32_t *kA = (uint32_t*)ctx->keyA.p, *kB = (uint32_t*)ctx->keyB.p, *vA = (uint32_t*)ctx->valA.p, *vB = (uint32_t*)ctx->valB.p;
-    const float4* pos = (const float4*)st.pos4.p;
-    const uint32_t mrows = std::min(div_up(N, kThreads), 1024u);
-    void* mpart = nullptr;
-    hipError_t e = hipMalloc(&mpart, (size_t)mrows * kMoments * sizeof(double));
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        (void)hipFree(npos); (void)hipFree(nrec);
-        return MSPLAT_OK;
-    }
-    hipLaunchKernelGGL(cloud_moments_kernel, dim3(mrows), dim3(kThreads), 0, s, pos, N, (double*)mpart);
-    hipLaunchKernelGGL(cloud_moments_finish, dim3(1), dim3(kThreads), 0, s, (const double*)mpart, mrows, acc);
-    hipLaunchKernelGGL(morton_kernel, dim3(div_up(N, kThreads)), dim3(kThreads), 0, s, pos, N, (const double*)acc, kA, vA);
-    const bool large = n64 > (2u << 20);
-    const uint32_t chunk = (uint32_t)kThreads * (large ? kSortItemsLarge : kSortItems);
-    const int grid = grid_for(div_up(N, chunk));
-    FrameParams fp0;
-    std::memset(&fp0, 0, sizeof(fp0));
-    uint32_t* hist = (uint32_t*)ctx->hist.p;
-    uint32_t* totals = (uint32_t*)ctx->totals.p;
-    for (int pass = 0; pass < 4; ++pass) {          // A -> B -> A -> B -> A
-        uint32_t *kin = (pass & 1) ? kB : kA, *vin = (pass & 1) ? vB : vA, *kout = (pass & 1) ? kA : kB, *vout = (pass & 1) ? vA : vB;
-#define MSPLAT_SP_UP(IT) hipLaunchKernelGGL((radix_upsweep<MODE_KEYS, IT>), dim3(grid), dim3(kThreads), 0, s, (const uint32_t*)kin, \
-        (const float4*)nullptr, (const uint32_t*)nullptr, N, N, pass * 8, hist, ctx->hist_stride, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, fp0)
-#define MSPLAT_SP_DOWN(AR, IT) hipLaunchKernelGGL((radix_downsweep<MODE_KEYS, true, AR, IT>), dim3(grid), dim3(kThreads), 0, s, \
-        (const uint32_t*)kin, (const uint32_t*)vin, (const float4*)nullptr, (const uint32_t*)nullptr, N, N, pass * 8, (const uint32_t*)hist, \
-        ctx->hist_stride, (const uint32_t*)totals, kout, vout, (uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr,     \
-        (uint32_t*)nullptr, fp0)
-        if (large) MSPLAT_SP_UP(kSortItemsLarge); else MSPLAT_SP_UP(kSortItems);
-        launch_scan(s, !large, hist, ctx->hist_stride, nullptr, N, N, chunk, totals);
-        if (large) { if (ctx->atomic_rank) MSPLAT_SP_DOWN(true, kSortItemsLarge); else MSPLAT_SP_DOWN(false, kSortItemsLarge); }
-        else { if (ctx->atomic_rank) MSPLAT_SP_DOWN(true, kSortItems); else MSPLAT_SP_DOWN(false, kSortItems); }
-#undef MSPLAT_SP_UP
-#undef MSPLAT_SP_DOWN
-    }
-    hipLaunchKernelGGL(gather_cloud_kernel, dim3(2048), dim3(kThreads), 0, s, (const uint32_t*)vA, N, F4, pos,
-                       (const float4*)st.recs.p, (float4*)npos, (float4*)nrec);
-    const uint32_t nboxes = div_up(N, kBoxSplats);
-    void* nbox = nullptr;
-    if (e == hipSuccess) e = hipMalloc(&nbox, (size_t)nboxes * sizeof(CullBox));
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(cull_boxes_kernel, dim3(nboxes), dim3(kThreads), 0, s, (const float4*)npos, N, (CullBox*)nbox);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) {
-        try {
-            st.order_host.resize(N);
-        } catch (const std::exception&) {
-            e = hipErrorOutOfMemory;
-        }
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(st.order_host.data(), vA, (size_t)N * 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(mpart);
-    if (e != hipSuccess) {
-        (void)hipFree(npos); (void)hipFree(nrec);
-        if (nbox) (void)hipFree(nbox);
-        st.order_host.clear();
-        return fail(ctx, MSPLAT_ERR_HIP, "spatial reordering of the cloud failed: %s", hipGetErrorString(e));
-    }
-    (void)hipFree(st.pos4.p); (void)hipFree(st.recs.p);
-    st.pos4.p = npos; st.pos4.bytes = need_pos;
-    st.recs.p = nrec; st.recs.bytes = need_rec;
-    st.boxes.p = nbox; st.boxes.bytes = (size_t)nboxes * sizeof(CullBox);
-    st.nboxes = nboxes;
-    st.reordered = true;
-    ctx->pos4 = st.pos4;
-    ctx->recs = st.recs;
-    return MSPLAT_OK;
-}
-
-int msplat_upload_cloud(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t stride_bytes,
-                        const msplat_attr_offsets* off, int full_sh)
-{
-    drain_async(ctx);
-    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
-    if ((!aos && n) || !off) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_upload_cloud: NULL argument");
-    if (stride_bytes % 4 != 0) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "stride must be a multiple of 4");
-    ctx->point_mode = false;
-    int rc = prepare_cloud_buffers(ctx, n, full_sh != 0, nullptr);
-    if (rc) return rc;
-    const int F4 = ctx->full_sh ? 16 : 8;
-
-    // repack: reference AoS (100 B / 244 B, arbitrary offsets) -> 16-byte aligned padded records with the
-    // reference's float order (gaussiancloud.cpp:32-56), plus the vec4(x,y,z,1) array of splatrenderer.cpp:106-111
-    const size_t chunk = 1u << 18;
-    std::vector<float> stage_rec, stage_pos;
-    try {      // the C ABI never throws
-        stage_rec.resize(chunk * F4 * 4);
-        stage_pos.resize(chunk * 4);
-    } catch (const std::exception&) {
-        return fail(ctx, MSPLAT_ERR_HIP, "msplat_upload_cloud: out of host memory for the staging buffers");
-    }
-    const uint32_t src_off_base[7] = {off->pos_with_alpha, off->r_sh0, off->g_sh0, off->b_sh0,
-                                      off->cov3_col0, off->cov3_col1, off->cov3_col2};
-    const uint32_t src_off_full[9] = {off->r_sh1, off->r_sh2, off->r_sh3, off->g_sh1, off->g_sh2, off->g_sh3,
-                                      off->b_sh1, off->b_sh2, off->b_sh3};
-    const uint32_t max_need = ctx->full_sh ? 16 : 12;
-    for (int k = 0; k < 7; ++k)
-        if (src_off_base[k] + (k < 4 ? 16u : 12u) > stride_bytes)
-            return fail(ctx, MSPLAT_ERR_INVALID_ARG, "attribute offset %u beyond stride %u", src_off_base[k], stride_bytes);
-    if (ctx->full_sh)
-        for (int k = 0; k < 9; ++k)
-            if (src_off_full[k] + 16u > stride_bytes)
-                return fail(ctx, MSPLAT_ERR_INVALID_ARG, "attribute offset %u beyond stride %u", src_off_full[k], stride_bytes);
-    (void)max_need;
-    const uint8_t* src = static_cast<const uint8_t*>(aos);
-    for (uint64_t base = 0; base < n; base += chunk) {
-        const size_t cnt = (size_t)std::min<uint64_t>(chunk, n - base);
-        for (size_t j = 0; j < cnt; ++j) {
-            const uint8_t* rec = src + (base + j) * stride_bytes;
-            float* d = stage_rec.data() + j * F4 * 4;
-            std::memcpy(d + 0, rec + off->pos_with_alpha, 16);
-            std::memcpy(d + 4, rec + off->r_sh0, 16);
-            std::memcpy(d + 8, rec + off->g_sh0, 16);
-            std::memcpy(d + 12, rec + off->b_sh0, 16);
-            std::memcpy(d + 16, rec + off->cov3_col0, 12);
-            std::memcpy(d + 19, rec + off->cov3_col1, 12);
-            std::memcpy(d + 22, rec + off->cov3_col2, 12);
-            if (ctx->full_sh) {
-                for (int k = 0; k < 9; ++k) std::memcpy(d + 25 + 4 * k, rec + src_off_full[k], 16);
-                d[61] = d[62] = d[63] = 0.0f;
-            } else {
-                for (int k = 25; k < 32; ++k) d[k] = 0.0f;
-            }
-            float* p = stage_pos.data() + j * 4;
-            p[0] = d[0]; p[1] = d[1]; p[2] = d[2]; p[3] = footprint_bound(d + 16, d[3]);      // .w: footprint bound for the band cull
-        }
-        HIP_TRY(ctx, hipMemcpy((char*)ctx->recs.p + base * F4 * 16, stage_rec.data(), cnt * F4 * 16, hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMemcpy((char*)ctx->pos4.p + base * 16, stage_pos.data(), cnt * 16, hipMemcpyHostToDevice));
-    }
-    if ((rc = spatial_reorder(ctx))) return rc;
-    ctx->has_cloud = true;
-    return MSPLAT_OK;
-}
-
-
-// GPU ingest: GaussianCloud::ImportPly's per-vertex math (gaussiancloud.cpp:254-361) as a HIP kernel over
-// the raw PLY vertex block -- SURVEY.md 8f-1.  `vertices` is host memory (n * layout->vertex_size bytes).
-int msplat_upload_ply_vertices(msplat_ctx* ctx, const void* vertices, uint64_t n, const msplat_ply_layout* layout,
-                               int full_sh)
-{
-    drain_async(ctx);
-    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
-    if ((!vertices && n) || !layout) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_upload_ply_vertices: NULL argument");
-    const uint32_t vs = layout->vertex_size;
-    if (vs == 0 || vs % 4 != 0 || vs > 1024)
-        return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "vertex size %u must be a multiple of 4 in (0, 1024]", vs);
-    const int32_t* offs = &layout->x;
-    constexpr int kProps = 3 + 3 + 45 + 1 + 3 + 4;     // x y z, f_dc, f_rest, opacity, scale, rot
-    static_assert(sizeof(msplat_ply_layout) == 4 + 4 * kProps, "msplat_ply_layout must be packed int32s");
-    for (int k = 0; k < kProps; ++k)
-        if (offs[k] >= 0 && ((uint32_t)offs[k] + 4u > vs || offs[k] % 4 != 0))
-            return fail(ctx, MSPLAT_ERR_INVALID_ARG, "property offset %d outside / misaligned in a %u-byte vertex", offs[k], vs);
-    bool has_rest = true;
-    for (int k = 0; k < 45; ++k) has_rest = has_rest && layout->f_rest[k] >= 0;
-    const bool full = full_sh != 0 && has_rest;      // f_rest is optional (gaussiancloud.cpp:188-205)
-    ctx->point_mode = false;
-    int rc = prepare_cloud_buffers(ctx, n, full, nullptr);
-    if (rc) return rc;
-    if (n) {
-        Buf raw;
-        if ((rc = buf_alloc(ctx, raw, (size_t)n * vs + 16))) return rc;
-        hipError_t e = hipMemcpyAsync(raw.p, vertices, (size_t)n * vs, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) {
-            const int grid = (int)div_up(n, 64);
-            const size_t lds = (size_t)64 * vs + 16;
-            PlyLayout kl;
-            static_assert(sizeof(PlyLayout) == sizeof(msplat_ply_layout), "layout mirror out of sync");
-            std::memcpy(&kl, layout, sizeof(kl));
-            if (full)
-                hipLaunchKernelGGL(ingest_kernel<true>, dim3(grid), dim3(64), lds, ctx->stream, (const char*)raw.p, n,
-                                   kl, (float4*)ctx->pos4.p, (float4*)ctx->recs.p);
-            else
-                hipLaunchKernelGGL(ingest_kernel<false>, dim3(grid), dim3(64), lds, ctx->stream, (const char*)raw.p, n,
-                                   kl, (float4*)ctx->pos4.p, (float4*)ctx->recs.p);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        buf_free(ctx, raw);
-        if (e != hipSuccess) return fail(ctx, MSPLAT_ERR_HIP, "GPU ingest failed: %s", hipGetErrorString(e));
-    }
-    if ((rc = spatial_reorder(ctx))) return rc;
-    ctx->has_cloud = true;
-    return MSPLAT_OK;
-}
-
-// ---- point clouds ------------------------------------------------------------------------
-static int build_sprite(msplat_ctx* ctx, const uint8_t* rgba8, uint32_t w, uint32_t h)
-{
-    // level 0 exactly as the reference prepares the texture: rows flipped so that t = 0 is the image's bottom row
-    // (core/image.cpp:108-111), colour pre-multiplied by alpha in 8 bits with truncation (image.cpp:144-157),
-    // texels decoded sRGB -> linear when the texture is flagged sRGB (pointrenderer.cpp:60, core/texture.cpp:63-70)
-    std::vector<uint8_t> builtin;
-    if (!rgba8) {
-        // built-in sprite: a shaded sphere, alpha 1 inside the disc with a one-texel soft rim
-        w = h = 128;
-        builtin.resize((size_t)w * h * 4);
-        for (uint32_t j = 0; j < h; ++j)
-            for (uint32_t i = 0; i < w; ++i) {
-                const float x = ((float)i + 0.5f) / (0.5f * w) - 1.0f, y = ((float)j + 0.5f) / (0.5f * h) - 1.0f;
-                const float d = std::sqrt(x * x + y * y);
-                const float a = std::min(1.0f, std::max(0.0f, (1.0f - d) * (0.5f * w)));
-                const float shade = 0.35f + 0.65f * std::sqrt(std::max(0.0f, 1.0f - d * d));
-                uint8_t* o = &builtin[((size_t)j * w + i) * 4];
-                o[0] = o[1] = o[2] = (uint8_t)(shade * 255.0f + 0.5f);
-                o[3] = (uint8_t)(a * 255.0f + 0.5f);
-            }
-        rgba8 = builtin.data();
-    }
-    if (w == 0 || h == 0 || w > 8192 || h > 8192) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "sprite size %ux%u outside [1,8192]^2", w, h);
-    SpriteParams sp{};
-    sp.w = (int)w;
-    sp.h = (int)h;
-    std::vector<float> chain;
-    chain.resize((size_t)w * h * 4);
-    const bool srgb = ctx->cfg.srgb != 0;
-    for (uint32_t j = 0; j < h; ++j)
-        for (uint32_t i = 0; i < w; ++i) {
-            const uint8_t* s = rgba8 + ((size_t)(h - 1 - j) * w + i) * 4;
-            float* o = &chain[((size_t)j * w + i) * 4];
-            const float alpha = (float)s[3] / 255.0f;
-            for (int c = 0; c < 3; ++c) {
-                const uint8_t pm = (uint8_t)((((float)s[c] / 255.0f) * alpha) * 255.0f);
-                const float v = (float)pm / 255.0f;
-                o[c] = srgb ? (v <= 0.04045f ? v / 12.92f : std::pow((v + 0.055f) / 1.055f, 2.4f)) : v;
-            }
-            o[3] = alpha;
-        }
-    // mip chain: 2x2 box filter down to 1x1, every level stored at 8 bits like the GL_RGBA8 / GL_SRGB8_ALPHA8 texture's own
-    // levels (glGenerateMipmap, core/texture.cpp:76)
-    int lw = (int)w, lh = (int)h, level = 0;
-    size_t off = 0;
-    sp.off[0] = 0;
-    while ((lw > 1 || lh > 1) && level + 1 < 14) {
-        const int nw = std::max(lw / 2, 1), nh = std::max(lh / 2, 1);
-        const size_t noff = off + (size_t)lw * lh;
-        chain.resize((noff + (size_t)nw * nh) * 4);
-        for (int j = 0; j < nh; ++j)
-            for (int i = 0; i < nw; ++i) {
-                const int i0 = std::min(2 * i, lw - 1), i1 = std::min(2 * i + 1, lw - 1);
-                const int j0 = std::min(2 * j, lh - 1), j1 = std::min(2 * j + 1, lh - 1);
-                for (int c = 0; c < 4; ++c) {
-                    const float a = chain[(off + (size_t)j0 * lw + i0) * 4 + c], b = chain[(off + (size_t)j0 * lw + i1) * 4 + c];
-                    const float cc = chain[(off + (size_t)j1 * lw + i0) * 4 + c], d = chain[(off + (size_t)j1 * lw + i1) * 4 + c];
-                    float m = (((a + b) + cc) + d) * 0.25f;
-                    // a derived level has the base level's 8-bit format (GL 4.6 8.14.4; sRGB-encoded colour for GL_SRGB8_ALPHA8):
-                    // filtered on decoded values, stored rounded to 8 bits, decoded again for sampling
-                    if (srgb && c < 3) {
-                        const float e = m <= 0.0031308f ? m * 12.92f : 1.055f * std::pow(m, 1.0f / 2.4f) - 0.055f;
-                        const float q = std::floor(e * 255.0f + 0.5f) / 255.0f;
-                        m = q <= 0.04045f ? q / 12.92f : std::pow((q + 0.055f) / 1.055f, 2.4f);
-                    } else {
-                        m = std::floor(m * 255.0f + 0.5f) / 255.0f;
-                    }
-                    chain[(noff + (size_t)j * nw + i) * 4 + c] = m;
-                }
-            }
-        off = noff;
-        lw = nw;
-        lh = nh;
-        sp.off[++level] = (uint32_t)off;
-    }
-    sp.levels = level + 1;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    int rc = buf_alloc(ctx, ctx->sprite, chain.size() * sizeof(float));
-    if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpy(ctx->sprite.p, chain.data(), chain.size() * sizeof(float), hipMemcpyHostToDevice));
-    ctx->sprite_params = sp;
-    return MSPLAT_OK;
-}
-
-int msplat_set_point_sprite(msplat_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height)
-{
-    drain_async(ctx);
-    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
-    return build_sprite(ctx, rgba8, width, height);
-}
-
-int msplat_upload_points(msplat_ctx* ctx, const void* aos, uint64_t n, uint32_t stride_bytes,
-                         uint32_t position_offset, uint32_t color_offset)
-{
-    drain_async(ctx);
-    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
-    if (!aos && n) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_upload_points: NULL argument");
-    if (stride_bytes % 4 != 0 || position_offset + 16u > stride_bytes || color_offset + 16u > stride_bytes)
-        return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_upload_points: bad stride / offsets (%u, %u, %u)", stride_bytes,
-                    position_offset, color_offset);
-    if (ctx->rop != MSPLAT_ROP_NONE)
-        return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "msplat_upload_points: render-target emulation is set on this context and the "
-                    "sprite compositor has none (msplat_set_target_emulation(ctx, MSPLAT_ROP_NONE) first)");
-    ctx->point_mode = true;
-    int rc = prepare_cloud_buffers(ctx, n, false, nullptr);
-    if (rc) { ctx->point_mode = false; return rc; }
-    std::vector<float> pos, col;
-    try {      // the C ABI never throws
-        pos.resize((size_t)std::max<uint64_t>(n, 1) * 4);
-        col.resize((size_t)std::max<uint64_t>(n, 1) * 4);
-    } catch (const std::exception&) {
-        return fail(ctx, MSPLAT_ERR_HIP, "msplat_upload_points: out of host memory for %llu points", (unsigned long long)n);
-    }
-    const uint8_t* src = static_cast<const uint8_t*>(aos);
-    for (uint64_t i = 0; i < n; ++i) {
-        std::memcpy(&pos[i * 4], src + i * stride_bytes + position_offset, 12);      // vec4(pos.xyz, pos[3]) -> w unused by the cull
-        pos[i * 4 + 3] = 0.0f;                                                        // .w = footprint bound slot (none for points)
-        std::memcpy(&col[i * 4], src + i * stride_bytes + color_offset, 16);
-    }
-    if (n) {
-        HIP_TRY(ctx, hipMemcpy(ctx->pos4.p, pos.data(), n * 16, hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMemcpy(ctx->recs.p, col.data(), n * 16, hipMemcpyHostToDevice));
-    }
-    ctx->has_cloud = true;
-    return MSPLAT_OK;
-}
-
-// device cloud -> reference AoS layout (100 B / 244 B records, gaussiancloud.cpp:32-56); parity tests
-int msplat_download_cloud(msplat_ctx* ctx, void* aos_out, uint64_t cap_bytes)
-{
-    drain_async(ctx);
-    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
-    if (!ctx->has_cloud) return fail(ctx, MSPLAT_ERR_NO_CLOUD, "no cloud uploaded");
-    if (ctx->point_mode) return fail(ctx, MSPLAT_ERR_UNSUPPORTED, "msplat_download_cloud: the context holds a point cloud");
-    const int F4 = ctx->full_sh ? 16 : 8;
-    const size_t rec_floats = ctx->full_sh ? 61 : 25;
-    if (cap_bytes < ctx->N * rec_floats * 4) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "output buffer too small");
-    if (ctx->N == 0) return MSPLAT_OK;
-    if (!aos_out) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "aos_out is NULL");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const size_t chunk = 1u << 18;
-    std::vector<float> stage;
-    try {
-        stage.resize(chunk * F4 * 4);
-    } catch (const std::exception&) {
-        return fail(ctx, MSPLAT_ERR_HIP, "msplat_download_cloud: out of host memory");
-    }
-    float* dst = static_cast<float*>(aos_out);
-    const bool ro = ctx->store && ctx->store->reordered;       // stored slot j = upload index order_host[j]
-    for (uint64_t base = 0; base < ctx->N; base += chunk) {
-        const size_t cnt = (size_t)std::min<uint64_t>(chunk, ctx->N - base);
-        HIP_TRY(ctx, hipMemcpy(stage.data(), (const char*)ctx->recs.p + base * F4 * 16, cnt * F4 * 16, hipMemcpyDeviceToHost));
-        for (size_t j = 0; j < cnt; ++j)
-            std::memcpy(dst + (ro ? (size_t)ctx->store->order_host[base + j] : base + j) * rec_floats, stage.data() + j * F4 * 4, rec_floats * 4);
-    }
-    return MSPLAT_OK;
-}
-
-int msplat_set_band_cull(msplat_ctx* ctx, int enable)
-{
-    drain_async(ctx);
-    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
-    ctx->band_cull = enable != 0;
-    return MSPLAT_OK;
-}
-
-int msplat_set_band_layout(msplat_ctx* ctx, int32_t first_row, int32_t row_count, int32_t block, int32_t stride)
-{
-    drain_async(ctx);
-    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
-    if (first_row < 0 || row_count < 0 || block < 1 || stride < block)
-        return fail(ctx, MSPLAT_ERR_INVALID_ARG,
-                    "msplat_set_band_layout: need first_row >= 0, row_count >= 0, block >= 1 and stride >= block (got %d, %d, %d, %d)",
-                    first_row, row_count, block, stride);
-    ctx->banded = true;
-    ctx->band_first = first_row;
-    ctx->band_count = row_count;
-    ctx->band_block = block;
-    ctx->band_stride = stride;
-    return MSPLAT_OK;
-}
-
-int msplat_set_band(msplat_ctx* ctx, int32_t row_mod, int32_t row_rem)
-{
-    drain_async(ctx);
-    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
-    if (row_mod < 1 || row_rem < 0 || row_rem >= row_mod)
-        return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_set_band: need row_mod >= 1 and 0 <= row_rem < row_mod");
-    if (row_mod == 1) {          // the whole image
-        ctx->banded = false;
-        ctx->band_first = 0; ctx->band_count = 0; ctx->band_block = 1; ctx->band_stride = 1;
-        return MSPLAT_OK;
-    }
-    return msplat_set_band_layout(ctx, row_rem, 0, 1, row_mod);       // rows t with t % row_mod == row_rem
-}
-
-// Contiguous bands whose row counts are proportional to weights[rank] (r6).  Why: rank 0 is the root of the row gather and sends
-// nothing, every other rank's band has to cross its xGMI link -- with equal bands a 2-GPU frame of BASELINE
-// configs[3] is bound by the one link (0.88 ms for 134 MB) and slower than one GPU.  Largest-remainder rounding; while rows last
-// every rank with a positive weight owns at least one.  bounds_out[i] .. bounds_out[i + 1] = the bin rows of rank i.
-int msplat_band_plan_weighted(int32_t rows_full, int32_t world, const float* weights, int32_t* bounds_out)
-{
-    if (!weights || !bounds_out || rows_full < 0 || world < 1)
-        return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_plan_weighted: need weights, bounds_out, rows_full >= 0, world >= 1");
-    double sum = 0.0;
-    for (int i = 0; i < world; ++i) {
-        if (!(weights[i] >= 0.0f) || !std::isfinite(weights[i]))
-            return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_plan_weighted: weight %d is negative or not finite", i);
-        sum += weights[i];
-    }
-    if (!(sum > 0.0)) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_plan_weighted: all weights are zero");
-    std::vector<int32_t> rows((size_t)world, 0);
-    std::vector<double> frac((size_t)world, 0.0);
-    int64_t given = 0;
-    for (int i = 0; i < world; ++i) {
-        const double x = (double)rows_full * weights[i] / sum;
-        rows[(size_t)i] = (int32_t)std::floor(x);
-        frac[(size_t)i] = x - std::floor(x);
-        given += rows[(size_t)i];
-    }
-    for (int64_t left = rows_full - given; left > 0; --left) {        // the largest remainders get the rows the floors left over
-        int best = 0;
-        for (int i = 1; i < world; ++i)
-            if (frac[(size_t)i] > frac[(size_t)best]) best = i;
-        rows[(size_t)best]++;
-        frac[(size_t)best] = -1.0;
-    }
-    for (int i = 0; i < world; ++i) {          // nobody with a positive weight stays empty while a larger band can spare a row
-        if (rows[(size_t)i] != 0 || !(weights[i] > 0.0f)) continue;
-        int big = 0;
-        for (int j = 1; j < world; ++j)
-            if (rows[(size_t)j] > rows[(size_t)big]) big = j;
-        if (rows[(size_t)big] >= 2) { rows[(size_t)big]--; rows[(size_t)i] = 1; }
-    }
-    bounds_out[0] = 0;
-    for (int i = 0; i < world; ++i) bounds_out[i + 1] = bounds_out[i] + rows[(size_t)i];
-    return MSPLAT_OK;
-}
-
-// Root weight (percent, >= 1) for MSPLAT_BANDS_ROOT_WEIGHTED from a linear cost model: a rank that owns r bin rows computes for
-// fixed_ms + ms_per_row * r; a rank other than the root also moves r * row_bytes over its own link of link_gbps GB/s -- at the
-// same time as it computes the next frame (overlap != 0: its cost is the larger of the two) or after it (their sum).  Returns
-// the percentage that minimises the slowest rank (searched over the row counts; host arithmetic).
-int msplat_band_root_weight(int32_t rows_full, int32_t world, double fixed_ms, double ms_per_row, double row_bytes, double link_gbps,
-                            int overlap)
-{
-    if (world < 2 || rows_full < world || !(ms_per_row >= 0.0) || !(link_gbps > 0.0)) return 100;
-    const double link_ms_per_row = row_bytes / (link_gbps * 1e6);
-    double best_t = 1e300;
-    int best_r = rows_full / world;
-    for (int r = 1; r * (world - 1) < rows_full; ++r) {             // r rows for every other rank, the rest for the root
-        const int root_rows = rows_full - r * (world - 1);
-        const double comp = fixed_ms + ms_per_row * r, link = link_ms_per_row * r;
-        const double other = overlap ? std::max(comp, link) : comp + link;
-        const double t = std::max(other, fixed_ms + ms_per_row * root_rows);
-        if (t < best_t) { best_t = t; best_r = r; }
-    }
-    const int root_rows = rows_full - best_r * (world - 1);
-    return std::max(1, (int)std::lround(100.0 * (double)root_rows / (double)best_r));
-}
-
-// The standard partitions of `rows_full` bin rows over `world` ranks: pure arithmetic, no context needed.
-int msplat_band_plan(int32_t kind, int32_t rows_full, int32_t world, int32_t rank, int32_t block_rows, int32_t* first_row,
-                     int32_t* row_count, int32_t* block, int32_t* stride)
-{
-    if (!first_row || !row_count || !block || !stride) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_plan: NULL output");
-    if (rows_full < 0 || world < 1 || rank < 0 || rank >= world)
-        return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_plan: need rows_full >= 0, world >= 1, 0 <= rank < world");
-    auto owned_below = [](int R, int first, int blk, int str) {      // owned rows t < R
-        if (R <= first) return 0;
-        const int d = R - first, k = d / str, j = d - k * str;
-        return k * blk + std::min(j, blk);
-    };
-    if (kind == MSPLAT_BANDS_CONTIGUOUS || kind == MSPLAT_BANDS_ROOT_WEIGHTED) {
-        int a = (int)(((int64_t)rows_full * rank) / world), b = (int)(((int64_t)rows_full * (rank + 1)) / world);
-        if (kind == MSPLAT_BANDS_ROOT_WEIGHTED) {
-            // contiguous bands, rank 0 -- the root of the row gather, which sends nothing -- weighted block_rows percent of another rank
-            if (block_rows < 1 || world > 4096)
-                return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_plan: root weight (block_rows, percent) must be >= 1");
-            std::vector<float> w((size_t)world, 100.0f);        // (whole numbers: the Python restatement arrives at the same floats)
-            std::vector<int32_t> bounds((size_t)world + 1);
-            w[0] = (float)block_rows;
-            const int rc = msplat_band_plan_weighted(rows_full, world, w.data(), bounds.data());
-            if (rc) return rc;
-            a = bounds[(size_t)rank]; b = bounds[(size_t)rank + 1];
-        }
-        // (row_count == 0 means "no limit" to msplat_set_band_layout: an empty band starts past the last row instead)
-        *first_row = b > a ? a : rows_full; *row_count = b - a; *block = std::max(1, b - a);
-        *stride = std::max(1, std::max(rows_full, b - a));
-        return MSPLAT_OK;
-    }
-    int k = 1;
-    if (kind == MSPLAT_BANDS_BLOCK_INTERLEAVED) {
-        if (block_rows < 1) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_plan: block_rows must be >= 1");
-        k = block_rows;
-    } else if (kind != MSPLAT_BANDS_INTERLEAVED) {
-        return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_band_plan: unknown kind %d", kind);
-    }
-    *first_row = rank * k; *block = k; *stride = world * k;
-    *row_count = owned_below(rows_full, rank * k, k, world * k);
-    return MSPLAT_OK;
-}
+#include "msplat_bands.hip.inc"
 
 static int make_frame_params(msplat_ctx* ctx, const float cameraMat[16], const float projMat[16],
                              const float viewport[4], const float nearFar[2], FrameParams& fp)
@@ -1986,7 +1312,7 @@ static void issue_binning(RenderChain& rc, int keep_overflow, int occ_pass)
     const bool ordered = !(wave_comp && comp_pool < comp_items);
     // r3: the upsweep of the row pass also counts the pairs per bin, and one extra workgroup of its downsweep turns the
     // counts into the list offsets (+ the heaviest-first order when it is wanted): tile_start_kernel / tile_order_kernel
-    // are not launched (MSPLAT_TILE_TABLE=search brings them back for comparison)
+    // are not launched (contexts with frames in flight keep them: msplat_config.frame_mode)
     uint32_t* bincnt = ctx->bin_counts ? (uint32_t*)ctx->bincnt.p : nullptr;
     const int g2 = grid_for(div_up(cap, kPairChunk));
     hipLaunchKernelGGL(radix_upsweep<MODE_PAIR>, dim3(g2), dim3(kThreads), 0, s, (const uint32_t*)ctx->pairsA.p,
@@ -2389,319 +1715,6 @@ static int render_stereo_impl(msplat_ctx* ctx, const float cam0[16], const float
     return MSPLAT_OK;
 }
 
-int msplat_sort_count(msplat_ctx* ctx, uint32_t* v)
-{
-    drain_async(ctx);
-    if (!ctx || !v) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
-    if (!ctx->has_sort) return fail(ctx, MSPLAT_ERR_NO_SORT, "no sort yet");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(v, ctx->counters.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return MSPLAT_OK;
-}
-
-static int copy_sorted(msplat_ctx* ctx, const Buf& src, uint32_t* dst, uint32_t cap)
-{
-    uint32_t v = 0;
-    int rc = msplat_sort_count(ctx, &v);
-    if (rc) return rc;
-    if (!dst && v) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "dst is NULL");
-    if (cap < v) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "capacity %u < sort count %u", cap, v);
-    if (v) HIP_TRY(ctx, hipMemcpy(dst, src.p, (size_t)v * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    return MSPLAT_OK;
-}
-
-int msplat_get_sorted_indices(msplat_ctx* ctx, uint32_t* dst, uint32_t cap)
-{
-    drain_async(ctx);
-    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
-    int rc = copy_sorted(ctx, ctx->valA, dst, cap);
-    if (rc == MSPLAT_OK && ctx->store && ctx->store->reordered) {      // storage slots -> upload indices
-        uint32_t v = 0;
-        if ((rc = msplat_sort_count(ctx, &v))) return rc;
-        const std::vector<uint32_t>& ord = ctx->store->order_host;
-        for (uint32_t i = 0; i < v; ++i) dst[i] = ord[dst[i]];
-    }
-    return rc;
-}
-
-// The storage order of the uploaded cloud: dst[j] = upload index of the splat in storage slot j (identity when the cloud
-// was not reordered; *reordered says which).  Equal depth keys are drawn in ascending storage slot.
-int msplat_get_storage_order(msplat_ctx* ctx, uint32_t* dst, uint64_t cap, int* reordered)
-{
-    drain_async(ctx);
-    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
-    if (!ctx->has_cloud) return fail(ctx, MSPLAT_ERR_NO_CLOUD, "no cloud uploaded");
-    const bool ro = ctx->store && ctx->store->reordered;
-    if (reordered) *reordered = ro ? 1 : 0;
-    if (dst) {
-        if (cap < ctx->N) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "capacity %llu < %llu splats", (unsigned long long)cap, (unsigned long long)ctx->N);
-        for (uint64_t j = 0; j < ctx->N; ++j) dst[j] = ro ? ctx->store->order_host[j] : (uint32_t)j;
-    }
-    return MSPLAT_OK;
-}
-
-// chunk-level cull, for the latest Sort's camera: bounding boxes box_live keeps / boxes in the cloud (0 / 0 for a cloud in upload
-// order); *listed = 1 when that Sort's pass 0 walked the listed boxes only.  Runs box_cull_kernel on demand; synchronises.
-int msplat_debug_get_cull_boxes(msplat_ctx* ctx, uint32_t* live, uint32_t* total, int* listed)
-{
-    drain_async(ctx);
-    if (!ctx || !live || !total) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
-    if (!ctx->has_sort) return fail(ctx, MSPLAT_ERR_NO_SORT, "no sort yet");
-    *live = *total = 0;
-    if (listed) *listed = ctx->last_sort_listed ? 1 : 0;
-    const CloudStore* st = ctx->store.get();
-    if (!(st && st->reordered && st->boxes.p)) return MSPLAT_OK;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const uint32_t wgs = div_up(st->nboxes, kBoxGroup);
-    Buf list, cnt;
-    int rc = buf_alloc(ctx, list, (size_t)wgs * kBoxGroup * 4);
-    if (!rc) rc = buf_alloc(ctx, cnt, 256 * 4);
-    if (!rc) {
-        hipLaunchKernelGGL(box_cull_kernel, dim3(wgs), dim3(kBoxGroup), 0, ctx->stream, (const CullBox*)st->boxes.p, st->nboxes,
-                           ctx->last_sort_fp, (uint32_t*)list.p, (uint32_t*)cnt.p);
-        uint32_t h[256];
-        hipError_t e = hipMemcpyAsync(h, cnt.p, (size_t)wgs * 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) rc = fail(ctx, MSPLAT_ERR_HIP, "msplat_debug_get_cull_boxes: %s", hipGetErrorString(e));
-        else for (uint32_t g = 0; g < wgs; ++g) *live += h[g];
-    }
-    buf_free(ctx, list);
-    buf_free(ctx, cnt);
-    *total = st->nboxes;
-    return rc;
-}
-
-int msplat_get_sorted_keys(msplat_ctx* ctx, uint32_t* dst, uint32_t cap)
-{
-    drain_async(ctx);
-    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
-    return copy_sorted(ctx, ctx->keyA, dst, cap);
-}
-
-int msplat_get_stats(msplat_ctx* ctx, msplat_stats* out)
-{
-    drain_async(ctx);
-    if (!ctx || !out) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (ctx->has_render) {   // "drawn" is a statistic only: counted on demand, not in the frame
-        uint32_t* counters = (uint32_t*)ctx->counters.p;
-        HIP_TRY(ctx, hipMemsetAsync(counters + 4, 0, 4 * sizeof(uint32_t), ctx->stream));
-        // counters + 6 is 8-byte aligned: the 64-bit pair count lives in words 6..7
-        hipLaunchKernelGGL(count_drawn_kernel, dim3(256), dim3(kThreads), 0, ctx->stream, (const uint32_t*)ctx->rect.p,
-                           (const float4*)ctx->rec2d.p, counters + 0, ctx->last_fp, counters + 4,
-                           (unsigned long long*)(counters + 6));
-    }
-    HIP_TRY(ctx, hipMemcpyAsync(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    std::memset(out, 0, sizeof(*out));
-    out->num_splats = ctx->N;
-    out->sort_count = ctx->has_sort ? cnt[0] : 0;
-    out->pairs = ctx->has_render ? cnt[1] : 0;
-    out->drawn = ctx->has_render ? cnt[4] : 0;
-    out->pairs_tile16 = ctx->has_render ? ((uint64_t)cnt[7] << 32 | cnt[6]) : 0;
-    out->tiles_x = ctx->last_fp.tiles_x;
-    out->tiles_y = ctx->last_fp.tiles_y;
-    out->width = ctx->last_fp.width;
-    out->height = ctx->last_fp.height;
-    out->pair_capacity = ctx->pair_cap;
-    out->device_bytes = ctx->device_bytes;
-    if (ctx->has_render && cnt[2] != 0)
-        return fail(ctx, MSPLAT_ERR_PAIR_OVERFLOW, "last render overflowed the pair buffer: need %u, capacity %llu",
-                    cnt[2], (unsigned long long)ctx->pair_cap);
-    return MSPLAT_OK;
-}
-
-int msplat_get_timings(msplat_ctx* ctx, msplat_timings* out)
-{
-    drain_async(ctx);
-    if (!ctx || !out) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
-    std::memset(out, 0, sizeof(*out));
-    if (!ctx->ev_ok) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "context created without enable_timing");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    // average over the sets recorded since the previous call (at most the kEvSets most recent)
-    const uint32_t ns = std::min<uint32_t>(ctx->sort_sets, msplat_ctx::kEvSets);
-    for (uint32_t k = 0; k < ns; ++k) {
-        float t = 0.0f;
-        HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->ev[k][0], ctx->ev[k][1]));
-        out->sort_total += t / ns;
-    }
-    const uint32_t nr = std::min<uint32_t>(ctx->render_sets, msplat_ctx::kEvSets);
-    for (uint32_t k = 0; k < nr; ++k) {
-        float a = 0, b = 0, c = 0, d = 0;
-        const bool two = (ctx->two_pass_sets_mask & (1u << k)) != 0u;     // a two-pass frame: every stage ran twice
-        HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev[k][2], ctx->ev[k][5]));
-        HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev[k][2], ctx->ev[k][3]));
-        HIP_TRY(ctx, hipEventElapsedTime(&c, ctx->ev[k][3], ctx->ev[k][4]));
-        HIP_TRY(ctx, hipEventElapsedTime(&d, ctx->ev[k][4], ctx->ev[k][two ? 8 : 5]));
-        if (two) {
-            float b2 = 0, c2 = 0, d2 = 0;
-            HIP_TRY(ctx, hipEventElapsedTime(&b2, ctx->ev[k][8], ctx->ev[k][9]));      // mask + gate + second projection
-            HIP_TRY(ctx, hipEventElapsedTime(&c2, ctx->ev[k][9], ctx->ev[k][10]));
-            HIP_TRY(ctx, hipEventElapsedTime(&d2, ctx->ev[k][10], ctx->ev[k][5]));
-            b += b2; c += c2; d += d2;
-        }
-        out->render_total += a / nr; out->project += b / nr; out->binning += c / nr; out->composite += d / nr;
-        if (ctx->comp_kernel_sets_mask & (1u << k)) {
-            float e = 0, e2 = 0;
-            HIP_TRY(ctx, hipEventElapsedTime(&e, ctx->ev[k][6], ctx->ev[k][7]));
-            if (two) HIP_TRY(ctx, hipEventElapsedTime(&e2, ctx->ev[k][11], ctx->ev[k][12]));
-            out->reserved[1] += e + e2;  // summed here, averaged below
-            out->reserved[2] += 1.0f;
-        }
-    }
-    if (out->reserved[2] > 0.0f) out->reserved[1] /= out->reserved[2];
-    out->reserved[0] = (float)nr;       // number of frames averaged
-    ctx->sort_sets = 0;
-    ctx->render_sets = 0;
-    return MSPLAT_OK;
-}
-
-int msplat_debug_get_projected(msplat_ctx* ctx, float* rec12, uint32_t* rect, uint32_t cap)
-{
-    drain_async(ctx);
-    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
-    if (!ctx->has_render) return fail(ctx, MSPLAT_ERR_NO_SORT, "no render yet");
-    uint32_t v = 0;
-    int rc = msplat_sort_count(ctx, &v);
-    if (rc) return rc;
-    if (cap < v) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "capacity %u < sort count %u", cap, v);
-    if (v && rec12) HIP_TRY(ctx, hipMemcpy(rec12, ctx->rec2d.p, (size_t)v * 48, hipMemcpyDeviceToHost));
-    if (v && rect) HIP_TRY(ctx, hipMemcpy(rect, ctx->rect.p, (size_t)v * 4, hipMemcpyDeviceToHost));
-    return MSPLAT_OK;
-}
-
-// On-device check of the ordering contracts of the last Sort (+ the last Render's bin lists, if there was one):
-// sorted keys ascend with ties in ascending splat index, every bin list ascends in draw-order rank.  A cheap guard
-// for the lane-ordered LDS-atomic ranking (probed at msplat_create, not documented hardware behaviour): call it in
-// debug builds or every few hundred frames; non-zero counts mean the context should be re-created with
-// MSPLAT_BALLOT_RANK=1.
-int msplat_debug_two_pass(msplat_ctx* ctx, float share, uint64_t* two_pass_frames, float* share_now)
-{
-    drain_async(ctx);
-    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
-    if (!(share >= 0.0f && share <= 1.0f)) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "msplat_debug_two_pass: share %g not in [0, 1]", (double)share);
-    ctx->occ_pinned = share > 0.0f;
-    if (ctx->occ_pinned) ctx->occ_frac = share;
-    if (two_pass_frames) *two_pass_frames = ctx->frames_two_pass;
-    if (share_now) *share_now = ctx->occ_frac;
-    return MSPLAT_OK;
-}
-
-int msplat_get_two_pass_info(msplat_ctx* ctx, uint64_t out[8])
-{
-    drain_async(ctx);
-    if (!ctx || !out) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
-    for (int k = 0; k < 8; ++k) out[k] = 0;
-    out[0] = ctx->frames_two_pass;
-    if (!ctx->last_render_two_pass || !ctx->h_flags) { out[0] = ctx->last_render_two_pass ? out[0] : 0; return MSPLAT_OK; }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    out[1] = __atomic_load_n(ctx->h_flags + 6, __ATOMIC_RELAXED);
-    out[2] = __atomic_load_n(ctx->h_flags + 7, __ATOMIC_RELAXED);
-    out[3] = __atomic_load_n(ctx->h_flags + 4, __ATOMIC_RELAXED);
-    out[4] = __atomic_load_n(ctx->h_flags + 8, __ATOMIC_RELAXED);
-    out[5] = __atomic_load_n(ctx->h_flags + 5, __ATOMIC_RELAXED);
-    out[6] = (uint64_t)ctx->last_fp.tiles_x * (uint64_t)ctx->last_fp.tiles_y;
-    out[7] = __atomic_load_n(ctx->h_flags + 1, __ATOMIC_RELAXED);
-    return MSPLAT_OK;
-}
-
-int msplat_debug_verify_order(msplat_ctx* ctx, uint32_t* key_violations, uint32_t* list_violations)
-{
-    drain_async(ctx);
-    if (!ctx || !key_violations || !list_violations) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
-    if (!ctx->has_sort) return fail(ctx, MSPLAT_ERR_NO_SORT, "no sort yet");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    uint32_t* counters = (uint32_t*)ctx->counters.p;
-    uint32_t* bad = counters + 12;
-    HIP_TRY(ctx, hipMemsetAsync(bad, 0, 2 * sizeof(uint32_t), ctx->stream));
-    const int nbins = ctx->has_render ? ctx->last_fp.tiles_x * ctx->last_fp.tiles_y : 0;
-    hipLaunchKernelGGL(verify_order_kernel, dim3(1024), dim3(kThreads), 0, ctx->stream, (const uint32_t*)ctx->keyA.p,
-                       (const uint32_t*)ctx->valA.p, (const uint32_t*)counters, nbins ? (const uint32_t*)ctx->tile_start.p : nullptr,
-                       (const uint32_t*)ctx->pairsB.p, (uint32_t)ctx->pair_cap, nbins, bad);
-    uint32_t h[2] = {0, 0};
-    HIP_TRY(ctx, hipMemcpyAsync(h, bad, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    *key_violations = h[0];
-    *list_violations = h[1];
-    return MSPLAT_OK;
-}
-
-int msplat_debug_get_tile_probe8(msplat_ctx* ctx, uint32_t* dst, uint32_t tile_cap)
-{
-    drain_async(ctx);
-    if (!ctx || !dst) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
-    if (!ctx->probe.p || !ctx->probe_on)
-        return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile probe not enabled (msplat_set_tile_probe, or MSPLAT_TILE_PROBE=1 before msplat_create)");
-    if (!ctx->has_render) return fail(ctx, MSPLAT_ERR_NO_SORT, "no render yet");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t ntiles = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y) * 4u;   // work items = (bin, quadrant)
-    if (tile_cap < ntiles) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile capacity too small (work items = bins x 4)");
-    HIP_TRY(ctx, hipMemcpy(dst, ctx->probe.p, (size_t)ntiles * kProbeWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    return MSPLAT_OK;
-}
-
-// sums the compositor probe of the last render (msplat_set_tile_probe): what the dominant kernel really fetched
-// and evaluated, for the roofline (bench.py) -- list entries it would fetch without early termination, pair words
-// and 48-byte records it did fetch, records that survived the exact footprint test, (pixel, splat) evaluations
-int msplat_get_composite_work(msplat_ctx* ctx, msplat_composite_work* out)
-{
-    drain_async(ctx);
-    if (!ctx || !out) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "NULL argument");
-    std::memset(out, 0, sizeof(*out));
-    if (!ctx->probe.p || !ctx->probe_on)
-        return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile probe not enabled (msplat_set_tile_probe)");
-    if (!ctx->has_render) return fail(ctx, MSPLAT_ERR_NO_SORT, "no render yet");
-    const uint32_t items = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y) * 4u;
-    std::vector<uint32_t> h;
-    try {
-        h.resize((size_t)items * kProbeWords);
-    } catch (const std::exception&) {
-        return fail(ctx, MSPLAT_ERR_HIP, "out of host memory");
-    }
-    int rc = msplat_debug_get_tile_probe8(ctx, h.data(), items);
-    if (rc) return rc;
-    for (uint32_t t = 0; t < items; ++t) {
-        const uint32_t* p = &h[(size_t)t * kProbeWords];
-        if (!p[7]) continue;
-        out->work_items += 1;
-        out->clocks_sum += p[0];
-        out->clocks_max = std::max<uint64_t>(out->clocks_max, p[0]);
-        out->records_composited += p[1];
-        out->pixel_evals += (uint64_t)p[1] * (uint64_t)(kTile * kTile);
-        out->batches += p[2];
-        out->inner_clocks_sum += p[3];
-        out->pair_words_fetched += p[4];
-        out->records_fetched += p[5];
-        out->list_entries += p[6];
-        out->useful_evals += (uint64_t)(p[7] - 1u);
-    }
-    return MSPLAT_OK;
-}
-
-int msplat_debug_get_tile_lists(msplat_ctx* ctx, uint32_t* tile_start, uint32_t tile_cap,
-                                uint32_t* pairs, uint64_t pair_cap)
-{
-    drain_async(ctx);
-    if (!ctx) return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "ctx is NULL");
-    if (!ctx->has_render) return fail(ctx, MSPLAT_ERR_NO_SORT, "no render yet");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t ntiles = (uint32_t)(ctx->last_fp.tiles_x * ctx->last_fp.tiles_y);
-    if (tile_cap < ntiles + 1) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "tile capacity too small");
-    if (tile_start) HIP_TRY(ctx, hipMemcpy(tile_start, ctx->tile_start.p, (size_t)(ntiles + 1) * 4, hipMemcpyDeviceToHost));
-    uint32_t cnt[4];
-    HIP_TRY(ctx, hipMemcpy(cnt, ctx->counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
-    const uint64_t d = std::min<uint64_t>(cnt[1], ctx->pair_cap);
-    if (pairs) {
-        if (pair_cap < d) return fail(ctx, MSPLAT_ERR_INVALID_ARG, "pair capacity too small");
-        if (d) HIP_TRY(ctx, hipMemcpy(pairs, ctx->pairsB.p, d * 4, hipMemcpyDeviceToHost));
-    }
-    return MSPLAT_OK;
-}
+#include "msplat_getters.hip.inc"
 
 }  // extern "C"

@@ -45,7 +45,7 @@ class _FrameArgs:
 class SplatRenderer:
     def __init__(self, device=0, fb_format="fp32", t_epsilon=-1.0, pair_capacity=0, stream=None,
                  enable_timing=False, frames_in_flight=1, rank_mode=_capi.RANK_AUTO, frame_mode=None,
-                 spatial_order=_capi.SPATIAL_AUTO, async_submit=None, two_pass=_capi.TWO_PASS_AUTO):
+                 spatial_order=_capi.SPATIAL_AUTO, async_submit=None, two_pass=_capi.TWO_PASS_AUTO, compositor_waves=None):
         """frames_in_flight > 1: every Sort moves on to the next of that many contexts (own stream and
         per-frame buffers, ONE shared cloud -- msplat_attach_cloud), so successive frames overlap on the
         GPU; Render and the getters use the context of the latest Sort.  `stream` is only used with depth 1;
@@ -70,6 +70,9 @@ class SplatRenderer:
         self._async = (self._depth > 1) if async_submit is None else bool(async_submit)
         # msplat_config.two_pass: may a Render run as two passes with occlusion feedback (same pixels, less work)?
         self._two_pass = int(two_pass)
+        # msplat_config.compositor_waves: persistent compositor waves per render (None: every item its own wave for one frame at a
+        # time, 1280 with frames in flight -- measured r3: pool sweep 768 .. 2048)
+        self._comp_waves = compositor_waves
         # msplat_config.frame_mode: kernels for one frame at a time, or for contexts that share the GPU with other frames in
         # flight (msplat.h, MSPLAT_FRAMES_*)
         self._frame_mode = int(frame_mode) if frame_mode is not None else (_capi.FRAMES_IN_FLIGHT if self._depth > 1 else _capi.FRAMES_AUTO)
@@ -116,7 +119,7 @@ class SplatRenderer:
         cfg.t_epsilon = self._t_eps
         cfg.pair_capacity = self._pair_cap
         cfg.enable_timing = int(self._timing)
-        cfg.compositor_waves = 0 if self._depth == 1 else 1280     # measured r3: pool sweep 768 .. 2048, DESIGN.md 5
+        cfg.compositor_waves = int(self._comp_waves) if self._comp_waves is not None else (0 if self._depth == 1 else 1280)
         cfg.rank_mode = self._rank_mode
         cfg.frame_mode = self._frame_mode
         cfg.spatial_order = self._spatial

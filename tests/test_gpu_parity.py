@@ -693,15 +693,15 @@ def test_large_viewport_4096_matches_oracle():
 
 def test_ballot_rank_fallback_matches_lds_atomic_rank(monkeypatch):
     """the stable ranking uses the return values of lane-ordered LDS atomics (probed at msplat_create); the ballot
-    path (MSPLAT_BALLOT_RANK=1) is the fallback.  Both must give the oracle's permutation, the same bin lists and pixels,
+    path (msplat_config.rank_mode = MSPLAT_RANK_BALLOT) is the fallback.  Both must give the oracle's permutation, the same bin lists and pixels,
     and pass the on-device order check (msplat_debug_verify_order)."""
     cloud = scenes.cloud_from_attrs(scenes.hard_attrs(9000, 23))             # duplicates: equal keys, tie order matters
     cam, proj, vp, nf = scenes.default_view(640, 400, yaw=0.4)
     mvp = orc.mat4_mul(proj, orc.mat4_inverse(cam))
     keys, idx = orc.sort(*orc.presort(cloud.as_array(), mvp, nf[1]))
     outs = []
-    # the ballot path is selected by msplat_config.rank_mode or, for a whole process, by MSPLAT_BALLOT_RANK=1
-    for kw, env in (({}, {}), ({"rank_mode": 1}, {}), ({}, {"MSPLAT_BALLOT_RANK": "1", "MSPLAT_SCAN_KERNELS": "1"})):
+    # the ballot path is selected by msplat_config.rank_mode (r6: the process-wide MSPLAT_BALLOT_RANK switch is gone)
+    for kw, env in (({}, {}), ({"rank_mode": 1}, {}), ({"rank_mode": 1}, {"MSPLAT_SCAN_KERNELS": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         r = make_renderer(cloud, **kw)
@@ -1384,18 +1384,19 @@ def test_sort_exact_for_every_key_range(zf, z, n, frame_mode):
 
 
 def test_wide_sort_and_legacy_sort_and_tile_tables_agree(monkeypatch):
-    """MSPLAT_SORT=lsd8 (four 8-bit passes) and MSPLAT_TILE_TABLE=search (tile_start_kernel / tile_order_kernel) are the r2
-    paths kept for comparison: bit-identical keys, permutation, bin lists and pixels"""
+    """MSPLAT_SORT=lsd8 (four 8-bit passes: the fallback without lane-ordered LDS atomics) and the in-flight kernel selection
+    (256-thread sort workgroups, tile_start_kernel / tile_order_kernel instead of the row pass's counts; msplat_config.frame_mode)
+    against the default: bit-identical keys, permutation, bin lists and pixels"""
+    from splatapult_amd import _capi
     cloud = scenes.synth_cloud(150000, 77, log_scale_mean=-3.6)
     cam, proj, vp, nf = scenes.default_view(800, 450, yaw=-0.3)
     res = []
-    for env in ({}, {"MSPLAT_SORT": "lsd8"}, {"MSPLAT_TILE_TABLE": "search"}, {"MSPLAT_WS_ITEMS": "16"}, {"MSPLAT_WS_THREADS": "256"},
-                {"MSPLAT_WS_THREADS": "256", "MSPLAT_WS_ITEMS": "16"}):
-        for k in ("MSPLAT_SORT", "MSPLAT_TILE_TABLE", "MSPLAT_WS_ITEMS", "MSPLAT_WS_THREADS"):
-            monkeypatch.delenv(k, raising=False)
+    for env, kw in (({}, {}), ({"MSPLAT_SORT": "lsd8"}, {}), ({}, {"frame_mode": _capi.FRAMES_IN_FLIGHT}),
+                    ({"MSPLAT_SORT": "lsd8"}, {"frame_mode": _capi.FRAMES_IN_FLIGHT})):
+        monkeypatch.delenv("MSPLAT_SORT", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        r = make_renderer(cloud)
+        r = make_renderer(cloud, **kw)
         r.Sort(cam, proj, vp, nf)
         img = r.Render(cam, proj, vp, nf)
         ts, pairs = r.debug_tile_lists()
@@ -1927,11 +1928,11 @@ def test_spatial_order_through_the_file_path_and_shared_clouds(tmp_path, monkeyp
     cloud (frames in flight) see the same storage order and render identical frames"""
     from splatapult_amd import synthetic
     from splatapult_amd.scene import GaussianCloud
-    monkeypatch.setenv("MSPLAT_SPATIAL_ORDER", "1")
+    from splatapult_amd import _capi
     n = 6000
     ply = str(tmp_path / "c.ply")
     synthetic.write_ply(ply, synthetic.generate(n, seed=91, pos_sigma=1.5, log_scale_mean=-3.0))
-    r = SplatRenderer(device=0, frames_in_flight=3)
+    r = SplatRenderer(device=0, frames_in_flight=3, spatial_order=_capi.SPATIAL_ON)      # (small cloud: ask for the Morton storage order)
     assert r.InitFromPly(ply, True, False), r.last_error()
     host = GaussianCloud()
     assert host.ImportPly(ply)

@@ -4,7 +4,7 @@
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-( time timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -p no:cacheprovider -rs ) > gpurun_out/r06e_gpu_tests.log 2>&1
+( time timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -rs ) > gpurun_out/r06e_gpu_tests.log 2>&1
 tail -15 gpurun_out/r06e_gpu_tests.log; grep "_check_whole_frame" gpurun_out/r06e_gpu_tests.log | head
 fps() { python -c "
 import json,sys

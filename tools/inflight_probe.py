@@ -19,9 +19,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from splatapult_amd import SplatRenderer, camera, synthetic  # noqa: E402
 
 
-def run(P, frames, cloud, W, H, probe=True):
+def run(P, frames, cloud, W, H, probe=True, pool=None):
     dev = torch.device("cuda:0")
-    r = SplatRenderer(device=0, fb_format="fp32", frames_in_flight=P)
+    r = SplatRenderer(device=0, fb_format="fp32", frames_in_flight=P, compositor_waves=pool)
     assert r.Init(cloud, False, False), r.last_error()
     fbs = [torch.zeros((((H + 31) // 32) * 32, W, 4), dtype=torch.float32, device=dev) for _ in range(P)]
     proj = camera.perspective(camera.FOVY, W / H)
@@ -56,11 +56,7 @@ def main():
     rows = []
     for label, p, env in (("serial, every item its own wave", 1, None), ("serial, pool of 1280 waves", 1, "1280"), ("%d in flight (pool 1280)" % P, P, None),
                           ("%d in flight, no probe" % P, P, "noprobe")):
-        if env == "1280":
-            os.environ["MSPLAT_COMP_WAVES"] = "1280"
-        else:
-            os.environ.pop("MSPLAT_COMP_WAVES", None)
-        ms, o = run(p, frames, cloud, W, H, probe=(env != "noprobe"))
+        ms, o = run(p, frames, cloud, W, H, probe=(env != "noprobe"), pool=1280 if env == "1280" else None)
         rows.append((label, ms, o))
         if o:
             print("%-36s %.4f ms/frame   items %d  item clocks: sum %.4g (inner loops %.4g = %.1f%%, outside %.4g)  mean %.0f max %.0f  batches %d  records %d"

@@ -14,7 +14,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-os.environ["MSPLAT_COMP_WAVES"] = "1024"          # a wave pool smaller than the item count: the bins are walked in storage order
+POOL = 1024          # msplat_config.compositor_waves: a wave pool smaller than the item count -- the bins are walked in storage order
 
 
 def main():
@@ -37,7 +37,7 @@ def main():
         cam = camera.orbit(wl["cam_z"], 2.0 * np.pi * args.pose / 64.0)
     proj = camera.perspective(camera.FOVY, W / H)
     vp, nf = [0, 0, W, H], [camera.Z_NEAR, camera.Z_FAR]
-    r = SplatRenderer(device=0, spatial_order=_capi.SPATIAL_OFF)
+    r = SplatRenderer(device=0, spatial_order=_capi.SPATIAL_OFF, compositor_waves=POOL)
     assert r.Init(cloud, False, False), r.last_error()
     r.set_tile_probe(True)
     r.Sort(cam, proj, vp, nf)

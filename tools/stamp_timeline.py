@@ -34,9 +34,9 @@ WAVES = {1: (16, 4), 2: (8, 4), 3: (16, 4), 4: (8, 4), 5: (1, 1), 6: (4, 4), 7: 
 REC = np.dtype([("kid", "<u4"), ("blk", "<u4"), ("hwid", "<u4"), ("xcc", "<u4"), ("t0", "<u8"), ("t1", "<u8")])
 
 
-def run(P, frames, cloud, W, H, L):
+def run(P, frames, cloud, W, H, L, pool=None):
     dev = torch.device("cuda:0")
-    r = SplatRenderer(device=0, fb_format="fp32", frames_in_flight=P)
+    r = SplatRenderer(device=0, fb_format="fp32", frames_in_flight=P, compositor_waves=pool)
     assert r.Init(cloud, False, False), r.last_error()
     fbs = [torch.zeros((((H + 31) // 32) * 32, W, 4), dtype=torch.float32, device=dev) for _ in range(P)]
     proj = camera.perspective(camera.FOVY, W / H)
@@ -137,13 +137,9 @@ def main():
     ms1, rec1 = run(1, frames, cloud, W, H, L)
     t1, w1 = table(rec1, frames, 1)
     launch_table(rec1, "one frame at a time")
-    variants = [("%d in flight" % P, {})] + [("%d in flight, compositor pool %s" % (P, w), {"MSPLAT_COMP_WAVES": w}) for w in sys.argv[3:]]
+    variants = [("%d in flight" % P, None)] + [("%d in flight, compositor pool %s" % (P, w), int(w)) for w in sys.argv[3:]]
     for label, env in variants:
-        for k, v in env.items():
-            os.environ[k] = v
-        msP, recP = run(P, frames, cloud, W, H, L)
-        for k in env:
-            os.environ.pop(k, None)
+        msP, recP = run(P, frames, cloud, W, H, L, pool=env)
         tP, wP = table(recP, frames, P)
         print("# config 2 (1 M splats, 1920x1080), stamps build: one frame at a time %.4f ms/frame (%d records), %s %.4f ms/frame (%d records; "
               "hash-table losses expected: a few %%)" % (ms1, len(rec1), label, msP, len(recP)))

@@ -22,7 +22,7 @@ int msplat_debug_get_projected(msplat_ctx* ctx, float* rec12, uint32_t* rect, ui
 int msplat_debug_get_tile_lists(msplat_ctx* ctx, uint32_t* tile_start, uint32_t tile_cap, uint32_t* pairs, uint64_t pair_cap);
 /* on-device self-check of the ordering contracts (sorted keys ascending, ties by ascending storage slot; every bin list
  * ascending in draw-order rank): violation counts, both 0 on a healthy context.  Guards the lane-ordered LDS-atomic ranking,
- * which msplat_create probes but the hardware does not document (MSPLAT_BALLOT_RANK=1 selects the ballot path) */
+ * which msplat_create probes but the hardware does not document (msplat_config.rank_mode = MSPLAT_RANK_BALLOT selects the ballot path) */
 int msplat_debug_verify_order(msplat_ctx* ctx, uint32_t* key_violations, uint32_t* list_violations);
 /* chunk-level cull for the latest Sort's camera: live / all bounding boxes (of 256 stored splats; 0 / 0 for a cloud in upload
  * order); *listed (may be NULL) = 1 when that Sort's first pass walked only the listed live boxes */
@@ -39,7 +39,7 @@ int msplat_get_two_pass_info(msplat_ctx* ctx, uint64_t out[8]);
 
 /* ---- compositor probe (bench statistics): per (bin, quadrant) work item 8 words {shader clocks, records composited, batches
  * staged, inner-loop clocks, pair words fetched, records fetched, bin-list length, 1 + evaluations with w > 0}.  Off by default (a few clock reads per
- * batch; a probed context renders in one pass); MSPLAT_TILE_PROBE=1 turns it on at msplat_create ---- */
+ * batch; a probed context renders in one pass) ---- */
 typedef struct msplat_composite_work {     /* sums over the work items of the latest render */
     uint64_t work_items;          /* 16x16 tiles composited */
     uint64_t list_entries;        /* sum of the bin-list lengths: what it would fetch without early termination */

@@ -39,7 +39,7 @@ timeout 600 python tools/band_table.py --workload cfg4 --world 8 --layouts conti
 grep -v "    rank" gpurun_out/${T}_cfg4_bands.log | tail -6
 # the 1/2/4/8-GPU prediction under bench.py's own protocol (4 frames in flight, blocks of 20 frames)
 for wl in cfg2 cfg4; do
-  timeout 1200 python tools/band_table.py --workload $wl --fif 4 --block 20 --worlds 2,4,8 --layouts auto,contiguous --out gpurun_out/${T}_${wl}_bands_fif4.json > gpurun_out/${T}_${wl}_bands_fif4.log 2>&1
+  timeout 1200 python tools/band_table.py --workload $wl --fif 4 --block 20 --worlds 2,4,8 --layouts auto,contiguous,weighted --out gpurun_out/${T}_${wl}_bands_fif4.json > gpurun_out/${T}_${wl}_bands_fif4.log 2>&1
   grep -E "^single|^G =" gpurun_out/${T}_${wl}_bands_fif4.log
 done
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_prof_rank3 -o run --output-format csv -- python $R/tools/band_rank_profile.py cfg4 8 3 block 8 100 > $R/gpurun_out/${T}_prof_rank3.log 2>&1)

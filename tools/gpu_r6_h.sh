@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the ablation code these variants were built from is in commit 8eef668; tools/build_variant.sh <name> -D...)
 # round 6, run h: what does each stage COST with four frames in flight?  Ablation builds (wrong pixels on purpose, same structure):
 # half the projection's record bytes, every second record skipped in the compositor's inner loop, the sort stopped after pass 0,
 # no compositor at all -- frames/s in flight and ms serial against the product build, same box

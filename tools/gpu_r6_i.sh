@@ -1,4 +1,5 @@
 #!/bin/bash
+# (project_kernel_mw is in commit 8eef668: tools/build_variant.sh projw4 -DMSPLAT_X_PROJ_WAVES=4)
 # round 6, run i: the plain projection as workgroups of 2 / 4 / 8 waves (same per-wave work): does a stream of one-wave workgroups
 # starve the other frames' multi-wave workgroups?  product build against the variants, same box, alternating
 cd ${GRAFT_REPO_ROOT:-.}

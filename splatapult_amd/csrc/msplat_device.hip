@@ -1222,15 +1222,6 @@ static void issue_projection(RenderChain& rc, int mode, float occ_frac)
         else MSPLAT_PROJECT(false, PROJ_TWO_VIEWS, pgrid, (const uint32_t*)d_Vsort, ex, v1);
     } else {
         const ProjExtra ex{nullptr, nullptr, nullptr, 0.0f};
-#ifdef MSPLAT_X_PROJ_WAVES
-        if (ctx->full_sh && zq == nullptr) {
-            constexpr int PW = MSPLAT_X_PROJ_WAVES;
-            hipLaunchKernelGGL((project_kernel_mw<true, PW>), dim3(std::max(1u, div_up(rc.N, 64u * PW))), dim3(64 * PW), 0, s,
-                               (const uint32_t*)ctx->valA.p, (const uint32_t*)d_Vsort, (const float4*)ctx->recs.p, pp, (float4*)ctx->rec2d.p,
-                               (uint32_t*)ctx->rect.p, (uint32_t*)nullptr);
-            return;
-        }
-#endif
         if (ctx->full_sh) MSPLAT_PROJECT(true, PROJ_PLAIN, pgrid, (const uint32_t*)d_Vsort, ex, ProjNoView1{0});
         else MSPLAT_PROJECT(false, PROJ_PLAIN, pgrid, (const uint32_t*)d_Vsort, ex, ProjNoView1{0});
     }
@@ -1408,10 +1399,6 @@ static int issue_compositor(RenderChain& rc, int occ_pass, int ev_c0, int ev_c1)
                                (const float4*)ctx->rec2d.p, (const uint32_t*)ctx->zq.p, d_out, pitch, fp, cap,
                                (const uint32_t*)ctx->tile_order.p, d_queue, (uint32_t)ntiles * 4u);
         ctx->comp_kernel_timed = false;
-#ifdef MSPLAT_ABLATE               // ablation build only: no compositor launch at all (MSPLAT_X_COMP_NONE) -- nothing is drawn
-    } else if (ntiles > 0 && getenv("MSPLAT_X_COMP_NONE") != nullptr) {
-        ctx->comp_kernel_timed = false;
-#endif
     } else if (ntiles > 0) {
         // on sampled frames the dominant kernel gets exact dispatch begin/end events (the plain stream
         // markers around the stages can be processed while the previous kernel is still draining)

@@ -56,11 +56,7 @@ __device__ __forceinline__ void project_block(const uint32_t r, const uint32_t r
         for (int it = 0; it < F4; ++it) {
             const int owner = it * RPI + lane / F4;
             const uint32_t oi = __shfl(i, owner, 64);
-#ifdef MSPLAT_X_PROJ_HALF          // ablation build only (tools/gpu_r6_h.sh): half the record bytes -- WRONG colours, same structure
-            tmp[it] = sub < F4 / 2 ? recs[(size_t)oi * F4 + sub] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#else
             tmp[it] = recs[(size_t)oi * F4 + sub];
-#endif
         }
 #pragma unroll
         for (int it = 0; it < F4; ++it) {
@@ -312,29 +308,6 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(const uint32_t* _
         project_block<FULL_SH, false>(r, r, r < V, lane, sorted_idx, recs, fp, fp.view, fp.proj, fp.eye, out_rec, out_rect, out_zq, s_stage);
     }
 }
-
-#ifdef MSPLAT_X_PROJ_WAVES
-// experiment (r6, tools/gpu_r6_i.sh): the plain projection with WAVES waves per workgroup -- same per-wave work and staging, fewer and
-// larger workgroups: does a stream of one-wave workgroups starve the other frames' 4-8-wave workgroups of launch slots?
-template <bool FULL_SH, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void project_kernel_mw(const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ d_V,
-                                                                const float4* __restrict__ recs, ProjParams fp,
-                                                                float4* __restrict__ out_rec, uint32_t* __restrict__ out_rect,
-                                                                uint32_t* __restrict__ out_zq)
-{
-    __builtin_amdgcn_s_setprio(kProjPrio);
-    MSPLAT_STAMP(KID_PROJECT);
-    constexpr int F4 = FULL_SH ? 16 : 8;
-    constexpr int STRIDE = F4 * 4 + 4;
-    __shared__ __attribute__((aligned(16))) float s_stage[WAVES][64 * STRIDE];
-    const uint32_t V = *d_V;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t vb = blockIdx.x * WAVES + (uint32_t)w;
-    if (vb * 64u >= V) return;
-    const uint32_t r = vb * 64u + (uint32_t)lane;
-    project_block<FULL_SH, false>(r, r, r < V, lane, sorted_idx, recs, fp, fp.view, fp.proj, fp.eye, out_rec, out_rect, out_zq, s_stage[w]);
-}
-#endif
 
 __device__ __forceinline__ uint32_t rect_width(uint32_t rc)
 {

@@ -137,3 +137,28 @@ def test_bench_two_pass_workload_reports_what_the_passes_did():
     tc = d["two_pass_check"]               # r5: two fresh contexts, two passes (the share the timed frames ended on) against one pass
     assert tc["bit_exact"] is True and tc["values_different"] == 0 and tc["values_compared"] >= 2 * 1920 * 1080 * 4
     assert tc["poses"] == [5, 37] and tc["two_pass_frames"] == 2 and 0.0 < tc["share"] <= 0.75
+
+
+def test_bench_ply_names_the_file_and_the_camera_source(tmp_path):
+    """`bench.py --ply` (BASELINE configs[2]: a real Inria scene when one is on the box) -- an Inria-style directory
+    (point_cloud/iteration_30000/point_cloud.ply with cameras.json two levels up, found like app.cpp:418-461 finds it): the line's
+    config.workload names the file, its SH degree and the camera source; without a cameras.json it says the orbit was used"""
+    sys.path.insert(0, ROOT)
+    from splatapult_amd import camera, synthetic
+    ply = tmp_path / "scene" / "point_cloud" / "iteration_30000" / "point_cloud.ply"
+    os.makedirs(ply.parent)
+    synthetic.write_ply(str(ply), synthetic.generate(30000, seed=5, pos_sigma=1.5, log_scale_mean=-3.2))
+    quick = ["--steps", "6", "--warmup", "2", "--prewarm", "12", "--serial-frames", "8", "--profile-frames", "1", "--no-cpu-baseline"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "tiny", "--ply", str(ply)] + quick,
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    w = d["config"]["workload"]
+    assert str(ply) in w and "30000 splats, SH3" in w and "no cameras.json found" in w and d["data"] == "file" and d["config"]["splats"] == 30000
+    synthetic.write_cameras_json(str(tmp_path / "scene" / "cameras.json"), synthetic.scene_cameras(12), 640, 360, camera.FOVY)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "tiny", "--ply", str(ply)] + quick,
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    w = d["config"]["workload"]
+    assert "cameras.json (12 poses, CamerasConfig::ImportJson)" in w and d["config"]["cameras"] == "cameras.json, 12 poses"

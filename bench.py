@@ -23,8 +23,10 @@ What is measured:
                           contract (4 B per list entry + 48 B per projected record actually loaded, counted by the
                           kernel's own probe on extra frames, + the framebuffer write) / serial launch duration vs
                           8 TB/s; beside it the SURVEY 8d formula bytes (52 D + W H bpp), the PMC traffic, and the
-                          VALU view -- (pixel, splat) evaluations/s and their share of the 157.3 TFLOP/s fp32 vector
-                          peak at SURVEY's 20 flop per evaluation -- because VALU, not HBM, bounds this kernel.
+                          VALU view -- (pixel, splat) evaluations/s, the flops the kernel EXECUTES for them (14.5 + 1
+                          v_exp_f32 per evaluation, counted in the ISA) as a share of the 157.3 TFLOP/s fp32 vector peak
+                          (the nominal 20 flop of SURVEY 8d beside it), and the share of the evaluations whose weight
+                          survives the discard (useful_eval_frac) -- because VALU, not HBM, bounds this kernel.
   cpu_baseline .......... the tiled CPU renderer of SURVEY 8d(ii) (oracle/msplat_cpu_tiled.c, kind "port-tiled": parallel
                           radix sort, tile binning, front-to-back with early termination; thread count from the cgroup
                           CPU quota) on a bounded sample of the same workload; rank 0, N = 1 only.
@@ -687,6 +689,10 @@ def main():
     E.dev = torch.device("cuda", E.local_rank)
     E.pg, E.cpu_group = {"backend": None, "world_size": 1}, None
     if E.world > 1:
+        # a first run on real multi-GPU hardware must not hang silently: if the invocation has not finished after 20 minutes every
+        # rank dumps where its threads are (stderr) and exits -- the driver then has a stack, not a timeout
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("MSPLAT_BENCH_WATCHDOG_S", "1200")), exit=True)
         if E.one_dev:
             dist.init_process_group("gloo")
         else:

@@ -114,6 +114,34 @@ def phase(msg):
         print("[bench %8.2f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
 
+def hbm_delivered(dev):
+    """what this box's HBM delivers to a plain copy, measured in this process after the timed region (r6): `roofline.peak` has to quote
+    the nominal 8 TB/s; a 1-GiB device-to-device copy (2 GiB moved, beyond the 256 MB of MALL) says what a stream gets here.  Context
+    for the fractions, never part of `value`.  (tools/ubench_stream.hip: plain reads 5.2-5.75 TB/s, copies 4.5-4.9 TB/s on this pool.)"""
+    import torch
+    try:
+        n = 1 << 28
+        src = torch.zeros(n, dtype=torch.float32, device=dev)
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(10):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            dst.copy_(src)
+            b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b))
+        del src, dst
+        ms = float(np.median(ts))
+        return {"copy_GBps": 2.0 * n * 4 / (ms * 1e-3) / 1e9, "copy_frac_of_peak": 2.0 * n * 4 / (ms * 1e-3) / HBM_PEAK,
+                "how": "torch Tensor.copy_ of 1 GiB on this device (2 GiB moved), median of 10, after the timed region"}
+    except Exception as e:      # noqa: BLE001 -- context only
+        return {"copy_GBps": None, "how": "not measured: %s" % e}
+
+
 def measure(E, args, key, ply=None, primary=True):
     """one workload on the current process group; returns the JSON dict (rank 0 uses it)"""
     import torch
@@ -559,6 +587,8 @@ def measure(E, args, key, ply=None, primary=True):
         "project_kernel_frac": ((312.0 * V) / (prof_serial["project"] * 1e-3) / HBM_PEAK)
         if prof_serial and prof_serial.get("project", 0) > 0 else None,
     }
+    if world == 1 and primary:
+        roof["hbm_delivered"] = hbm_delivered(dev)
     out = {
         "metric": "frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,

@@ -187,7 +187,8 @@ def measure(E, args, key, ply=None, primary=True):
     two_pass = {"auto": _capi.TWO_PASS_AUTO, "on": _capi.TWO_PASS_ON, "off": _capi.TWO_PASS_OFF}[args.two_pass]
     r = SplatRenderer(device=E.local_rank, fb_format=wl["fb"], stream=stream.cuda_stream,
                       enable_timing=args.timing_stride, frames_in_flight=P,
-                      async_submit=None if args.async_submit < 0 else bool(args.async_submit), two_pass=two_pass)
+                      async_submit=None if args.async_submit < 0 else bool(args.async_submit), two_pass=two_pass,
+                      compositor_waves=args.compositor_waves, cu_partition=None if args.cu_partition == "auto" else False)
 
     def init(rr):
         # a file is rendered the way the app would: Ply::Parse on the host + GaussianCloud::ImportPly's math on the GPU
@@ -587,8 +588,7 @@ def measure(E, args, key, ply=None, primary=True):
         "project_kernel_frac": ((312.0 * V) / (prof_serial["project"] * 1e-3) / HBM_PEAK)
         if prof_serial and prof_serial.get("project", 0) > 0 else None,
     }
-    if world == 1 and primary:
-        roof["hbm_delivered"] = hbm_delivered(dev)
+    roof["hbm_delivered"] = hbm_delivered(dev) if (world == 1 and primary) else None      # (N > 1: the N = 1 line of the same box has it)
     out = {
         "metric": "frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -603,6 +603,7 @@ def measure(E, args, key, ply=None, primary=True):
                    "exchange": (("msplat_band_exchange (C ABI, RCCL group of ncclSend / ncclRecv per run of rows on the context's stream)" if comm is not None
                                  else "torch.distributed batch_isend_irecv (%s)" % dist.get_backend()) + ("; " + exchange_note if exchange_note else "")) if world > 1 else None,
                    "frames_in_flight": P, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                   "cu_partition": [p for p, _ in r.cu_partitions()],        # MSPLAT_CU_* of every context's stream (0 all, 1 even, 2 odd)
                    "async_submit": bool(r._async),
                    "two_pass": {"mode": args.two_pass,
                                 "timed_region": dict(tp_flight, frames_total=tp_frames_flight, share_pass1=tp_share_flight) if tp_flight else None,
@@ -674,6 +675,11 @@ def main():
     ap.add_argument("--profile-frames", type=int, default=6, help="extra frames (outside the timed regions) for V/D/work statistics")
     ap.add_argument("--serial-frames", type=int, default=128, help="frames of the serial (one stream, one at a time) phase")
     ap.add_argument("--prewarm", type=int, default=400, help="untimed frames before the warm-up (runtime pool growth)")
+    ap.add_argument("--cu-partition", default="auto", choices=["auto", "off"],
+                    help="auto: four frames in flight -> the contexts' streams alternate between the even and the odd CU positions of every "
+                         "XCD (msplat_config.cu_partition, the shims' rule); off: every stream on every CU (A/B)")
+    ap.add_argument("--compositor-waves", type=int, default=None,
+                    help="persistent compositor waves per launch (msplat_config.compositor_waves; default: the library's choice -- A/B runs)")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="frames overlapped on the GPU (one context + stream + framebuffer per frame in flight, one shared "
                          "cloud); 1 = strictly serial frames (latency mode)")

@@ -13,10 +13,8 @@
  */
 #ifndef MSPLAT_H
 #define MSPLAT_H
-
 #include <stddef.h>
 #include <stdint.h>
-
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -41,6 +39,8 @@ enum { MSPLAT_TWO_PASS_AUTO = 0, MSPLAT_TWO_PASS_ON = 1, MSPLAT_TWO_PASS_OFF = 2
 enum { MSPLAT_SPATIAL_AUTO = 0, MSPLAT_SPATIAL_ON = 1, MSPLAT_SPATIAL_OFF = 2 };     /* msplat_config.spatial_order */
 enum { MSPLAT_FRAMES_AUTO = 0, MSPLAT_FRAMES_SERIAL = 1, MSPLAT_FRAMES_IN_FLIGHT = 2 }; /* msplat_config.frame_mode */
 enum { MSPLAT_RANK_AUTO = 0, MSPLAT_RANK_BALLOT = 1 };                               /* msplat_config.rank_mode */
+/* msplat_config.cu_partition: every CU, or the even / odd CU positions of every XCD (4 frames in flight alternate: +3-5 %) */
+enum { MSPLAT_CU_ALL = 0, MSPLAT_CU_EVEN = 1, MSPLAT_CU_ODD = 2 };
 enum { MSPLAT_BANDS_CONTIGUOUS = 0, MSPLAT_BANDS_INTERLEAVED = 1, MSPLAT_BANDS_BLOCK_INTERLEAVED = 2, MSPLAT_BANDS_ROOT_WEIGHTED = 3 };
 
 typedef struct msplat_ctx msplat_ctx;
@@ -70,7 +70,7 @@ typedef struct msplat_config {
                                   issues their launches; a queued call's failure or overflow warning is returned by the next
                                   msplat_synchronize / msplat_stream_wait */
     int32_t two_pass;          /* MSPLAT_TWO_PASS_*: may a Render run as two passes with occlusion feedback (same pixels) */
-    int32_t reserved0;         /* 0 */
+    int32_t cu_partition;      /* MSPLAT_CU_*: the CUs a stream the library creates itself (stream == NULL) may use; frames in flight */
 } msplat_config;
 
 /* Byte offsets of the attributes inside one AoS record: the BinaryAttribute offsets SplatRenderer::BuildVertexArrayObject binds

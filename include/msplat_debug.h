@@ -62,6 +62,10 @@ int msplat_get_composite_work(msplat_ctx* ctx, msplat_composite_work* out);
 int msplat_debug_band_exchange_loopback(msplat_ctx* ctx, void* comm, int32_t kind, int32_t block_rows, int32_t world, int32_t rank,
                                         const void* src, void* dst, uint64_t pitch_bytes, int32_t width, int32_t height, int32_t flags);
 
+/* ---- msplat_config.cu_partition: the MSPLAT_CU_* the context's own stream really got (MSPLAT_CU_ALL on a caller's stream or when
+ * the runtime refused the mask); mask8 != NULL: the stream's CU mask as hipExtStreamGetCUMask reports it (8 words) ---- */
+int msplat_debug_cu_partition(msplat_ctx* ctx, uint32_t* mask8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ SPATIAL_AUTO, SPATIAL_ON, SPATIAL_OFF = 0, 1, 2
 TWO_PASS_AUTO, TWO_PASS_ON, TWO_PASS_OFF = 0, 1, 2          # msplat_config.two_pass
 BANDS_CONTIGUOUS, BANDS_INTERLEAVED, BANDS_BLOCK_INTERLEAVED, BANDS_ROOT_WEIGHTED = 0, 1, 2, 3
 EXCHANGE_WIRE_FP16 = 1              # msplat_band_exchange flags
+CU_ALL, CU_EVEN, CU_ODD = 0, 1, 2    # msplat_config.cu_partition
 # "weighted": contiguous bands, rank 0 (the gather's root) weighted block_rows PERCENT of another rank (msplat.h)
 BAND_KINDS = {"contiguous": BANDS_CONTIGUOUS, "interleaved": BANDS_INTERLEAVED, "block": BANDS_BLOCK_INTERLEAVED,
               "weighted": BANDS_ROOT_WEIGHTED}
@@ -35,7 +36,7 @@ class Config(C.Structure):
                 ("srgb", C.c_int32), ("t_epsilon", C.c_float), ("pair_capacity", C.c_uint64),
                 ("stream", C.c_void_p), ("enable_timing", C.c_int32), ("compositor_waves", C.c_int32),
                 ("rank_mode", C.c_int32), ("frame_mode", C.c_int32), ("spatial_order", C.c_int32), ("async_submit", C.c_int32),
-                ("two_pass", C.c_int32), ("reserved0", C.c_int32)]
+                ("two_pass", C.c_int32), ("cu_partition", C.c_int32)]
 
 
 class AttrOffsets(C.Structure):
@@ -89,6 +90,7 @@ SYMBOLS = [
     ("msplat_band_root_weight", C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]),
     ("msplat_get_stream", C.c_void_p, [C.c_void_p]),
     ("msplat_get_fb_format", C.c_int, [C.c_void_p]),
+    ("msplat_debug_cu_partition", C.c_int, [C.c_void_p, C.c_void_p]),
     ("msplat_group_create", C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(Config)]),
     ("msplat_group_destroy", None, [C.c_void_p]),
     ("msplat_group_last_error", C.c_char_p, [C.c_void_p]),

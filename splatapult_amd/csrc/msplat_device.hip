@@ -121,6 +121,7 @@ struct msplat_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    int cu_partition = MSPLAT_CU_ALL;      // what the context's own stream really got (msplat_config.cu_partition)
     std::string err;
 
     // cloud
@@ -346,6 +347,8 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: bad spatial_order %d", c.spatial_order);
     if (c.two_pass < MSPLAT_TWO_PASS_AUTO || c.two_pass > MSPLAT_TWO_PASS_OFF)
         return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: bad two_pass %d", c.two_pass);
+    if (c.cu_partition < MSPLAT_CU_ALL || c.cu_partition > MSPLAT_CU_ODD)
+        return fail(nullptr, MSPLAT_ERR_INVALID_ARG, "msplat_create: bad cu_partition %d", c.cu_partition);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -366,7 +369,23 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
     if (c.stream) {
         ctx->stream = (hipStream_t)c.stream;
     } else {
-        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        // cu_partition (r6): the stream runs on the even or the odd CU positions of every XCD.  Mask bit 8 c + x is CU c of XCD x, and a
+        // set bit enables CU c in EVERY XCD (tools/ubench_cumask.hip): a partition by XCD does not exist.  Two of four frames in
+        // flight per half: each stream's launches compete with one other stream's instead of three (sort and binning stages -27 %,
+        // projection and compositor slower, the frame 3-5 % faster: tools/gpu_r6_q.sh).  Without the extension: every CU, as before.
+        e = hipErrorNotSupported;
+        if (c.cu_partition == MSPLAT_CU_EVEN || c.cu_partition == MSPLAT_CU_ODD) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount == 256) {
+                uint32_t mask[8] = {0};
+                for (int i = 0; i < 256; ++i)
+                    if ((i / 8) % 2 == c.cu_partition - MSPLAT_CU_EVEN) mask[i / 32] |= 1u << (i % 32);
+                e = hipExtStreamCreateWithCUMask(&ctx->stream, 8, mask);
+                ctx->cu_partition = e == hipSuccess ? c.cu_partition : MSPLAT_CU_ALL;
+            }
+            if (e != hipSuccess) (void)hipGetLastError();
+        }
+        if (e != hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
             delete ctx;
             return fail(nullptr, MSPLAT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));

@@ -127,8 +127,12 @@ public:
             c.frame_mode = MSPLAT_FRAMES_IN_FLIGHT;   // kernels that co-schedule well with other frames' kernels (+2-3 %)
             c.async_submit = 1;                       // a worker thread per context issues its launches (msplat.h)
         }
+        // r6: an even number >= 4 of frames in flight: the contexts' streams alternate between the even and the odd CU positions of
+        // every XCD -- two frames per half of the CUs instead of four on all of them (+3-5 %)
+        const bool halves = framesInFlight >= 4 && framesInFlight % 2 == 0 && cfg.cu_partition == MSPLAT_CU_ALL;
         for (int k = 0; k < framesInFlight; ++k) {
             msplat_ctx* h = nullptr;
+            if (halves) c.cu_partition = MSPLAT_CU_EVEN + (k & 1);
             if (msplat_create(&h, &c) != MSPLAT_OK) {
                 std::fprintf(stderr, "[msplat][E] %s\n", msplat_last_error(nullptr));
                 DestroyContexts();

@@ -45,7 +45,8 @@ class _FrameArgs:
 class SplatRenderer:
     def __init__(self, device=0, fb_format="fp32", t_epsilon=-1.0, pair_capacity=0, stream=None,
                  enable_timing=False, frames_in_flight=1, rank_mode=_capi.RANK_AUTO, frame_mode=None,
-                 spatial_order=_capi.SPATIAL_AUTO, async_submit=None, two_pass=_capi.TWO_PASS_AUTO, compositor_waves=None):
+                 spatial_order=_capi.SPATIAL_AUTO, async_submit=None, two_pass=_capi.TWO_PASS_AUTO, compositor_waves=None,
+                 cu_partition=None):
         """frames_in_flight > 1: every Sort moves on to the next of that many contexts (own stream and
         per-frame buffers, ONE shared cloud -- msplat_attach_cloud), so successive frames overlap on the
         GPU; Render and the getters use the context of the latest Sort.  `stream` is only used with depth 1;
@@ -73,6 +74,10 @@ class SplatRenderer:
         # msplat_config.compositor_waves: persistent compositor waves per render (None: every item its own wave for one frame at a
         # time, 1280 with frames in flight -- measured r3: pool sweep 768 .. 2048)
         self._comp_waves = compositor_waves
+        # msplat_config.cu_partition (r6): None = the shims' rule -- with an even number >= 4 of frames in flight the contexts' streams
+        # alternate between the even and the odd CU positions of every XCD (two frames per half: +3-5 %), else every CU;
+        # False / 0 = every CU; or one MSPLAT_CU_* per context
+        self._cu_partition = cu_partition
         # msplat_config.frame_mode: kernels for one frame at a time, or for contexts that share the GPU with other frames in
         # flight (msplat.h, MSPLAT_FRAMES_*)
         self._frame_mode = int(frame_mode) if frame_mode is not None else (_capi.FRAMES_IN_FLIGHT if self._depth > 1 else _capi.FRAMES_AUTO)
@@ -125,7 +130,12 @@ class SplatRenderer:
         cfg.spatial_order = self._spatial
         cfg.async_submit = 1 if self._async else 0
         cfg.two_pass = self._two_pass
+        halves = self._depth >= 4 and self._depth % 2 == 0 if self._cu_partition is None else False
         for k in range(self._depth):
+            if isinstance(self._cu_partition, (list, tuple)):
+                cfg.cu_partition = int(self._cu_partition[k])
+            else:
+                cfg.cu_partition = (_capi.CU_EVEN + (k & 1)) if halves else int(self._cu_partition or 0)
             if isinstance(self._stream, (list, tuple)):       # one caller-owned stream per frame in flight
                 cfg.stream = self._stream[k]
             else:
@@ -393,6 +403,16 @@ class SplatRenderer:
         a, b = C.c_uint32(), C.c_uint32()
         _capi.check(self._ctx, self._lib.msplat_debug_verify_order(self._ctx, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def cu_partitions(self):
+        """per context: (MSPLAT_CU_* its stream got, the stream's CU mask as the runtime reports it: 8 words)"""
+        out = []
+        for h in self._ctxs:
+            m = (C.c_uint32 * 8)()
+            rc = self._lib.msplat_debug_cu_partition(h, m)
+            _capi.check(h, rc if rc < 0 else 0)
+            out.append((rc, list(m)))
+        return out
 
     def debug_tile_probe(self):
         st = self.stats()

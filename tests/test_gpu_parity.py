@@ -2333,3 +2333,53 @@ def test_every_combination_of_the_render_target_emulations_gives_the_same_pixels
             combos += 1
         plain.close()
     assert combos == 20
+
+
+@pytest.mark.gpu
+def test_cu_partition_halves_for_four_frames_in_flight():
+    """r6, msplat_config.cu_partition: with four frames in flight the shims' contexts alternate between the even and the odd CU
+    positions of every XCD (hipExtStreamCreateWithCUMask).  The streams really carry the masks -- 128 CUs each, disjoint, together
+    all 256 --, the frames are the serial frames bit for bit, one context on a half renders the same pixels as one on every CU, a
+    caller's stream is never masked, and a bad value is refused."""
+    import torch
+    from splatapult_amd import _capi
+    cloud = scenes.synth_cloud(80000, 92, log_scale_mean=-3.4)
+    W, H = 800, 450
+    Hpad = (H + bin_px() - 1) // bin_px() * bin_px()
+    views = [scenes.default_view(W, H, yaw=0.07 * k, x=0.04 * k) for k in range(9)]
+    r1 = make_renderer(cloud)
+    assert r1.cu_partitions()[0][0] == _capi.CU_ALL
+    serial = []
+    for cam, proj, vp, nf in views:
+        r1.Sort(cam, proj, vp, nf)
+        serial.append(r1.Render(cam, proj, vp, nf))
+    rp = make_renderer(cloud, frames_in_flight=4)
+    parts = rp.cu_partitions()
+    assert [p for p, _ in parts] == [_capi.CU_EVEN, _capi.CU_ODD, _capi.CU_EVEN, _capi.CU_ODD]
+    bits = [int.from_bytes(np.asarray(m, np.uint32).tobytes(), "little") for _, m in parts]
+    assert all(bin(b).count("1") == 128 for b in bits), [bin(b).count("1") for b in bits]
+    assert bits[0] == bits[2] and bits[1] == bits[3] and bits[0] & bits[1] == 0 and bits[0] | bits[1] == (1 << 256) - 1
+    assert make_renderer(cloud, frames_in_flight=3).cu_partitions()[1][0] == _capi.CU_ALL        # the rule: an even depth >= 4
+    assert make_renderer(cloud, frames_in_flight=4, cu_partition=False).cu_partitions()[3][0] == _capi.CU_ALL
+    dev = torch.device("cuda", 0)
+    fbs = [torch.zeros((Hpad, W, 4), dtype=torch.float32, device=dev) for _ in views]
+    torch.cuda.synchronize()
+    for k, (cam, proj, vp, nf) in enumerate(views):
+        rp.Sort(cam, proj, vp, nf)
+        rp.Render(cam, proj, vp, nf, out_ptr=fbs[k].data_ptr(), pitch_bytes=W * 16)
+    rp.synchronize()
+    for k in range(len(views)):
+        assert np.array_equal(fbs[k][:H].cpu().numpy(), serial[k]), k
+    # one context on one half: the same frame
+    for part in (_capi.CU_EVEN, _capi.CU_ODD):
+        rh = make_renderer(cloud, cu_partition=part)
+        assert rh.cu_partitions()[0][0] == part
+        cam, proj, vp, nf = views[3]
+        rh.Sort(cam, proj, vp, nf)
+        assert np.array_equal(rh.Render(cam, proj, vp, nf), serial[3])
+    # a caller's stream is used as it is
+    st = torch.cuda.Stream()
+    rc = make_renderer(cloud, stream=st.cuda_stream, cu_partition=_capi.CU_ODD)
+    assert rc.cu_partitions()[0][0] == _capi.CU_ALL
+    bad = SplatRenderer(device=0, cu_partition=3)
+    assert not bad.Init(cloud, False, False) and "cu_partition" in bad.last_error()

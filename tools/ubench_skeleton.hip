@@ -77,7 +77,16 @@ int main(int argc, char** argv)
     unsigned* sink;
     CHECK(hipMalloc(&sink, 64));
     std::vector<hipStream_t> st(8);
-    for (auto& s : st) CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    // argv[1] = "halves": stream k runs on the even (k even) / odd (k odd) CU positions of every XCD (hipExtStreamCreateWithCUMask:
+    // mask bit 8 c + x = position c of XCD x) -- msplat_config.cu_partition's partition; "quarters": position c % 4 == k % 4
+    const int groups = argc > 1 && !strcmp(argv[1], "halves") ? 2 : argc > 1 && !strcmp(argv[1], "quarters") ? 4 : 1;
+    for (size_t k = 0; k < st.size(); ++k) {
+        if (groups == 1) { CHECK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking)); continue; }
+        unsigned mask[8] = {0};
+        for (int i = 0; i < 256; ++i) if ((i / 8) % groups == (int)k % groups) mask[i / 32] |= 1u << (i % 32);
+        CHECK(hipExtStreamCreateWithCUMask(&st[k], 8, mask));
+    }
+    printf("# streams: %s\n", groups == 1 ? "every CU" : groups == 2 ? "halves of the CU positions (even / odd)" : "quarters of the CU positions");
 #define OPT1(T, V) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wait_kernel<T, V>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536))
 #define OPT(T) do { OPT1(T, 16); OPT1(T, 40); OPT1(T, 64); OPT1(T, 80); OPT1(T, 88); OPT1(T, 96); OPT1(T, 104); OPT1(T, 112); OPT1(T, 128); } while (0)
     OPT(64); OPT(128); OPT(256); OPT(512); OPT(1024);

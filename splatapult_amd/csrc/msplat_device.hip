@@ -153,7 +153,6 @@ struct msplat_ctx {
     uint32_t ws_threads = 512;  // 256 (4 waves, 40 / 56 KB of LDS) for contexts that share the GPU with other frames
     bool wide_sort = true;      // MSPLAT_SORT=lsd8 (or no lane-ordered LDS atomics): the four 8-bit passes
     bool wide_sort_cfg = true;  // what the context asked for; wide_sort = what the uploaded cloud gets (alloc_cloud_buffers)
-    bool ws_forced = false;     // MSPLAT_SORT=wide: no size rule
     uint32_t sort_parity = 0;
     bool tables_dirty = false;  // a launch failed: clear every self-cleaning table before the next frame
     // per-bin pair counts taken by the row pass's upsweep (r3): list offsets + work order without tile_start_kernel
@@ -462,7 +461,6 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
             if (lds_state[dslot] < 0) { (void)hipGetLastError(); ctx->wide_sort = false; }
         }
         ctx->wide_sort_cfg = ctx->wide_sort;
-        if (const char* sk = getenv("MSPLAT_SORT")) ctx->ws_forced = std::string(sk) == "wide";
     }
     if (rc != MSPLAT_OK) {
         std::string msg = ctx->err;

@@ -22,11 +22,15 @@ def main():
     ap.add_argument("--pool", type=int, default=1280)
     ap.add_argument("--blocks", default="20,200")
     ap.add_argument("--label", default="")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
     a = ap.parse_args()
     parts = [int(x) for x in a.parts.split(",")]
     P = len(parts)
-    W, H = 1920, 1080
-    cloud = synthetic.make_cloud(1_000_000, seed=0x5EED1234, full_sh=True, pos_sigma=1.5)
+    W, H = (4096, 4096) if a.workload == "cfg4" else (1920, 1080)
+    if a.workload == "cfg2":
+        cloud, cam_z = synthetic.make_cloud(1_000_000, seed=0x5EED1234, full_sh=True, pos_sigma=1.5), 7.0
+    else:
+        cloud, cam_z = synthetic.make_cloud(6_000_000, seed=0x5EED6000, full_sh=True, pos_sigma=3.0), 12.0
     fm = _capi.FRAMES_IN_FLIGHT if a.frame_mode == "inflight" else _capi.FRAMES_SERIAL
     r = SplatRenderer(device=0, fb_format="fp32", frames_in_flight=P, compositor_waves=a.pool, cu_partition=parts, frame_mode=fm)
     assert r.Init(cloud, False, False), r.last_error()
@@ -34,7 +38,7 @@ def main():
     fbs = [torch.zeros((((H + 31) // 32) * 32, W, 4), dtype=torch.float32, device=dev) for _ in range(P)]
     proj = camera.perspective(camera.FOVY, W / H)
     vp, nf = [0, 0, W, H], [camera.Z_NEAR, camera.Z_FAR]
-    poses = [camera.orbit(7.0, 2.0 * math.pi * k / 64.0) for k in range(64)]
+    poses = [camera.orbit(cam_z, 2.0 * math.pi * k / 64.0) for k in range(64)]
     step = [0]
 
     def frames(n):
@@ -56,7 +60,7 @@ def main():
             frames(blk)
             ts.append((time.perf_counter() - t0) / blk)
         out.append("%d-frame blocks %.0f frames/s" % (blk, 1.0 / float(np.median(ts))))
-    print("%-44s parts %s got %s, %s, pool %d: %s" % (a.label, parts, [p for p, _ in r.cu_partitions()], a.frame_mode, a.pool, "; ".join(out)), flush=True)
+    print("%-44s %s parts %s got %s, %s, pool %d: %s" % (a.label, a.workload, parts, [p for p, _ in r.cu_partitions()], a.frame_mode, a.pool, "; ".join(out)), flush=True)
     r.close()
 
 

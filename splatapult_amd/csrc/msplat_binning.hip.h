@@ -18,7 +18,7 @@ namespace msplat {
 //                     partitioned by column tx;       word = (row << 24) | rank
 //   pass 2 (radix_*<MODE_PAIR>): partition by the row byte; the downsweep rewrites the word to
 //                     (tx << 24) | rank (tx recovered from the input position), so that inside a
-//                     row the words are ascending and tile_start_kernel can binary-search them.
+//                     row the words are ascending (a bin's list is one run of its row).
 // ------------------------------------------------------------------------------------------
 
 template <int BIN_CHUNK>
@@ -344,61 +344,6 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && BIN_CHUNK == kBinChunk) ?
         __syncthreads();
         if (helper) break;           // a helper serves one (chunk, column block)
     }
-}
-
-// per bin: first position of its list in the final pair array.  The array is sorted by (row, word)
-// with word = (tx << 24) | rank, so inside row vty the words are ascending: lower_bound(tx << 24).
-// One WAVE per bin and a 64-ary search: every step probes 64 evenly spaced words of the remaining range with
-// one gather, so a row segment of 100 k words needs 3 dependent loads instead of 17 (this kernel was a
-// 2 k-thread latency chain: 7.8 us at 1920x1080).
-// (the compositors' sharded work queue, see queue_next below)
-constexpr int kTileStartBins = kThreads / 64;      // bins per workgroup
-__global__ __launch_bounds__(kThreads) void tile_start_kernel(const uint32_t* __restrict__ pairs,
-                                                              const uint32_t* __restrict__ row_totals,
-                                                              const uint32_t* __restrict__ d_D, uint32_t cap,
-                                                              int tiles_x, int ntiles,
-                                                              uint32_t* __restrict__ tile_start,
-                                                              uint32_t* __restrict__ gsum_zero, uint32_t gsum_zero_rows,
-                                                              uint32_t* __restrict__ queue_reset)
-{
-    MSPLAT_CHAIN_ENTER();
-    MSPLAT_STAMP(KID_TILE_START);
-    // (the compositors' work queue starts empty every frame; tile_order_kernel does it when it runs)
-    if (queue_reset != nullptr && blockIdx.x == 0 && threadIdx.x < kQueueShards) queue_reset[threadIdx.x * kQueueStride] = 0u;
-    __shared__ uint32_t s_row[kThreads + 1];
-    __shared__ uint32_t s_tmp[4];
-    if (gsum_zero != nullptr)      // scan-free path: the row pass's group table for the NEXT frame, see radix_upsweep
-        for (uint32_t row = blockIdx.x; row < gsum_zero_rows; row += gridDim.x) gsum_zero[(size_t)row * 256 + threadIdx.x] = 0u;
-    {
-        const uint32_t t = row_totals[threadIdx.x];
-        uint32_t tot;
-        const uint32_t incl = block_incl_scan(t, s_tmp, tot);
-        s_row[threadIdx.x] = incl - t;
-        if (threadIdx.x == 255) s_row[256] = incl;
-    }
-    __syncthreads();
-    const uint32_t D = min(*d_D, cap);
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * kTileStartBins + (threadIdx.x >> 6);
-    if (tile == 0 && lane == 0) tile_start[ntiles] = D;
-    if (tile >= ntiles) return;
-    const int vty = tile / tiles_x;
-    const uint32_t tx = (uint32_t)(tile - vty * tiles_x);
-    uint32_t lo = min(s_row[vty], D), hi = min(s_row[vty + 1], D);     // the answer lies in [lo, hi]
-    const uint32_t key = tx << 24;
-    while (lo < hi) {                                                  // wave-uniform
-        const uint32_t len = hi - lo;
-        const uint32_t step = (len + 64u) / 65u;                       // >= 1
-        const uint32_t p = lo + ((uint32_t)lane + 1u) * step - 1u;     // probe j = lane: ascending positions
-        const bool below = (p < hi) && (pairs[p] < key);
-        const uint32_t c = (uint32_t)__popcll(__ballot(below));        // probes 0..c-1 are below the key (sorted input)
-        const uint32_t pc = lo + (c + 1u) * step - 1u;                 // probe c: first probe not below, if it exists
-        const uint32_t nlo = c ? lo + c * step : lo;                   // = p[c-1] + 1
-        const uint32_t nhi = (c < 64u && pc < hi) ? pc : hi;
-        lo = nlo;
-        hi = nhi;
-    }
-    if (lane == 0) tile_start[tile] = lo;
 }
 
 // Self-check of the two ordering contracts everything downstream relies on (the stable ranking rests on

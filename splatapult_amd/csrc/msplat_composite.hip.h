@@ -41,45 +41,6 @@ __global__ __launch_bounds__(kThreads) void iota_kernel(uint32_t* __restrict__ d
     dst[blockIdx.x * kThreads + threadIdx.x] = blockIdx.x * kThreads + threadIdx.x;
 }
 
-// tiles ordered by descending list length (counting sort on len/16): the compositor's waves pull tiles
-// from this list through an atomic queue, heaviest first (longest-processing-time-first scheduling)
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ tile_start, int ntiles,
-                                                          uint32_t* __restrict__ order,
-                                                          uint32_t* __restrict__ queue)
-{
-    if (threadIdx.x < kQueueShards) queue[threadIdx.x * kQueueStride] = 0u;      // the compositors' work queue starts empty every frame
-
-    __shared__ uint32_t s_cnt[256];
-    __shared__ uint32_t s_off[256];
-    if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < ntiles; i += 1024) {
-        const uint32_t len = tile_start[i + 1] - tile_start[i];
-        atomicAdd(&s_cnt[255u - min(len >> 4, 255u)], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {          // one wave scans the 256 buckets (4 per lane)
-        uint32_t c[4], sum = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { c[k] = s_cnt[threadIdx.x * 4 + k]; sum += c[k]; }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t t = __shfl_up(incl, d, 64);
-            if ((int)threadIdx.x >= d) incl += t;
-        }
-        uint32_t run = incl - sum;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { s_off[threadIdx.x * 4 + k] = run; run += c[k]; }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < ntiles; i += 1024) {
-        const uint32_t len = tile_start[i + 1] - tile_start[i];
-        const uint32_t pos = atomicAdd(&s_off[255u - min(len >> 4, 255u)], 1u);
-        order[pos] = (uint32_t)i;      // order inside a bucket is irrelevant (tiles are independent)
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // composite: one 16x16 workgroup per tile, front-to-back over the tile's depth-ordered list
 // (reverse of the reference's back-to-front ROP blend; algebraically identical -- SURVEY 8a-12):

@@ -155,9 +155,8 @@ struct msplat_ctx {
     bool wide_sort_cfg = true;  // what the context asked for; wide_sort = what the uploaded cloud gets (alloc_cloud_buffers)
     uint32_t sort_parity = 0;
     bool tables_dirty = false;  // a launch failed: clear every self-cleaning table before the next frame
-    // per-bin pair counts taken by the row pass's upsweep (r3): list offsets + work order without tile_start_kernel
+    // per-bin pair counts taken by the row pass's upsweep (r3): list offsets + work order (no kernel of their own)
     Buf bincnt;
-    bool bin_counts = true;     // contexts with frames in flight: tile_start_kernel / tile_order_kernel (measured r3 / r5: the better form there)
     // (XCD-contiguous chunk ranges: on for the sort's downsweeps -- 6 M splats 196 -> 185 us, no change at 1 M -- and the row
     //  pass's downsweep -- 6 M / 4096^2 binning 347 -> 327 us: a column's chunks write adjacent runs of every row --, off for the
     //  column pass's downsweep, where they were measured slower: 453 -> 509 us.  Fixed since r4.)
@@ -433,7 +432,6 @@ int msplat_create(msplat_ctx** out, const msplat_config* cfg)
         // frames in flight: kernels that co-schedule well (msplat.h); AUTO and any stale padding value = one frame at a time
         ctx->wide_sort = true;
         ctx->ws_threads = c.frame_mode == MSPLAT_FRAMES_IN_FLIGHT ? (uint32_t)kWsThreadsSmall : (uint32_t)kWsThreads;
-        ctx->bin_counts = c.frame_mode != MSPLAT_FRAMES_IN_FLIGHT;
         if (const char* sk = getenv("MSPLAT_SORT")) ctx->wide_sort = std::string(sk) != "lsd8";
         if (!ctx->atomic_rank) ctx->wide_sort = false;       // the wide kernels rank with lane-ordered LDS atomics only
         ctx->spatial_mode = c.spatial_order;
@@ -1328,16 +1326,17 @@ static void issue_binning(RenderChain& rc, int keep_overflow, int occ_pass)
     const uint32_t comp_pool = (ctx->comp_waves_auto && comp_items <= (stereo ? 40960u : 20480u)) ? comp_items : (uint32_t)ctx->comp_waves;
     const bool ordered = !(wave_comp && comp_pool < comp_items);
     // r3: the upsweep of the row pass also counts the pairs per bin, and one extra workgroup of its downsweep turns the
-    // counts into the list offsets (+ the heaviest-first order when it is wanted): tile_start_kernel / tile_order_kernel
-    // are not launched (contexts with frames in flight keep them: msplat_config.frame_mode)
-    uint32_t* bincnt = ctx->bin_counts ? (uint32_t*)ctx->bincnt.p : nullptr;
+    // counts into the list offsets (+ the heaviest-first order when it is wanted).  (r3-r5: contexts with frames in flight
+    // searched the offsets in the partitioned array with a kernel of their own, 1 % faster then; equal in r6 under the CU halves
+    // -- 6290 / 6298, 2478-2514 / 2485-2494, 1363-1403 / 1384-1403 frames/s at 1 M, 6 M, 6 M / 4096^2 -- and removed: one launch less.)
+    uint32_t* bincnt = (uint32_t*)ctx->bincnt.p;
     const int g2 = grid_for(div_up(cap, kPairChunk));
     hipLaunchKernelGGL(radix_upsweep<MODE_PAIR>, dim3(g2), dim3(kThreads), 0, s, (const uint32_t*)ctx->pairsA.p,
                        nullptr, d_D, 0u, cap, 24, (uint32_t*)ctx->hist2.p, ctx->hist2_stride, fused2 ? gB2 : nullptr, gB1,
                        ctx->gsumB1_rows, fp, (const uint32_t*)totals1, bincnt, ctx->gsupB2);
     if (!fused2)
         launch_scan(s, ctx->N <= (2u << 20), (uint32_t*)ctx->hist2.p, ctx->hist2_stride, d_D, 0u, cap, (uint32_t)kPairChunk, totals2);
-    const int g2d = g2 + (bincnt ? 1 : 0);
+    const int g2d = g2 + 1;
     if (ctx->atomic_rank)
         hipLaunchKernelGGL((radix_downsweep<MODE_PAIR, false, true>), dim3(g2d), dim3(kThreads), 0, s,
                            (const uint32_t*)ctx->pairsA.p, nullptr, nullptr, d_D, 0u, cap, 24,
@@ -1352,14 +1351,6 @@ static void issue_binning(RenderChain& rc, int keep_overflow, int occ_pass)
                            (uint32_t*)ctx->pairsB.p, nullptr, nullptr, (const uint32_t*)totals1,
                            fused2 ? (const uint32_t*)gB2 : nullptr, fused2 ? totals2 : nullptr, fp, bincnt,
                            (uint32_t*)ctx->tile_start.p, (uint32_t*)ctx->tile_order.p, d_queue, ntiles, (ordered ? 1 : 0) | 2, ctx->gsupB2);
-    if (!bincnt) {
-        hipLaunchKernelGGL(tile_start_kernel, dim3(std::max(1, (ntiles + kTileStartBins - 1) / kTileStartBins)), dim3(kThreads), 0, s,
-                           (const uint32_t*)ctx->pairsB.p, (const uint32_t*)totals2, d_D, cap, fp.tiles_x, ntiles,
-                           (uint32_t*)ctx->tile_start.p, gB2, ctx->gsumB2_rows, ordered ? nullptr : d_queue);
-        if (ordered)
-            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)ctx->tile_start.p, ntiles,
-                               (uint32_t*)ctx->tile_order.p, d_queue);
-    }
     rc.ordered = ordered;
     rc.comp_items = comp_items;
     rc.comp_pool = comp_pool;

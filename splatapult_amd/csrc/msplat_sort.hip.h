@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE == MODE_KEYS && SORT
     // lb.list != nullptr (MODE_CULL): pass 0 over the listed live boxes only (virtual positions), see ws_upsweep
     // gsum != nullptr: scan-free path -- hist holds raw per-chunk counts, prefixes come from the group tables;
     // otherwise hist holds exclusive prefixes and totals the digit totals (radix_scan*).
-    // totals_out != nullptr: workgroup 0 publishes the digit totals (the row totals tile_start_kernel needs).
+    // totals_out != nullptr: workgroup 0 publishes the digit totals (the row totals the list offsets are built from).
     // bincnt != nullptr (MODE_PAIR, r3): workgroup 0 of the grid does not move pairs, it builds the bins' list
     // offsets and work order from the counts the upsweep took (tile_table_role); the others are the workers.
     constexpr int ITEMS = RadixCfg<MODE, SORT_ITEMS>::ITEMS;
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(kThreads, (ATOMIC_RANK && MODE == MODE_KEYS && SORT
                 uint32_t kout = key[r];
                 if (MODE == MODE_PAIR) {
                     // input is ordered by (column, rank): recover the column from the input position and
-                    // store (tx << 24) | rank, so each row of the result is ascending (tile_start_kernel).
+                    // store (tx << 24) | rank, so each row of the result is ascending.
                     // The wave's positions are consecutive and a column holds ~D/tiles_x words, so almost
                     // every wave sits inside one column: search once per wave, then walk.
                     const uint32_t i = base + r * 64 + lane;

@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 from splatapult_amd import SplatRenderer, _capi, camera, synthetic  # noqa: E402
 
 NAMES = {1: "ws_upsweep<cull>", 2: "ws_downsweep<cull>", 3: "ws_upsweep", 4: "ws_downsweep", 5: "project_kernel", 6: "bin1_upsweep",
-         7: "bin1_downsweep", 8: "radix_upsweep<pair>", 9: "radix_downsweep<pair>", 10: "tile_start_kernel", 11: "composite_kernel",
+         7: "bin1_downsweep", 8: "radix_upsweep<pair>", 9: "radix_downsweep<pair>", 10: "tile_start_kernel (removed at the end of r6)", 11: "composite_kernel",
          12: "box_cull_kernel", 13: "radix_upsweep", 14: "radix_downsweep"}
 # waves per workgroup and LDS bytes per workgroup in each frame mode (serial / in flight), from the launch code and tools/kres.sh
 WAVES = {1: (16, 4), 2: (8, 4), 3: (16, 4), 4: (8, 4), 5: (1, 1), 6: (4, 4), 7: (4, 4), 8: (4, 4), 9: (4, 4), 10: (4, 4), 11: (1, 1)}

@@ -36,7 +36,9 @@ REC = np.dtype([("kid", "<u4"), ("blk", "<u4"), ("hwid", "<u4"), ("xcc", "<u4"),
 
 def run(P, frames, cloud, W, H, L, pool=None):
     dev = torch.device("cuda:0")
-    r = SplatRenderer(device=0, fb_format="fp32", frames_in_flight=P, compositor_waves=pool)
+    # STAMP_CU_PARTITION=off: every context's stream on every CU (the shims' default for 4 frames in flight: two per half, r6)
+    r = SplatRenderer(device=0, fb_format="fp32", frames_in_flight=P, compositor_waves=pool,
+                      cu_partition=False if os.environ.get("STAMP_CU_PARTITION") == "off" else None)
     assert r.Init(cloud, False, False), r.last_error()
     fbs = [torch.zeros((((H + 31) // 32) * 32, W, 4), dtype=torch.float32, device=dev) for _ in range(P)]
     proj = camera.perspective(camera.FOVY, W / H)

@@ -46,7 +46,7 @@ def _check_contract(d, n):
     assert 0.0 < v["frac_of_fp32_vector_peak"] < v["frac_of_fp32_vector_peak_nominal_20_flop"] < 1.0 and v["flop_per_eval_executed"] == 14.5
     assert 0.05 < v["useful_eval_frac"] < 1.0
     # r6: what the box's HBM delivers to a plain copy, measured in the same process (context for the fractions of the nominal peak)
-    assert cfg["cu_partition"] == [1, 2, 1, 2], cfg["cu_partition"]       # r6: four frames in flight, two per half of the CUs
+    assert cfg["cu_partition"] in ([1, 2, 1, 2], [0, 0, 0, 0]), cfg["cu_partition"]       # r6: four frames in flight, two per half of the CUs ([0, 0, 0, 0]: not a 256-CU device)
     hd = r["hbm_delivered"]
     assert (hd is None) if d["n_gpus"] > 1 else (hd["copy_GBps"] is not None and 1000.0 < hd["copy_GBps"] < 8000.0), hd
     assert (d["timed_seconds"] >= 1.5 or n > 1) and d["timed_blocks"] >= 2 and d["block_ms"]["min"] <= d["block_ms"]["median"] <= d["block_ms"]["max"]

@@ -2355,6 +2355,10 @@ def test_cu_partition_halves_for_four_frames_in_flight():
         serial.append(r1.Render(cam, proj, vp, nf))
     rp = make_renderer(cloud, frames_in_flight=4)
     parts = rp.cu_partitions()
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        # (a partitioned MI355X: the library keeps every stream on every CU; the rest of this test is about the masks)
+        assert [p for p, _ in parts] == [_capi.CU_ALL] * 4
+        pytest.skip("not a 256-CU device: msplat_config.cu_partition falls back to every CU")
     assert [p for p, _ in parts] == [_capi.CU_EVEN, _capi.CU_ODD, _capi.CU_EVEN, _capi.CU_ODD]
     bits = [int.from_bytes(np.asarray(m, np.uint32).tobytes(), "little") for _, m in parts]
     assert all(bin(b).count("1") == 128 for b in bits), [bin(b).count("1") for b in bits]
